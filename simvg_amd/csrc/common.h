@@ -1,0 +1,76 @@
+// Shared device/host helpers for libsimvg_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SIMVG_OK 0
+#define SIMVG_ERR_ARG (-1)
+#define SIMVG_ERR_HIP (-2)
+
+extern "C" void simvg_set_error(const char* msg);
+
+#define SIMVG_CHECK_ARG(cond, msg)            \
+  do {                                        \
+    if (!(cond)) {                            \
+      simvg_set_error(msg);                   \
+      return SIMVG_ERR_ARG;                   \
+    }                                         \
+  } while (0)
+
+#define SIMVG_LAUNCH_CHECK()                               \
+  do {                                                     \
+    hipError_t e__ = hipGetLastError();                    \
+    if (e__ != hipSuccess) {                               \
+      simvg_set_error(hipGetErrorString(e__));             \
+      return SIMVG_ERR_HIP;                                \
+    }                                                      \
+  } while (0)
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // MFMA A/B fragment (8 bf16)
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;    // MFMA 16x16 accumulator
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) {
+  return __uint_as_float(((unsigned int)v) << 16);
+}
+// round-to-nearest-even, NaN preserved (matches torch .to(bfloat16))
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  unsigned int u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+  return (unsigned int)f32_to_bf16(lo) | ((unsigned int)f32_to_bf16(hi) << 16);
+}
+__device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// hardware transpose read: 16-lane group reads a [4 rows][16 cols] bf16 block (each lane supplies
+// the address of 4 contiguous elements: lane p -> row p>>2, cols 4*(p&3)..+3) and lane i receives
+// column i, rows 0..3.
+__device__ __forceinline__ bf16x4_t lds_read_tr16(const void* lds_addr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)(lds_addr));
+}
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

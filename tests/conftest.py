@@ -1,0 +1,27 @@
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: full-size CPU oracle cases (tens of seconds)")
+
+
+def has_gpu():
+    return torch.cuda.is_available()
+
+
+@pytest.fixture(scope="session")
+def golden():
+    def load(name):
+        return torch.load(os.path.join(GOLDEN, name + ".pt"), weights_only=False)
+    return load
