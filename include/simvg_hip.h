@@ -1,0 +1,106 @@
+/* libsimvg_hip.so -- C ABI of the MI355X-native (gfx950) SimVG hot path.
+ *
+ * Drop-in boundary: plain C functions, one per fused op and direction.  All pointers
+ * are DEVICE pointers owned by the caller (PyTorch-ROCm allocator: tensor.data_ptr()); the library
+ * never allocates; every call only ENQUEUES on the passed hipStream_t (no hidden synchronisation);
+ * return 0 on success, <0 on error (message via simvg_last_error()); no global mutable state besides
+ * the thread-local error string.  Matrices are row-major with explicit leading dimensions (elements).
+ * "bf16" = raw bfloat16 bits (uint16_t).  Weights keep the reference state_dict layout [out, in].
+ *
+ * Row layout of every activation matrix is MODALITY-MAJOR: the vision tokens of all samples first
+ * ([B*Nv] rows), then the text tokens ([B*Nt] rows).  `split` = B*Nv is where the multiway "A"
+ * (vision) expert ends and the "B" (text) expert begins; split == 0 means a single expert / group.
+ * This replaces torchscale's MultiwayNetwork split/cat (reference beit3_base.py:128-130,362-364).
+ *
+ * The reference has no FFI for this path (it is eager PyTorch on top of torchscale / detrex; reference
+ * setup.py:120 `ext_modules=[]`); each entry point cites the reference call site whose arithmetic it
+ * replaces.  Paths are relative to the reference root.
+ */
+#ifndef SIMVG_HIP_H
+#define SIMVG_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* simvg_stream_t; /* == hipStream_t */
+
+/* ---- library ---- */
+int simvg_version(void);
+const char* simvg_last_error(void);
+
+/* ---- dense contractions (bf16 MFMA, fp32 accumulate) -------------------------------------------
+ * C[M,N] = A[M,K] . W[g][N,K]^T (+bias[g][N]) (+act) ; optional pre-activation copy (bf16) ; optional
+ * fused residual: C = residual + row_scale[sample(m)] * (...), the DropPath + residual_connection of
+ * simvg/models/vis_encs/beit/beit3_base.py:146-151,166-169.  act: 0 none, 1 exact-erf GELU, 2 ReLU.
+ * Replaces the multiway nn.Linear calls of torchscale MultiheadAttention (q/k/v/out_proj) and
+ * FeedForwardNetwork (fc1 -> gelu, fc2) invoked at beit3_base.py:137-145,159, the patch-embed Conv2d
+ * (beit3_base.py:461, after simvg_im2col) and the head projections
+ * simvg/models/heads/tgqs_kd_detr_head/tgqs_kd_detr_head.py:377-379. */
+int simvg_gemm_nt(const void* A_bf16, int lda, const void* W_bf16, long w_group_stride, int ldw,
+                  const float* bias, int bias_group_stride, void* C, int ldc, int c_is_f32,
+                  void* aux_preact_bf16, int ldaux, const float* residual, int ldres,
+                  const float* row_scale, int rows_per_sample0, int rows_per_sample1,
+                  int M, int N, int K, int split, int act, simvg_stream_t stream);
+/* dW[g][N,K] += dY[M,N]^T . X[M,K]  (weight gradient of the same Linears; fp32 accumulate) */
+int simvg_gemm_tn(const void* dY_bf16, int lddy, const void* X_bf16, int ldx, float* dW, long dw_group_stride,
+                  int lddw, int M, int N, int K, int split, simvg_stream_t stream);
+/* out[g][N] += column sums of Y over the rows of group g (bias gradients) */
+int simvg_colsum(const void* Y_bf16, int ldy, float* out, int out_group_stride, int M, int N, int split,
+                 simvg_stream_t stream);
+
+/* ---- LayerNorm (multiway gamma/beta by row group) -----------------------------------------------
+ * torch.nn.LayerNorm under MultiwayWrapper: beit3_base.py:136 (self_attn_layer_norm), :157
+ * (final_layer_norm), :396-397 (encoder.layer_norm), torchscale inner_attn_ln / ffn_layernorm; and the
+ * decoder norms of heads/tgqs_kd_detr_head/transformer.py:119-132. */
+int simvg_ln_fwd(const void* x, int x_is_bf16, int ldx, const float* gamma, const float* beta, int group_stride,
+                 void* y_bf16, int ldy, float* y_f32, int ldy32, float* mean, float* rstd,
+                 int M, int D, int split, float eps, simvg_stream_t stream);
+/* dx = LN'(dy); outputs: bf16 dx (optionally * GELU'(u), fusing the activation backward of fc1), and/or
+ * fp32 (dres + dx) = the residual-stream gradient, with an optional bf16 copy * row_scale (DropPath). */
+int simvg_ln_bwd(const void* dy_bf16, int lddy, const void* x, int x_is_bf16, int ldx, const float* mean,
+                 const float* rstd, const float* gamma, int group_stride, float* dgamma, float* dbeta,
+                 void* dx_bf16, int lddxb, const void* gelu_u_bf16, int ldu, const float* dres,
+                 float* dx_f32, int lddxf, void* dx_scaled_bf16, int lddxs, const float* row_scale,
+                 int rows_per_sample0, int rows_per_sample1, int M, int D, int split, simvg_stream_t stream);
+
+/* ---- fused encoder self-attention ----------------------------------------------------------------
+ * softmax(scale * Q K^T + key_padding(-inf)) V per (sample, head), head_dim 64, N = Nv+Nt <= 448.
+ * torchscale MultiheadAttention.forward as called at beit3_base.py:137-145 (bmm, masked_fill, fp32
+ * softmax, bmm, head merge).  qkv: [M, 3D] = q | k | v columns.  pad: [B,Nt] bytes, 1 = padded key. */
+int simvg_attn_fwd(const void* qkv_bf16, int ldqkv, void* out_bf16, int ldo, float* lse, const unsigned char* pad,
+                   int B, int H, int Nv, int Nt, int D, float scale, simvg_stream_t stream);
+int simvg_attn_bwd(const void* qkv_bf16, int ldqkv, const void* out_bf16, int ldo, const void* dout_bf16, int lddo,
+                   void* dqkv_bf16, int lddqkv, const float* lse, float* delta_ws, const unsigned char* pad,
+                   int B, int H, int Nv, int Nt, int D, float scale, simvg_stream_t stream);
+
+/* ---- embedding stage -------------------------------------------------------------------------------
+ * torchscale VisionEmbedding / TextEmbedding / PositionalEmbedding as wired by BEiT3.forward and
+ * Encoder.forward_embedding (beit3_base.py:461-475,317-334) and the pad zeroing at :367. */
+int simvg_im2col(const float* img_nchw, void* cols_bf16, int B, int S, int P, simvg_stream_t stream);
+int simvg_embed_fwd(const float* patch, int ldp, const float* cls, const float* posA, const float* posB,
+                    const float* text_embed, const long long* ids, const unsigned char* pad, float* x, int ldx,
+                    int B, int np, int T, int D, simvg_stream_t stream);
+int simvg_embed_bwd(const float* dx, int lddx, void* dpatch_bf16, int lddp, float* dcls, float* dposA, float* dposB,
+                    float* dtext, const long long* ids, const unsigned char* pad, int B, int np, int T, int D,
+                    simvg_stream_t stream);
+
+/* ---- weight preparation (fp32 master -> bf16 compute copies, plain + transposed) ---------------- */
+typedef struct {
+  const float* src; void* dst_bf16; void* dst_t_bf16; int rows, cols; int tile_start; int pad_;
+} simvg_weight_desc;
+int simvg_weight_prep(const void* descs_dev, int n_desc, int total_tiles, simvg_stream_t stream);
+int simvg_cast_f32_to_bf16(const float* src, void* dst_bf16, long n, simvg_stream_t stream);
+int simvg_cast_bf16_to_f32(const void* src_bf16, float* dst, long n, simvg_stream_t stream);
+
+/* ---- hardware-semantics probes (tests/test_kernels_gpu.py) ---------------------------------------- */
+int simvg_probe_mfma(const void* a_bf16, const void* b_bf16, float* out, simvg_stream_t stream);
+int simvg_probe_tr16(const int* byte_addr, void* out_i16, simvg_stream_t stream);
+int simvg_probe_glds(const void* src_i16, const int* perm, void* out_i16, simvg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIMVG_HIP_H */

@@ -1,0 +1,80 @@
+"""ctypes binding of libsimvg_hip.so (the C-ABI declared in include/simvg_hip.h).
+
+Fails loudly when the library is missing: the product path has NO CPU / PyTorch fallback.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsimvg_hip.so")
+
+c_void_p, c_int, c_long, c_float = C.c_void_p, C.c_int, C.c_long, C.c_float
+
+
+class WeightDesc(C.Structure):
+    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("dst_t", c_void_p), ("rows", c_int), ("cols", c_int),
+                ("tile_start", c_int), ("pad_", c_int)]
+
+
+_SIGS = {
+    "simvg_gemm_nt": [c_void_p, c_int, c_void_p, c_long, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
+                      c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                      c_void_p],
+    "simvg_gemm_tn": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "simvg_colsum": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "simvg_ln_fwd": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                     c_void_p, c_int, c_int, c_int, c_float, c_void_p],
+    "simvg_ln_bwd": [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                     c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                     c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "simvg_attn_fwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                       c_float, c_void_p],
+    "simvg_attn_bwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
+                       c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
+    "simvg_im2col": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "simvg_embed_fwd": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                        c_int, c_int, c_int, c_int, c_void_p],
+    "simvg_embed_bwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                        c_int, c_int, c_int, c_int, c_void_p],
+    "simvg_weight_prep": [c_void_p, c_int, c_int, c_void_p],
+    "simvg_cast_f32_to_bf16": [c_void_p, c_void_p, c_long, c_void_p],
+    "simvg_cast_bf16_to_f32": [c_void_p, c_void_p, c_long, c_void_p],
+    "simvg_probe_mfma": [c_void_p, c_void_p, c_void_p, c_void_p],
+    "simvg_probe_tr16": [c_void_p, c_void_p, c_void_p],
+    "simvg_probe_glds": [c_void_p, c_void_p, c_void_p, c_void_p],
+}
+
+_lib = None
+
+
+class SimvgHipError(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SimvgHipError(
+            f"{LIB_PATH} not found: build it with `python -m simvg_amd.build` (hipcc --offload-arch=gfx950). "
+            "simvg_amd has no CPU or eager-PyTorch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in _SIGS.items():
+        fn = getattr(lib, name)   # AttributeError here == header / library mismatch
+        fn.argtypes = args
+        fn.restype = c_int
+    lib.simvg_last_error.restype = C.c_char_p
+    lib.simvg_last_error.argtypes = []
+    lib.simvg_version.restype = c_int
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return sorted(_SIGS) + ["simvg_last_error", "simvg_version"]
+
+
+def check(rc, what):
+    if rc != 0:
+        raise SimvgHipError(f"{what} failed (rc={rc}): {load().simvg_last_error().decode()}")

@@ -1,0 +1,380 @@
+// Fused multi-head self-attention for the BEiT-3 encoder (gfx950), forward and backward.
+//
+// Replaces torchscale MultiheadAttention's  q*scale -> bmm(q,k^T) -> masked_fill(-inf) ->
+// softmax(fp32) -> bmm(p,v) -> head merge  (reference call site beit3_base.py:137-145, SURVEY.md
+// §2.3 E7-E12).  The score matrix never goes to HBM.
+//
+// Geometry of the path: N = 1 + (640/32)^2 + 20 = 421 tokens, head_dim 64.  One workgroup owns one
+// (sample, head): the whole K and V (448 x 64 bf16 each, 144-B padded rows) sit in LDS; each wave
+// takes 16 query rows at a time, holds the complete S^T = K·Q^T strip (28 tiles of 16x16) in
+// registers, does an exact (non-online) fp32 softmax with wavefront shuffles for the row reduce,
+// and feeds P straight back as the MFMA B operand of O^T = V^T·P^T (V^T fragments come from
+// ds_read_b64_tr_b16).  MFMA is used for the two contractions only.
+//
+// Token rows are laid out modality-major: vision rows of all samples first ([B*Nv, .]), then text
+// rows ([B*Nt, .]); token t of sample b lives at row  t < Nv ? b*Nv + t : B*Nv + b*Nt + (t - Nv).
+#include "common.h"
+
+namespace {
+
+constexpr int HD = 64;          // head dim
+constexpr int ROWB = 144;       // LDS row stride in bytes (128 B data + 16 B pad)
+constexpr int MAX_KT = 28;      // 28 * 16 = 448 >= 421 keys
+
+struct AttnArgs {
+  const bf16_t* qkv; int ld;    // [M, 3*D]
+  bf16_t* out; int ldo;         // [M, D]   forward output / saved O in backward
+  const bf16_t* dout; int lddo; // [M, D]   backward: grad of O
+  bf16_t* dqkv; int lddq;       // [M, 3*D] backward: grads
+  float* lse;                   // [B*H, N]
+  float* delta;                 // [B*H, N]
+  const unsigned char* pad;     // [B, Nt] 1 = padded text key, or null
+  int B, H, Nv, Nt, D;
+  float scale;
+};
+
+__device__ __forceinline__ long tok_row(const AttnArgs& a, int b, int t) {
+  return t < a.Nv ? (long)b * a.Nv + t : (long)a.B * a.Nv + (long)b * a.Nt + (t - a.Nv);
+}
+
+// copy rows [0,nrows_pad) x 64 bf16 of one head into LDS (zero beyond N)
+__device__ __forceinline__ void load_head_to_lds(const AttnArgs& a, const bf16_t* base, int ld, int col0, int b, int N,
+                                                 int nrows_pad, char* lds) {
+  for (int c = threadIdx.x; c < nrows_pad * 8; c += blockDim.x) {
+    const int row = c >> 3, slot = c & 7;
+    u32x4_t v = (u32x4_t){0u, 0u, 0u, 0u};
+    if (row < N) v = *(const u32x4_t*)(base + tok_row(a, b, row) * ld + col0 + slot * 8);
+    *(u32x4_t*)(lds + row * ROWB + slot * 16) = v;
+  }
+}
+
+__device__ __forceinline__ bf16x8_t lds_frag(const char* lds, int row, int slot) {
+  return *(const bf16x8_t*)(lds + row * ROWB + slot * 16);
+}
+
+// transposed fragment for contraction over LDS rows: lane (i = lane&15 -> column c0 + i,
+// g = lane>>4); rows rowA+4g..+3 (elements 0..3) and rowB+4g..+3 (elements 4..7)
+__device__ __forceinline__ bf16x8_t lds_frag_tr(const char* lds, int rowA, int rowB, int c0, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  const int off = (4 * g + (i >> 2)) * ROWB + (c0 + 4 * (i & 3)) * 2;
+  const bf16x4_t lo = lds_read_tr16(lds + rowA * ROWB + off);
+  const bf16x4_t hi = lds_read_tr16(lds + rowB * ROWB + off);
+  return (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+__device__ __forceinline__ bf16x8_t pack8(const float* lo, const float* hi) {
+  union { bf16x8_t v; unsigned int u[4]; } r;
+  r.u[0] = pack_bf16x2(lo[0], lo[1]); r.u[1] = pack_bf16x2(lo[2], lo[3]);
+  r.u[2] = pack_bf16x2(hi[0], hi[1]); r.u[3] = pack_bf16x2(hi[2], hi[3]);
+  return r.v;
+}
+
+__device__ __forceinline__ void fill_key_bias(const AttnArgs& a, int b, int N, int npad, float* bias) {
+  for (int k = threadIdx.x; k < npad; k += blockDim.x) {
+    bool masked = k >= N;
+    if (!masked && a.pad && k >= a.Nv) masked = a.pad[b * a.Nt + (k - a.Nv)] != 0;
+    bias[k] = masked ? -INFINITY : 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int N = a.Nv + a.Nt;
+  const int nkt = (N + 15) >> 4, ns2 = (nkt + 1) >> 1, npad = ns2 * 32;
+  char* ldsK = smem;
+  char* ldsV = smem + npad * ROWB;
+  float* bias = (float*)(smem + 2 * npad * ROWB);
+  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+
+  load_head_to_lds(a, a.qkv, a.ld, a.D + h * HD, b, N, npad, ldsK);
+  load_head_to_lds(a, a.qkv, a.ld, 2 * a.D + h * HD, b, N, npad, ldsV);
+  fill_key_bias(a, b, N, npad, bias);
+  __syncthreads();
+
+  for (int qb = wave; qb < nkt; qb += nwaves) {
+    const int tq = qb * 16 + j;
+    const bf16_t* qp = a.qkv + tok_row(a, b, tq < N ? tq : N - 1) * a.ld + h * HD + 8 * g;
+    const bf16x8_t q0 = *(const bf16x8_t*)qp, q1 = *(const bf16x8_t*)(qp + 32);
+    f32x4_t s[MAX_KT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < MAX_KT; ++kt) {
+      if (kt < nkt) {
+        f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(ldsK, kt * 16 + j, g), q0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(ldsK, kt * 16 + j, 4 + g), q1, acc, 0, 0, 0);
+        const f32x4_t kb = *(const f32x4_t*)(bias + kt * 16 + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          acc[r] = acc[r] * a.scale + kb[r];
+          mx = fmaxf(mx, acc[r]);
+        }
+        s[kt] = acc;
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < MAX_KT; ++kt) {
+      if (kt < nkt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __expf(s[kt][r] - mx);
+          s[kt][r] = p;
+          sum += p;
+        }
+      }
+    }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    f32x4_t o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s2 = 0; s2 < MAX_KT / 2; ++s2) {
+      if (s2 < ns2) {
+        float lo[4], hi[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          lo[r] = s[2 * s2][r];
+          hi[r] = (2 * s2 + 1 < nkt) ? s[2 * s2 + 1][r] : 0.f;
+        }
+        const bf16x8_t pf = pack8(lo, hi);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const bf16x8_t vf = lds_frag_tr(ldsV, s2 * 32, s2 * 32 + 16, dt * 16, lane);
+          o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
+        }
+      }
+    }
+    if (tq < N) {
+      const float inv = 1.f / sum;
+      bf16_t* op = a.out + tok_row(a, b, tq) * a.ldo + h * HD + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        *(u32x2_t*)(op + dt * 16) = (u32x2_t){pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv),
+                                             pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv)};
+      if (g == 0 && a.lse) a.lse[(long)blockIdx.x * N + tq] = mx + __logf(sum);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward, part 1: dQ (+ delta = rowsum(dO*O)).  K and V resident in LDS.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int N = a.Nv + a.Nt;
+  const int nkt = (N + 15) >> 4, ns2 = (nkt + 1) >> 1, npad = ns2 * 32;
+  char* ldsK = smem;
+  char* ldsV = smem + npad * ROWB;
+  float* bias = (float*)(smem + 2 * npad * ROWB);
+  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+
+  load_head_to_lds(a, a.qkv, a.ld, a.D + h * HD, b, N, npad, ldsK);
+  load_head_to_lds(a, a.qkv, a.ld, 2 * a.D + h * HD, b, N, npad, ldsV);
+  fill_key_bias(a, b, N, npad, bias);
+  __syncthreads();
+
+  for (int qb = wave; qb < nkt; qb += nwaves) {
+    const int tq = qb * 16 + j;
+    const long row = tok_row(a, b, tq < N ? tq : N - 1);
+    const bf16_t* qp = a.qkv + row * a.ld + h * HD + 8 * g;
+    const bf16x8_t q0 = *(const bf16x8_t*)qp, q1 = *(const bf16x8_t*)(qp + 32);
+    const bf16_t* dop = a.dout + row * a.lddo + h * HD + 8 * g;
+    const bf16x8_t d0 = *(const bf16x8_t*)dop, d1 = *(const bf16x8_t*)(dop + 32);
+    const bf16_t* op = a.out + row * a.ldo + h * HD + 8 * g;
+    const bf16x8_t o0 = *(const bf16x8_t*)op, o1 = *(const bf16x8_t*)(op + 32);
+    float dl = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      dl += bf16_to_f32((bf16_t)d0[e]) * bf16_to_f32((bf16_t)o0[e]);
+      dl += bf16_to_f32((bf16_t)d1[e]) * bf16_to_f32((bf16_t)o1[e]);
+    }
+    dl += __shfl_xor(dl, 16, 64);
+    dl += __shfl_xor(dl, 32, 64);
+    const float lse = a.lse[(long)blockIdx.x * N + (tq < N ? tq : N - 1)];
+    if (tq < N && g == 0) a.delta[(long)blockIdx.x * N + tq] = dl;
+
+    u32x2_t dsb[MAX_KT];
+#pragma unroll
+    for (int kt = 0; kt < MAX_KT; ++kt) {
+      if (kt < nkt) {
+        f32x4_t sa = (f32x4_t){0.f, 0.f, 0.f, 0.f}, dp = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(ldsK, kt * 16 + j, g), q0, sa, 0, 0, 0);
+        sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(ldsK, kt * 16 + j, 4 + g), q1, sa, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(ldsV, kt * 16 + j, g), d0, dp, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(ldsV, kt * 16 + j, 4 + g), d1, dp, 0, 0, 0);
+        const f32x4_t kb = *(const f32x4_t*)(bias + kt * 16 + 4 * g);
+        float ds[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __expf(sa[r] * a.scale + kb[r] - lse);
+          ds[r] = p * (dp[r] - dl);
+        }
+        dsb[kt] = (u32x2_t){pack_bf16x2(ds[0], ds[1]), pack_bf16x2(ds[2], ds[3])};
+      }
+    }
+    f32x4_t dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s2 = 0; s2 < MAX_KT / 2; ++s2) {
+      if (s2 < ns2) {
+        union { bf16x8_t v; unsigned int u[4]; } pf;
+        pf.u[0] = dsb[2 * s2][0]; pf.u[1] = dsb[2 * s2][1];
+        if (2 * s2 + 1 < nkt) { pf.u[2] = dsb[2 * s2 + 1][0]; pf.u[3] = dsb[2 * s2 + 1][1]; }
+        else { pf.u[2] = 0u; pf.u[3] = 0u; }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const bf16x8_t kf = lds_frag_tr(ldsK, s2 * 32, s2 * 32 + 16, dt * 16, lane);
+          dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, pf.v, dq[dt], 0, 0, 0);
+        }
+      }
+    }
+    if (tq < N) {
+      bf16_t* gp = a.dqkv + tok_row(a, b, tq) * a.lddq + h * HD + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        *(u32x2_t*)(gp + dt * 16) = (u32x2_t){pack_bf16x2(dq[dt][0] * a.scale, dq[dt][1] * a.scale),
+                                             pack_bf16x2(dq[dt][2] * a.scale, dq[dt][3] * a.scale)};
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward, part 2: dK, dV.  Q and dO resident in LDS; each wave owns 16 keys at a time.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int N = a.Nv + a.Nt;
+  const int nkt = (N + 15) >> 4, ns2 = (nkt + 1) >> 1, npad = ns2 * 32;
+  char* ldsQ = smem;
+  char* ldsDO = smem + npad * ROWB;
+  float* lse_s = (float*)(smem + 2 * npad * ROWB);
+  float* dl_s = lse_s + npad;
+  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+
+  load_head_to_lds(a, a.qkv, a.ld, h * HD, b, N, npad, ldsQ);
+  load_head_to_lds(a, a.dout, a.lddo, h * HD, b, N, npad, ldsDO);
+  for (int q = threadIdx.x; q < npad; q += blockDim.x) {
+    lse_s[q] = q < N ? a.lse[(long)blockIdx.x * N + q] : INFINITY;   // exp(.. - inf) = 0 for pad rows
+    dl_s[q] = q < N ? a.delta[(long)blockIdx.x * N + q] : 0.f;
+  }
+  __syncthreads();
+
+  for (int kb = wave; kb < nkt; kb += nwaves) {
+    const int tk = kb * 16 + j;
+    const long row = tok_row(a, b, tk < N ? tk : N - 1);
+    const bf16_t* kp = a.qkv + row * a.ld + a.D + h * HD + 8 * g;
+    const bf16x8_t k0 = *(const bf16x8_t*)kp, k1 = *(const bf16x8_t*)(kp + 32);
+    const bf16_t* vp = a.qkv + row * a.ld + 2 * a.D + h * HD + 8 * g;
+    const bf16x8_t v0 = *(const bf16x8_t*)vp, v1 = *(const bf16x8_t*)(vp + 32);
+    bool masked = tk >= N;
+    if (!masked && a.pad && tk >= a.Nv) masked = a.pad[b * a.Nt + (tk - a.Nv)] != 0;
+    const float kbias = masked ? -INFINITY : 0.f;
+
+    f32x4_t dk[4], dv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dk[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+
+    for (int s2 = 0; s2 < ns2; ++s2) {
+      float p[2][4], ds[2][4];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int qt = 2 * s2 + hh;   // rows qt*16.. exist in LDS (zero-filled beyond N)
+        f32x4_t sa = (f32x4_t){0.f, 0.f, 0.f, 0.f}, dp = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(ldsQ, qt * 16 + j, g), k0, sa, 0, 0, 0);
+        sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(ldsQ, qt * 16 + j, 4 + g), k1, sa, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(ldsDO, qt * 16 + j, g), v0, dp, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(ldsDO, qt * 16 + j, 4 + g), v1, dp, 0, 0, 0);
+        const f32x4_t l4 = *(const f32x4_t*)(lse_s + qt * 16 + 4 * g);
+        const f32x4_t d4 = *(const f32x4_t*)(dl_s + qt * 16 + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pr = __expf(sa[r] * a.scale + kbias - l4[r]);
+          p[hh][r] = pr;
+          ds[hh][r] = pr * (dp[r] - d4[r]);
+        }
+      }
+      const bf16x8_t pf = pack8(p[0], p[1]);
+      const bf16x8_t dsf = pack8(ds[0], ds[1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16x8_t dof = lds_frag_tr(ldsDO, s2 * 32, s2 * 32 + 16, dt * 16, lane);
+        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, pf, dv[dt], 0, 0, 0);
+        const bf16x8_t qf = lds_frag_tr(ldsQ, s2 * 32, s2 * 32 + 16, dt * 16, lane);
+        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, dsf, dk[dt], 0, 0, 0);
+      }
+    }
+    if (tk < N) {
+      bf16_t* gk = a.dqkv + tok_row(a, b, tk) * a.lddq + a.D + h * HD + 4 * g;
+      bf16_t* gv = a.dqkv + tok_row(a, b, tk) * a.lddq + 2 * a.D + h * HD + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        *(u32x2_t*)(gk + dt * 16) = (u32x2_t){pack_bf16x2(dk[dt][0] * a.scale, dk[dt][1] * a.scale),
+                                             pack_bf16x2(dk[dt][2] * a.scale, dk[dt][3] * a.scale)};
+        *(u32x2_t*)(gv + dt * 16) = (u32x2_t){pack_bf16x2(dv[dt][0], dv[dt][1]), pack_bf16x2(dv[dt][2], dv[dt][3])};
+      }
+    }
+  }
+}
+
+template <typename K>
+int set_lds_limit(K kernel, size_t bytes) {
+  return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
+}
+
+}  // namespace
+
+static int attn_check(int B, int H, int Nv, int Nt, int D, int ld) {
+  if (B <= 0 || H <= 0 || Nv < 0 || Nt < 0 || Nv + Nt <= 0) return 0;
+  if (D != H * HD) return 0;
+  if (Nv + Nt > MAX_KT * 16) return 0;
+  if (ld % 8 != 0) return 0;
+  return 1;
+}
+
+extern "C" int simvg_attn_fwd(const void* qkv, int ldqkv, void* out, int ldo, float* lse, const unsigned char* pad,
+                              int B, int H, int Nv, int Nt, int D, float scale, hipStream_t stream) {
+  SIMVG_CHECK_ARG(attn_check(B, H, Nv, Nt, D, ldqkv) && ldo % 8 == 0,
+                  "attn_fwd: need head_dim 64, Nv+Nt <= 448, 16-B aligned rows");
+  AttnArgs a{(const bf16_t*)qkv, ldqkv, (bf16_t*)out, ldo, nullptr, 0, nullptr, 0, lse, nullptr, pad, B, H, Nv, Nt, D, scale};
+  const int N = Nv + Nt, npad = ((cdiv(N, 16) + 1) / 2) * 32;
+  const size_t shm = (size_t)2 * npad * ROWB + npad * sizeof(float);
+  static bool once = set_lds_limit(attn_fwd_kernel, 160 * 1024);
+  (void)once;
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H), dim3(512), shm, stream, a);
+  SIMVG_LAUNCH_CHECK();
+  return SIMVG_OK;
+}
+
+extern "C" int simvg_attn_bwd(const void* qkv, int ldqkv, const void* out, int ldo, const void* dout, int lddo,
+                              void* dqkv, int lddqkv, const float* lse, float* delta_ws, const unsigned char* pad,
+                              int B, int H, int Nv, int Nt, int D, float scale, hipStream_t stream) {
+  SIMVG_CHECK_ARG(attn_check(B, H, Nv, Nt, D, ldqkv) && ldo % 8 == 0 && lddo % 8 == 0 && lddqkv % 8 == 0,
+                  "attn_bwd: need head_dim 64, Nv+Nt <= 448, 16-B aligned rows");
+  SIMVG_CHECK_ARG(lse && delta_ws, "attn_bwd: lse and delta workspace required");
+  AttnArgs a{(const bf16_t*)qkv, ldqkv, (bf16_t*)out, ldo, (const bf16_t*)dout, lddo, (bf16_t*)dqkv, lddqkv,
+             (float*)lse, delta_ws, pad, B, H, Nv, Nt, D, scale};
+  const int N = Nv + Nt, npad = ((cdiv(N, 16) + 1) / 2) * 32;
+  const size_t shm1 = (size_t)2 * npad * ROWB + npad * sizeof(float);
+  const size_t shm2 = (size_t)2 * npad * ROWB + 2 * npad * sizeof(float);
+  static bool once1 = set_lds_limit(attn_bwd_dq_kernel, 160 * 1024);
+  static bool once2 = set_lds_limit(attn_bwd_dkv_kernel, 160 * 1024);
+  (void)once1; (void)once2;
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(B * H), dim3(512), shm1, stream, a);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(B * H), dim3(512), shm2, stream, a);
+  SIMVG_LAUNCH_CHECK();
+  return SIMVG_OK;
+}

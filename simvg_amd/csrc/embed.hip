@@ -1,0 +1,236 @@
+// Embedding stage of the BEiT-3 encoder and weight preparation (gfx950).  All HBM-bound.
+//
+//  simvg_im2col      : fp32 NCHW image -> bf16 patch matrix [B*np, 3*P*P] (k = c*P*P + ky*P + kx), the
+//                      A operand of the patch-embed GEMM (torchscale VisionEmbedding.proj, a Conv2d with
+//                      kernel = stride = P; reference call site beit3_base.py:461)
+//  simvg_embed_fwd   : assemble the fp32 residual stream, modality-major:
+//                      vision rows [B, 1+np]: cls | patch + posA[t+2];  text rows [B, T]:
+//                      (text_embed[id] + posB[j+2]) * (1 - pad)       (beit3_base.py:463-475,317-334,367)
+//  simvg_embed_bwd   : the matching gradients (patch grad as bf16 for the wgrad GEMM, cls / position
+//                      tables reduced over the batch, text table by atomics)
+//  simvg_weight_prep : fp32 master weights -> bf16 compute copies, plain and transposed, batched over a
+//                      descriptor table (one launch per optimizer step)
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, bf16_t* __restrict__ cols,
+                                                     int B, int S, int P, long total4) {
+  const int G = S / P, K = 3 * P * P;
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total4; t += (long)gridDim.x * 256) {
+    const long e = t * 4;
+    const int x = (int)(e % S);
+    const long r = e / S;
+    const int y = (int)(r % S);
+    const long bc = r / S;
+    const int c = (int)(bc % 3), b = (int)(bc / 3);
+    const f32x4_t v = *(const f32x4_t*)(img + e);
+    const int py = y / P, ky = y - py * P, px = x / P, kx = x - px * P;
+    bf16_t* o = cols + ((long)b * G * G + py * G + px) * K + c * P * P + ky * P + kx;
+    *(u32x2_t*)o = (u32x2_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+  }
+}
+
+struct EmbedArgs {
+  const float* patch; int ldp;     // [B*np, D] fp32 (conv output incl. bias)
+  const float* cls;                // [D]
+  const float* posA;               // [np+3, D]
+  const float* posB;               // [1024, D]
+  const float* text_embed;         // [V, D]
+  const long long* ids;            // [B, T]
+  const unsigned char* pad;        // [B, T] or null
+  float* x; int ldx;               // [B*(np+1) + B*T, D]
+  int B, np, T, D;
+};
+
+__global__ __launch_bounds__(256) void embed_fwd_kernel(EmbedArgs a) {
+  const int Nv = a.np + 1;
+  const long Mv = (long)a.B * Nv;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= Mv + (long)a.B * a.T) return;
+  const int lane = threadIdx.x & 63;
+  float* xr = a.x + row * a.ldx;
+  if (row < Mv) {
+    const int b = (int)(row / Nv), t = (int)(row - (long)b * Nv);
+    const float* src = t == 0 ? a.cls : a.patch + ((long)b * a.np + (t - 1)) * a.ldp;
+    const float* pos = a.posA + (long)(t + 2) * a.D;
+    for (int c = lane * 4; c < a.D; c += 256) {
+      const f32x4_t s = *(const f32x4_t*)(src + c), p = *(const f32x4_t*)(pos + c);
+      *(f32x4_t*)(xr + c) = s + p;
+    }
+  } else {
+    const long r = row - Mv;
+    const int b = (int)(r / a.T), jn = (int)(r - (long)b * a.T);
+    const float keep = (a.pad && a.pad[r]) ? 0.f : 1.f;
+    const float* src = a.text_embed + (long)a.ids[r] * a.D;
+    const float* pos = a.posB + (long)(jn + 2) * a.D;
+    for (int c = lane * 4; c < a.D; c += 256) {
+      const f32x4_t s = *(const f32x4_t*)(src + c), p = *(const f32x4_t*)(pos + c);
+      *(f32x4_t*)(xr + c) = (s + p) * keep;
+    }
+  }
+}
+
+struct EmbedBwdArgs {
+  const float* dx; int lddx;       // [M, D]
+  bf16_t* dpatch; int lddp;        // [B*np, D] bf16
+  float* dcls;                     // [D]
+  float* dposA;                    // [np+3, D]
+  float* dposB;                    // [1024, D]
+  float* dtext;                    // [V, D]
+  const long long* ids;
+  const unsigned char* pad;
+  int B, np, T, D;
+};
+
+// one block per vision token position t (reduction over the batch), then one block per text position j
+__global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs a) {
+  const int Nv = a.np + 1;
+  const long Mv = (long)a.B * Nv;
+  const int pos = blockIdx.x;
+  if (pos < Nv) {
+    const int t = pos;
+    for (int c = threadIdx.x * 4; c < a.D; c += 1024) {
+      f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      for (int b = 0; b < a.B; ++b) {
+        const f32x4_t v = *(const f32x4_t*)(a.dx + ((long)b * Nv + t) * a.lddx + c);
+        s += v;
+        if (t > 0)
+          *(u32x2_t*)(a.dpatch + ((long)b * a.np + (t - 1)) * a.lddp + c) =
+              (u32x2_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+      }
+      float* dp = a.dposA + (long)(t + 2) * a.D + c;
+      *(f32x4_t*)dp = *(const f32x4_t*)dp + s;
+      if (t == 0) *(f32x4_t*)(a.dcls + c) = *(const f32x4_t*)(a.dcls + c) + s;
+    }
+  } else {
+    const int jn = pos - Nv;
+    for (int c = threadIdx.x * 4; c < a.D; c += 1024) {
+      f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      for (int b = 0; b < a.B; ++b) {
+        const long r = (long)b * a.T + jn;
+        if (a.pad && a.pad[r]) continue;
+        const f32x4_t v = *(const f32x4_t*)(a.dx + (Mv + r) * a.lddx + c);
+        s += v;
+        float* te = a.dtext + (long)a.ids[r] * a.D + c;
+        atomicAdd(te + 0, v[0]); atomicAdd(te + 1, v[1]); atomicAdd(te + 2, v[2]); atomicAdd(te + 3, v[3]);
+      }
+      float* dp = a.dposB + (long)(jn + 2) * a.D + c;
+      *(f32x4_t*)dp = *(const f32x4_t*)dp + s;
+    }
+  }
+}
+
+struct WeightDesc {      // mirrored by simvg_amd/_lib.py (ctypes)
+  const float* src;      // [rows, cols] fp32
+  bf16_t* dst;           // [rows, cols] bf16 or null
+  bf16_t* dst_t;         // [cols, rows] bf16 or null
+  int rows, cols;
+  int tile_start;        // first 32x32 tile index of this matrix in the launch
+  int pad_;
+};
+
+__global__ __launch_bounds__(256) void weight_prep_kernel(const WeightDesc* __restrict__ descs, int n) {
+  __shared__ float tile[32][33];
+  int lo = 0, hi = n - 1;
+  const int bid = blockIdx.x;
+  while (lo < hi) {   // last descriptor with tile_start <= bid
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].tile_start <= bid) lo = mid; else hi = mid - 1;
+  }
+  const WeightDesc d = descs[lo];
+  const int tiles_c = (d.cols + 31) >> 5;
+  const int tl = bid - d.tile_start;
+  const int r0 = (tl / tiles_c) * 32, c0 = (tl % tiles_c) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + ty + 8 * k, c = c0 + tx;
+    float v = 0.f;
+    if (r < d.rows && c < d.cols) {
+      v = d.src[(long)r * d.cols + c];
+      if (d.dst) d.dst[(long)r * d.cols + c] = f32_to_bf16(v);
+    }
+    tile[ty + 8 * k][tx] = v;
+  }
+  if (!d.dst_t) return;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + ty + 8 * k, r = r0 + tx;
+    if (r < d.rows && c < d.cols) d.dst_t[(long)c * d.rows + r] = f32_to_bf16(tile[tx][ty + 8 * k]);
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n4) {
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n4; t += (long)gridDim.x * 256) {
+    const f32x4_t v = *(const f32x4_t*)(src + t * 4);
+    *(u32x2_t*)(dst + t * 4) = (u32x2_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, long n4) {
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n4; t += (long)gridDim.x * 256) {
+    const u32x2_t v = *(const u32x2_t*)(src + t * 4);
+    *(f32x4_t*)(dst + t * 4) = (f32x4_t){__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xffff0000u),
+                                         __uint_as_float(v[1] << 16), __uint_as_float(v[1] & 0xffff0000u)};
+  }
+}
+
+}  // namespace
+
+extern "C" int simvg_im2col(const float* img, void* cols_bf16, int B, int S, int P, hipStream_t stream) {
+  SIMVG_CHECK_ARG(B > 0 && S > 0 && P > 0 && S % P == 0 && P % 4 == 0, "im2col: S must be a multiple of P, P of 4");
+  const long total4 = (long)B * 3 * S * S / 4;
+  const int grid = (int)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
+  hipLaunchKernelGGL(im2col_kernel, dim3(grid), dim3(256), 0, stream, img, (bf16_t*)cols_bf16, B, S, P, total4);
+  SIMVG_LAUNCH_CHECK();
+  return SIMVG_OK;
+}
+
+extern "C" int simvg_embed_fwd(const float* patch, int ldp, const float* cls, const float* posA, const float* posB,
+                               const float* text_embed, const long long* ids, const unsigned char* pad, float* x,
+                               int ldx, int B, int np, int T, int D, hipStream_t stream) {
+  SIMVG_CHECK_ARG(B > 0 && np > 0 && T >= 0 && D % 4 == 0 && ldx % 4 == 0 && ldp % 4 == 0, "embed_fwd: bad geometry");
+  SIMVG_CHECK_ARG(T + 2 <= 1024, "embed_fwd: text longer than the position table");
+  EmbedArgs a{patch, ldp, cls, posA, posB, text_embed, ids, pad, x, ldx, B, np, T, D};
+  const long rows = (long)B * (np + 1 + T);
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3((int)((rows + 3) / 4)), dim3(256), 0, stream, a);
+  SIMVG_LAUNCH_CHECK();
+  return SIMVG_OK;
+}
+
+extern "C" int simvg_embed_bwd(const float* dx, int lddx, void* dpatch_bf16, int lddp, float* dcls, float* dposA,
+                               float* dposB, float* dtext, const long long* ids, const unsigned char* pad, int B,
+                               int np, int T, int D, hipStream_t stream) {
+  SIMVG_CHECK_ARG(B > 0 && np > 0 && T >= 0 && D % 4 == 0 && lddx % 4 == 0 && lddp % 4 == 0, "embed_bwd: bad geometry");
+  EmbedBwdArgs a{dx, lddx, (bf16_t*)dpatch_bf16, lddp, dcls, dposA, dposB, dtext, ids, pad, B, np, T, D};
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(np + 1 + T), dim3(256), 0, stream, a);
+  SIMVG_LAUNCH_CHECK();
+  return SIMVG_OK;
+}
+
+extern "C" int simvg_weight_prep(const void* descs_dev, int n_desc, int total_tiles, hipStream_t stream) {
+  SIMVG_CHECK_ARG(descs_dev && n_desc > 0 && total_tiles > 0, "weight_prep: empty descriptor table");
+  hipLaunchKernelGGL(weight_prep_kernel, dim3(total_tiles), dim3(256), 0, stream, (const WeightDesc*)descs_dev, n_desc);
+  SIMVG_LAUNCH_CHECK();
+  return SIMVG_OK;
+}
+
+extern "C" int simvg_cast_f32_to_bf16(const float* src, void* dst, long n, hipStream_t stream) {
+  SIMVG_CHECK_ARG(n > 0 && n % 4 == 0, "cast: n must be a positive multiple of 4");
+  const long n4 = n / 4;
+  const int grid = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid), dim3(256), 0, stream, src, (bf16_t*)dst, n4);
+  SIMVG_LAUNCH_CHECK();
+  return SIMVG_OK;
+}
+
+extern "C" int simvg_cast_bf16_to_f32(const void* src, float* dst, long n, hipStream_t stream) {
+  SIMVG_CHECK_ARG(n > 0 && n % 4 == 0, "cast: n must be a positive multiple of 4");
+  const long n4 = n / 4;
+  const int grid = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(cast_f32_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)src, dst, n4);
+  SIMVG_LAUNCH_CHECK();
+  return SIMVG_OK;
+}

@@ -1,0 +1,367 @@
+// bf16 MFMA GEMMs for the SimVG hot path (gfx950).
+//
+//  simvg_gemm_nt : C[M,N] = A[M,K] · W[g][N,K]^T (+bias) (+GELU/ReLU) (+residual·row_scale)
+//                  "multiway" = two row groups (vision rows | text rows) with their own W/bias,
+//                  replacing torchscale MultiwayNetwork's split -> A(x1), B(x2) -> cat
+//                  (reference call sites beit3_base.py:137-145,159; SURVEY.md §2.3 E6,E14,E16,E19).
+//                  Used for forward and (with the transposed weight copy) for dgrad.
+//  simvg_gemm_tn : dW[g][N,K] += dY[M,N]^T · X[M,K]   (wgrad; split over M, fp32 atomics)
+//
+// Tile 128x128x64, 256 threads = 2x2 waves of 64x64, v_mfma_f32_16x16x32_bf16.
+// HBM->LDS by global_load_lds (16 B/lane, LDS image lane-linear, XOR swizzle applied on the
+// SOURCE address and on the ds_read address), double-buffered, one barrier per K-tile.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
+
+struct GemmNTArgs {
+  const bf16_t* A; int lda;
+  const bf16_t* W; long w_gstride; int ldw;
+  const float* bias; int bias_gstride;
+  void* C; int ldc; int c_f32;
+  bf16_t* aux; int ldaux;
+  const float* res; int ldres;
+  const float* row_scale; int rps0, rps1;
+  int M, N, K, split, act;
+};
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  // bijective XCD-aware remap: XCD x (= bid % 8) walks a contiguous chunk of the tile space
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// stage one [128 rows][64 k] bf16 tile: 16 wave-instructions of 1 KiB, 4 per wave
+__device__ __forceinline__ void stage_tile_k64(const bf16_t* base, int ld, int row0, int row_last, int k0,
+                                               char* lds, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int inst = wave * 4 + i;
+    const int r = inst * 8 + (lane >> 3);
+    int row = row0 + r;
+    row = row < row_last ? row : row_last;
+    const int lslot = (lane & 7) ^ (r & 7);
+    const bf16_t* src = base + (long)row * ld + k0 + lslot * 8;
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds + inst * 1024), 16, 0, 0);
+  }
+}
+
+__device__ __forceinline__ bf16x8_t read_frag_k64(const char* lds, int row, int lslot) {
+  return *(const bf16x8_t*)(lds + row * 128 + ((lslot ^ (row & 7)) << 4));
+}
+
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = (a.N + BN - 1) / BN;
+  const int tm0 = (a.split + BM - 1) / BM;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+  const int group = tile_m >= tm0;
+  const int row0 = group ? a.split + (tile_m - tm0) * BM : tile_m * BM;
+  const int row_end = group ? a.M : a.split;
+  const int n0 = tile_n * BN;
+  const bf16_t* W = a.W + (long)group * a.w_gstride;
+
+#define ldsA(c) (smem + (c) * 2 * TILE_BYTES)
+#define ldsB(c) (smem + TILE_BYTES + (c) * 2 * TILE_BYTES)
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = a.K / BK;
+  stage_tile_k64(a.A, a.lda, row0, row_end - 1, 0, ldsA(0), wave, lane);
+  stage_tile_k64(W, a.ldw, n0, a.N - 1, 0, ldsB(0), wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      stage_tile_k64(a.A, a.lda, row0, row_end - 1, (kt + 1) * BK, ldsA(cur ^ 1), wave, lane);
+      stage_tile_k64(W, a.ldw, n0, a.N - 1, (kt + 1) * BK, ldsB(cur ^ 1), wave, lane);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8_t fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fa[i] = read_frag_k64(ldsA(cur), wm * 64 + i * 16 + (lane & 15), s * 4 + (lane >> 4));
+        fb[i] = read_frag_k64(ldsB(cur), wn * 64 + i * 16 + (lane & 15), s * 4 + (lane >> 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          // D[n_local][m_local]: lane holds 4 consecutive n for one m -> vector stores
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---------------- epilogue ----------------
+  const float* bias = a.bias ? a.bias + (long)group * a.bias_gstride : nullptr;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = row0 + wm * 64 + i * 16 + (lane & 15);
+    if (m >= row_end) continue;
+    float rs = 1.f;
+    if (a.row_scale) {
+      const int sample = group ? (m - a.split) / a.rps1 : m / a.rps0;
+      rs = a.row_scale[sample];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
+      if (n >= a.N) continue;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      const bool full = (n + 3 < a.N);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (bias && (full || n + r < a.N)) v[r] += bias[n + r];
+      if (a.aux) {
+        bf16_t* p = a.aux + (long)m * a.ldaux + n;
+        if (full) {
+          *(u32x2_t*)p = (u32x2_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        } else {
+          for (int r = 0; r < 4 && n + r < a.N; ++r) p[r] = f32_to_bf16(v[r]);
+        }
+      }
+      if (a.act == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+      } else if (a.act == 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      if (a.res) {
+        const float* rp = a.res + (long)m * a.ldres + n;
+        if (full) {
+          const f32x4_t rv = *(const f32x4_t*)rp;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = rv[r] + rs * v[r];
+        } else {
+          for (int r = 0; r < 4 && n + r < a.N; ++r) v[r] = rp[r] + rs * v[r];
+        }
+      } else if (a.row_scale) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= rs;
+      }
+      if (a.c_f32) {
+        float* p = (float*)a.C + (long)m * a.ldc + n;
+        if (full) {
+          *(f32x4_t*)p = (f32x4_t){v[0], v[1], v[2], v[3]};
+        } else {
+          for (int r = 0; r < 4 && n + r < a.N; ++r) p[r] = v[r];
+        }
+      } else {
+        bf16_t* p = (bf16_t*)a.C + (long)m * a.ldc + n;
+        if (full) {
+          *(u32x2_t*)p = (u32x2_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        } else {
+          for (int r = 0; r < 4 && n + r < a.N; ++r) p[r] = f32_to_bf16(v[r]);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// wgrad: dW[g][n][k] += sum_m dY[m][n] * X[m][k]
+// ------------------------------------------------------------------------------------------
+struct GemmTNArgs {
+  const bf16_t* dY; int lddy;
+  const bf16_t* X; int ldx;
+  float* dW; long dw_gstride; int lddw;
+  int M, N, K, split, rows_per_chunk, chunks0;
+};
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero_page[64];  // 256 B of zeros
+
+// stage [64 m-rows][128 cols] bf16 (256 B rows): 16 wave-instructions (4 rows each), 4 per wave
+__device__ __forceinline__ void stage_tile_m64(const bf16_t* base, int ld, int m0, int m_end, int c0, int ncols,
+                                               char* lds, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int inst = wave * 4 + i;
+    const int r = inst * 4 + (lane >> 4);
+    const int lslot = (lane & 15) ^ ((r & 3) << 1);
+    const int row = m0 + r, col = c0 + lslot * 8;
+    const bf16_t* src = (row < m_end && col < ncols) ? base + (long)row * ld + col
+                                                      : (const bf16_t*)g_zero_page;
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds + inst * 1024), 16, 0, 0);
+  }
+}
+
+// transposed fragment: lane (i = lane&15 -> column c0+i, g = lane>>4 -> rows ms+8g..+7)
+__device__ __forceinline__ bf16x8_t read_frag_tr(const char* lds, int ms, int c0, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  const int col = c0 + 4 * (i & 3);          // this lane supplies 4 contiguous columns of row (i>>2)
+  const int lslot = col >> 3, within = (col & 7) * 2;
+  bf16x8_t out;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row = ms + 8 * g + 4 * h + (i >> 2);
+    const bf16x4_t v = lds_read_tr16(lds + row * 256 + ((lslot ^ ((row & 3) << 1)) << 4) + within);
+    out[4 * h + 0] = v[0]; out[4 * h + 1] = v[1]; out[4 * h + 2] = v[2]; out[4 * h + 3] = v[3];
+  }
+  return out;
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int tiles_k = (a.K + 127) / 128;
+  const int tile_n = blockIdx.x / tiles_k, tile_k = blockIdx.x - tile_n * tiles_k;
+  const int chunk = blockIdx.y;
+  const int group = chunk >= a.chunks0;
+  const int m_begin = group ? a.split + (chunk - a.chunks0) * a.rows_per_chunk : chunk * a.rows_per_chunk;
+  const int g_end = group ? a.M : a.split;
+  const int m_end = min(m_begin + a.rows_per_chunk, g_end);
+  if (m_begin >= m_end) return;
+  const int n0 = tile_n * 128, k0 = tile_k * 128;
+
+#define ldsY(c) (smem + (c) * 32768)
+#define ldsX(c) (smem + 16384 + (c) * 32768)
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int nt = (m_end - m_begin + 63) / 64;
+  stage_tile_m64(a.dY, a.lddy, m_begin, m_end, n0, a.N, ldsY(0), wave, lane);
+  stage_tile_m64(a.X, a.ldx, m_begin, m_end, k0, a.K, ldsX(0), wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nt) {
+      stage_tile_m64(a.dY, a.lddy, m_begin + (t + 1) * 64, m_end, n0, a.N, ldsY(cur ^ 1), wave, lane);
+      stage_tile_m64(a.X, a.ldx, m_begin + (t + 1) * 64, m_end, k0, a.K, ldsX(cur ^ 1), wave, lane);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8_t fy[4], fx[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fy[i] = read_frag_tr(ldsY(cur), s * 32, wn * 64 + i * 16, lane);
+        fx[i] = read_frag_tr(ldsX(cur), s * 32, wk * 64 + i * 16, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], fx[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  float* dW = a.dW + (long)group * a.dw_gstride;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + wk * 64 + j * 16 + (lane & 15);
+      if (k >= a.K) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn * 64 + i * 16 + 4 * (lane >> 4) + r;
+        if (n < a.N) atomicAdd(dW + (long)n * a.lddw + k, acc[i][j][r]);
+      }
+    }
+}
+
+// column sums by row group: out[g][n] += sum_{m in group g} Y[m][n]   (bias gradients)
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* Y, int ldy, float* out, int out_gstride,
+                                                     int M, int N, int split, int rows_per_chunk, int chunks0) {
+  __shared__ float red[8][256 + 8];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int chunk = blockIdx.y;
+  const int group = chunk >= chunks0;
+  const int m_begin = group ? split + (chunk - chunks0) * rows_per_chunk : chunk * rows_per_chunk;
+  const int m_end = min(m_begin + rows_per_chunk, group ? M : split);
+  const int n = blockIdx.x * 256 + tx * 8;
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (n < N) {
+    for (int m = m_begin + ty; m < m_end; m += 8) {
+      const u32x4_t v = *(const u32x4_t*)(Y + (long)m * ldy + n);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        s[2 * q] += __uint_as_float(v[q] << 16);
+        s[2 * q + 1] += __uint_as_float(v[q] & 0xffff0000u);
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) red[ty][tx * 8 + q] = s[q];
+  __syncthreads();
+  const int c = threadIdx.x;
+  float t = 0.f;
+#pragma unroll
+  for (int y = 0; y < 8; ++y) t += red[y][c];
+  const int nn = blockIdx.x * 256 + c;
+  if (nn < N && m_begin < m_end) atomicAdd(out + (long)group * out_gstride + nn, t);
+}
+
+}  // namespace
+
+extern "C" int simvg_gemm_nt(const void* A, int lda, const void* W, long w_gstride, int ldw,
+                             const float* bias, int bias_gstride, void* C, int ldc, int c_is_f32,
+                             void* aux_preact, int ldaux, const float* residual, int ldres,
+                             const float* row_scale, int rows_per_sample0, int rows_per_sample1,
+                             int M, int N, int K, int split, int act, hipStream_t stream) {
+  SIMVG_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm_nt: empty problem");
+  SIMVG_CHECK_ARG(K % BK == 0, "gemm_nt: K must be a multiple of 64");
+  SIMVG_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0, "gemm_nt: leading dims must keep 16-B alignment");
+  SIMVG_CHECK_ARG(split >= 0 && split <= M, "gemm_nt: split out of range");
+  SIMVG_CHECK_ARG(act >= 0 && act <= 2, "gemm_nt: act must be 0 (none), 1 (gelu) or 2 (relu)");
+  if (split == 0) split = M;  // single group uses group 0 weights
+  GemmNTArgs a{(const bf16_t*)A, lda, (const bf16_t*)W, w_gstride, ldw, bias, bias_gstride, C, ldc, c_is_f32,
+               (bf16_t*)aux_preact, ldaux, residual, ldres, row_scale,
+               rows_per_sample0 > 0 ? rows_per_sample0 : 1, rows_per_sample1 > 0 ? rows_per_sample1 : 1,
+               M, N, K, split, act};
+  const int tiles = (cdiv(split, BM) + cdiv(M - split, BM)) * cdiv(N, BN);
+  hipLaunchKernelGGL(gemm_nt_kernel, dim3(tiles), dim3(256), 4 * TILE_BYTES, stream, a);
+  SIMVG_LAUNCH_CHECK();
+  return SIMVG_OK;
+}
+
+extern "C" int simvg_gemm_tn(const void* dY, int lddy, const void* X, int ldx, float* dW, long dw_gstride,
+                             int lddw, int M, int N, int K, int split, hipStream_t stream) {
+  SIMVG_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm_tn: empty problem");
+  SIMVG_CHECK_ARG(N % 8 == 0 && K % 8 == 0 && lddy % 8 == 0 && ldx % 8 == 0, "gemm_tn: N, K, ld must be multiples of 8");
+  SIMVG_CHECK_ARG(split >= 0 && split <= M, "gemm_tn: split out of range");
+  if (split == 0) split = M;
+  const int tiles = cdiv(N, 128) * cdiv(K, 128);
+  // split the contraction (rows) so that the grid fills the chip about twice over
+  int want = cdiv(1024, tiles);
+  int rpc = cdiv(cdiv(M, want), 64) * 64;
+  if (rpc < 256) rpc = 256;
+  const int chunks0 = cdiv(split, rpc), chunks1 = cdiv(M - split, rpc);
+  GemmTNArgs a{(const bf16_t*)dY, lddy, (const bf16_t*)X, ldx, dW, dw_gstride, lddw, M, N, K, split, rpc, chunks0};
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, chunks0 + chunks1), dim3(256), 65536, stream, a);
+  SIMVG_LAUNCH_CHECK();
+  return SIMVG_OK;
+}
+
+extern "C" int simvg_colsum(const void* Y, int ldy, float* out, int out_gstride, int M, int N, int split,
+                            hipStream_t stream) {
+  SIMVG_CHECK_ARG(M > 0 && N > 0 && N % 8 == 0 && ldy % 8 == 0, "colsum: N, ld must be multiples of 8");
+  if (split == 0) split = M;
+  const int rpc = 512;
+  const int chunks0 = cdiv(split, rpc), chunks1 = cdiv(M - split, rpc);
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 256), chunks0 + chunks1), dim3(256), 0, stream,
+                     (const bf16_t*)Y, ldy, out, out_gstride, M, N, split, rpc, chunks0);
+  SIMVG_LAUNCH_CHECK();
+  return SIMVG_OK;
+}

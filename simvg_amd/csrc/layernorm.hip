@@ -1,0 +1,263 @@
+// Multiway LayerNorm forward / backward (gfx950).  HBM-bound: one wave per row, 16-B vector
+// loads, the row lives in registers between the statistics and the normalise pass.
+//
+// Replaces torch.nn.LayerNorm wrapped by torchscale MultiwayNetwork (reference call sites
+// beit3_base.py:136,157,396-397 and torchscale MultiheadAttention.inner_attn_ln /
+// FeedForwardNetwork.ffn_layernorm; SURVEY.md §2.3 E5,E13,E18,E20) and the detrex decoder's
+// nn.LayerNorm (transformer.py:47-49,119-121).  Rows [0,split) use gamma/beta group 0 ("A",
+// vision), rows [split,M) group 1 ("B", text).
+#include "common.h"
+
+namespace {
+
+template <typename T> struct Ld4;
+template <> struct Ld4<float> {
+  static __device__ __forceinline__ void ld(const float* p, float* v) {
+    const f32x4_t t = *(const f32x4_t*)p;
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+  }
+};
+template <> struct Ld4<bf16_t> {
+  static __device__ __forceinline__ void ld(const bf16_t* p, float* v) {
+    const u32x2_t t = *(const u32x2_t*)p;
+    v[0] = __uint_as_float(t[0] << 16); v[1] = __uint_as_float(t[0] & 0xffff0000u);
+    v[2] = __uint_as_float(t[1] << 16); v[3] = __uint_as_float(t[1] & 0xffff0000u);
+  }
+};
+__device__ __forceinline__ void st4_bf16(bf16_t* p, const float* v) {
+  *(u32x2_t*)p = (u32x2_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+}
+
+template <typename TIn, int NIT>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const TIn* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, int gstride, bf16_t* __restrict__ y,
+                                                     int ldy, float* __restrict__ y32, int ldy32, float* __restrict__ mean,
+                                                     float* __restrict__ rstd, int M, int D, int split, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int g = row >= split;
+  const TIn* xr = x + (long)row * ldx;
+  float v[NIT][4];
+  float s = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = (it * 64 + lane) * 4;
+    if (c < D) {
+      Ld4<TIn>::ld(xr + c, v[it]);
+      s += (v[it][0] + v[it][1]) + (v[it][2] + v[it][3]);
+    } else {
+      v[it][0] = v[it][1] = v[it][2] = v[it][3] = 0.f;
+    }
+  }
+  const float mu = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = (it * 64 + lane) * 4;
+    if (c < D) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const float d = v[it][k] - mu; q += d * d; }
+    }
+  }
+  const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+  if (lane == 0) {
+    if (mean) mean[row] = mu;
+    if (rstd) rstd[row] = rs;
+  }
+  const float* gm = gamma + (long)g * gstride;
+  const float* bt = beta + (long)g * gstride;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = (it * 64 + lane) * 4;
+    if (c < D) {
+      const f32x4_t gv = *(const f32x4_t*)(gm + c), bv = *(const f32x4_t*)(bt + c);
+      float o[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = (v[it][k] - mu) * rs * gv[k] + bv[k];
+      if (y) st4_bf16(y + (long)row * ldy + c, o);
+      if (y32) *(f32x4_t*)(y32 + (long)row * ldy32 + c) = (f32x4_t){o[0], o[1], o[2], o[3]};
+    }
+  }
+}
+
+// Backward.  Each block owns `rows_per_block` consecutive rows of ONE group; each wave walks its
+// rows, accumulating dgamma/dbeta for its columns in registers; one LDS reduction + atomics per block.
+//   dx = rstd * (dy*gamma - mean(dy*gamma) - xhat * mean(dy*gamma*xhat))
+//   out_bf16 : dx [* gelu'(u)]                       (feeds a dgrad GEMM)
+//   out_f32  : dres + dx  (+ bf16 copy * row_scale)   (residual-stream gradient)
+template <typename TIn, int NIT>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, const TIn* __restrict__ x, int ldx,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, int gstride,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     bf16_t* __restrict__ out_bf16, int ldob, const bf16_t* __restrict__ gelu_u, int ldu,
+                                                     const float* __restrict__ dres, float* __restrict__ out_f32, int ldof,
+                                                     bf16_t* __restrict__ out_scaled, int ldos, const float* __restrict__ row_scale,
+                                                     int rps0, int rps1, int M, int D, int split, int rows_per_block, int blocks0) {
+  extern __shared__ float red[];  // [2][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int blk = blockIdx.x;
+  const int g = blk >= blocks0;
+  const int r_begin = g ? split + (blk - blocks0) * rows_per_block : blk * rows_per_block;
+  const int r_end = min(r_begin + rows_per_block, g ? M : split);
+  const float* gm = gamma + (long)g * gstride;
+  float gv[NIT][4], ag[NIT][4], ab[NIT][4];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = (it * 64 + lane) * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { ag[it][k] = 0.f; ab[it][k] = 0.f; gv[it][k] = 0.f; }
+    if (c < D) {
+      const f32x4_t t = *(const f32x4_t*)(gm + c);
+      gv[it][0] = t[0]; gv[it][1] = t[1]; gv[it][2] = t[2]; gv[it][3] = t[3];
+    }
+  }
+  const float invD = 1.f / (float)D;
+  for (int row = r_begin + wave; row < r_end; row += 4) {
+    const float mu = mean[row], rs = rstd[row];
+    float xh[NIT][4], dyv[NIT][4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = (it * 64 + lane) * 4;
+      if (c < D) {
+        float xv[4];
+        Ld4<TIn>::ld(x + (long)row * ldx + c, xv);
+        Ld4<bf16_t>::ld(dy + (long)row * lddy + c, dyv[it]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          xh[it][k] = (xv[k] - mu) * rs;
+          const float dg = dyv[it][k] * gv[it][k];
+          s1 += dg;
+          s2 += dg * xh[it][k];
+          ag[it][k] += dyv[it][k] * xh[it][k];
+          ab[it][k] += dyv[it][k];
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { xh[it][k] = 0.f; dyv[it][k] = 0.f; }
+      }
+    }
+    const float c1 = wave_sum(s1) * invD, c2 = wave_sum(s2) * invD;
+    float scl = 1.f;
+    if (out_scaled && row_scale) scl = row_scale[g ? (row - split) / rps1 : row / rps0];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = (it * 64 + lane) * 4;
+      if (c < D) {
+        float dx[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dx[k] = rs * (dyv[it][k] * gv[it][k] - c1 - xh[it][k] * c2);
+        if (out_bf16) {
+          if (gelu_u) {
+            float u[4];
+            Ld4<bf16_t>::ld(gelu_u + (long)row * ldu + c, u);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dx[k] *= gelu_erf_grad(u[k]);
+          }
+          st4_bf16(out_bf16 + (long)row * ldob + c, dx);
+        }
+        if (out_f32) {
+          if (dres) {
+            const f32x4_t t = *(const f32x4_t*)(dres + (long)row * ldof + c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dx[k] += t[k];
+          }
+          *(f32x4_t*)(out_f32 + (long)row * ldof + c) = (f32x4_t){dx[0], dx[1], dx[2], dx[3]};
+          if (out_scaled) {
+            float t[4] = {dx[0] * scl, dx[1] * scl, dx[2] * scl, dx[3] * scl};
+            st4_bf16(out_scaled + (long)row * ldos + c, t);
+          }
+        }
+      }
+    }
+  }
+  // block reduction of dgamma / dbeta over the 4 waves in LDS (ds_add_f32), then one global
+  // atomic per column
+  float* rg = red;
+  float* rb = red + D;
+  for (int c = threadIdx.x; c < 2 * D; c += 256) red[c] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = (it * 64 + lane) * 4;
+    if (c < D) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { atomicAdd(&rg[c + k], ag[it][k]); atomicAdd(&rb[c + k], ab[it][k]); }
+    }
+  }
+  __syncthreads();
+  if (r_begin < r_end) {
+    for (int c = threadIdx.x; c < D; c += 256) {
+      atomicAdd(dgamma + (long)g * gstride + c, rg[c]);
+      atomicAdd(dbeta + (long)g * gstride + c, rb[c]);
+    }
+  }
+}
+
+}  // namespace
+
+#define LN_DISPATCH_NIT(D, CALL)                                     \
+  do {                                                               \
+    const int nit__ = ((D) + 255) / 256;                             \
+    if (nit__ <= 1) { CALL(1); }                                     \
+    else if (nit__ <= 3) { CALL(3); }                                \
+    else if (nit__ <= 4) { CALL(4); }                                \
+    else if (nit__ <= 8) { CALL(8); }                                \
+    else if (nit__ <= 12) { CALL(12); }                              \
+    else { CALL(16); }                                               \
+  } while (0)
+
+extern "C" int simvg_ln_fwd(const void* x, int x_is_bf16, int ldx, const float* gamma, const float* beta,
+                            int group_stride, void* y_bf16, int ldy, float* y_f32, int ldy32, float* mean,
+                            float* rstd, int M, int D, int split, float eps, hipStream_t stream) {
+  SIMVG_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 4096, "ln_fwd: D must be a multiple of 4 and <= 4096");
+  SIMVG_CHECK_ARG(ldx % 4 == 0 && (y_bf16 == nullptr || ldy % 4 == 0), "ln_fwd: leading dims must be multiples of 4");
+  SIMVG_CHECK_ARG(y_bf16 || y_f32, "ln_fwd: no output");
+  if (split == 0) split = M;
+  const dim3 grid(cdiv(M, 4)), block(256);
+#define CALL(N_)                                                                                                   \
+  if (x_is_bf16)                                                                                                   \
+    hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, N_>), grid, block, 0, stream, (const bf16_t*)x, ldx, gamma, beta,    \
+                       group_stride, (bf16_t*)y_bf16, ldy, y_f32, ldy32, mean, rstd, M, D, split, eps);            \
+  else                                                                                                             \
+    hipLaunchKernelGGL((ln_fwd_kernel<float, N_>), grid, block, 0, stream, (const float*)x, ldx, gamma, beta,      \
+                       group_stride, (bf16_t*)y_bf16, ldy, y_f32, ldy32, mean, rstd, M, D, split, eps)
+  LN_DISPATCH_NIT(D, CALL);
+#undef CALL
+  SIMVG_LAUNCH_CHECK();
+  return SIMVG_OK;
+}
+
+extern "C" int simvg_ln_bwd(const void* dy_bf16, int lddy, const void* x, int x_is_bf16, int ldx, const float* mean,
+                            const float* rstd, const float* gamma, int group_stride, float* dgamma, float* dbeta,
+                            void* dx_bf16, int lddxb, const void* gelu_u_bf16, int ldu, const float* dres,
+                            float* dx_f32, int lddxf, void* dx_scaled_bf16, int lddxs, const float* row_scale,
+                            int rows_per_sample0, int rows_per_sample1, int M, int D, int split,
+                            hipStream_t stream) {
+  SIMVG_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 4096, "ln_bwd: D must be a multiple of 4 and <= 4096");
+  SIMVG_CHECK_ARG(dx_bf16 || dx_f32, "ln_bwd: no output");
+  SIMVG_CHECK_ARG(!(dx_scaled_bf16 && !dx_f32), "ln_bwd: scaled bf16 copy requires the f32 output");
+  if (split == 0) split = M;
+  const int rpb = 32;
+  const int blocks0 = cdiv(split, rpb), blocks1 = cdiv(M - split, rpb);
+  const dim3 grid(blocks0 + blocks1), block(256);
+  const size_t shm = (size_t)2 * D * sizeof(float);
+  const int rps0 = rows_per_sample0 > 0 ? rows_per_sample0 : 1, rps1 = rows_per_sample1 > 0 ? rows_per_sample1 : 1;
+#define CALL(N_)                                                                                                        \
+  if (x_is_bf16)                                                                                                        \
+    hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, N_>), grid, block, shm, stream, (const bf16_t*)dy_bf16, lddy,             \
+                       (const bf16_t*)x, ldx, mean, rstd, gamma, group_stride, dgamma, dbeta, (bf16_t*)dx_bf16, lddxb,  \
+                       (const bf16_t*)gelu_u_bf16, ldu, dres, dx_f32, lddxf, (bf16_t*)dx_scaled_bf16, lddxs, row_scale, \
+                       rps0, rps1, M, D, split, rpb, blocks0);                                                          \
+  else                                                                                                                  \
+    hipLaunchKernelGGL((ln_bwd_kernel<float, N_>), grid, block, shm, stream, (const bf16_t*)dy_bf16, lddy,              \
+                       (const float*)x, ldx, mean, rstd, gamma, group_stride, dgamma, dbeta, (bf16_t*)dx_bf16, lddxb,   \
+                       (const bf16_t*)gelu_u_bf16, ldu, dres, dx_f32, lddxf, (bf16_t*)dx_scaled_bf16, lddxs, row_scale, \
+                       rps0, rps1, M, D, split, rpb, blocks0)
+  LN_DISPATCH_NIT(D, CALL);
+#undef CALL
+  SIMVG_LAUNCH_CHECK();
+  return SIMVG_OK;
+}

@@ -1,0 +1,211 @@
+"""Tensor-level wrappers over the C-ABI (one Python function per exported kernel entry point).
+
+Pointers are `tensor.data_ptr()` of caller-owned PyTorch-ROCm tensors; every call enqueues on the
+current HIP stream and never synchronises.  PyTorch here is device memory + streams only.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+BF16 = torch.bfloat16
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, dtype=None, name="tensor"):
+    if not t.is_cuda:
+        raise _lib.SimvgHipError(f"{name} must live in HBM (got a CPU tensor): simvg_amd has no CPU path")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if t.stride(-1) != 1:
+        raise ValueError(f"{name}: innermost dimension must be contiguous")
+    return t
+
+
+def gemm_nt(a, w, bias=None, out=None, out_dtype=BF16, split=0, act=0, aux_preact=None, residual=None,
+            row_scale=None, rows_per_sample=(1, 1), w_group_stride=None, bias_group_stride=None):
+    """out[M,N] = a[M,K] @ w[g][N,K]^T (+bias) (+act) (+residual + row_scale*...).  w: [N,K] or [2,N,K]."""
+    lib = _lib.load()
+    _chk(a, BF16, "a"); _chk(w, BF16, "w")
+    M, K = a.shape
+    N = w.shape[-2]
+    assert w.shape[-1] == K
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=out_dtype)
+    if w_group_stride is None:
+        w_group_stride = w.stride(0) if w.dim() == 3 else 0
+    if bias is not None:
+        _chk(bias, torch.float32, "bias")
+        if bias_group_stride is None:
+            bias_group_stride = bias.stride(0) if bias.dim() == 2 else 0
+    rc = lib.simvg_gemm_nt(_p(a), a.stride(0), _p(w), w_group_stride, w.stride(-2), _p(bias), bias_group_stride or 0,
+                           _p(out), out.stride(0), int(out.dtype == torch.float32),
+                           _p(aux_preact), aux_preact.stride(0) if aux_preact is not None else 0,
+                           _p(residual), residual.stride(0) if residual is not None else 0,
+                           _p(row_scale), rows_per_sample[0], rows_per_sample[1], M, N, K, split, act, _stream())
+    _lib.check(rc, "simvg_gemm_nt")
+    return out
+
+
+def gemm_tn(dy, x, dw, split=0, dw_group_stride=None):
+    """dw[g][N,K] += dy[M,N]^T @ x[M,K]   (fp32 accumulate into dw)."""
+    lib = _lib.load()
+    _chk(dy, BF16, "dy"); _chk(x, BF16, "x"); _chk(dw, torch.float32, "dw")
+    M, N = dy.shape
+    K = x.shape[1]
+    if dw_group_stride is None:
+        dw_group_stride = dw.stride(0) if dw.dim() == 3 else 0
+    rc = lib.simvg_gemm_tn(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), dw_group_stride, dw.stride(-2),
+                           M, N, K, split, _stream())
+    _lib.check(rc, "simvg_gemm_tn")
+    return dw
+
+
+def colsum(y, out, split=0, out_group_stride=None):
+    lib = _lib.load()
+    _chk(y, BF16, "y"); _chk(out, torch.float32, "out")
+    M, N = y.shape
+    if out_group_stride is None:
+        out_group_stride = out.stride(0) if out.dim() == 2 else 0
+    rc = lib.simvg_colsum(_p(y), y.stride(0), _p(out), out_group_stride, M, N, split, _stream())
+    _lib.check(rc, "simvg_colsum")
+    return out
+
+
+def ln_fwd(x, gamma, beta, split=0, eps=1e-5, out_bf16=True, out_f32=False, save_stats=True, y=None, y32=None):
+    """gamma/beta: [D] or [2,D] fp32.  Returns (y_bf16|None, y_f32|None, mean, rstd)."""
+    lib = _lib.load()
+    _chk(x, None, "x")
+    M, D = x.shape
+    gs = gamma.stride(0) if gamma.dim() == 2 else 0
+    if out_bf16 and y is None:
+        y = torch.empty(M, D, device=x.device, dtype=BF16)
+    if out_f32 and y32 is None:
+        y32 = torch.empty(M, D, device=x.device, dtype=torch.float32)
+    mean = torch.empty(M, device=x.device, dtype=torch.float32) if save_stats else None
+    rstd = torch.empty(M, device=x.device, dtype=torch.float32) if save_stats else None
+    rc = lib.simvg_ln_fwd(_p(x), int(x.dtype == BF16), x.stride(0), _p(gamma), _p(beta), gs, _p(y),
+                          y.stride(0) if y is not None else 0, _p(y32), y32.stride(0) if y32 is not None else 0,
+                          _p(mean), _p(rstd), M, D, split, eps, _stream())
+    _lib.check(rc, "simvg_ln_fwd")
+    return y, y32, mean, rstd
+
+
+def ln_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, split=0, dx_bf16=None, gelu_u=None, dres=None, dx_f32=None,
+           dx_scaled=None, row_scale=None, rows_per_sample=(1, 1)):
+    lib = _lib.load()
+    _chk(dy, BF16, "dy")
+    M, D = dy.shape
+    gs = gamma.stride(0) if gamma.dim() == 2 else 0
+    rc = lib.simvg_ln_bwd(_p(dy), dy.stride(0), _p(x), int(x.dtype == BF16), x.stride(0), _p(mean), _p(rstd),
+                          _p(gamma), gs, _p(dgamma), _p(dbeta), _p(dx_bf16),
+                          dx_bf16.stride(0) if dx_bf16 is not None else 0, _p(gelu_u),
+                          gelu_u.stride(0) if gelu_u is not None else 0, _p(dres), _p(dx_f32),
+                          dx_f32.stride(0) if dx_f32 is not None else 0, _p(dx_scaled),
+                          dx_scaled.stride(0) if dx_scaled is not None else 0, _p(row_scale),
+                          rows_per_sample[0], rows_per_sample[1], M, D, split, _stream())
+    _lib.check(rc, "simvg_ln_bwd")
+
+
+def attn_fwd(qkv, B, H, Nv, Nt, pad=None, out=None, scale=None):
+    """qkv: [M, 3*D] bf16, modality-major rows.  Returns (out [M,D] bf16, lse [B*H, N] fp32)."""
+    lib = _lib.load()
+    _chk(qkv, BF16, "qkv")
+    M, D3 = qkv.shape
+    D = D3 // 3
+    N = Nv + Nt
+    if out is None:
+        out = torch.empty(M, D, device=qkv.device, dtype=BF16)
+    lse = torch.empty(B * H, N, device=qkv.device, dtype=torch.float32)
+    if scale is None:
+        scale = (D // H) ** -0.5
+    rc = lib.simvg_attn_fwd(_p(qkv), qkv.stride(0), _p(out), out.stride(0), _p(lse), _p(pad), B, H, Nv, Nt, D,
+                            scale, _stream())
+    _lib.check(rc, "simvg_attn_fwd")
+    return out, lse
+
+
+def attn_bwd(qkv, out, dout, lse, B, H, Nv, Nt, pad=None, dqkv=None, scale=None):
+    lib = _lib.load()
+    M, D3 = qkv.shape
+    D = D3 // 3
+    if dqkv is None:
+        dqkv = torch.empty_like(qkv)
+    delta = torch.empty_like(lse)
+    if scale is None:
+        scale = (D // H) ** -0.5
+    rc = lib.simvg_attn_bwd(_p(qkv), qkv.stride(0), _p(out), out.stride(0), _p(dout), dout.stride(0), _p(dqkv),
+                            dqkv.stride(0), _p(lse), _p(delta), _p(pad), B, H, Nv, Nt, D, scale, _stream())
+    _lib.check(rc, "simvg_attn_bwd")
+    return dqkv
+
+
+def im2col(img, P, out=None):
+    lib = _lib.load()
+    _chk(img, torch.float32, "img")
+    assert img.is_contiguous()
+    B, Cc, S, S2 = img.shape
+    assert Cc == 3 and S == S2
+    if out is None:
+        out = torch.empty(B * (S // P) ** 2, 3 * P * P, device=img.device, dtype=BF16)
+    _lib.check(lib.simvg_im2col(_p(img), _p(out), B, S, P, _stream()), "simvg_im2col")
+    return out
+
+
+def embed_fwd(patch, cls, posA, posB, text_embed, ids, pad, B, np_, T, x=None):
+    lib = _lib.load()
+    D = patch.shape[1]
+    if x is None:
+        x = torch.empty(B * (np_ + 1 + T), D, device=patch.device, dtype=torch.float32)
+    rc = lib.simvg_embed_fwd(_p(patch), patch.stride(0), _p(cls), _p(posA), _p(posB), _p(text_embed), _p(ids),
+                             _p(pad), _p(x), x.stride(0), B, np_, T, D, _stream())
+    _lib.check(rc, "simvg_embed_fwd")
+    return x
+
+
+def embed_bwd(dx, dpatch, dcls, dposA, dposB, dtext, ids, pad, B, np_, T):
+    lib = _lib.load()
+    D = dx.shape[1]
+    rc = lib.simvg_embed_bwd(_p(dx), dx.stride(0), _p(dpatch), dpatch.stride(0), _p(dcls), _p(dposA), _p(dposB),
+                             _p(dtext), _p(ids), _p(pad), B, np_, T, D, _stream())
+    _lib.check(rc, "simvg_embed_bwd")
+
+
+def cast_bf16(src, dst=None):
+    lib = _lib.load()
+    if dst is None:
+        dst = torch.empty(src.shape, device=src.device, dtype=BF16)
+    _lib.check(lib.simvg_cast_f32_to_bf16(_p(src), _p(dst), src.numel(), _stream()), "simvg_cast_f32_to_bf16")
+    return dst
+
+
+class WeightPrep:
+    """Batched fp32 -> bf16 (+ transposed bf16) conversion of many weight matrices in ONE launch."""
+
+    def __init__(self, entries, device):
+        # entries: list of (src fp32 2-D tensor, dst bf16 | None, dst_t bf16 | None)
+        n = len(entries)
+        arr = (_lib.WeightDesc * n)()
+        tiles = 0
+        self._keep = entries
+        for i, (src, dst, dst_t) in enumerate(entries):
+            rows, cols = src.shape
+            assert src.is_contiguous() and (dst is None or dst.is_contiguous()) and (dst_t is None or dst_t.is_contiguous())
+            arr[i] = _lib.WeightDesc(src.data_ptr(), dst.data_ptr() if dst is not None else None,
+                                     dst_t.data_ptr() if dst_t is not None else None, rows, cols, tiles, 0)
+            tiles += ((rows + 31) // 32) * ((cols + 31) // 32)
+        raw = bytes(arr)
+        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+        self.n, self.tiles = n, tiles
+
+    def run(self):
+        lib = _lib.load()
+        _lib.check(lib.simvg_weight_prep(_p(self.table), self.n, self.tiles, _stream()), "simvg_weight_prep")

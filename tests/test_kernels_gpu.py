@@ -1,0 +1,345 @@
+"""GPU (MI355X) op-level parity: every HIP kernel against fp32/fp64 torch math on the CPU, on the same
+bf16-representable inputs.  Tolerances: kernels accumulate in fp32 and store bf16 (8 mantissa bits,
+half-ulp 2^-9 ~ 2e-3 relative), so bf16 outputs are compared at 1e-2 of the reference scale and fp32
+outputs at 1e-3 (inputs to the MFMA are bf16-exact, products are exact in fp32)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _ops():
+    from simvg_amd import hip_ops
+    return hip_ops
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def rnd_bf16(*shape, scale=1.0, gen=None):
+    """fp32 CPU tensor whose values are exactly representable in bf16."""
+    return (torch.randn(*shape, generator=gen) * scale).to(torch.bfloat16).float()
+
+
+def assert_close(got, ref, tol, what=""):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), f"{what}: non-finite values"
+    scale = max(float(ref.abs().max()), 1e-6)
+    err = float((got - ref).abs().max())
+    assert err <= tol * scale, f"{what}: max err {err:.4g} vs scale {scale:.4g} (tol {tol})"
+
+
+# ------------------------------------------------------------------------------------------
+# hardware semantics the kernels rely on
+# ------------------------------------------------------------------------------------------
+def test_probe_mfma_layout():
+    import ctypes as C
+    from simvg_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(0)
+    a = rnd_bf16(16, 32, gen=g)
+    b = rnd_bf16(32, 16, gen=g)          # asymmetric on purpose
+    out = torch.zeros(64, 4, device=DEV)
+    ad, bd = bf(a).to(DEV), bf(b).to(DEV)
+    _lib.check(lib.simvg_probe_mfma(C.c_void_p(ad.data_ptr()), C.c_void_p(bd.data_ptr()), C.c_void_p(out.data_ptr()),
+                                    None), "probe_mfma")
+    torch.cuda.synchronize()
+    ref = a @ b
+    got = torch.zeros(16, 16)
+    o = out.cpu()
+    for lane in range(64):
+        for r in range(4):
+            got[(lane >> 4) * 4 + r, lane & 15] = o[lane, r]   # C/D: col = lane&15, row = (lane>>4)*4 + r
+    assert_close(got, ref, 1e-5, "mfma 16x16x32 C/D layout")
+
+
+def test_probe_tr16_semantics():
+    import ctypes as C
+    from simvg_amd import _lib
+    lib = _lib.load()
+    stride = 144
+    addr = torch.zeros(64, dtype=torch.int32)
+    for lane in range(64):
+        g, i = lane >> 4, lane & 15
+        addr[lane] = g * 1024 + (i >> 2) * stride + (i & 3) * 8
+    out = torch.zeros(64, 4, dtype=torch.int16, device=DEV)
+    ad = addr.to(DEV)
+    _lib.check(lib.simvg_probe_tr16(C.c_void_p(ad.data_ptr()), C.c_void_p(out.data_ptr()), None), "probe_tr16")
+    torch.cuda.synchronize()
+    o = out.cpu()
+    exp = torch.zeros(64, 4, dtype=torch.int16)
+    for lane in range(64):
+        g, i = lane >> 4, lane & 15
+        for r in range(4):
+            exp[lane, r] = (g * 1024 + r * stride + i * 2) // 2   # lane i <- column i, rows 0..3
+    if not torch.equal(o, exp):
+        print("observed tr16 table (lane: 4 element indices):")
+        for lane in range(64):
+            print(lane, o[lane].tolist(), "expected", exp[lane].tolist())
+    assert torch.equal(o, exp)
+
+
+def test_probe_glds_lane_linear():
+    import ctypes as C
+    from simvg_amd import _lib
+    lib = _lib.load()
+    src = torch.arange(512, dtype=torch.int16)
+    perm = torch.randperm(64, generator=torch.Generator().manual_seed(1)).to(torch.int32)
+    out = torch.zeros(512, dtype=torch.int16, device=DEV)
+    sd, pd = src.to(DEV), perm.to(DEV)
+    _lib.check(lib.simvg_probe_glds(C.c_void_p(sd.data_ptr()), C.c_void_p(pd.data_ptr()), C.c_void_p(out.data_ptr()),
+                                    None), "probe_glds")
+    torch.cuda.synchronize()
+    exp = torch.cat([src[p * 8:(p + 1) * 8] for p in perm.tolist()])   # LDS image = lane-linear
+    assert torch.equal(out.cpu(), exp)
+
+
+# ------------------------------------------------------------------------------------------
+# GEMMs
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K,split", [(300, 192, 128, 200), (1684, 768, 768, 1604), (257, 64, 64, 0),
+                                         (1684, 3072, 768, 1604), (640, 768, 3072, 512)])
+@pytest.mark.parametrize("mode", ["plain", "bias_gelu_aux", "residual_scale_f32", "relu_f32"])
+def test_gemm_nt(M, N, K, split, mode):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    a = rnd_bf16(M, K, gen=g)
+    ng = 2 if split else 1
+    w = rnd_bf16(ng, N, K, scale=K ** -0.5, gen=g)
+    bias = torch.randn(ng, N, generator=g)
+    sp = split if split else M
+
+    def ref_lin(with_bias):
+        y = torch.cat([a[:sp] @ w[0].t(), a[sp:] @ w[-1].t()], 0)
+        if with_bias:
+            y = y + torch.cat([bias[0].expand(sp, N), bias[-1].expand(M - sp, N)], 0)
+        return y
+
+    ad, wd, bd = bf(a).to(DEV), bf(w).to(DEV), bias.to(DEV)
+    if mode == "plain":
+        out = ops.gemm_nt(ad, wd, split=split)
+        assert_close(out, ref_lin(False), 1e-2, "gemm plain")
+    elif mode == "bias_gelu_aux":
+        aux = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        out = ops.gemm_nt(ad, wd, bias=bd, split=split, act=1, aux_preact=aux)
+        u = ref_lin(True)
+        assert_close(aux, u, 1e-2, "gemm aux preact")
+        assert_close(out, F.gelu(u), 1e-2, "gemm gelu")
+    elif mode == "residual_scale_f32":
+        rps = (50, 21) if split else (M, 1)
+        nsamp = max(math.ceil(sp / rps[0]), math.ceil((M - sp) / rps[1]) if split else 1)
+        scale = torch.rand(nsamp, generator=g) + 0.5
+        res = torch.randn(M, N, generator=g)
+        rows = torch.arange(M)
+        samp = torch.where(rows < sp, rows // rps[0], (rows - sp) // rps[1])
+        out = ops.gemm_nt(ad, wd, bias=bd, split=split, residual=res.to(DEV), row_scale=scale.to(DEV),
+                          rows_per_sample=rps, out_dtype=torch.float32)
+        assert_close(out, res + scale[samp][:, None] * ref_lin(True), 1e-3, "gemm residual")
+    else:
+        out = ops.gemm_nt(ad, wd, bias=bd, split=split, act=2, out_dtype=torch.float32)
+        assert_close(out, F.relu(ref_lin(True)), 1e-3, "gemm relu f32")
+
+
+@pytest.mark.parametrize("M,N,K,split", [(300, 192, 128, 200), (1684, 768, 768, 1604), (5000, 128, 256, 0),
+                                         (1684, 3072, 768, 1604), (1684, 768, 3072, 1604)])
+def test_gemm_tn_and_colsum(M, N, K, split):
+    ops = _ops()
+    g = torch.Generator().manual_seed(7 * M + N)
+    dy = rnd_bf16(M, N, gen=g)
+    x = rnd_bf16(M, K, gen=g)
+    sp = split if split else M
+    ng = 2 if split else 1
+    init = torch.randn(ng, N, K, generator=g)
+    dw = init.clone().to(DEV)
+    ops.gemm_tn(bf(dy).to(DEV), bf(x).to(DEV), dw, split=split)
+    ref = init.clone().double()
+    ref[0] += dy[:sp].double().t() @ x[:sp].double()
+    if split:
+        ref[1] += dy[sp:].double().t() @ x[sp:].double()
+    assert_close(dw, ref.float(), 1e-4, "wgrad (accumulates into dW)")
+    db = torch.zeros(ng, N, device=DEV)
+    ops.colsum(bf(dy).to(DEV), db, split=split)
+    refb = torch.stack([dy[:sp].double().sum(0)] + ([dy[sp:].double().sum(0)] if split else [])).float()
+    assert_close(db, refb, 1e-4, "colsum")
+
+
+# ------------------------------------------------------------------------------------------
+# LayerNorm
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,D,split", [(100, 768, 70), (37, 3072, 0), (64, 256, 0), (90, 1024, 33), (50, 128, 20),
+                                       (41, 4096, 11)])
+@pytest.mark.parametrize("xdtype", ["f32", "bf16"])
+def test_layernorm_fwd_bwd(M, D, split, xdtype):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M * D)
+    x = torch.randn(M, D, generator=g) * 2 + 0.5
+    if xdtype == "bf16":
+        x = x.to(torch.bfloat16).float()
+    ng = 2 if split else 1
+    gamma = 1 + 0.2 * torch.randn(ng, D, generator=g)
+    beta = 0.1 * torch.randn(ng, D, generator=g)
+    sp = split if split else M
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y_ref = torch.cat([F.layer_norm(xr[:sp], (D,), gr[0], br[0], 1e-5), F.layer_norm(xr[sp:], (D,), gr[-1], br[-1], 1e-5)], 0)
+    xd = x.to(DEV) if xdtype == "f32" else bf(x).to(DEV)
+    y, y32, mean, rstd = ops.ln_fwd(xd, gamma.to(DEV), beta.to(DEV), split=split, out_bf16=True, out_f32=True)
+    assert_close(y32, y_ref, 1e-5 if xdtype == "f32" else 1e-5, "ln fwd f32")
+    assert_close(y, y_ref, 1e-2, "ln fwd bf16")
+    # backward
+    dy = rnd_bf16(M, D, gen=g)
+    y_ref.backward(dy)
+    dgamma, dbeta = torch.zeros(ng, D, device=DEV), torch.zeros(ng, D, device=DEV)
+    dres = torch.randn(M, D, generator=g)
+    rps = (7, 3) if split else (5, 1)
+    nsamp = max(math.ceil(sp / rps[0]), math.ceil((M - sp) / rps[1]) if split else 1)
+    scale = torch.rand(nsamp, generator=g) + 0.5
+    dx_f32 = torch.empty(M, D, device=DEV)
+    dx_scaled = torch.empty(M, D, device=DEV, dtype=torch.bfloat16)
+    ops.ln_bwd(bf(dy).to(DEV), xd, mean, rstd, gamma.to(DEV), dgamma, dbeta, split=split, dres=dres.to(DEV),
+               dx_f32=dx_f32, dx_scaled=dx_scaled, row_scale=scale.to(DEV), rows_per_sample=rps)
+    assert_close(dx_f32, dres + xr.grad, 1e-4, "ln bwd dx (+residual)")
+    rows = torch.arange(M)
+    samp = torch.where(rows < sp, rows // rps[0], (rows - sp) // rps[1])
+    assert_close(dx_scaled, (dres + xr.grad) * scale[samp][:, None], 1e-2, "ln bwd scaled bf16 copy")
+    assert_close(dgamma, gr.grad, 1e-4, "ln bwd dgamma")
+    assert_close(dbeta, br.grad, 1e-4, "ln bwd dbeta")
+    # bf16 output with fused GELU'
+    u = rnd_bf16(M, D, gen=g)
+    dxb = torch.empty(M, D, device=DEV, dtype=torch.bfloat16)
+    dgamma.zero_(); dbeta.zero_()
+    ops.ln_bwd(bf(dy).to(DEV), xd, mean, rstd, gamma.to(DEV), dgamma, dbeta, split=split, dx_bf16=dxb, gelu_u=bf(u).to(DEV))
+    ur = u.clone().requires_grad_(True)
+    F.gelu(ur).backward(xr.grad)
+    assert_close(dxb, ur.grad, 1e-2, "ln bwd * gelu'")
+
+
+# ------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------
+def _mm_rows(B, Nv, Nt):
+    """modality-major row index of token (b, t)."""
+    idx = torch.zeros(B, Nv + Nt, dtype=torch.long)
+    for b in range(B):
+        idx[b, :Nv] = b * Nv + torch.arange(Nv)
+        idx[b, Nv:] = B * Nv + b * Nt + torch.arange(Nt)
+    return idx
+
+
+@pytest.mark.parametrize("B,H,Nv,Nt", [(2, 2, 17, 20), (2, 12, 401, 20), (1, 3, 50, 0), (3, 2, 100, 7)])
+def test_attention_fwd_bwd(B, H, Nv, Nt):
+    ops = _ops()
+    d, N = 64, Nv + Nt
+    D = H * d
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    qkv_tok = rnd_bf16(B, N, 3 * D, gen=g)                        # token-major reference layout
+    pad = torch.zeros(B, max(Nt, 1), dtype=torch.uint8)
+    for b in range(B):
+        if Nt:
+            pad[b, Nt - (3 + 4 * b) % Nt:] = 1   # every sample has a different number of padded text keys
+    idx = _mm_rows(B, Nv, Nt)
+    qkv_mm = torch.zeros(B * N, 3 * D)
+    qkv_mm[idx.reshape(-1)] = qkv_tok.reshape(B * N, 3 * D)
+    # reference (torchscale MultiheadAttention math, fp32)
+    t = qkv_tok.clone().requires_grad_(True)
+    q, k, v = t.split(D, dim=-1)
+    q = q.view(B, N, H, d).transpose(1, 2) * d ** -0.5
+    k = k.view(B, N, H, d).transpose(1, 2)
+    v = v.view(B, N, H, d).transpose(1, 2)
+    w = q @ k.transpose(-1, -2)
+    kpm = torch.cat([torch.zeros(B, Nv, dtype=torch.bool), pad[:, :Nt].bool()], 1)
+    w = w.masked_fill(kpm[:, None, None, :], float("-inf"))
+    p = torch.softmax(w, -1)
+    o_ref = (p @ v).transpose(1, 2).reshape(B, N, D)
+    qd = bf(qkv_mm).to(DEV)
+    padd = pad[:, :Nt].contiguous().to(DEV) if Nt else None
+    out, lse = ops.attn_fwd(qd, B, H, Nv, Nt, pad=padd)
+    out_tok = out.float().cpu()[idx.reshape(-1)].view(B, N, D)
+    assert_close(out_tok, o_ref, 1.5e-2, "attention fwd")
+    lse_ref = torch.logsumexp(w, -1).reshape(B * H, N)
+    assert_close(lse, lse_ref, 1e-3, "attention lse")
+    # backward
+    do_tok = rnd_bf16(B, N, D, gen=g)
+    o_ref.backward(do_tok)
+    do_mm = torch.zeros(B * N, D)
+    do_mm[idx.reshape(-1)] = do_tok.reshape(B * N, D)
+    dqkv = ops.attn_bwd(qd, out, bf(do_mm).to(DEV), lse, B, H, Nv, Nt, pad=padd)
+    dq_tok = dqkv.float().cpu()[idx.reshape(-1)].view(B, N, 3 * D)
+    for name, sl in [("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))]:
+        assert_close(dq_tok[..., sl], t.grad[..., sl], 2e-2, "attention bwd " + name)
+
+
+# ------------------------------------------------------------------------------------------
+# embedding stage
+# ------------------------------------------------------------------------------------------
+def test_im2col_matches_conv():
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    B, S, P, D = 2, 128, 32, 64
+    img = rnd_bf16(B, 3, S, S, gen=g)
+    w = rnd_bf16(D, 3, P, P, scale=0.02, gen=g)
+    cols = ops.im2col(img.to(DEV), P)
+    y = ops.gemm_nt(cols, bf(w.view(D, -1)).to(DEV), out_dtype=torch.float32)
+    ref = F.conv2d(img, w, stride=P).flatten(2).transpose(1, 2).reshape(B * (S // P) ** 2, D)
+    assert_close(y, ref, 1e-3, "patch embed = im2col + GEMM")
+
+
+def test_embed_fwd_bwd():
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    B, np_, T, D, V = 3, 16, 20, 128, 1000
+    patch = torch.randn(B * np_, D, generator=g)
+    cls = torch.randn(D, generator=g)
+    posA = torch.randn(np_ + 3, D, generator=g)
+    posB = torch.randn(1024, D, generator=g)
+    table = torch.randn(V, D, generator=g)
+    ids = torch.randint(0, V, (B, T), generator=g)
+    ids[:, 0] = 0
+    pad = torch.zeros(B, T, dtype=torch.uint8)
+    pad[0, 5:] = 1
+    pad[2, 12:] = 1
+    leaves = [t.clone().requires_grad_(True) for t in (patch, cls, posA, posB, table)]
+    pr, cr, ar, br_, tr = leaves
+    x1 = torch.cat([cr.view(1, 1, D).expand(B, 1, D), pr.view(B, np_, D)], 1) + ar[2:2 + np_ + 1][None]
+    x2 = (F.embedding(ids, tr) + br_[2:2 + T][None]) * (1 - pad.float())[..., None]
+    x_ref = torch.cat([x1.reshape(-1, D), x2.reshape(-1, D)], 0)
+    x = ops.embed_fwd(patch.to(DEV), cls.to(DEV), posA.to(DEV), posB.to(DEV), table.to(DEV), ids.to(DEV), pad.to(DEV),
+                      B, np_, T)
+    assert_close(x, x_ref, 1e-6, "embed fwd")
+    dx = torch.randn(B * (np_ + 1 + T), D, generator=g)
+    x_ref.backward(dx)
+    dpatch = torch.empty(B * np_, D, device=DEV, dtype=torch.bfloat16)
+    dcls, dposA, dposB, dtext = (torch.zeros(s, device=DEV) for s in [(D,), (np_ + 3, D), (1024, D), (V, D)])
+    ops.embed_bwd(dx.to(DEV), dpatch, dcls, dposA, dposB, dtext, ids.to(DEV), pad.to(DEV), B, np_, T)
+    assert_close(dpatch, pr.grad, 1e-2, "embed bwd dpatch")
+    assert_close(dcls, cr.grad, 1e-5, "embed bwd dcls")
+    assert_close(dposA, ar.grad, 1e-5, "embed bwd dposA")
+    assert_close(dposB, br_.grad, 1e-5, "embed bwd dposB")
+    assert_close(dtext, tr.grad, 1e-5, "embed bwd dtext")
+
+
+def test_weight_prep():
+    ops = _ops()
+    g = torch.Generator().manual_seed(9)
+    mats = [torch.randn(r, c, generator=g).to(DEV) for r, c in [(70, 33), (128, 256), (5, 300)]]
+    entries = []
+    for i, m in enumerate(mats):
+        dst = torch.empty_like(m, dtype=torch.bfloat16) if i != 2 else None
+        dst_t = torch.empty(m.shape[1], m.shape[0], device=DEV, dtype=torch.bfloat16) if i != 0 else None
+        entries.append((m, dst, dst_t))
+    wp = ops.WeightPrep(entries, DEV)
+    wp.run()
+    torch.cuda.synchronize()
+    for m, dst, dst_t in entries:
+        if dst is not None:
+            assert torch.equal(dst, m.to(torch.bfloat16))
+        if dst_t is not None:
+            assert torch.equal(dst_t, m.t().contiguous().to(torch.bfloat16))
