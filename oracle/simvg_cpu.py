@@ -33,7 +33,7 @@ def make_cfg(vit_type="base", num_queries=1, img_size=640, patch_size=32, max_to
     elif vit_type == "large":  # Q4: rop_path_rate typo -> drop path 0 (beit3.py:54)
         enc = dict(embed_dim=1024, heads=16, ffn_dim=4096, layers=24, drop_path_rate=0.0)
     elif vit_type == "tiny":   # test-only geometry (G2 fixtures), not a reference config
-        enc = dict(embed_dim=64, heads=4, ffn_dim=128, layers=2, drop_path_rate=0.0)
+        enc = dict(embed_dim=128, heads=2, ffn_dim=256, layers=2, drop_path_rate=0.0)
     else:
         raise TypeError("please select the <vit_type> from ['base','large']")
     cfg = dict(vit_type=vit_type, img_size=img_size, patch_size=patch_size, max_token=max_token,
@@ -111,8 +111,8 @@ def encoder_layer(sd, cfg, x, mask, split, i, dp_scale=None, p="vis_enc.beit3.")
     a = (w @ v).transpose(1, 2).reshape(B, N, D)
     a = _mw_ln(sd, L + "self_attn.inner_attn_ln", a, split, eps)
     a = _mw_linear(sd, L + "self_attn.out_proj", a, split)
-    if dp_scale is not None:
-        a = a * dp_scale[:, None, None]
+    if dp_scale is not None and dp_scale[0] is not None:   # DropPath, attention branch (beit3_base.py:148-149)
+        a = a * dp_scale[0][:, None, None]
     x = residual + a
     residual = x
     h = _mw_ln(sd, L + "final_layer_norm", x, split, eps)
@@ -125,15 +125,16 @@ def encoder_layer(sd, cfg, x, mask, split, i, dp_scale=None, p="vis_enc.beit3.")
         return F.linear(t, sd[f"{L}ffn.{e}.fc2.weight"], sd[f"{L}ffn.{e}.fc2.bias"])
 
     h = _mw(h, split, lambda t: ffn(t, "A"), lambda t: ffn(t, "B"))
-    if dp_scale is not None:
-        h = h * dp_scale[:, None, None]
+    if dp_scale is not None and dp_scale[1] is not None:   # second, independent DropPath draw (:166-167)
+        h = h * dp_scale[1][:, None, None]
     return residual + h
 
 
 def beit3_forward(sd, cfg, img, ids, pad, dp_scales=None, p="vis_enc.beit3.", return_hidden=False):
     """BEIT3.forward (beit3.py:176-185): -> img_feat [B,HW,D], text_feat [B,T,D], cls_feat [B,D].
 
-    dp_scales: optional [layers, 2? no: layers, B] per-sample DropPath factors (mask/(1-p)); None = eval.
+    dp_scales: optional list over layers of (attn_scale [B] | None, ffn_scale [B] | None) per-sample
+    DropPath factors (bernoulli mask / keep_prob); None = eval mode.
     """
     x, mask, split = encoder_embed(sd, cfg, img, ids, pad, p)
     hidden = [x]

@@ -1,0 +1,378 @@
+"""BEIT3 -- the BEiT-3 multiway ViT encoder of SimVG on MI355X (HIP engine behind the reference API).
+
+Host-side mirror of `simvg/models/vis_encs/beit/beit3.py:29-185` (class BEIT3, registered in
+VIS_ENCODERS, same constructor kwargs, `forward(image, question, padding_mask) -> (img_feat,
+text_feat, cls_feat)`) with the arithmetic of `beit3_base.py:127-172,317-407,441-488` and the
+torchscale leaf modules executed by hand-written gfx950 kernels through libsimvg_hip.so.
+
+MI355X-first design (not a translation of the eager graph):
+ * tokens are stored MODALITY-MAJOR ([B*Nv vision rows | B*Nt text rows]) so each multiway Linear /
+   LayerNorm is one grouped launch over two contiguous row ranges -- no split/cat copies;
+ * fp32 residual stream, bf16 GEMM operands, fp32 accumulate / LayerNorm / softmax / GELU;
+ * DropPath + residual add are fused into the out-proj / fc2 GEMM epilogues; the residual-gradient add
+   and the DropPath scaling of the next dgrad operand are fused into the LayerNorm backward;
+ * q|k|v (both experts) are one [2,3D,D] grouped GEMM; dgrad uses a transposed bf16 weight copy made by
+   the batched weight-prep kernel, so forward and dgrad share one NT GEMM kernel;
+ * forward and backward are sequenced by hand over pre-allocated HBM workspaces (activations for the
+   whole B=64 step are ~14 GB of the 288 GB) -- no autograd graph inside the encoder.
+state_dict keys are exactly the reference's.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ... import builder
+from .... import hip_ops as ops
+from ....arena import ParamArena
+
+BF16 = torch.bfloat16
+
+_VIT = {"base": dict(embed_dim=768, heads=12, ffn_dim=3072, layers=12),
+        "large": dict(embed_dim=1024, heads=16, ffn_dim=4096, layers=24)}
+
+
+class _Bag(nn.Module):
+    """Parameter container; nested bags reproduce the reference's module paths."""
+
+
+def _set_param(root, key, tensor):
+    parts = key.split(".")
+    m = root
+    for p in parts[:-1]:
+        if p not in m._modules:
+            m.add_module(p, _Bag())
+        m = m._modules[p]
+    m.register_parameter(parts[-1], nn.Parameter(tensor))
+
+
+def _trunc_normal(shape, std=0.02):
+    t = torch.empty(shape)
+    nn.init.trunc_normal_(t, mean=0.0, std=std, a=-std, b=std)   # modeling_utils.py:17-18
+    return t
+
+
+@builder.VIS_ENCODERS.register_module()
+class BEIT3(nn.Module):
+    def __init__(self, img_size=384, patch_size=32, vit_type="base", drop_path_rate=0.1, vocab_size=64010,
+                 norm_layer=None, freeze_layer=-1, vision_embed_proj_interpolate=False, pretrain=None,
+                 encoder_cfg=None):
+        super().__init__()
+        if encoder_cfg is not None:           # explicit geometry (tests); not a reference config
+            geo = dict(encoder_cfg)
+            dpr = drop_path_rate
+        elif vit_type == "base":
+            geo, dpr = dict(_VIT["base"]), drop_path_rate
+        elif vit_type == "large":
+            geo, dpr = dict(_VIT["large"]), 0.0   # Q4: reference passes `rop_path_rate` -> drop path 0 (beit3.py:54)
+        else:
+            raise TypeError("please select the <vit_type> from ['base','large']")
+        self.D, self.H, self.F, self.L = geo["embed_dim"], geo["heads"], geo["ffn_dim"], geo["layers"]
+        if self.D // self.H != 64:
+            raise ValueError("the gfx950 attention kernel is built for head_dim 64 (ViT-B/L)")
+        self.img_size, self.patch_size, self.vocab_size = img_size, patch_size, vocab_size
+        self.np = (img_size // patch_size) ** 2
+        self.hidden_size = self.D
+        self.ln_eps = 1e-5
+        self.drop_path_probs = [float(v) for v in np.linspace(0, dpr, self.L)] if dpr > 0 else [0.0] * self.L
+        self.vision_embed_proj_interpolate = vision_embed_proj_interpolate
+        self._build_parameters()
+        self._arena = None
+        self._ws = {}
+        self._prep_version = -1
+        self._anchor = None
+        if isinstance(pretrain, str):
+            from ....checkpoint import load_beit3_pretrain
+            load_beit3_pretrain(self, pretrain)
+        self.frozen_stages = -1
+        if freeze_layer >= 0:
+            self.frozen_stages = min(freeze_layer, self.L)
+            self._freeze_stages()
+
+    # ------------------------------------------------------------------ parameters (reference schema)
+    def _build_parameters(self):
+        D, F_, P = self.D, self.F, self.patch_size
+        root = _Bag()
+        self.beit3 = root
+        _set_param(root, "text_embed.weight", torch.randn(self.vocab_size, D) * D ** -0.5)
+        _set_param(root, "vision_embed.mask_token", torch.zeros(1, 1, D))
+        _set_param(root, "vision_embed.cls_token", torch.zeros(1, 1, D))
+        fan_in = 3 * P * P
+        bound = 1.0 / math.sqrt(fan_in)        # nn.Conv2d default init
+        _set_param(root, "vision_embed.proj.weight", torch.empty(D, 3, P, P).uniform_(-bound, bound))
+        _set_param(root, "vision_embed.proj.bias", torch.empty(D).uniform_(-bound, bound))
+        _set_param(root, "encoder.embed_positions.A.weight", torch.randn(self.np + 3, D))
+        _set_param(root, "encoder.embed_positions.B.weight", torch.randn(1024, D))
+        for i in range(self.L):
+            l = f"encoder.layers.{i}."
+            for proj in ["k_proj", "v_proj", "q_proj", "out_proj"]:
+                for m in "AB":
+                    _set_param(root, f"{l}self_attn.{proj}.{m}.weight", _trunc_normal((D, D)))
+                    _set_param(root, f"{l}self_attn.{proj}.{m}.bias", torch.zeros(D))
+            for ln in ["self_attn.inner_attn_ln", "self_attn_layer_norm"]:
+                for m in "AB":
+                    _set_param(root, f"{l}{ln}.{m}.weight", torch.ones(D))
+                    _set_param(root, f"{l}{ln}.{m}.bias", torch.zeros(D))
+            for m in "AB":
+                _set_param(root, f"{l}ffn.{m}.fc1.weight", _trunc_normal((F_, D)))
+                _set_param(root, f"{l}ffn.{m}.fc1.bias", torch.zeros(F_))
+                _set_param(root, f"{l}ffn.{m}.fc2.weight", _trunc_normal((D, F_)))
+                _set_param(root, f"{l}ffn.{m}.fc2.bias", torch.zeros(D))
+                _set_param(root, f"{l}ffn.{m}.ffn_layernorm.weight", torch.ones(F_))
+                _set_param(root, f"{l}ffn.{m}.ffn_layernorm.bias", torch.zeros(F_))
+            for m in "AB":
+                _set_param(root, f"{l}final_layer_norm.{m}.weight", torch.ones(D))
+                _set_param(root, f"{l}final_layer_norm.{m}.bias", torch.zeros(D))
+        for m in "AB":
+            _set_param(root, f"encoder.layer_norm.{m}.weight", torch.ones(D))
+            _set_param(root, f"encoder.layer_norm.{m}.bias", torch.zeros(D))
+
+    def _freeze_stages(self):   # beit3.py:78-90
+        for i in range(self.frozen_stages):
+            for p in self.beit3.encoder.layers[i].parameters():
+                p.requires_grad = False
+
+    def get_num_layers(self):
+        return self.L
+
+    # ------------------------------------------------------------------ arena + bf16 compute copies
+    def _groups(self):
+        D, F_, L = self.D, self.F, self.L
+        g = []
+        for i in range(L):
+            l = f"beit3.encoder.layers.{i}."
+            sa = l + "self_attn."
+            g.append((f"wqkv{i}", [f"{sa}{p}.{m}.weight" for m in "AB" for p in ("q_proj", "k_proj", "v_proj")], (2, 3 * D, D)))
+            g.append((f"bqkv{i}", [f"{sa}{p}.{m}.bias" for m in "AB" for p in ("q_proj", "k_proj", "v_proj")], (2, 3 * D)))
+            g.append((f"wout{i}", [f"{sa}out_proj.{m}.weight" for m in "AB"], (2, D, D)))
+            g.append((f"bout{i}", [f"{sa}out_proj.{m}.bias" for m in "AB"], (2, D)))
+            for tag, ln in [("ln1", l + "self_attn_layer_norm"), ("lni", sa + "inner_attn_ln"), ("ln2", l + "final_layer_norm")]:
+                g.append((f"{tag}g{i}", [f"{ln}.{m}.weight" for m in "AB"], (2, D)))
+                g.append((f"{tag}b{i}", [f"{ln}.{m}.bias" for m in "AB"], (2, D)))
+            g.append((f"w1{i}", [f"{l}ffn.{m}.fc1.weight" for m in "AB"], (2, F_, D)))
+            g.append((f"b1{i}", [f"{l}ffn.{m}.fc1.bias" for m in "AB"], (2, F_)))
+            g.append((f"lnfg{i}", [f"{l}ffn.{m}.ffn_layernorm.weight" for m in "AB"], (2, F_)))
+            g.append((f"lnfb{i}", [f"{l}ffn.{m}.ffn_layernorm.bias" for m in "AB"], (2, F_)))
+            g.append((f"w2{i}", [f"{l}ffn.{m}.fc2.weight" for m in "AB"], (2, D, F_)))
+            g.append((f"b2{i}", [f"{l}ffn.{m}.fc2.bias" for m in "AB"], (2, D)))
+        g.append(("lnog", [f"beit3.encoder.layer_norm.{m}.weight" for m in "AB"], (2, D)))
+        g.append(("lnob", [f"beit3.encoder.layer_norm.{m}.bias" for m in "AB"], (2, D)))
+        return g
+
+    def _ensure_engine(self, device):
+        if self._arena is not None and self._arena.device == device and self._arena.intact():
+            return
+        named = {n: p for n, p in self.named_parameters()}
+        self._arena = ParamArena(named, self._groups(), device)
+        A = self._arena
+        D, F_, L, P = self.D, self.F, self.L, self.patch_size
+
+        def bf(*shape):
+            return torch.empty(*shape, device=device, dtype=BF16)
+
+        self.wb = {"patch": bf(D, 3 * P * P)}
+        entries = [(A.params["beit3.vision_embed.proj.weight"].data.view(D, 3 * P * P), self.wb["patch"], None)]
+        for i in range(L):
+            for tag, n, k in [("wqkv", 3 * D, D), ("wout", D, D), ("w1", F_, D), ("w2", D, F_)]:
+                self.wb[f"{tag}{i}"] = bf(2, n, k)
+                self.wb[f"{tag}T{i}"] = bf(2, k, n)
+                for gi in range(2):
+                    entries.append((A.views[f"{tag}{i}"][gi], self.wb[f"{tag}{i}"][gi], self.wb[f"{tag}T{i}"][gi]))
+        self._prep = ops.WeightPrep(entries, device)
+        self._prep_version = -1
+        self._ws = {}
+        self._anchor = torch.zeros(1, device=device, requires_grad=True)
+
+    def _refresh_weights(self):
+        v = self._arena.flat._version
+        if v != self._prep_version:
+            self._prep.run()
+            self._prep_version = v
+
+    def layer_param_names(self, i):
+        pre = f"beit3.encoder.layers.{i}."
+        return [n for n in self._arena.params if n.startswith(pre)]
+
+    # ------------------------------------------------------------------ workspaces
+    def _workspace(self, B, T, device, save):
+        key = (B, T, save)
+        ws = self._ws.get(key)
+        if ws is not None:
+            return ws
+        D, F_, L, P, H = self.D, self.F, self.L, self.patch_size, self.H
+        Nv = self.np + 1
+        M = B * (Nv + T)
+
+        def bf(*s):
+            return torch.empty(*s, device=device, dtype=BF16)
+
+        def f32(*s):
+            return torch.empty(*s, device=device, dtype=torch.float32)
+
+        ws = dict(cols=bf(B * self.np, 3 * P * P), patch=f32(B * self.np, D), out=bf(M, D), out32=None)
+        nx = 2 * L + 1 if save else 3
+        ws["xs"] = [f32(M, D) for _ in range(nx)]
+        nl = L if save else 1
+        ws["layer"] = []
+        for _ in range(nl):
+            ws["layer"].append(dict(h=bf(M, D), qkv=bf(M, 3 * D), o=bf(M, D), lse=None, o2=bf(M, D), h2=bf(M, D),
+                                    u=bf(M, F_), g=bf(M, F_), g2=bf(M, F_), stats={}))
+        if save:
+            ws.update(dx=f32(M, D), dyb=bf(M, D), dF=bf(M, F_), dF2=bf(M, F_), dD=bf(M, D), dO=bf(M, D),
+                      dQKV=bf(M, 3 * D), dpatch=bf(B * self.np, D))
+        self._ws[key] = ws
+        return ws
+
+    # ------------------------------------------------------------------ engine: forward
+    def _engine_forward(self, img, ids, pad_u8, dp, save):
+        A = self._arena
+        V = A.views
+        B, T = ids.shape
+        D, F_, L, H, P = self.D, self.F, self.L, self.H, self.patch_size
+        Nv = self.np + 1
+        Mv = B * Nv
+        M = Mv + B * T
+        rps = (Nv, max(T, 1))
+        eps = self.ln_eps
+        ws = self._workspace(B, T, img.device, save)
+        prm = A.params
+        ops.im2col(img, P, out=ws["cols"])
+        ops.gemm_nt(ws["cols"], self.wb["patch"], bias=prm["beit3.vision_embed.proj.bias"].data, out=ws["patch"])
+        xs = ws["xs"]
+        ops.embed_fwd(ws["patch"], prm["beit3.vision_embed.cls_token"].data, prm["beit3.encoder.embed_positions.A.weight"].data,
+                      prm["beit3.encoder.embed_positions.B.weight"].data, prm["beit3.text_embed.weight"].data,
+                      ids, pad_u8, B, self.np, T, x=xs[0])
+        for i in range(L):
+            st = ws["layer"][i if save else 0]
+            x_in = xs[2 * i] if save else xs[(2 * i) % 3]
+            x_mid = xs[2 * i + 1] if save else xs[(2 * i + 1) % 3]
+            x_out = xs[2 * i + 2] if save else xs[(2 * i + 2) % 3]
+            s = st["stats"]
+            _, _, s["m1"], s["r1"] = ops.ln_fwd(x_in, V[f"ln1g{i}"], V[f"ln1b{i}"], split=Mv, eps=eps, y=st["h"], save_stats=save)
+            ops.gemm_nt(st["h"], self.wb[f"wqkv{i}"], bias=V[f"bqkv{i}"], out=st["qkv"], split=Mv)
+            _, st["lse"] = ops.attn_fwd(st["qkv"], B, H, Nv, T, pad=pad_u8, out=st["o"])
+            _, _, s["m2"], s["r2"] = ops.ln_fwd(st["o"], V[f"lnig{i}"], V[f"lnib{i}"], split=Mv, eps=eps, y=st["o2"], save_stats=save)
+            ops.gemm_nt(st["o2"], self.wb[f"wout{i}"], bias=V[f"bout{i}"], out=x_mid, split=Mv, residual=x_in,
+                        row_scale=None if dp is None else dp[i][0], rows_per_sample=rps)
+            _, _, s["m3"], s["r3"] = ops.ln_fwd(x_mid, V[f"ln2g{i}"], V[f"ln2b{i}"], split=Mv, eps=eps, y=st["h2"], save_stats=save)
+            ops.gemm_nt(st["h2"], self.wb[f"w1{i}"], bias=V[f"b1{i}"], out=st["g"], split=Mv, act=1,
+                        aux_preact=st["u"] if save else None)
+            _, _, s["m4"], s["r4"] = ops.ln_fwd(st["g"], V[f"lnfg{i}"], V[f"lnfb{i}"], split=Mv, eps=eps, y=st["g2"], save_stats=save)
+            ops.gemm_nt(st["g2"], self.wb[f"w2{i}"], bias=V[f"b2{i}"], out=x_out, split=Mv, residual=x_mid,
+                        row_scale=None if dp is None else dp[i][1], rows_per_sample=rps)
+        x_last = xs[2 * L] if save else xs[(2 * L) % 3]
+        _, _, mF, rF = ops.ln_fwd(x_last, V["lnog"], V["lnob"], split=Mv, eps=eps, y=ws["out"], save_stats=save)
+        ws["final_stats"] = (mF, rF)
+        ws["ctx"] = (B, T, ids, pad_u8, dp)
+        return ws["out"], ws
+
+    # ------------------------------------------------------------------ engine: backward
+    def _engine_backward(self, ws, dout, layer_done_cb=None):
+        A = self._arena
+        V, G = A.views, A.grad_views
+        B, T, ids, pad_u8, dp = ws["ctx"]
+        D, F_, L, H = self.D, self.F, self.L, self.H
+        Nv = self.np + 1
+        Mv = B * Nv
+        rps = (Nv, max(T, 1))
+        xs = ws["xs"]
+        dx, dyb, dF, dF2, dD, dO, dQKV = ws["dx"], ws["dyb"], ws["dF"], ws["dF2"], ws["dD"], ws["dO"], ws["dQKV"]
+        mF, rF = ws["final_stats"]
+        ops.ln_bwd(dout, xs[2 * L], mF, rF, V["lnog"], G["lnog"], G["lnob"], split=Mv, dx_f32=dx, dx_scaled=dyb,
+                   row_scale=None if dp is None else dp[L - 1][1], rows_per_sample=rps)
+        for i in reversed(range(L)):
+            st = ws["layer"][i]
+            s = st["stats"]
+            # ---- FFN branch: x_out = x_mid + dp1 * fc2(LN(gelu(fc1(LN(x_mid)))))
+            ops.gemm_nt(dyb, self.wb[f"w2T{i}"], out=dF, split=Mv)
+            ops.gemm_tn(dyb, st["g2"], G[f"w2{i}"], split=Mv)
+            ops.colsum(dyb, G[f"b2{i}"], split=Mv)
+            ops.ln_bwd(dF, st["g"], s["m4"], s["r4"], V[f"lnfg{i}"], G[f"lnfg{i}"], G[f"lnfb{i}"], split=Mv,
+                       dx_bf16=dF2, gelu_u=st["u"])
+            ops.gemm_nt(dF2, self.wb[f"w1T{i}"], out=dD, split=Mv)
+            ops.gemm_tn(dF2, st["h2"], G[f"w1{i}"], split=Mv)
+            ops.colsum(dF2, G[f"b1{i}"], split=Mv)
+            ops.ln_bwd(dD, xs[2 * i + 1], s["m3"], s["r3"], V[f"ln2g{i}"], G[f"ln2g{i}"], G[f"ln2b{i}"], split=Mv,
+                       dres=dx, dx_f32=dx, dx_scaled=dyb, row_scale=None if dp is None else dp[i][0], rows_per_sample=rps)
+            # ---- attention branch: x_mid = x_in + dp0 * out_proj(LN(attn(qkv(LN(x_in)))))
+            ops.gemm_nt(dyb, self.wb[f"woutT{i}"], out=dD, split=Mv)
+            ops.gemm_tn(dyb, st["o2"], G[f"wout{i}"], split=Mv)
+            ops.colsum(dyb, G[f"bout{i}"], split=Mv)
+            ops.ln_bwd(dD, st["o"], s["m2"], s["r2"], V[f"lnig{i}"], G[f"lnig{i}"], G[f"lnib{i}"], split=Mv, dx_bf16=dO)
+            ops.attn_bwd(st["qkv"], st["o"], dO, st["lse"], B, H, Nv, T, pad=pad_u8, dqkv=dQKV)
+            ops.gemm_nt(dQKV, self.wb[f"wqkvT{i}"], out=dD, split=Mv)
+            ops.gemm_tn(dQKV, st["h"], G[f"wqkv{i}"], split=Mv)
+            ops.colsum(dQKV, G[f"bqkv{i}"], split=Mv)
+            ops.ln_bwd(dD, xs[2 * i], s["m1"], s["r1"], V[f"ln1g{i}"], G[f"ln1g{i}"], G[f"ln1b{i}"], split=Mv,
+                       dres=dx, dx_f32=dx, dx_scaled=dyb,
+                       row_scale=None if (dp is None or i == 0) else dp[i - 1][1], rows_per_sample=rps)
+            if layer_done_cb is not None:
+                layer_done_cb(i)
+        ops.embed_bwd(dx, ws["dpatch"], A.grad("beit3.vision_embed.cls_token").view(-1),
+                      A.grad("beit3.encoder.embed_positions.A.weight"), A.grad("beit3.encoder.embed_positions.B.weight"),
+                      A.grad("beit3.text_embed.weight"), ids, pad_u8, B, self.np, T)
+        P = self.patch_size
+        ops.gemm_tn(ws["dpatch"], ws["cols"], A.grad("beit3.vision_embed.proj.weight").view(D, 3 * P * P))
+        ops.colsum(ws["dpatch"], A.grad("beit3.vision_embed.proj.bias"))
+        if layer_done_cb is not None:
+            layer_done_cb(-1)
+
+    # ------------------------------------------------------------------ public API
+    def _drop_path_scales(self, B, device):
+        if not self.training or all(p == 0.0 for p in self.drop_path_probs):
+            return None
+        out = []
+        for p in self.drop_path_probs:   # two independent draws per layer (beit3_base.py:148-149,166-167)
+            if p == 0.0:
+                out.append((None, None))
+                continue
+            keep = 1.0 - p
+            m = torch.empty(2, B, device=device).bernoulli_(keep).div_(keep)
+            out.append((m[0], m[1]))
+        return out
+
+    def encode(self, image, question, padding_mask=None, dp_scales=None):
+        """-> encoder output [B*Nv + B*Nt, D] bf16, modality-major rows (the fused model path)."""
+        if not image.is_cuda:
+            raise ops._lib.SimvgHipError("BEIT3 (simvg_amd) runs on an MI355X only: inputs must be HIP tensors")
+        device = image.device
+        self._ensure_engine(device)
+        self._refresh_weights()
+        B, T = question.shape
+        img = image.contiguous().float()
+        ids = question.contiguous().long()
+        pad_u8 = None if padding_mask is None else (padding_mask != 0).to(torch.uint8).contiguous()
+        if dp_scales is None:
+            dp_scales = self._drop_path_scales(B, device)
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        return _EncoderFn.apply(self, img, ids, pad_u8, dp_scales, need_grad, self._anchor)
+
+    def split_output(self, out, B, T):
+        Nv = self.np + 1
+        vis = out[:B * Nv].view(B, Nv, self.D)
+        txt = out[B * Nv:].view(B, T, self.D)
+        return vis[:, 1:], txt, vis[:, 0]
+
+    def forward(self, image, question, padding_mask, **kwargs):
+        """Reference API (beit3.py:176-185): -> img_feat [B,np,D], text_feat [B,T,D], cls_feat [B,D] (fp32)."""
+        out = self.encode(image, question, padding_mask)
+        img_feat, text_feat, cls_feat = self.split_output(out.float(), *question.shape)
+        return img_feat, text_feat, cls_feat
+
+
+class _EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, enc, img, ids, pad_u8, dp, need_grad, anchor):
+        out, ws = enc._engine_forward(img, ids, pad_u8, dp, save=need_grad)
+        ctx.enc, ctx.ws = enc, ws
+        ctx.mark_non_differentiable()
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        enc = ctx.enc
+        enc._arena.begin_backward()
+        hook = getattr(enc, "_grad_ready_hook", None)
+        enc._engine_backward(ctx.ws, dout.contiguous(), hook)
+        return (None,) * 7
