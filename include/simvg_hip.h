@@ -60,7 +60,7 @@ int simvg_ln_fwd(const void* x, int x_is_bf16, int ldx, const float* gamma, cons
                  int M, int D, int split, float eps, simvg_stream_t stream);
 /* dx = LN'(dy); outputs: bf16 dx (optionally * GELU'(u), fusing the activation backward of fc1), and/or
  * fp32 (dres + dx) = the residual-stream gradient, with an optional bf16 copy * row_scale (DropPath). */
-int simvg_ln_bwd(const void* dy_bf16, int lddy, const void* x, int x_is_bf16, int ldx, const float* mean,
+int simvg_ln_bwd(const void* dy, int dy_is_f32, int lddy, const void* x, int x_is_bf16, int ldx, const float* mean,
                  const float* rstd, const float* gamma, int group_stride, float* dgamma, float* dbeta,
                  void* dx_bf16, int lddxb, const void* gelu_u_bf16, int ldu, const float* dres,
                  float* dx_f32, int lddxf, void* dx_scaled_bf16, int lddxs, const float* row_scale,
@@ -75,6 +75,40 @@ int simvg_attn_fwd(const void* qkv_bf16, int ldqkv, void* out_bf16, int ldo, flo
 int simvg_attn_bwd(const void* qkv_bf16, int ldqkv, const void* out_bf16, int ldo, const void* dout_bf16, int lddo,
                    void* dqkv_bf16, int lddqkv, const float* lse, float* delta_ws, const unsigned char* pad,
                    int B, int H, int Nv, int Nt, int D, float scale, simvg_stream_t stream);
+
+/* ---- decoder head: exact-fp32 small GEMM, small multi-head attention --------------------------------
+ * C[M,N] (+)= sum_k A(m,k) B(k,n) (+bias[n]) (+addend[m % addend_rows][n]) (+ReLU), arbitrary strides (forward,
+ * dgrad and wgrad of the head's nn.Linear layers: detrex MultiheadAttention / FFN built at
+ * heads/tgqs_kd_detr_head/transformer.py:106-125, heads/utils.py:39-46 MLP, tgqs_kd_detr_head.py:378-379,
+ * 415-416,427-428) on v_mfma_f32_16x16x4_f32. */
+int simvg_gemm_f32(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc,
+                   const float* bias, const float* addend, long ld_addend, int addend_rows, int M, int N, int K,
+                   int accumulate, int act, simvg_stream_t stream);
+/* torch.nn.MultiheadAttention core (heads of 32) for <= 16 queries: softmax(scale q k^T + key_padding) [* dropout] v
+ * (detrex MultiheadAttention wrapper; decoder layers transformer.py:167-186). */
+int simvg_attn_small_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo,
+                         float* P, const unsigned char* key_padding_mask, const float* drop_mult, int B, int H, int Lq,
+                         int Lk, int kv_rows_per_batch, float scale, simvg_stream_t stream);
+int simvg_attn_small_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* P,
+                         const unsigned char* key_padding_mask, const float* drop_mult, const float* dout, int lddo,
+                         float* dq, int lddq, float* dk, int lddk, float* dv, int lddv, int B, int H, int Lq, int Lk,
+                         int kv_rows_per_batch, float scale, simvg_stream_t stream);
+
+/* ---- matcher + criterion (no host synchronisation) ------------------------------------------------------
+ * detrex HungarianMatcher (ce_cost; cost_class 1, cost_bbox 5, cost_giou 2 at tgqs_kd_detr_head.py:132-137) with the
+ * LSAP solved on the device instead of SciPy on the host; prepare_soft_targets (tgqs_kd_detr_head.py:207-268,
+ * score_iou_weighted); SetCriterion.forward + calc_loss weighting (core/criterion/criterion.py:108-271,
+ * tgqs_kd_detr_head.py:340-350,484-507) with analytic gradients.  coef_mode: 0 coef, 1 coef*(1-w), 2 coef*w. */
+int simvg_match(const float* logits, const float* boxes, const float* tboxes, const int* tlabels, const int* tcount,
+                int* match, int L, int B, int nq, int TM, float cost_class, float cost_bbox, float cost_giou,
+                simvg_stream_t stream);
+int simvg_soft_targets(const float* logits, const float* boxes, const int* match, const float* tboxes, const int* tcount,
+                       float* pboxes, int* plabels, int* pcount, float* pweight, float* scalars4, int B, int nq, int TM,
+                       simvg_stream_t stream);
+int simvg_criterion(const float* logits, const float* boxes, const int* match, const float* tboxes, const int* tlabels,
+                    const float* num_boxes, const float* weights_distill, float* dlogits, float* dboxes, float* out,
+                    int L, int B, int nq, int TM, int coef_mode, float coef, float eos_coef, float w_class, float w_bbox,
+                    float w_giou, simvg_stream_t stream);
 
 /* ---- embedding stage -------------------------------------------------------------------------------
  * torchscale VisionEmbedding / TextEmbedding / PositionalEmbedding as wired by BEiT3.forward and

@@ -27,6 +27,9 @@ CASES = {
     "base_nq1":       ("base", 1, 640, 2, False, 13, 23),
     "base_nq10_grec": ("base", 10, 640, 3, True, 14, 24),
     "large_nq1":      ("large", 1, 640, 1, False, 15, 25),
+    # reference-style initialisation (what training from scratch / the benchmark uses)
+    "base_nq1_refinit":       ("base", 1, 640, 2, False, 16, 26),
+    "base_nq10_grec_refinit": ("base", 10, 640, 3, True, 17, 27),
 }
 
 GRAD_KEYS = [  # sampled gradient probes (first 16 elements + norm)
@@ -82,7 +85,8 @@ def run_case(name, check_only=False):
     cfg = O.make_cfg(vit, nq, img_size)
     t0 = time.time()
     model = build_reference(vit, nq, img_size, cfg)
-    sd = W.golden_state_dict(cfg, wseed)
+    refinit = name.endswith("_refinit")
+    sd = W.reference_init_state_dict(cfg, wseed) if refinit else W.golden_state_dict(cfg, wseed)
     missing = model.load_state_dict(sd, strict=True)
     batch = W.synthetic_batch(cfg, B, iseed, grec)
     model.eval()   # dropout / DropPath identity; losses are still computed by forward_train
@@ -150,7 +154,7 @@ def run_case(name, check_only=False):
     # ---------------- fixture ----------------
     tiny = vit == "tiny"
     fx = dict(
-        name=name, vit=vit, num_queries=nq, img_size=img_size, B=B, grec=grec, wseed=wseed, iseed=iseed,
+        name=name, refinit=refinit, vit=vit, num_queries=nq, img_size=img_size, B=B, grec=grec, wseed=wseed, iseed=iseed,
         torch_version=torch.__version__,
         losses={k: float(v) for k, v in losses.items()},
         tok_logits=hout["outputs_class_token_branch"].detach().clone(),

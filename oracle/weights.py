@@ -101,6 +101,54 @@ def golden_state_dict(cfg, seed):
     return sd
 
 
+def reference_init_state_dict(cfg, seed):
+    """The distributions of the reference's OWN initialisation: BEiT3Wrapper._init_weights
+    (modeling_utils.py:102-109: trunc-normal(0.02, clipped at +-0.02) Linear weights, zero biases, unit LayerNorm),
+    torchscale embedding inits (text N(0, D^-1/2), positions N(0,1), zero cls/mask tokens), nn.Conv2d / nn.Linear
+    defaults, xavier for the DETR decoder (transformer.py:200-203), nn.Embedding N(0,1) for query_embed.
+    Seeded here (not RNG-identical to the reference constructor) so that fixtures are regenerable."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def uni(shape, bound):
+        return (torch.rand(shape, generator=g) * 2 - 1) * bound
+
+    for key, shape, kind in state_dict_spec(cfg):
+        enc = key.startswith("vis_enc.")
+        if kind == "eos":
+            t = torch.tensor([1.0, cfg.eos_coef])
+        elif kind == "g":
+            t = torch.ones(shape)
+        elif kind == "tok":
+            t = torch.zeros(shape)
+        elif kind == "emb":
+            t = torch.randn(shape, generator=g) * cfg.embed_dim ** -0.5
+        elif kind == "pos":
+            t = torch.randn(shape, generator=g)
+        elif kind == "b":
+            if enc and "vision_embed.proj" not in key:
+                t = torch.zeros(shape)
+            elif "in_proj_bias" in key or "out_proj.bias" in key:
+                t = torch.zeros(shape)
+            else:
+                fan_in = {"vis_enc.beit3.vision_embed.proj.bias": 3 * cfg.patch_size ** 2}.get(key)
+                if fan_in is None:
+                    wshape = dict((k, s) for k, s, _ in state_dict_spec(cfg))[key[:-4] + "weight"]
+                    fan_in = math.prod(wshape[1:])
+                t = uni(shape, fan_in ** -0.5)
+        elif kind == "w":
+            fan_in = math.prod(shape[1:])
+            if enc and "vision_embed.proj" not in key:
+                t = (torch.randn(shape, generator=g) * 0.02).clamp_(-0.02, 0.02)
+            elif key.startswith("head.transformer.decoder.") or "in_proj_weight" in key:
+                fan_out = shape[0]
+                t = uni(shape, math.sqrt(6.0 / (fan_in + fan_out)))      # xavier_uniform
+            else:
+                t = uni(shape, fan_in ** -0.5)                           # kaiming_uniform(a=sqrt(5))
+        sd[key] = t
+    return sd
+
+
 def synthetic_batch(cfg, B, seed, grec=False):
     """RefCOCO-shape synthetic inputs: fp32 image N(0,1), XLM-R-style ids
     [0, t1..tm, 2, 1...] with m~U{2..10}, int64 pad mask (1 = pad, quirk Q1), xyxy pixel gt boxes."""

@@ -24,7 +24,7 @@ _SIGS = {
     "simvg_colsum": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "simvg_ln_fwd": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
                      c_void_p, c_int, c_int, c_int, c_float, c_void_p],
-    "simvg_ln_bwd": [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+    "simvg_ln_bwd": [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                      c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
                      c_int, c_int, c_int, c_int, c_int, c_void_p],
     "simvg_attn_fwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
@@ -39,6 +39,20 @@ _SIGS = {
     "simvg_weight_prep": [c_void_p, c_int, c_int, c_void_p],
     "simvg_cast_f32_to_bf16": [c_void_p, c_void_p, c_long, c_void_p],
     "simvg_cast_bf16_to_f32": [c_void_p, c_void_p, c_long, c_void_p],
+    "simvg_gemm_f32": [c_void_p, c_long, c_long, c_void_p, c_long, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long,
+                       c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "simvg_attn_small_fwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
+                             c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
+    "simvg_attn_small_bwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                             c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
+                             c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
+    "simvg_match": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                    c_float, c_float, c_float, c_void_p],
+    "simvg_soft_targets": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                           c_void_p, c_int, c_int, c_int, c_void_p],
+    "simvg_criterion": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                        c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float,
+                        c_void_p],
     "simvg_probe_mfma": [c_void_p, c_void_p, c_void_p, c_void_p],
     "simvg_probe_tr16": [c_void_p, c_void_p, c_void_p],
     "simvg_probe_glds": [c_void_p, c_void_p, c_void_p, c_void_p],

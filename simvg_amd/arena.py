@@ -17,11 +17,12 @@ ALIGN = 64  # elements (256 B)
 
 
 class ParamArena:
-    def __init__(self, named_params, groups, device):
+    def __init__(self, named_params, groups, device, no_grad=()):
         """named_params: ordered dict name -> Parameter.  groups: list of (view_name, [param names], shape)
         describing fused views; parameters not named in any group are laid out afterwards in order."""
         self.device = torch.device(device)
         self.params = dict(named_params)
+        self.no_grad = set(no_grad)     # parameters the path never differentiates (their .grad stays None)
         order, seen = [], set()
         self._group_spec = []
         for vname, names, shape in groups:
@@ -79,7 +80,7 @@ class ParamArena:
         zeroed first; otherwise kernels keep accumulating (PyTorch's += semantics)."""
         fresh = False
         for n, p in self.params.items():
-            if not p.requires_grad:
+            if not p.requires_grad or n in self.no_grad:
                 continue
             g = p.grad
             if g is None or g.data_ptr() != self._grad_of[n].data_ptr():
@@ -88,6 +89,6 @@ class ParamArena:
         if fresh:
             self.flat_grad.zero_()
             for n, p in self.params.items():
-                if p.requires_grad:
+                if p.requires_grad and n not in self.no_grad:
                     p.grad = self._grad_of[n]
         return fresh

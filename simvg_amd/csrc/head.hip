@@ -1,0 +1,280 @@
+// Decoder-head kernels (gfx950): everything that runs on the [B*num_queries, 256] query rows.
+//
+//  simvg_gemm_f32      : exact-fp32 strided GEMM on v_mfma_f32_16x16x4_f32 (bitwise an fmaf chain) for the
+//                        small Linears of the head (M = B*nq .. B*20 rows): forward, dgrad and wgrad are the
+//                        same kernel with different strides.  Replaces nn.Linear inside detrex
+//                        MultiheadAttention/FFN (transformer.py:106-125), heads/utils.py MLP (:39-46) and
+//                        tgqs_kd_detr_head.py:378-379,415-416,427-428.
+//  simvg_attn_small_*  : torch.nn.MultiheadAttention core (8 heads x 32) for nq <= 16 queries against
+//                        <= 512 keys (self-attn over queries, cross-attn to 20 text keys / 400 patches),
+//                        with key_padding_mask and optional attention-dropout mask; fp32, one workgroup per
+//                        (sample, head).  (detrex MultiheadAttention)
+#include "common.h"
+
+namespace {
+
+struct SGArgs {
+  const float* A; long sam, sak;
+  const float* B; long sbk, sbn;
+  float* C; long ldc;
+  const float* bias;
+  const float* addend; long lda2;     // optional C += addend[m % add_rows][n]
+  int add_rows;
+  int M, N, K, accumulate, act;
+};
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(SGArgs a) {
+  __shared__ float As[16][68];
+  __shared__ float Bs[16][68];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  f32x4_t acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < a.K; k0 += 16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + 256 * i;
+      int m, k;
+      if (a.sak == 1) { k = e & 15; m = e >> 4; } else { m = e & 63; k = e >> 6; }
+      float v = 0.f;
+      if (m0 + m < a.M && k0 + k < a.K) v = a.A[(long)(m0 + m) * a.sam + (long)(k0 + k) * a.sak];
+      As[k][m] = v;
+      int n, kb;
+      if (a.sbn == 1) { n = e & 63; kb = e >> 6; } else { kb = e & 15; n = e >> 4; }
+      float w = 0.f;
+      if (n0 + n < a.N && k0 + kb < a.K) w = a.B[(long)(k0 + kb) * a.sbk + (long)(n0 + n) * a.sbn];
+      Bs[kb][n] = w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const float av = As[kk * 4 + (lane >> 4)][wave * 16 + (lane & 15)];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float bv = Bs[kk * 4 + (lane >> 4)][j * 16 + (lane & 15)];
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + j * 16 + (lane & 15);
+    if (n >= a.N) continue;
+    const float bv = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + wave * 16 + 4 * (lane >> 4) + r;
+      if (m >= a.M) continue;
+      float v = acc[j][r] + bv;
+      if (a.addend) v += a.addend[(long)(m % a.add_rows) * a.lda2 + n];
+      if (a.act == 2) v = fmaxf(v, 0.f);
+      float* p = a.C + (long)m * a.ldc + n;
+      *p = a.accumulate ? *p + v : v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+struct SAArgs {
+  const float* q; int ldq;      // [B*Lq, E] (+ column offset already applied)
+  const float* k; int ldk;      // [B*Lk, E]
+  const float* v; int ldv;
+  float* out; int ldo;          // [B*Lq, E]
+  float* P;                     // [B, H, Lq, Lk] softmax probabilities (saved for backward)
+  const unsigned char* kpm;     // [B, Lk] 1 = masked, or null
+  const float* drop;            // [B, H, Lq, Lk] dropout multipliers (0 or 1/(1-p)), or null
+  const float* dout; int lddo;
+  float* dq; int lddq;
+  float* dk; int lddk;
+  float* dv; int lddv;
+  int B, H, Lq, Lk, kv_rows;
+  float scale;
+};
+
+constexpr int SHD = 32;
+
+__global__ __launch_bounds__(256) void attn_small_fwd_kernel(SAArgs a) {
+  extern __shared__ float sm[];
+  float* qs = sm;                     // [Lq][32]
+  float* sc = sm + a.Lq * SHD;        // [Lq][Lk]
+  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int e = tid; e < a.Lq * SHD; e += 256)
+    qs[e] = a.q[(long)(b * a.Lq + e / SHD) * a.ldq + h * SHD + (e % SHD)] * a.scale;
+  __syncthreads();
+  for (int kk = tid; kk < a.Lk; kk += 256) {
+    float kr[SHD];
+    const float* kp = a.k + (long)(b * a.kv_rows + kk) * a.ldk + h * SHD;
+#pragma unroll
+    for (int d = 0; d < SHD; d += 4) {
+      const f32x4_t t = *(const f32x4_t*)(kp + d);
+      kr[d] = t[0]; kr[d + 1] = t[1]; kr[d + 2] = t[2]; kr[d + 3] = t[3];
+    }
+    const bool masked = a.kpm && a.kpm[b * a.Lk + kk];
+    for (int qi = 0; qi < a.Lq; ++qi) {
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < SHD; ++d) s += qs[qi * SHD + d] * kr[d];
+      sc[qi * a.Lk + kk] = masked ? -INFINITY : s;
+    }
+  }
+  __syncthreads();
+  for (int qi = wave; qi < a.Lq; qi += 4) {
+    float mx = -INFINITY;
+    for (int kk = lane; kk < a.Lk; kk += 64) mx = fmaxf(mx, sc[qi * a.Lk + kk]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int kk = lane; kk < a.Lk; kk += 64) {
+      const float p = __expf(sc[qi * a.Lk + kk] - mx);
+      sc[qi * a.Lk + kk] = p;
+      sum += p;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    float* Pg = a.P + ((long)blockIdx.x * a.Lq + qi) * a.Lk;
+    const float* dr = a.drop ? a.drop + ((long)blockIdx.x * a.Lq + qi) * a.Lk : nullptr;
+    for (int kk = lane; kk < a.Lk; kk += 64) {
+      const float p = sc[qi * a.Lk + kk] * inv;
+      Pg[kk] = p;
+      sc[qi * a.Lk + kk] = dr ? p * dr[kk] : p;
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < a.Lq * SHD; e += 256) {
+    const int qi = e / SHD, d = e % SHD;
+    float o = 0.f;
+    const float* vp = a.v + (long)(b * a.kv_rows) * a.ldv + h * SHD + d;
+    for (int kk = 0; kk < a.Lk; ++kk) o += sc[qi * a.Lk + kk] * vp[(long)kk * a.ldv];
+    a.out[(long)(b * a.Lq + qi) * a.ldo + h * SHD + d] = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_small_bwd_kernel(SAArgs a) {
+  extern __shared__ float sm[];
+  float* qs = sm;                           // [Lq][32] (unscaled)
+  float* dos = qs + a.Lq * SHD;             // [Lq][32]
+  float* ds = dos + a.Lq * SHD;             // [Lq][Lk]  dS
+  float* pd = ds + a.Lq * a.Lk;             // [Lq][Lk]  P * dropmask
+  float* rs = pd + a.Lq * a.Lk;             // [Lq] rowsum(dP * P)
+  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int e = tid; e < a.Lq * SHD; e += 256) {
+    const long r = (long)(b * a.Lq + e / SHD);
+    qs[e] = a.q[r * a.ldq + h * SHD + (e % SHD)];
+    dos[e] = a.dout[r * a.lddo + h * SHD + (e % SHD)];
+  }
+  __syncthreads();
+  // dP = (dO . V^T) * drop ; dV = (P*drop)^T dO
+  for (int kk = tid; kk < a.Lk; kk += 256) {
+    float vr[SHD], dvr[SHD];
+    const float* vp = a.v + (long)(b * a.kv_rows + kk) * a.ldv + h * SHD;
+#pragma unroll
+    for (int d = 0; d < SHD; d += 4) {
+      const f32x4_t t = *(const f32x4_t*)(vp + d);
+      vr[d] = t[0]; vr[d + 1] = t[1]; vr[d + 2] = t[2]; vr[d + 3] = t[3];
+      dvr[d] = dvr[d + 1] = dvr[d + 2] = dvr[d + 3] = 0.f;
+    }
+    for (int qi = 0; qi < a.Lq; ++qi) {
+      const long pi = ((long)blockIdx.x * a.Lq + qi) * a.Lk + kk;
+      const float p = a.P[pi];
+      const float dm = a.drop ? a.drop[pi] : 1.f;
+      float dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < SHD; ++d) {
+        dp += dos[qi * SHD + d] * vr[d];
+        dvr[d] += p * dm * dos[qi * SHD + d];
+      }
+      ds[qi * a.Lk + kk] = dp * dm;   // dP wrt softmax output
+      pd[qi * a.Lk + kk] = p;
+    }
+    float* gp = a.dv + (long)(b * a.kv_rows + kk) * a.lddv + h * SHD;
+#pragma unroll
+    for (int d = 0; d < SHD; d += 4) *(f32x4_t*)(gp + d) = (f32x4_t){dvr[d], dvr[d + 1], dvr[d + 2], dvr[d + 3]};
+  }
+  __syncthreads();
+  for (int qi = wave; qi < a.Lq; qi += 4) {
+    float s = 0.f;
+    for (int kk = lane; kk < a.Lk; kk += 64) s += ds[qi * a.Lk + kk] * pd[qi * a.Lk + kk];
+    s = wave_sum(s);
+    if (lane == 0) rs[qi] = s;
+  }
+  __syncthreads();
+  for (int e = tid; e < a.Lq * a.Lk; e += 256) {
+    const int qi = e / a.Lk;
+    ds[e] = pd[e] * (ds[e] - rs[qi]) * a.scale;      // dS * scale (masked keys: P = 0 -> 0)
+  }
+  __syncthreads();
+  // dQ[qi][d] = sum_k dS[qi][k] K[k][d]
+  for (int e = tid; e < a.Lq * SHD; e += 256) {
+    const int qi = e / SHD, d = e % SHD;
+    float o = 0.f;
+    const float* kp = a.k + (long)(b * a.kv_rows) * a.ldk + h * SHD + d;
+    for (int kk = 0; kk < a.Lk; ++kk) o += ds[qi * a.Lk + kk] * kp[(long)kk * a.ldk];
+    a.dq[(long)(b * a.Lq + qi) * a.lddq + h * SHD + d] = o;
+  }
+  // dK[k][d] = sum_q dS[q][k] Q[q][d]
+  for (int kk = tid; kk < a.Lk; kk += 256) {
+    float acc[SHD];
+#pragma unroll
+    for (int d = 0; d < SHD; ++d) acc[d] = 0.f;
+    for (int qi = 0; qi < a.Lq; ++qi) {
+      const float s = ds[qi * a.Lk + kk];
+#pragma unroll
+      for (int d = 0; d < SHD; ++d) acc[d] += s * qs[qi * SHD + d];
+    }
+    float* gp = a.dk + (long)(b * a.kv_rows + kk) * a.lddk + h * SHD;
+#pragma unroll
+    for (int d = 0; d < SHD; d += 4) *(f32x4_t*)(gp + d) = (f32x4_t){acc[d], acc[d + 1], acc[d + 2], acc[d + 3]};
+  }
+}
+
+}  // namespace
+
+extern "C" int simvg_gemm_f32(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C,
+                              long ldc, const float* bias, const float* addend, long ld_addend, int addend_rows,
+                              int M, int N, int K, int accumulate, int act, hipStream_t stream) {
+  SIMVG_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm_f32: empty problem");
+  SIMVG_CHECK_ARG(act == 0 || act == 2, "gemm_f32: act must be 0 (none) or 2 (relu)");
+  SGArgs a{A, sam, sak, B, sbk, sbn, C, ldc, bias, addend, ld_addend, addend_rows > 0 ? addend_rows : 1, M, N, K,
+           accumulate, act};
+  hipLaunchKernelGGL(gemm_f32_kernel, dim3(cdiv(N, 64), cdiv(M, 64)), dim3(256), 0, stream, a);
+  SIMVG_LAUNCH_CHECK();
+  return SIMVG_OK;
+}
+
+extern "C" int simvg_attn_small_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                                    float* out, int ldo, float* P, const unsigned char* key_padding_mask,
+                                    const float* drop_mult, int B, int H, int Lq, int Lk, int kv_rows_per_batch,
+                                    float scale, hipStream_t stream) {
+  SIMVG_CHECK_ARG(B > 0 && H > 0 && Lq > 0 && Lq <= 16 && Lk > 0 && Lk <= 1024, "attn_small: Lq <= 16, Lk <= 1024");
+  SIMVG_CHECK_ARG(ldk % 4 == 0 && ldv % 4 == 0, "attn_small: K/V rows must be 16-B aligned");
+  SAArgs a{q, ldq, k, ldk, v, ldv, out, ldo, P, key_padding_mask, drop_mult, nullptr, 0, nullptr, 0, nullptr, 0,
+           nullptr, 0, B, H, Lq, Lk, kv_rows_per_batch > 0 ? kv_rows_per_batch : Lk, scale};
+  const size_t shm = (size_t)(Lq * SHD + Lq * Lk) * sizeof(float);
+  static bool once = hipFuncSetAttribute((const void*)attn_small_fwd_kernel,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+  (void)once;
+  hipLaunchKernelGGL(attn_small_fwd_kernel, dim3(B * H), dim3(256), shm, stream, a);
+  SIMVG_LAUNCH_CHECK();
+  return SIMVG_OK;
+}
+
+extern "C" int simvg_attn_small_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                                    const float* P, const unsigned char* key_padding_mask, const float* drop_mult,
+                                    const float* dout, int lddo, float* dq, int lddq, float* dk, int lddk, float* dv,
+                                    int lddv, int B, int H, int Lq, int Lk, int kv_rows_per_batch, float scale,
+                                    hipStream_t stream) {
+  SIMVG_CHECK_ARG(B > 0 && H > 0 && Lq > 0 && Lq <= 16 && Lk > 0 && Lk <= 1024, "attn_small: Lq <= 16, Lk <= 1024");
+  SIMVG_CHECK_ARG(ldk % 4 == 0 && ldv % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0, "attn_small: rows must be 16-B aligned");
+  SAArgs a{q, ldq, k, ldk, v, ldv, nullptr, 0, (float*)P, key_padding_mask, drop_mult, dout, lddo, dq, lddq, dk, lddk,
+           dv, lddv, B, H, Lq, Lk, kv_rows_per_batch > 0 ? kv_rows_per_batch : Lk, scale};
+  const size_t shm = (size_t)(2 * Lq * SHD + 2 * Lq * Lk + Lq) * sizeof(float);
+  static bool once = hipFuncSetAttribute((const void*)attn_small_bwd_kernel,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+  (void)once;
+  hipLaunchKernelGGL(attn_small_bwd_kernel, dim3(B * H), dim3(256), shm, stream, a);
+  SIMVG_LAUNCH_CHECK();
+  return SIMVG_OK;
+}

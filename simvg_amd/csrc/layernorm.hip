@@ -86,8 +86,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIn* __restrict__ x, 
 //   dx = rstd * (dy*gamma - mean(dy*gamma) - xhat * mean(dy*gamma*xhat))
 //   out_bf16 : dx [* gelu'(u)]                       (feeds a dgrad GEMM)
 //   out_f32  : dres + dx  (+ bf16 copy * row_scale)   (residual-stream gradient)
-template <typename TIn, int NIT>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, const TIn* __restrict__ x, int ldx,
+template <typename TIn, typename TDy, int NIT>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy, int lddy, const TIn* __restrict__ x, int ldx,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, int gstride,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
       if (c < D) {
         float xv[4];
         Ld4<TIn>::ld(x + (long)row * ldx + c, xv);
-        Ld4<bf16_t>::ld(dy + (long)row * lddy + c, dyv[it]);
+        Ld4<TDy>::ld(dy + (long)row * lddy + c, dyv[it]);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           xh[it][k] = (xv[k] - mu) * rs;
@@ -230,7 +230,7 @@ extern "C" int simvg_ln_fwd(const void* x, int x_is_bf16, int ldx, const float* 
   return SIMVG_OK;
 }
 
-extern "C" int simvg_ln_bwd(const void* dy_bf16, int lddy, const void* x, int x_is_bf16, int ldx, const float* mean,
+extern "C" int simvg_ln_bwd(const void* dy_bf16, int dy_is_f32, int lddy, const void* x, int x_is_bf16, int ldx, const float* mean,
                             const float* rstd, const float* gamma, int group_stride, float* dgamma, float* dbeta,
                             void* dx_bf16, int lddxb, const void* gelu_u_bf16, int ldu, const float* dres,
                             float* dx_f32, int lddxf, void* dx_scaled_bf16, int lddxs, const float* row_scale,
@@ -238,6 +238,7 @@ extern "C" int simvg_ln_bwd(const void* dy_bf16, int lddy, const void* x, int x_
                             hipStream_t stream) {
   SIMVG_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 4096, "ln_bwd: D must be a multiple of 4 and <= 4096");
   SIMVG_CHECK_ARG(dx_bf16 || dx_f32, "ln_bwd: no output");
+  SIMVG_CHECK_ARG(!dy_is_f32 || (D <= 256 && !x_is_bf16), "ln_bwd: fp32 dy is only built for the head (D <= 256, fp32 x)");
   SIMVG_CHECK_ARG(!(dx_scaled_bf16 && !dx_f32), "ln_bwd: scaled bf16 copy requires the f32 output");
   if (split == 0) split = M;
   const int rpb = 32;
@@ -245,14 +246,22 @@ extern "C" int simvg_ln_bwd(const void* dy_bf16, int lddy, const void* x, int x_
   const dim3 grid(blocks0 + blocks1), block(256);
   const size_t shm = (size_t)2 * D * sizeof(float);
   const int rps0 = rows_per_sample0 > 0 ? rows_per_sample0 : 1, rps1 = rows_per_sample1 > 0 ? rows_per_sample1 : 1;
+  if (dy_is_f32) {
+    hipLaunchKernelGGL((ln_bwd_kernel<float, float, 1>), grid, block, shm, stream, (const float*)dy_bf16, lddy,
+                       (const float*)x, ldx, mean, rstd, gamma, group_stride, dgamma, dbeta, (bf16_t*)dx_bf16, lddxb,
+                       (const bf16_t*)gelu_u_bf16, ldu, dres, dx_f32, lddxf, (bf16_t*)dx_scaled_bf16, lddxs, row_scale,
+                       rps0, rps1, M, D, split, rpb, blocks0);
+    SIMVG_LAUNCH_CHECK();
+    return SIMVG_OK;
+  }
 #define CALL(N_)                                                                                                        \
   if (x_is_bf16)                                                                                                        \
-    hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, N_>), grid, block, shm, stream, (const bf16_t*)dy_bf16, lddy,             \
+    hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, bf16_t, N_>), grid, block, shm, stream, (const bf16_t*)dy_bf16, lddy,             \
                        (const bf16_t*)x, ldx, mean, rstd, gamma, group_stride, dgamma, dbeta, (bf16_t*)dx_bf16, lddxb,  \
                        (const bf16_t*)gelu_u_bf16, ldu, dres, dx_f32, lddxf, (bf16_t*)dx_scaled_bf16, lddxs, row_scale, \
                        rps0, rps1, M, D, split, rpb, blocks0);                                                          \
   else                                                                                                                  \
-    hipLaunchKernelGGL((ln_bwd_kernel<float, N_>), grid, block, shm, stream, (const bf16_t*)dy_bf16, lddy,              \
+    hipLaunchKernelGGL((ln_bwd_kernel<float, bf16_t, N_>), grid, block, shm, stream, (const bf16_t*)dy_bf16, lddy,              \
                        (const float*)x, ldx, mean, rstd, gamma, group_stride, dgamma, dbeta, (bf16_t*)dx_bf16, lddxb,   \
                        (const bf16_t*)gelu_u_bf16, ldu, dres, dx_f32, lddxf, (bf16_t*)dx_scaled_bf16, lddxs, row_scale, \
                        rps0, rps1, M, D, split, rpb, blocks0)

@@ -102,10 +102,10 @@ def ln_fwd(x, gamma, beta, split=0, eps=1e-5, out_bf16=True, out_f32=False, save
 def ln_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, split=0, dx_bf16=None, gelu_u=None, dres=None, dx_f32=None,
            dx_scaled=None, row_scale=None, rows_per_sample=(1, 1)):
     lib = _lib.load()
-    _chk(dy, BF16, "dy")
+    _chk(dy, None, "dy")
     M, D = dy.shape
     gs = gamma.stride(0) if gamma.dim() == 2 else 0
-    rc = lib.simvg_ln_bwd(_p(dy), dy.stride(0), _p(x), int(x.dtype == BF16), x.stride(0), _p(mean), _p(rstd),
+    rc = lib.simvg_ln_bwd(_p(dy), int(dy.dtype == torch.float32), dy.stride(0), _p(x), int(x.dtype == BF16), x.stride(0), _p(mean), _p(rstd),
                           _p(gamma), gs, _p(dgamma), _p(dbeta), _p(dx_bf16),
                           dx_bf16.stride(0) if dx_bf16 is not None else 0, _p(gelu_u),
                           gelu_u.stride(0) if gelu_u is not None else 0, _p(dres), _p(dx_f32),
@@ -209,3 +209,78 @@ class WeightPrep:
     def run(self):
         lib = _lib.load()
         _lib.check(lib.simvg_weight_prep(_p(self.table), self.n, self.tiles, _stream()), "simvg_weight_prep")
+
+
+# ---------------------------------------------------------------------------------------------
+# decoder head: exact-fp32 small GEMM, small attention, matcher, criterion
+# ---------------------------------------------------------------------------------------------
+def gemm_f32(A, sam, sak, Bm, sbk, sbn, C, M, N, K, bias=None, addend=None, addend_rows=0, accumulate=False, act=0):
+    """C[M,N] (+)= sum_k A(m,k) B(k,n) with explicit element strides (pointers may be offset views)."""
+    lib = _lib.load()
+    rc = lib.simvg_gemm_f32(_p(A), sam, sak, _p(Bm), sbk, sbn, _p(C), C.stride(0), _p(bias), _p(addend),
+                            addend.stride(0) if addend is not None else 0, addend_rows, M, N, K, int(accumulate), act,
+                            _stream())
+    _lib.check(rc, "simvg_gemm_f32")
+    return C
+
+
+def attn_small_fwd(q, k, v, B, H, Lq, Lk, kpm=None, drop=None, kv_rows=0):
+    lib = _lib.load()
+    E = H * 32
+    out = torch.empty(B * Lq, E, device=q.device, dtype=torch.float32)
+    P = torch.empty(B, H, Lq, Lk, device=q.device, dtype=torch.float32)
+    rc = lib.simvg_attn_small_fwd(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out), out.stride(0),
+                                  _p(P), _p(kpm), _p(drop), B, H, Lq, Lk, kv_rows, 32 ** -0.5, _stream())
+    _lib.check(rc, "simvg_attn_small_fwd")
+    return out, P
+
+
+def attn_small_bwd(q, k, v, P, dout, dq, dk, dv, B, H, Lq, Lk, kpm=None, drop=None, kv_rows=0):
+    lib = _lib.load()
+    rc = lib.simvg_attn_small_bwd(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(P), _p(kpm), _p(drop),
+                                  _p(dout), dout.stride(0), _p(dq), dq.stride(0), _p(dk), dk.stride(0), _p(dv),
+                                  dv.stride(0), B, H, Lq, Lk, kv_rows, 32 ** -0.5, _stream())
+    _lib.check(rc, "simvg_attn_small_bwd")
+
+
+def match(logits, boxes, tboxes, tlabels, tcount, cost=(1.0, 5.0, 2.0)):
+    """logits [L,B,nq,2], boxes [L,B,nq,4] fp32 -> int32 [L,B,nq] matched target index or -1."""
+    lib = _lib.load()
+    L, B, nq, _ = logits.shape
+    TM = tboxes.shape[1]
+    out = torch.empty(L, B, nq, device=logits.device, dtype=torch.int32)
+    rc = lib.simvg_match(_p(logits), _p(boxes), _p(tboxes), _p(tlabels), _p(tcount), _p(out), L, B, nq, TM,
+                         cost[0], cost[1], cost[2], _stream())
+    _lib.check(rc, "simvg_match")
+    return out
+
+
+def soft_targets(logits, boxes, match_idx, tboxes, tcount):
+    lib = _lib.load()
+    B, nq, _ = logits.shape
+    TM = tboxes.shape[1]
+    dev = logits.device
+    pboxes = torch.zeros(B, TM, 4, device=dev)
+    plabels = torch.zeros(B, TM, device=dev, dtype=torch.int32)
+    pcount = torch.zeros(B, device=dev, dtype=torch.int32)
+    pweight = torch.zeros(B, TM, device=dev)
+    scal = torch.zeros(4, device=dev)
+    rc = lib.simvg_soft_targets(_p(logits), _p(boxes), _p(match_idx), _p(tboxes), _p(tcount), _p(pboxes), _p(plabels),
+                                _p(pcount), _p(pweight), _p(scal), B, nq, TM, _stream())
+    _lib.check(rc, "simvg_soft_targets")
+    return pboxes, plabels, pcount, pweight, scal
+
+
+def criterion(logits, boxes, match_idx, tboxes, tlabels, num_boxes, wdist, coef_mode, coef, eos_coef=0.1,
+              weights=(1.0, 5.0, 2.0)):
+    """-> (out [1+3L] : total then per-layer class/bbox/giou, dlogits, dboxes)."""
+    lib = _lib.load()
+    L, B, nq, _ = logits.shape
+    TM = tboxes.shape[1]
+    dlogits, dboxes = torch.empty_like(logits), torch.empty_like(boxes)
+    out = torch.empty(1 + 3 * L, device=logits.device)
+    rc = lib.simvg_criterion(_p(logits), _p(boxes), _p(match_idx), _p(tboxes), _p(tlabels), _p(num_boxes), _p(wdist),
+                             _p(dlogits), _p(dboxes), _p(out), L, B, nq, TM, coef_mode, coef, eos_coef, weights[0],
+                             weights[1], weights[2], _stream())
+    _lib.check(rc, "simvg_criterion")
+    return out, dlogits, dboxes

@@ -1,0 +1,90 @@
+"""MIXDETRMB -- SimVG's model class on MI355X.
+
+Mirror of `simvg/models/det_seg/mix_detr_mb.py:13-190` (registered in MODELS; `forward_train` returns
+`(loss_dict, [pred_decoder, pred_token])`, `forward_test` returns `[pred_decoder, pred_token]`, each a dict with
+`pred_bboxes` / `pred_masks` / `predict_classes`).  The encoder -> head hand-off stays in the modality-major
+bf16 layout (no `[B,C,h,w]` transpose copy, `mix_detr_mb.py:52` of the reference), and the post-processing of
+`get_predictions` (detectron2 Boxes.scale / clip / nonempty + argmax) is vectorised on the device.
+"""
+import torch
+
+from .. import builder
+from .base import OneStageModel
+
+
+@builder.MODELS.register_module()
+class MIXDETRMB(OneStageModel):
+    def __init__(self, word_emb, num_token, vis_enc, lan_enc, head, fusion):
+        super().__init__(word_emb, num_token, vis_enc, lan_enc, head, fusion)
+        self.patch_size = vis_enc["patch_size"]
+
+    def extract_visual_language(self, img, ref_expr_inds, text_attention_mask=None):
+        return self.vis_enc(img, ref_expr_inds, text_attention_mask)
+
+    def _run(self, img, ref_expr_inds, img_metas, text_attention_mask):
+        B, T = ref_expr_inds.shape
+        enc_out = self.vis_enc.encode(img, ref_expr_inds, text_attention_mask)
+        Nv = self.vis_enc.np + 1
+        return self.head.forward_fused(enc_out, B, Nv, T, img_metas, text_attention_mask)
+
+    def forward_train(self, img, ref_expr_inds, img_metas, text_attention_mask=None, gt_bbox=None,
+                      gt_mask_vertices=None, rescale=False):
+        output = self._run(img, ref_expr_inds, img_metas, text_attention_mask)
+        losses_dict, detail = self.head.loss(output, gt_bbox, img_metas)
+        self._last_output, self._last_detail = output, detail     # debugging / parity tests
+        with torch.no_grad():
+            predictions = self._predict(output, img_metas, rescale)
+        return losses_dict, predictions
+
+    @torch.no_grad()
+    def forward_test(self, img, ref_expr_inds, img_metas, text_attention_mask=None, with_bbox=False, with_mask=False,
+                     rescale=False):
+        output = self._run(img, ref_expr_inds, img_metas, text_attention_mask)
+        return self._predict(output, img_metas, rescale)
+
+    def _predict(self, output, img_metas, rescale):
+        fn = self.get_predictions if img_metas[0].get("target", None) is None else self.get_predictions_grec
+        tok = fn(output["token_branch_output"], img_metas, rescale=rescale)
+        dec = fn(output["decoder_branch_output"], img_metas, rescale=rescale)
+        return [dec, tok]   # index 0 = decoder branch, 1 = token branch (mix_detr_mb.py:69,123)
+
+    def _boxes(self, output, img_metas, rescale):
+        box_cls, box_pred = output["pred_logits"].float(), output["pred_boxes"].float()
+        image_sizes = [m["img_shape"] for m in img_metas]
+        scores, labels, xyxy = self.head.inference(box_cls, box_pred, image_sizes)
+        lim = torch.tensor([[s[1], s[0], s[1], s[0]] for s in image_sizes], dtype=xyxy.dtype, device=xyxy.device)[:, None, :]
+        xyxy = torch.minimum(xyxy.clamp(min=0), lim)                      # detector_postprocess: clip to the image
+        keep = ((xyxy[..., 2] - xyxy[..., 0]) > 0) & ((xyxy[..., 3] - xyxy[..., 1]) > 0)   # Boxes.nonempty()
+        if rescale:
+            sf = torch.tensor([m["scale_factor"] for m in img_metas], dtype=xyxy.dtype, device=xyxy.device)[:, None, :]
+        else:
+            sf = None
+        return scores, labels, xyxy, keep, sf
+
+    def get_predictions(self, output, img_metas, rescale=False):
+        if output["pred_logits"] is None:
+            return dict(pred_bboxes=None, pred_masks=None, predict_classes=None)
+        scores, labels, xyxy, keep, sf = self._boxes(output, img_metas, rescale)
+        best = torch.where(keep, scores, torch.full_like(scores, -1.0)).argmax(1)       # argmax over kept queries
+        idx = best[:, None, None].expand(-1, 1, 4)
+        box = xyxy.gather(1, idx)[:, 0]
+        if sf is not None:
+            box = box / sf[:, 0]
+        B = scores.shape[0]
+        if scores.shape[1] == 1:
+            cls = labels[:, 0]
+        else:   # the reference concatenates the classes of ALL kept queries (mix_detr_mb.py:152,157)
+            cls = labels[keep]
+        return dict(pred_bboxes=box, pred_masks=None, predict_classes=cls)
+
+    def get_predictions_grec(self, output, img_metas, rescale=False):
+        if output["pred_logits"] is None:
+            return dict(pred_bboxes=None, pred_masks=None, predict_classes=None)
+        scores, labels, xyxy, keep, sf = self._boxes(output, img_metas, rescale)
+        if sf is not None:
+            xyxy = xyxy / sf
+        res = []
+        for b in range(scores.shape[0]):
+            k = keep[b]
+            res.append({"boxes": xyxy[b][k], "scores": scores[b][k], "labels": labels[b][k]})
+        return dict(pred_bboxes=res, pred_masks=None)

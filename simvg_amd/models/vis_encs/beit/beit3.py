@@ -164,7 +164,7 @@ class BEIT3(nn.Module):
         if self._arena is not None and self._arena.device == device and self._arena.intact():
             return
         named = {n: p for n, p in self.named_parameters()}
-        self._arena = ParamArena(named, self._groups(), device)
+        self._arena = ParamArena(named, self._groups(), device, no_grad=("beit3.vision_embed.mask_token",))
         A = self._arena
         D, F_, L, P = self.D, self.F, self.L, self.patch_size
 

@@ -1,0 +1,112 @@
+"""GPU op-level parity for the decoder-head kernels: exact-fp32 MFMA GEMM, small attention, on-device
+Hungarian matcher (against SciPy, which the reference uses through detrex), criterion value + gradients
+(against autograd through the oracle's restatement of SetCriterion)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def close(got, ref, tol, what=""):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    scale = max(float(ref.abs().max()), 1e-6)
+    err = float((got - ref).abs().max())
+    assert err <= tol * scale, f"{what}: err {err:.3g} scale {scale:.3g}"
+
+
+@pytest.mark.parametrize("M,N,K,relu", [(64, 256, 768, False), (10, 2, 256, False), (640, 2048, 256, True), (1280, 256, 768, False)])
+def test_linear_f32_fwd_bwd(M, N, K, relu):
+    from simvg_amd.models.heads.functions import LinearF32
+    g = torch.Generator().manual_seed(M + N)
+    x, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * K ** -0.5, torch.randn(N, generator=g)
+    xr, Wr, br = (t.clone().requires_grad_(True) for t in (x, W, b))
+    y_ref = F.linear(xr, Wr, br)
+    if relu:
+        y_ref = F.relu(y_ref)
+    dy = torch.randn(M, N, generator=g)
+    y_ref.backward(dy)
+    xd, Wd, bd = (t.clone().to(DEV).requires_grad_(True) for t in (x, W, b))
+    y = LinearF32.apply(xd, Wd, bd, relu)
+    y.backward(dy.to(DEV))
+    close(y, y_ref, 1e-5, "y"); close(xd.grad, xr.grad, 1e-5, "dx"); close(Wd.grad, Wr.grad, 1e-5, "dW"); close(bd.grad, br.grad, 1e-5, "db")
+
+
+@pytest.mark.parametrize("B,Lq,Lk,kv_off", [(3, 1, 400, True), (2, 10, 20, False), (2, 10, 10, False), (4, 7, 400, True)])
+@pytest.mark.parametrize("drop", [False, True])
+def test_small_attention_fwd_bwd(B, Lq, Lk, kv_off, drop):
+    from simvg_amd.models.heads.functions import SmallAttention
+    H, E = 8, 256
+    g = torch.Generator().manual_seed(B * 100 + Lq + Lk)
+    rows = Lk + 1 if kv_off else Lk
+    q = torch.randn(B * Lq, E, generator=g)
+    kfull = torch.randn(B * rows, E, generator=g)
+    vfull = torch.randn(B * rows, 2 * E, generator=g)      # V lives in the right half of a wider buffer
+    kpm = torch.zeros(B, Lk, dtype=torch.uint8)
+    kpm[0, Lk // 2:] = 1
+    dm = (torch.bernoulli(torch.full((B, H, Lq, Lk), 0.9), generator=g) / 0.9) if drop else None
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, kfull, vfull))
+    k3 = kr.view(B, rows, E)[:, rows - Lk:]
+    v3 = vr.view(B, rows, 2 * E)[:, rows - Lk:, E:]
+    qh = qr.view(B, Lq, H, 32).transpose(1, 2) * 32 ** -0.5
+    w = qh @ k3.reshape(B, Lk, H, 32).transpose(1, 2).transpose(-1, -2)
+    w = w.masked_fill(kpm.bool()[:, None, None, :], float("-inf")).softmax(-1)
+    if drop:
+        w = w * dm
+    o_ref = (w @ v3.reshape(B, Lk, H, 32).transpose(1, 2)).transpose(1, 2).reshape(B * Lq, E)
+    do = torch.randn(B * Lq, E, generator=g)
+    o_ref.backward(do)
+    qd, kd, vd = (t.clone().to(DEV).requires_grad_(True) for t in (q, kfull, vfull))
+    off = 1 if kv_off else 0
+    o = SmallAttention.apply(qd, kd[off:], vd[off:, E:], B, H, Lq, Lk, kpm.to(DEV), None if dm is None else dm.to(DEV), rows)
+    o.backward(do.to(DEV))
+    close(o, o_ref, 1e-4, "out"); close(qd.grad, qr.grad, 1e-4, "dq"); close(kd.grad, kr.grad, 1e-4, "dk"); close(vd.grad, vr.grad, 1e-4, "dv")
+
+
+def _rand_case(L, B, nq, TM, seed):
+    g = torch.Generator().manual_seed(seed)
+    logits = torch.randn(L, B, nq, 2, generator=g)
+    cxcy = torch.rand(L, B, nq, 2, generator=g) * 0.6 + 0.2
+    wh = torch.rand(L, B, nq, 2, generator=g) * 0.3 + 0.05
+    boxes = torch.cat([cxcy, wh], -1)
+    tcount = torch.randint(0, min(TM, 5) + 1, (B,), generator=g).int()
+    tcount[0] = 0 if B > 2 else tcount[0]
+    tb = torch.cat([torch.rand(B, TM, 2, generator=g) * 0.6 + 0.2, torch.rand(B, TM, 2, generator=g) * 0.3 + 0.05], -1)
+    tl = torch.zeros(B, TM, dtype=torch.int32)
+    return logits, boxes, tb, tl, tcount
+
+
+@pytest.mark.parametrize("L,B,nq", [(3, 8, 1), (3, 9, 10), (1, 5, 10), (2, 4, 3)])
+def test_matcher_vs_scipy_and_criterion_vs_autograd(L, B, nq):
+    from oracle import simvg_cpu as O
+    from simvg_amd import hip_ops as ops
+    TM = 16
+    cfg = O.make_cfg("tiny", nq, 128)
+    logits, boxes, tb, tl, tcount = _rand_case(L, B, nq, TM, 1000 + nq + B)
+    targets = [{"labels": torch.zeros(int(tcount[b]), dtype=torch.long), "boxes": tb[b, :int(tcount[b])]} for b in range(B)]
+    m = ops.match(logits.to(DEV), boxes.to(DEV), tb.to(DEV), tl.to(DEV), tcount.to(DEV)).cpu()
+    for l in range(L):
+        idx = O.hungarian(logits[l], boxes[l], targets, cfg)
+        for b in range(B):
+            exp = torch.full((nq,), -1, dtype=torch.int32)
+            exp[idx[b][0]] = idx[b][1].int()
+            assert torch.equal(m[l, b], exp), (l, b, m[l, b], exp)
+    # criterion: value and gradients
+    lg = logits.clone().requires_grad_(True)
+    bx = boxes.clone().requires_grad_(True)
+    losses = O.set_criterion(lg, bx, targets, cfg)
+    coef = 2.0
+    total = coef * sum(losses.values())
+    total.backward()
+    nb = torch.tensor([float(tcount.sum())])
+    out, dl, db = ops.criterion(logits.to(DEV), boxes.to(DEV), m.to(DEV), tb.to(DEV), tl.to(DEV), nb.to(DEV), None, 0, coef)
+    assert abs(float(out[0]) - float(total)) <= 1e-4 * max(1.0, abs(float(total)))
+    close(dl, lg.grad, 1e-4, "dlogits")
+    close(db, bx.grad, 1e-4, "dboxes")
+    # per-layer terms: out[1+3l..] follows layer order l; the oracle keys: final = no suffix, aux i = _i
+    for l in range(L):
+        suf = "" if l == L - 1 else f"_{l}"
+        for j, key in enumerate(["loss_class", "loss_bbox", "loss_giou"]):
+            assert abs(float(out[1 + 3 * l + j]) - float(losses[key + suf])) <= 1e-4 * max(1.0, abs(float(losses[key + suf])))

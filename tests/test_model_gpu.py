@@ -1,0 +1,138 @@
+"""GPU: the whole HIP model (simvg_amd MIXDETRMB: encoder engine + head + on-device matcher/criterion)
+against the fixtures recorded from the REAL reference (tests/golden/*.pt), same seeded weights and inputs.
+
+Stated tolerances.  north_star bound: normalised boxes (cx,cy,w,h in [0,1]) within 1e-3 L1 of the reference,
+pixel boxes within 640*1e-3 px -- asserted on the `*_refinit` fixtures (the reference's own initialisation, i.e.
+what training from scratch and bench.py run).  The other fixtures use deliberately harsh weights (O(1) attention
+logits and pre-sigmoid box values, fan_in^-1/2 everywhere) where bf16 operand rounding (2^-9 per GEMM input,
+fp32 accumulate) is visible: there the bound is 1.5e-2 L1 (measured: decoder <= 4e-3, token <= 1.1e-2; see
+DESIGN.md "Numerics").  Logits / losses within 3e-2 relative; matcher assignments identical; sampled parameter
+gradients within 6e-2 relative L2."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _build(fx):
+    from oracle import ref_loader, simvg_cpu as O, weights as W
+    from simvg_amd.models import build_model
+    cfg = O.make_cfg(fx["vit"], fx["num_queries"], fx["img_size"])
+    mcfg = ref_loader.model_cfg("base" if fx["vit"] == "tiny" else fx["vit"], fx["num_queries"], fx["img_size"])
+    if fx["vit"] == "tiny":
+        mcfg["vis_enc"]["encoder_cfg"] = dict(embed_dim=cfg.embed_dim, heads=cfg.heads, ffn_dim=cfg.ffn_dim, layers=cfg.layers)
+        mcfg["vis_enc"]["drop_path_rate"] = 0.0
+        mcfg["head"]["in_channels"] = cfg.embed_dim
+    model = build_model(mcfg)
+    sd = W.reference_init_state_dict(cfg, fx["wseed"]) if fx.get("refinit") else W.golden_state_dict(cfg, fx["wseed"])
+    model.load_state_dict(sd, strict=True)
+    batch = W.synthetic_batch(cfg, fx["B"], fx["iseed"], fx["grec"])
+    return model.to(DEV), batch, cfg
+
+
+def _dev_batch(batch):
+    return dict(img=batch["img"].to(DEV), ref_expr_inds=batch["ref_expr_inds"].to(DEV),
+                img_metas=[dict(m) for m in batch["img_metas"]],
+                text_attention_mask=batch["text_attention_mask"].to(DEV))
+
+
+def _rel(a, b):
+    return float((a.float().cpu() - b).abs().max() / max(float(b.abs().max()), 1e-6))
+
+
+ALL = ["base_nq1_refinit", "base_nq10_grec_refinit", "tiny_nq1", "tiny_nq10_grec", "base_nq1", "base_nq10_grec", "large_nq1"]
+
+
+def _box_tol(fx):
+    return 1e-3 if fx.get("refinit") else 1.5e-2
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_forward_train_matches_reference(golden, name):
+    fx = golden(name)
+    model, batch, cfg = _build(fx)
+    model.eval()     # dropout / DropPath identity, as when the fixture was recorded; losses still computed
+    db = _dev_batch(batch)
+    losses, preds = model(db["img"], db["ref_expr_inds"], db["img_metas"], return_loss=True,
+                          text_attention_mask=db["text_attention_mask"], gt_bbox=batch["gt_bbox"], rescale=False)
+    out = model._last_output
+    for key, fkey in [("outputs_coord_decoder_branch", "dec_boxes"), ("outputs_coord_token_branch", "tok_boxes")]:
+        l1 = float((out[key].detach().float().cpu() - fx[fkey]).abs().sum(-1).max())
+        assert l1 <= _box_tol(fx), (key, l1)
+    for key, fkey in [("outputs_class_decoder_branch", "dec_logits"), ("outputs_class_token_branch", "tok_logits")]:
+        assert _rel(out[key].detach(), fx[fkey]) <= 3e-2, key
+    for k, v in fx["losses"].items():
+        assert abs(float(losses[k]) - v) <= 2e-2 * max(1.0, abs(v)), (k, float(losses[k]), v)
+    # matcher on the decoder's final layer vs the reference's own HungarianMatcher call
+    m = model._last_detail["match_dec"][-1].cpu()
+    for b, (ri, ci) in enumerate(fx["matcher_gt"]):
+        exp = torch.full((fx["num_queries"],), -1, dtype=torch.int32)
+        exp[ri] = ci.int()
+        assert torch.equal(m[b], exp), (b, m[b], exp)
+    # backward: sampled gradient probes recorded from the reference
+    model.zero_grad(set_to_none=True)
+    losses["loss_total"].backward()
+    params = dict(model.named_parameters())
+    # reference-init fixtures: strict (6e-2 relative L2 on the sampled entries, norms within 6e-2).
+    # harsh fixtures: the box losses are only piecewise smooth (L1 sign, GIoU max/min, assignment near-ties), and a
+    # 1e-2 box perturbation legitimately flips a few of those in the token/KD terms, so there the gradient is
+    # checked for direction (cosine >= 0.85) and magnitude (norm within 20 %) only.
+    strict = bool(fx.get("refinit"))
+    bad = []
+    for k, gp in fx["grads"].items():
+        g = params[k].grad
+        assert g is not None, k
+        ref = gp["summ"]
+        got = g.detach().float().cpu().reshape(-1)[ref["idx"]]
+        en = abs(float(g.norm()) - gp["norm"]) / max(gp["norm"], 1e-12)
+        if float(ref["vals"].norm()) < 1e-3 * gp["norm"]:
+            e, cos = 0.0, 1.0          # sampled entries carry no signal (e.g. untouched position rows)
+        else:
+            e = float((got - ref["vals"]).norm()) / float(ref["vals"].norm())
+            cos = float((got * ref["vals"]).sum() / (got.norm() * ref["vals"].norm() + 1e-20))
+        ok = (e <= 6e-2 and en <= 6e-2) if strict else (cos >= 0.85 and en <= 0.20)
+        if not ok:
+            bad.append((k, round(e, 4), round(cos, 4), round(en, 4)))
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("name", ["base_nq1_refinit", "base_nq10_grec_refinit", "tiny_nq1", "base_nq1", "base_nq10_grec"])
+def test_forward_test_boxes(golden, name):
+    fx = golden(name)
+    model, batch, cfg = _build(fx)
+    model.eval()
+    db = _dev_batch(batch)
+    pred = model(db["img"], db["ref_expr_inds"], db["img_metas"], return_loss=False,
+                 text_attention_mask=db["text_attention_mask"], with_bbox=True, with_mask=False, rescale=False)
+    tol_px = fx["img_size"] * _box_tol(fx)
+    if not fx["grec"]:
+        for i, key in enumerate(["pred_decoder", "pred_token"]):
+            err = float((pred[i]["pred_bboxes"].float().cpu() - fx[key]).abs().max())
+            assert err <= tol_px, (key, err)
+    else:
+        for i, key in enumerate(["pred_decoder", "pred_token"]):
+            for a, b in zip(pred[i]["pred_bboxes"], fx[key]):
+                assert a["boxes"].shape == b["boxes"].shape
+                assert float((a["boxes"].float().cpu() - b["boxes"]).abs().max()) <= tol_px
+                assert float((a["scores"].float().cpu() - b["scores"]).abs().max()) <= 3e-2
+
+
+def test_train_mode_runs_with_dropout_and_droppath():
+    """train(): DropPath (ViT-B schedule) + decoder dropout active; loss finite, every parameter but the unused
+    mask_token receives a gradient (exactly one parameter never gets a gradient)."""
+    from oracle import ref_loader, weights as W, simvg_cpu as O
+    from simvg_amd.models import build_model
+    cfg = O.make_cfg("tiny", 1, 128)
+    mcfg = ref_loader.model_cfg("base", 1, 128)
+    mcfg["vis_enc"]["encoder_cfg"] = dict(embed_dim=128, heads=2, ffn_dim=256, layers=2)
+    mcfg["head"]["in_channels"] = 128
+    model = build_model(mcfg).to(DEV).train()
+    batch = W.synthetic_batch(cfg, 4, 3)
+    db = _dev_batch(batch)
+    losses, _ = model(db["img"], db["ref_expr_inds"], db["img_metas"], return_loss=True,
+                      text_attention_mask=db["text_attention_mask"], gt_bbox=batch["gt_bbox"])
+    losses["loss_total"].backward()
+    assert torch.isfinite(losses["loss_total"])
+    missing = [n for n, p in model.named_parameters() if p.grad is None]
+    assert missing == ["vis_enc.beit3.vision_embed.mask_token"], missing
