@@ -1,0 +1,213 @@
+#!/usr/bin/env python
+"""bench.py -- SimVG hot-path throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one full training step of MIXDETRMB (ViT-B/32 BEiT-3, 640x640 image + 20-token expression,
+num_queries=1, B = 64 per GPU, train mode: DropPath + decoder dropout) on synthetic RefCOCO-shape data already
+resident in HBM: forward_train (encoder + head + on-device matcher/criterion) -> zero_grad -> backward (+ RCCL
+all-reduce of the gradient arenas when N > 1) -> global-norm clip 0.15 -> Adam(amsgrad) -> bf16 weight refresh.
+Nothing is skipped inside the timed region.  Prints ONE JSON line on rank 0.
+
+Extra objects in the line:
+  roofline     : the dominant kernel (bf16 MFMA GEMM `gemm_nt_kernel`): algorithmic FLOPs of its launches divided by
+                 their HIP-event-measured durations (events recorded on the launch stream during the timed steps).
+  cpu_baseline : the CPU oracle (oracle/simvg_cpu.py, a restatement pinned to the reference) timed on the host
+                 cores of the same box on a bounded sample (rank 0, N == 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_PAIR_FWD_BWD = 241.33e9     # ViT-B/32 @640, nq=1, forward+backward
+MFMA_BF16_PEAK_TFLOPS = 2500.0       # gfx950 dense bf16 (MI355X_MICROARCH.md)
+
+
+def model_cfg(num_queries=1, vit="base"):
+    return dict(
+        type="MIXDETRMB",
+        vis_enc=dict(type="BEIT3", img_size=640, patch_size=32, vit_type=vit, drop_path_rate=0.1, vocab_size=64010,
+                     freeze_layer=-1, vision_embed_proj_interpolate=True, pretrain=None),
+        lan_enc=None, fusion=None,
+        head=dict(type="TextGuidedQuerySelectKDDETRHead", num_queries=num_queries, text_max_token=20,
+                  in_channels=768 if vit == "base" else 1024, embed_dim=256, decoder_freeze=False, num_classes=1,
+                  aux_loss=True, num_encoder_layers=6, num_decoder_layers=3, only_decoder=True, text_embed_aug=False,
+                  branch_loss_weight={"decoder": 1.0, "balanced_distill": {"token": 2.0, "distill": 1.0}},
+                  distill_type="hard_weighted", prepare_target_mode="score_iou_weighted", share_predicthead=False,
+                  num_token_mlp_layers=1, mlp_aux_loss=False, text_guided_query_generation=True, num_tgqg_layers=2))
+
+
+def synthetic_batch(B, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    S, T, V = 640, 20, 64010
+    img = torch.randn(B, 3, S, S, generator=g)
+    ids = torch.ones(B, T, dtype=torch.int64)
+    pad = torch.ones(B, T, dtype=torch.int64)
+    for b in range(B):
+        m = int(torch.randint(2, 11, (1,), generator=g))
+        ids[b, 0] = 0
+        ids[b, 1:1 + m] = torch.randint(4, V, (m,), generator=g)
+        ids[b, 1 + m] = 2
+        pad[b, :m + 2] = 0
+    xy = torch.rand(B, 2, generator=g) * 400
+    wh = 32 + torch.rand(B, 2, generator=g) * 208
+    gt = torch.cat([xy, xy + wh], 1).to(device)
+    metas = [dict(img_shape=(S, S, 3), pad_shape=(S, S, 3), ori_shape=(S, S, 3), scale_factor=[1.0] * 4,
+                  filename=f"synthetic_{b}.jpg", expression="synthetic") for b in range(B)]
+    return dict(img=img.to(device), ref_expr_inds=ids.to(device), text_attention_mask=pad.to(device), img_metas=metas,
+                gt_bbox=[gt[b] for b in range(B)])
+
+
+def cpu_baseline(batch_size=2, max_threads=32):
+    """The oracle's training step (forward_train + backward + clip + Adam amsgrad) on the host cores.
+    Bounded sample: the thread count is capped (eager PyTorch on hundreds of threads is slower, not faster, for the
+    ~1400 small ops of this model -- measured 678 s/step with 256 threads) and one B=2 step is timed."""
+    from oracle import simvg_cpu as O, weights as W
+    torch.set_num_threads(max(1, min(os.cpu_count() or 1, max_threads)))
+    cfg = O.make_cfg("base", 1, 640)
+    sd = W.reference_init_state_dict(cfg, 1)
+    params = {k: v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "empty_weight" not in k}
+    sd.update(params)
+    opt = torch.optim.Adam(list(params.values()), lr=5e-4, betas=(0.9, 0.98), eps=1e-9, amsgrad=True)
+
+    def step(B, seed):
+        b = W.synthetic_batch(cfg, B, seed)
+        losses, _, _ = O.forward_train(sd, cfg, b["img"], b["ref_expr_inds"], b["img_metas"], b["text_attention_mask"], b["gt_bbox"])
+        opt.zero_grad()
+        losses["loss_total"].backward()
+        torch.nn.utils.clip_grad_norm_(list(params.values()), 0.15)
+        opt.step()
+
+    step(1, 0)                    # untimed warm-up (allocator, MKL threads, Adam state)
+    t0 = time.perf_counter()
+    step(batch_size, 1)
+    dt = time.perf_counter() - t0
+    return dict(value=round(batch_size / dt, 4), unit="pairs/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"1 training step (fwd+bwd+clip+Adam amsgrad), ViT-B/32 @640, B={batch_size}, fp32, {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE: 64)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="per-op HIP-event breakdown on stderr")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    import torch.distributed as dist
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+    from simvg_amd.models import build_model
+    from simvg_amd.dist import GradReducer
+    from simvg_amd.optim import FlatAdam
+    from simvg_amd import hip_ops
+
+    torch.manual_seed(1234)
+    model = build_model(model_cfg()).to(device).train()
+    if world > 1:   # identical replicas
+        for p in model.parameters():
+            dist.broadcast(p.data, 0)
+    B = a.batch
+    batch = synthetic_batch(B, 1000 + rank, device)
+    model.vis_enc._ensure_engine(device)
+    opt = FlatAdam(model, lr=5e-4, max_norm=0.15)
+    reducer = GradReducer(model)
+
+    def step():
+        losses, _ = model(batch["img"], batch["ref_expr_inds"], batch["img_metas"], return_loss=True,
+                          text_attention_mask=batch["text_attention_mask"], gt_bbox=batch["gt_bbox"], rescale=False)
+        opt.zero_grad()
+        reducer.begin()
+        losses["loss_total"].backward()
+        reducer.finish()
+        opt.step()
+        return losses
+
+    for _ in range(a.warmup):
+        step()
+    timer = hip_ops.KernelTimer(only=None if a.breakdown else {"gemm_nt"}) if rank == 0 else None
+    hip_ops.set_timer(timer)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        losses = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    hip_ops.set_timer(None)
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    loss_val = float(losses["loss_total"])
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    pairs = world * B * a.steps
+    value = pairs / dt
+    summ = timer.summary()
+    g = summ["gemm_nt"]
+    ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "gemm_nt_hbm_traffic.json")
+    if os.path.exists(tfile):
+        try:
+            traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "image-text pairs/sec (whole node), RefCOCO 640x640 bs=64/GPU, 1/2/4/8 MI355X",
+        "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "ViT-B/32 SimVG (MIXDETRMB), synthetic RefCOCO 640x640 + 20-token expr, num_queries=1, "
+                               "full training step: forward+backward bf16 (fp32 accumulate, fp32 residual/master), "
+                               "DropPath+dropout on, clip 0.15, Adam(amsgrad)",
+                   "global_batch": world * B, "per_gpu_batch": B, "tokens_per_pair": 421,
+                   "parallelism": f"dp{world}", "loss_total": round(loss_val, 4)},
+        "model_tflops_per_gpu": round(value / world * FLOP_PER_PAIR_FWD_BWD / 1e12, 2),
+        "model_mfma_frac": round(value / world * FLOP_PER_PAIR_FWD_BWD / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+        "roofline": {"kernel": "gemm_nt_kernel (bf16 MFMA 16x16x32, 128x128x64 tile)", "bound": "mfma",
+                     "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
+                     "launches": g["calls"], "avg_launch_us": round(g["ms"] / g["calls"] * 1e3, 2),
+                     "share_of_step": round(g["ms"] / (dt * 1e3), 4)},
+    }
+    if a.breakdown:
+        tot = dt * 1e3
+        for k, d in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
+            tf = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["flops"] else 0.0
+            gb = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+            print(f"[breakdown] {k:10s} calls/step {d['calls'] / a.steps:7.1f}  ms/step {d['ms'] / a.steps:8.3f} "
+                  f"({100 * d['ms'] / tot:5.1f} %)  {tf:8.1f} TFLOP/s  {gb:8.1f} GB/s(algorithmic)", file=sys.stderr)
+    if world == 1 and not a.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline()
+        except Exception as e:   # the oracle is a checker; never let it take the GPU number down
+            out["cpu_baseline"] = {"error": repr(e)}
+    if world > 1:
+        dist.destroy_process_group()
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,70 @@
+"""Data-parallel gradient reduction for the MI355X hot path: one process per GPU, RCCL over xGMI through
+`torch.distributed` (backend "nccl" == RCCL on ROCm; "gloo" in the CPU tests).
+
+Replaces the reference's `MMDistributedDataParallel(find_unused_parameters=True)` (tools/train.py:102-104, C2 in
+SURVEY.md 2.4).  MI355X-first: gradients already live in flat fp32 arenas, so the exchange is a handful of large
+contiguous all-reduces -- one per encoder layer, issued asynchronously from inside the hand-sequenced backward the
+moment that layer's wgrads are written (overlapping the remaining backward), then one for the embeddings and one
+for the head.  No per-tensor buckets, no unused-parameter search.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradReducer:
+    def __init__(self, model, bucket_bytes=None):
+        self.model = model
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.pending = []
+        self.enc = getattr(model, "vis_enc", None)
+        self._done_layers = set()
+        if self.enc is not None:
+            self.enc._grad_ready_hook = self._on_layer_done
+
+    # called by BEIT3._engine_backward after layer i (i = L-1 .. 0), then with -1 after the embedding stage
+    def _on_layer_done(self, i):
+        if self.world == 1:
+            return
+        A = self.enc._arena
+        if i >= 0:
+            lo, hi = A.slice_of(self.enc.layer_param_names(i))
+            self._launch(A.flat_grad[lo:hi])
+            self._done_layers.add(i)
+        else:
+            # everything that is not a layer slice: embeddings, position tables, final LayerNorm
+            spans = sorted(A.slice_of(self.enc.layer_param_names(l)) for l in range(self.enc.L))
+            cur = 0
+            for lo, hi in spans:
+                if lo > cur:
+                    self._launch(A.flat_grad[cur:lo])
+                cur = max(cur, hi)
+            if cur < A.total:
+                self._launch(A.flat_grad[cur:])
+
+    def _launch(self, t):
+        if t.numel():
+            self.pending.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
+            self._scale.append(t)
+
+    def begin(self):
+        self.pending, self._scale = [], []
+
+    def finish(self):
+        """Call after loss.backward(): reduces the head gradients, waits for everything, averages."""
+        if self.world == 1:
+            return
+        head = [p for n, p in self.model.named_parameters() if not n.startswith("vis_enc.") and p.grad is not None]
+        if head:
+            flat = torch.cat([p.grad.reshape(-1) for p in head])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            flat.div_(self.world)
+            off = 0
+            for p in head:
+                n = p.numel()
+                p.grad.copy_(flat[off:off + n].view_as(p.grad))
+                off += n
+        for w in self.pending:
+            w.wait()
+        for t in self._scale:
+            t.div_(self.world)
+        self.pending, self._scale = [], []

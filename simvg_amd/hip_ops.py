@@ -11,6 +11,45 @@ from . import _lib
 
 BF16 = torch.bfloat16
 
+# optional per-launch timing (bench.py): an object with .add(name, ev_start, ev_end, flops, bytes)
+_timer = None
+
+
+def set_timer(t):
+    global _timer
+    _timer = t
+
+
+class KernelTimer:
+    """HIP-event brackets around individual kernel launches, recorded on the launch stream."""
+
+    def __init__(self, only=None):
+        self.rec, self.only = [], only
+
+    def start(self, name):
+        if self.only is not None and name not in self.only:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def stop(self, name, e0, flops=0.0, nbytes=0.0):
+        if e0 is None:
+            return
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.rec.append((name, e0, e1, flops, nbytes))
+
+    def summary(self):
+        out = {}
+        for name, e0, e1, fl, nb in self.rec:
+            d = out.setdefault(name, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
+            d["calls"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += fl
+            d["bytes"] += nb
+        return out
+
 
 def _p(t):
     return None if t is None else C.c_void_p(t.data_ptr())
@@ -46,11 +85,14 @@ def gemm_nt(a, w, bias=None, out=None, out_dtype=BF16, split=0, act=0, aux_preac
         _chk(bias, torch.float32, "bias")
         if bias_group_stride is None:
             bias_group_stride = bias.stride(0) if bias.dim() == 2 else 0
+    t0 = _timer.start("gemm_nt") if _timer is not None else None
     rc = lib.simvg_gemm_nt(_p(a), a.stride(0), _p(w), w_group_stride, w.stride(-2), _p(bias), bias_group_stride or 0,
                            _p(out), out.stride(0), int(out.dtype == torch.float32),
                            _p(aux_preact), aux_preact.stride(0) if aux_preact is not None else 0,
                            _p(residual), residual.stride(0) if residual is not None else 0,
                            _p(row_scale), rows_per_sample[0], rows_per_sample[1], M, N, K, split, act, _stream())
+    if t0 is not None:
+        _timer.stop("gemm_nt", t0, 2.0 * M * N * K, 2.0 * (M * K + N * K) + out.element_size() * M * N)
     _lib.check(rc, "simvg_gemm_nt")
     return out
 
@@ -63,8 +105,11 @@ def gemm_tn(dy, x, dw, split=0, dw_group_stride=None):
     K = x.shape[1]
     if dw_group_stride is None:
         dw_group_stride = dw.stride(0) if dw.dim() == 3 else 0
+    t0 = _timer.start("gemm_tn") if _timer is not None else None
     rc = lib.simvg_gemm_tn(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), dw_group_stride, dw.stride(-2),
                            M, N, K, split, _stream())
+    if t0 is not None:
+        _timer.stop("gemm_tn", t0, 2.0 * M * N * K, 2.0 * M * (N + K) + 4.0 * N * K)
     _lib.check(rc, "simvg_gemm_tn")
     return dw
 
@@ -75,7 +120,10 @@ def colsum(y, out, split=0, out_group_stride=None):
     M, N = y.shape
     if out_group_stride is None:
         out_group_stride = out.stride(0) if out.dim() == 2 else 0
+    t0 = _timer.start("colsum") if _timer is not None else None
     rc = lib.simvg_colsum(_p(y), y.stride(0), _p(out), out_group_stride, M, N, split, _stream())
+    if t0 is not None:
+        _timer.stop("colsum", t0, 0.0, 2.0 * M * N)
     _lib.check(rc, "simvg_colsum")
     return out
 
@@ -92,9 +140,12 @@ def ln_fwd(x, gamma, beta, split=0, eps=1e-5, out_bf16=True, out_f32=False, save
         y32 = torch.empty(M, D, device=x.device, dtype=torch.float32)
     mean = torch.empty(M, device=x.device, dtype=torch.float32) if save_stats else None
     rstd = torch.empty(M, device=x.device, dtype=torch.float32) if save_stats else None
+    t0 = _timer.start("ln_fwd") if _timer is not None else None
     rc = lib.simvg_ln_fwd(_p(x), int(x.dtype == BF16), x.stride(0), _p(gamma), _p(beta), gs, _p(y),
                           y.stride(0) if y is not None else 0, _p(y32), y32.stride(0) if y32 is not None else 0,
                           _p(mean), _p(rstd), M, D, split, eps, _stream())
+    if t0 is not None:
+        _timer.stop("ln_fwd", t0, 0.0, float(M) * D * (x.element_size() + (2 if y is not None else 0) + (4 if y32 is not None else 0)))
     _lib.check(rc, "simvg_ln_fwd")
     return y, y32, mean, rstd
 
@@ -105,6 +156,7 @@ def ln_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, split=0, dx_bf16=None, gelu_
     _chk(dy, None, "dy")
     M, D = dy.shape
     gs = gamma.stride(0) if gamma.dim() == 2 else 0
+    t0 = _timer.start("ln_bwd") if _timer is not None else None
     rc = lib.simvg_ln_bwd(_p(dy), int(dy.dtype == torch.float32), dy.stride(0), _p(x), int(x.dtype == BF16), x.stride(0), _p(mean), _p(rstd),
                           _p(gamma), gs, _p(dgamma), _p(dbeta), _p(dx_bf16),
                           dx_bf16.stride(0) if dx_bf16 is not None else 0, _p(gelu_u),
@@ -112,6 +164,10 @@ def ln_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, split=0, dx_bf16=None, gelu_
                           dx_f32.stride(0) if dx_f32 is not None else 0, _p(dx_scaled),
                           dx_scaled.stride(0) if dx_scaled is not None else 0, _p(row_scale),
                           rows_per_sample[0], rows_per_sample[1], M, D, split, _stream())
+    if t0 is not None:
+        nb = dy.element_size() + x.element_size() + (2 if dx_bf16 is not None else 0) + (2 if gelu_u is not None else 0) \
+            + (4 if dres is not None else 0) + (4 if dx_f32 is not None else 0) + (2 if dx_scaled is not None else 0)
+        _timer.stop("ln_bwd", t0, 0.0, float(M) * D * nb)
     _lib.check(rc, "simvg_ln_bwd")
 
 
@@ -127,8 +183,11 @@ def attn_fwd(qkv, B, H, Nv, Nt, pad=None, out=None, scale=None):
     lse = torch.empty(B * H, N, device=qkv.device, dtype=torch.float32)
     if scale is None:
         scale = (D // H) ** -0.5
+    t0 = _timer.start("attn_fwd") if _timer is not None else None
     rc = lib.simvg_attn_fwd(_p(qkv), qkv.stride(0), _p(out), out.stride(0), _p(lse), _p(pad), B, H, Nv, Nt, D,
                             scale, _stream())
+    if t0 is not None:
+        _timer.stop("attn_fwd", t0, 4.0 * B * H * N * N * (D // H), 2.0 * M * 4 * D)
     _lib.check(rc, "simvg_attn_fwd")
     return out, lse
 
@@ -142,8 +201,11 @@ def attn_bwd(qkv, out, dout, lse, B, H, Nv, Nt, pad=None, dqkv=None, scale=None)
     delta = torch.empty_like(lse)
     if scale is None:
         scale = (D // H) ** -0.5
+    t0 = _timer.start("attn_bwd") if _timer is not None else None
     rc = lib.simvg_attn_bwd(_p(qkv), qkv.stride(0), _p(out), out.stride(0), _p(dout), dout.stride(0), _p(dqkv),
                             dqkv.stride(0), _p(lse), _p(delta), _p(pad), B, H, Nv, Nt, D, scale, _stream())
+    if t0 is not None:
+        _timer.stop("attn_bwd", t0, 10.0 * B * H * (Nv + Nt) ** 2 * (D // H), 2.0 * M * 8 * D)
     _lib.check(rc, "simvg_attn_bwd")
     return dqkv
 

@@ -196,7 +196,7 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
         srcs = [self._P("input_proj.weight")] + [self._P(f"transformer.decoder.layers.{i}.attentions.1.attn.in_proj_weight")
                                                 for i in range(self.num_decoder_layers)]
         version = tuple(p._version for p in srcs) + (srcs[0].data_ptr(),)
-        if self._prep is not None and version == self._prep_version:
+        if self._prep is not None and version == self._prep_version and not self.training:
             return
         if self._prep is None or self._prep_dev != device or self._prep_ptrs != [p.data_ptr() for p in srcs]:
             def bf(*s):
@@ -356,28 +356,34 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
 
     # ------------------------------------------------------------------ targets + losses (:207-268, 456-572)
     def _pack_targets(self, gt_bbox, img_metas, device):
-        """GT -> normalised cxcywh target arrays (drops category_id == -1 entries), built on the host from the
-        python list the data pipeline provides, one H2D copy."""
+        """GT -> normalised cxcywh target arrays (prepare_soft_targets :215-234; drops category_id == -1 entries).
+        Counts / indices come from host metadata (shapes, img_metas); the boxes themselves stay where they are
+        (CPU or HBM) and are packed with device ops -- no device-to-host synchronisation."""
         B, TM = len(gt_bbox), self.max_targets
-        boxes = torch.zeros(B, TM, 4)
-        count = torch.zeros(B, dtype=torch.int32)
-        gts = [g.detach().float().cpu() if torch.is_tensor(g) else torch.as_tensor(g, dtype=torch.float32) for g in gt_bbox]
-        for b, (tb, meta) in enumerate(zip(gts, img_metas)):
+        rows, dst, whwh, counts = [], [], [], []
+        for b, (tb, meta) in enumerate(zip(gt_bbox, img_metas)):
+            tb = tb if torch.is_tensor(tb) else torch.as_tensor(tb, dtype=torch.float32)
             h, w = meta["img_shape"][:2]
             if tb.dim() == 1:
                 tb = tb.unsqueeze(0)
+                keep = [0]
             else:
                 assert int(tb.shape[0]) == len(meta["target"])
                 keep = [i for i, t in enumerate(meta["target"]) if t["category_id"] != -1]
-                tb = tb[keep] if keep else tb[:0]
-            k = tb.shape[0]
-            if k > TM:
+            if len(keep) > TM:
                 raise ValueError(f"more than {TM} targets in one image")
-            if k:
-                t = tb / torch.tensor([w, h, w, h], dtype=torch.float32)
-                boxes[b, :k] = torch.stack([(t[:, 0] + t[:, 2]) / 2, (t[:, 1] + t[:, 3]) / 2, t[:, 2] - t[:, 0], t[:, 3] - t[:, 1]], -1)
-            count[b] = k
-        return boxes.to(device), torch.zeros(B, TM, dtype=torch.int32, device=device), count.to(device)
+            if keep:
+                rows.append(tb[keep].to(device=device, dtype=torch.float32, non_blocking=True))
+                dst += [b * TM + j for j in range(len(keep))]
+                whwh += [[w, h, w, h]] * len(keep)
+            counts.append(len(keep))
+        boxes = torch.zeros(B * TM, 4, device=device)
+        if rows:
+            t = torch.cat(rows, 0) / torch.tensor(whwh, dtype=torch.float32).to(device, non_blocking=True)
+            cx = torch.stack([(t[:, 0] + t[:, 2]) / 2, (t[:, 1] + t[:, 3]) / 2, t[:, 2] - t[:, 0], t[:, 3] - t[:, 1]], -1)
+            boxes[torch.tensor(dst, dtype=torch.long).to(device, non_blocking=True)] = cx
+        count = torch.tensor(counts, dtype=torch.int32).to(device, non_blocking=True)
+        return boxes.view(B, TM, 4), torch.zeros(B, TM, dtype=torch.int32, device=device), count
 
     def loss(self, output, gt_bbox, img_metas):
         dl, dbx = output["outputs_class_decoder_branch"], output["outputs_coord_decoder_branch"]

@@ -185,8 +185,10 @@ class BEIT3(nn.Module):
         self._anchor = torch.zeros(1, device=device, requires_grad=True)
 
     def _refresh_weights(self):
+        # training: the optimizer rewrites the arena every step -> always refresh (one launch, ~1.4 GB of traffic);
+        # eval: refresh only when the arena's version counter moved (load_state_dict, in-place edits)
         v = self._arena.flat._version
-        if v != self._prep_version:
+        if self.training or v != self._prep_version:
             self._prep.run()
             self._prep_version = v
 
