@@ -1,0 +1,80 @@
+"""CPU (gloo, world_size 2): the data-parallel exchange of simvg_amd.dist.GradReducer -- per-layer slices of the
+flat gradient arena + head gradients -- averages to exactly what a single process sees on the concatenated batch.
+The encoder engine itself needs a GPU, so a stand-in object exposes the same arena / hook surface."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _FakeEnc(torch.nn.Module):
+    """Same surface as BEIT3 for the reducer: _arena, L, layer_param_names(i), _grad_ready_hook."""
+
+    def __init__(self, L=3, D=8):
+        super().__init__()
+        self.L = L
+        self.beit3 = torch.nn.Module()
+        self.beit3.emb = torch.nn.Parameter(torch.zeros(5, D))
+        self.beit3.encoder = torch.nn.Module()
+        self.beit3.encoder.layers = torch.nn.ModuleList([torch.nn.Linear(D, D) for _ in range(L)])
+        self.beit3.encoder.layer_norm = torch.nn.LayerNorm(D)
+        from simvg_amd.arena import ParamArena
+        self._arena = ParamArena(dict(self.named_parameters()), [], "cpu")
+        self._grad_ready_hook = None
+
+    def layer_param_names(self, i):
+        return [n for n in self._arena.params if n.startswith(f"beit3.encoder.layers.{i}.")]
+
+
+class _FakeModel(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.vis_enc = _FakeEnc()
+        self.head = torch.nn.Linear(8, 2)
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from simvg_amd.dist import GradReducer
+    torch.manual_seed(0)
+    model = _FakeModel()
+    red = GradReducer(model)
+    A = model.vis_enc._arena
+    g = torch.Generator().manual_seed(100 + rank)
+    red.begin()
+    A.begin_backward()
+    A.flat_grad.copy_(torch.randn(A.total, generator=g))          # this rank's local gradients
+    model.head.weight.grad = torch.randn(2, 8, generator=g)
+    model.head.bias.grad = torch.randn(2, generator=g)
+    local = (A.flat_grad.clone(), model.head.weight.grad.clone(), model.head.bias.grad.clone())
+    for i in reversed(range(model.vis_enc.L)):                     # what BEIT3._engine_backward does
+        model.vis_enc._grad_ready_hook(i)
+    model.vis_enc._grad_ready_hook(-1)
+    red.finish()
+    gathered = [None] * world
+    dist.all_gather_object(gathered, local)
+    exp_flat = sum(x[0] for x in gathered) / world
+    exp_w = sum(x[1] for x in gathered) / world
+    ok = (torch.allclose(A.flat_grad, exp_flat, atol=1e-6) and torch.allclose(model.head.weight.grad, exp_w, atol=1e-6)
+          and all(torch.equal(p.grad, A.grad(n)) for n, p in A.params.items()))
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_world2_gloo():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}
