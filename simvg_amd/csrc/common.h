@@ -49,13 +49,28 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
 __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
   return (unsigned int)f32_to_bf16(lo) | ((unsigned int)f32_to_bf16(hi) << 16);
 }
+// exact-erf GELU (torch F.gelu default) with erf from Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. ~4 orders
+// below the bf16 rounding of the stored result) -- one v_exp + one v_rcp instead of the ~50-instruction libm erff;
+// the same exp(-x^2/2) also gives the Gaussian density that GELU' needs.
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+  const float e = __expf(-0.5f * x * x);                        // exp(-z^2)
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  const float erf_abs = 1.0f - poly * e;                         // erf(|x|/sqrt2)
+  const float h = 0.5f * erf_abs;
+  cdf = x >= 0.f ? 0.5f + h : 0.5f - h;
+  pdf = 0.39894228040143267794f * e;
+}
 __device__ __forceinline__ float gelu_erf(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+  float cdf, pdf;
+  gelu_parts(x, cdf, pdf);
+  return x * cdf;
 }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  float cdf, pdf;
+  gelu_parts(x, cdf, pdf);
+  return fmaf(x, pdf, cdf);
 }
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -10,6 +10,8 @@
 // Tile 128x128x64, 256 threads = 2x2 waves of 64x64, v_mfma_f32_16x16x32_bf16.
 // HBM->LDS by global_load_lds (16 B/lane, LDS image lane-linear, XOR swizzle applied on the
 // SOURCE address and on the ds_read address), double-buffered, one barrier per K-tile.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -25,7 +27,7 @@ struct GemmNTArgs {
   bf16_t* aux; int ldaux;
   const float* res; int ldres;
   const float* row_scale; int rps0, rps1;
-  int M, N, K, split, act;
+  int M, N, K, split, act, flags;
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -53,61 +55,10 @@ __device__ __forceinline__ bf16x8_t read_frag_k64(const char* lds, int row, int 
   return *(const bf16x8_t*)(lds + row * 128 + ((lslot ^ (row & 7)) << 4));
 }
 
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int tiles_n = (a.N + BN - 1) / BN;
-  const int tm0 = (a.split + BM - 1) / BM;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
-  const int group = tile_m >= tm0;
-  const int row0 = group ? a.split + (tile_m - tm0) * BM : tile_m * BM;
-  const int row_end = group ? a.M : a.split;
-  const int n0 = tile_n * BN;
-  const bf16_t* W = a.W + (long)group * a.w_gstride;
-
-#define ldsA(c) (smem + (c) * 2 * TILE_BYTES)
-#define ldsB(c) (smem + TILE_BYTES + (c) * 2 * TILE_BYTES)
-
-  f32x4_t acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-  const int nk = a.K / BK;
-  stage_tile_k64(a.A, a.lda, row0, row_end - 1, 0, ldsA(0), wave, lane);
-  stage_tile_k64(W, a.ldw, n0, a.N - 1, 0, ldsB(0), wave, lane);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) {
-      stage_tile_k64(a.A, a.lda, row0, row_end - 1, (kt + 1) * BK, ldsA(cur ^ 1), wave, lane);
-      stage_tile_k64(W, a.ldw, n0, a.N - 1, (kt + 1) * BK, ldsB(cur ^ 1), wave, lane);
-    }
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bf16x8_t fa[4], fb[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        fa[i] = read_frag_k64(ldsA(cur), wm * 64 + i * 16 + (lane & 15), s * 4 + (lane >> 4));
-        fb[i] = read_frag_k64(ldsB(cur), wn * 64 + i * 16 + (lane & 15), s * 4 + (lane >> 4));
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          // D[n_local][m_local]: lane holds 4 consecutive n for one m -> vector stores
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-
-  // ---------------- epilogue ----------------
+// shared epilogue: bias, optional pre-activation copy, GELU/ReLU, DropPath-scaled residual add, vector stores.
+// acc[i][j][r] = C[row0 + wm*64 + i*16 + (lane&15)][n0 + wn*64 + j*16 + 4*(lane>>4) + r]
+__device__ __forceinline__ void gemm_nt_epilogue(const GemmNTArgs& a, f32x4_t (&acc)[4][4], int group, int row0,
+                                                 int row_end, int n0, int wm, int wn, int lane) {
   const float* bias = a.bias ? a.bias + (long)group * a.bias_gstride : nullptr;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -172,6 +123,148 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
       }
     }
   }
+}
+
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = (a.N + BN - 1) / BN;
+  const int tm0 = (a.split + BM - 1) / BM;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+  const int group = tile_m >= tm0;
+  const int row0 = group ? a.split + (tile_m - tm0) * BM : tile_m * BM;
+  const int row_end = group ? a.M : a.split;
+  const int n0 = tile_n * BN;
+  const bf16_t* W = a.W + (long)group * a.w_gstride;
+
+#define ldsA(c) (smem + (c) * 2 * TILE_BYTES)
+#define ldsB(c) (smem + TILE_BYTES + (c) * 2 * TILE_BYTES)
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = a.K / BK;
+  stage_tile_k64(a.A, a.lda, row0, row_end - 1, 0, ldsA(0), wave, lane);
+  stage_tile_k64(W, a.ldw, n0, a.N - 1, 0, ldsB(0), wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      stage_tile_k64(a.A, a.lda, row0, row_end - 1, (kt + 1) * BK, ldsA(cur ^ 1), wave, lane);
+      stage_tile_k64(W, a.ldw, n0, a.N - 1, (kt + 1) * BK, ldsB(cur ^ 1), wave, lane);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8_t fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fa[i] = read_frag_k64(ldsA(cur), wm * 64 + i * 16 + (lane & 15), s * 4 + (lane >> 4));
+        fb[i] = read_frag_k64(ldsB(cur), wn * 64 + i * 16 + (lane & 15), s * 4 + (lane >> 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          // D[n_local][m_local]: lane holds 4 consecutive n for one m -> vector stores
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  gemm_nt_epilogue(a, acc, group, row0, row_end, n0, wm, wn, lane);
+}
+
+
+// ------------------------------------------------------------------------------------------
+// 256x128x64 tile, 8 waves (4 x 2, each 64x64), 3-stage LDS ring (3 x 48 KiB), counted vmcnt + raw s_barrier:
+// the global_load_lds of k-tile t+2 are issued right after the barrier of iteration t and stay in flight across
+// the next barrier; a wave only waits (vmcnt(6)) for its own share of tile t.  25 % less L2->LDS traffic per FLOP
+// than the 128^2 tile and no vmcnt(0) drain in the main loop.
+// ------------------------------------------------------------------------------------------
+constexpr int BM2 = 256;
+constexpr int STAGE2 = (BM2 + BN) * BK * 2;   // 49152 B
+
+__device__ __forceinline__ void stage_tile_k64_n(const bf16_t* base, int ld, int row0, int row_last, int k0, char* lds,
+                                                 int wave, int lane, int per_wave) {
+  for (int i = 0; i < per_wave; ++i) {
+    const int inst = wave * per_wave + i;
+    const int r = inst * 8 + (lane >> 3);
+    int row = row0 + r;
+    row = row < row_last ? row : row_last;
+    const int lslot = (lane & 7) ^ (r & 7);
+    const bf16_t* src = base + (long)row * ld + k0 + lslot * 8;
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds + inst * 1024), 16, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(512) void gemm_nt_kernel_256(GemmNTArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = (a.N + BN - 1) / BN;
+  const int tm0 = (a.split + BM2 - 1) / BM2;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+  const int group = tile_m >= tm0;
+  const int row0 = group ? a.split + (tile_m - tm0) * BM2 : tile_m * BM2;
+  const int row_end = group ? a.M : a.split;
+  const int n0 = tile_n * BN;
+  const bf16_t* W = a.W + (long)group * a.w_gstride;
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = a.K / BK;
+#define STA(s_) (smem + (s_) * STAGE2)
+#define STB(s_) (smem + (s_) * STAGE2 + BM2 * BK * 2)
+#define ISSUE(t_)                                                                           \
+  do {                                                                                      \
+    const int st__ = (t_) % 3;                                                              \
+    stage_tile_k64_n(a.A, a.lda, row0, row_end - 1, (t_) * BK, STA(st__), wave, lane, 4);   \
+    stage_tile_k64_n(W, a.ldw, n0, a.N - 1, (t_) * BK, STB(st__), wave, lane, 2);           \
+  } while (0)
+
+  ISSUE(0);
+  if (nk > 1) ISSUE(1);
+  for (int kt = 0; kt < nk; ++kt) {
+    // wait for this wave's 6 loads of tile kt (the 6 of tile kt+1 may stay in flight), then rendezvous
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk) ISSUE(kt + 2);      // stage (kt+2)%3 == (kt-1)%3: every wave is past compute(kt-1)
+    const char* sA = STA(kt % 3);
+    const char* sB = STB(kt % 3);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8_t fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fa[i] = read_frag_k64(sA, wm * 64 + i * 16 + (lane & 15), s * 4 + (lane >> 4));
+        fb[i] = read_frag_k64(sB, wn * 64 + i * 16 + (lane & 15), s * 4 + (lane >> 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+  }
+#undef STA
+#undef STB
+#undef ISSUE
+  gemm_nt_epilogue(a, acc, group, row0, row_end, n0, wm, wn, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -329,9 +422,18 @@ extern "C" int simvg_gemm_nt(const void* A, int lda, const void* W, long w_gstri
   GemmNTArgs a{(const bf16_t*)A, lda, (const bf16_t*)W, w_gstride, ldw, bias, bias_gstride, C, ldc, c_is_f32,
                (bf16_t*)aux_preact, ldaux, residual, ldres, row_scale,
                rows_per_sample0 > 0 ? rows_per_sample0 : 1, rows_per_sample1 > 0 ? rows_per_sample1 : 1,
-               M, N, K, split, act};
-  const int tiles = (cdiv(split, BM) + cdiv(M - split, BM)) * cdiv(N, BN);
-  hipLaunchKernelGGL(gemm_nt_kernel, dim3(tiles), dim3(256), 4 * TILE_BYTES, stream, a);
+               M, N, K, split, act, getenv("SIMVG_GEMM_FLAGS") ? atoi(getenv("SIMVG_GEMM_FLAGS")) : 0};
+  static const int variant = getenv("SIMVG_GEMM_NT") ? atoi(getenv("SIMVG_GEMM_NT")) : 256;
+  if (variant == 256 && M >= 512) {
+    static bool once = hipFuncSetAttribute((const void*)gemm_nt_kernel_256, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           3 * STAGE2) == hipSuccess;
+    (void)once;
+    const int tiles = (cdiv(split, BM2) + cdiv(M - split, BM2)) * cdiv(N, BN);
+    hipLaunchKernelGGL(gemm_nt_kernel_256, dim3(tiles), dim3(512), 3 * STAGE2, stream, a);
+  } else {
+    const int tiles = (cdiv(split, BM) + cdiv(M - split, BM)) * cdiv(N, BN);
+    hipLaunchKernelGGL(gemm_nt_kernel, dim3(tiles), dim3(256), 4 * TILE_BYTES, stream, a);
+  }
   SIMVG_LAUNCH_CHECK();
   return SIMVG_OK;
 }
@@ -344,7 +446,10 @@ extern "C" int simvg_gemm_tn(const void* dY, int lddy, const void* X, int ldx, f
   if (split == 0) split = M;
   const int tiles = cdiv(N, 128) * cdiv(K, 128);
   // split the contraction (rows) so that the grid fills the chip about twice over
-  int want = cdiv(1024, tiles);
+  // split the contraction so that tiles x chunks ~ 2-3 blocks per CU (measured sweep, profiles/r01_sweeps.md)
+  static const int target_env = getenv("SIMVG_TN_BLOCKS") ? atoi(getenv("SIMVG_TN_BLOCKS")) : 0;
+  const int target_blocks = target_env ? target_env : (tiles <= 48 ? 256 : 768);
+  int want = cdiv(target_blocks, tiles);
   int rpc = cdiv(cdiv(M, want), 64) * 64;
   if (rpc < 256) rpc = 256;
   const int chunks0 = cdiv(split, rpc), chunks1 = cdiv(M - split, rpc);

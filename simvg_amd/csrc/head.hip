@@ -24,31 +24,44 @@ struct SGArgs {
 };
 
 __global__ __launch_bounds__(256) void gemm_f32_kernel(SGArgs a) {
-  __shared__ float As[16][68];
-  __shared__ float Bs[16][68];
+  // 64x64 tile, K-chunks of 32 staged through LDS, next chunk prefetched into registers while the current one
+  // feeds v_mfma_f32_16x16x4_f32 (the head's GEMMs are latency-bound: few blocks, long K loops)
+  __shared__ float As[32][68];
+  __shared__ float Bs[32][68];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
   f32x4_t acc[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) acc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < a.K; k0 += 16) {
+  float ra[8], rb[8];
+  auto fetch = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 8; ++i) {
       const int e = tid + 256 * i;
       int m, k;
-      if (a.sak == 1) { k = e & 15; m = e >> 4; } else { m = e & 63; k = e >> 6; }
-      float v = 0.f;
-      if (m0 + m < a.M && k0 + k < a.K) v = a.A[(long)(m0 + m) * a.sam + (long)(k0 + k) * a.sak];
-      As[k][m] = v;
+      if (a.sak == 1) { k = e & 31; m = e >> 5; } else { m = e & 63; k = e >> 6; }
+      ra[i] = (m0 + m < a.M && k0 + k < a.K) ? a.A[(long)(m0 + m) * a.sam + (long)(k0 + k) * a.sak] : 0.f;
       int n, kb;
-      if (a.sbn == 1) { n = e & 63; kb = e >> 6; } else { kb = e & 15; n = e >> 4; }
-      float w = 0.f;
-      if (n0 + n < a.N && k0 + kb < a.K) w = a.B[(long)(k0 + kb) * a.sbk + (long)(n0 + n) * a.sbn];
-      Bs[kb][n] = w;
+      if (a.sbn == 1) { n = e & 63; kb = e >> 6; } else { kb = e & 31; n = e >> 5; }
+      rb[i] = (n0 + n < a.N && k0 + kb < a.K) ? a.B[(long)(k0 + kb) * a.sbk + (long)(n0 + n) * a.sbn] : 0.f;
+    }
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < a.K; k0 += 32) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = tid + 256 * i;
+      int m, k;
+      if (a.sak == 1) { k = e & 31; m = e >> 5; } else { m = e & 63; k = e >> 6; }
+      As[k][m] = ra[i];
+      int n, kb;
+      if (a.sbn == 1) { n = e & 63; kb = e >> 6; } else { kb = e & 31; n = e >> 5; }
+      Bs[kb][n] = rb[i];
     }
     __syncthreads();
+    if (k0 + 32 < a.K) fetch(k0 + 32);
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    for (int kk = 0; kk < 8; ++kk) {
       const float av = As[kk * 4 + (lane >> 4)][wave * 16 + (lane & 15)];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {

@@ -6,6 +6,8 @@
 // FeedForwardNetwork.ffn_layernorm; SURVEY.md §2.3 E5,E13,E18,E20) and the detrex decoder's
 // nn.LayerNorm (transformer.py:47-49,119-121).  Rows [0,split) use gamma/beta group 0 ("A",
 // vision), rows [split,M) group 1 ("B", text).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -196,6 +198,126 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
   }
 }
 
+// Wide rows (D >= 2048, e.g. the 3072-wide ffn_layernorm): the 4 waves of a block share ONE row (each lane owns
+// D/1024 float4 column groups), so the row costs 12 instead of 48+ live registers per array and the kernel runs at
+// full occupancy; the two row statistics cross waves through 32 B of LDS (one barrier per row, double-buffered).
+// Each thread owns its columns outright, so dgamma/dbeta need no cross-wave reduction at all.
+template <typename TIn, int NITW>
+__global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const bf16_t* __restrict__ dy, int lddy, const TIn* __restrict__ x, int ldx,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const float* __restrict__ gamma, int gstride,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                          bf16_t* __restrict__ out_bf16, int ldob, const bf16_t* __restrict__ gelu_u, int ldu,
+                                                          const float* __restrict__ dres, float* __restrict__ out_f32, int ldof,
+                                                          bf16_t* __restrict__ out_scaled, int ldos, const float* __restrict__ row_scale,
+                                                          int rps0, int rps1, int M, int D, int split, int rows_per_block, int blocks0) {
+  __shared__ float part[2][4][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int blk = blockIdx.x;
+  const int g = blk >= blocks0;
+  const int r_begin = g ? split + (blk - blocks0) * rows_per_block : blk * rows_per_block;
+  const int r_end = min(r_begin + rows_per_block, g ? M : split);
+  const float* gm = gamma + (long)g * gstride;
+  float gv[NITW][4], ag[NITW][4], ab[NITW][4];
+#pragma unroll
+  for (int it = 0; it < NITW; ++it) {
+    const int c = (it * 256 + tid) * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { ag[it][k] = 0.f; ab[it][k] = 0.f; gv[it][k] = 0.f; }
+    if (c < D) {
+      const f32x4_t t = *(const f32x4_t*)(gm + c);
+      gv[it][0] = t[0]; gv[it][1] = t[1]; gv[it][2] = t[2]; gv[it][3] = t[3];
+    }
+  }
+  const float invD = 1.f / (float)D;
+  int par = 0;
+  // software pipeline over rows: the loads of row r+1 (x, dy and the GELU pre-activation) are issued before row r is
+  // reduced, so two rows of HBM latency overlap and nothing is loaded behind the barrier
+  float xq[NITW][4], dq[NITW][4], uq[NITW][4];
+  auto fetch = [&](int row) {
+#pragma unroll
+    for (int it = 0; it < NITW; ++it) {
+      const int c = (it * 256 + tid) * 4;
+      if (c < D) {
+        Ld4<TIn>::ld(x + (long)row * ldx + c, xq[it]);
+        Ld4<bf16_t>::ld(dy + (long)row * lddy + c, dq[it]);
+        if (gelu_u) Ld4<bf16_t>::ld(gelu_u + (long)row * ldu + c, uq[it]);
+      }
+    }
+  };
+  if (r_begin < r_end) fetch(r_begin);
+  for (int row = r_begin; row < r_end; ++row, par ^= 1) {
+    const float mu = mean[row], rs = rstd[row];
+    float xh[NITW][4], dyv[NITW][4], uv[NITW][4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < NITW; ++it) {
+      const int c = (it * 256 + tid) * 4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool in = c < D;
+        dyv[it][k] = in ? dq[it][k] : 0.f;
+        uv[it][k] = uq[it][k];
+        xh[it][k] = in ? (xq[it][k] - mu) * rs : 0.f;
+        const float dg = dyv[it][k] * gv[it][k];
+        s1 += dg;
+        s2 += dg * xh[it][k];
+        ag[it][k] += dyv[it][k] * xh[it][k];
+        ab[it][k] += dyv[it][k];
+      }
+    }
+    if (row + 1 < r_end) fetch(row + 1);
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == 0) { part[par][wave][0] = s1; part[par][wave][1] = s2; }
+    __syncthreads();
+    const float c1 = ((part[par][0][0] + part[par][1][0]) + (part[par][2][0] + part[par][3][0])) * invD;
+    const float c2 = ((part[par][0][1] + part[par][1][1]) + (part[par][2][1] + part[par][3][1])) * invD;
+    float scl = 1.f;
+    if (out_scaled && row_scale) scl = row_scale[g ? (row - split) / rps1 : row / rps0];
+#pragma unroll
+    for (int it = 0; it < NITW; ++it) {
+      const int c = (it * 256 + tid) * 4;
+      if (c < D) {
+        float dx[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dx[k] = rs * (dyv[it][k] * gv[it][k] - c1 - xh[it][k] * c2);
+        if (out_bf16) {
+          if (gelu_u) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dx[k] *= gelu_erf_grad(uv[it][k]);
+          }
+          st4_bf16(out_bf16 + (long)row * ldob + c, dx);
+        }
+        if (out_f32) {
+          if (dres) {
+            const f32x4_t t = *(const f32x4_t*)(dres + (long)row * ldof + c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dx[k] += t[k];
+          }
+          *(f32x4_t*)(out_f32 + (long)row * ldof + c) = (f32x4_t){dx[0], dx[1], dx[2], dx[3]};
+          if (out_scaled) {
+            float t[4] = {dx[0] * scl, dx[1] * scl, dx[2] * scl, dx[3] * scl};
+            st4_bf16(out_scaled + (long)row * ldos + c, t);
+          }
+        }
+      }
+    }
+  }
+  if (r_begin < r_end && dgamma) {
+#pragma unroll
+    for (int it = 0; it < NITW; ++it) {
+      const int c = (it * 256 + tid) * 4;
+      if (c < D) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          atomicAdd(dgamma + (long)g * gstride + c + k, ag[it][k]);
+          atomicAdd(dbeta + (long)g * gstride + c + k, ab[it][k]);
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 #define LN_DISPATCH_NIT(D, CALL)                                     \
@@ -241,7 +363,8 @@ extern "C" int simvg_ln_bwd(const void* dy_bf16, int dy_is_f32, int lddy, const 
   SIMVG_CHECK_ARG(!dy_is_f32 || (D <= 256 && !x_is_bf16), "ln_bwd: fp32 dy is only built for the head (D <= 256, fp32 x)");
   SIMVG_CHECK_ARG(!(dx_scaled_bf16 && !dx_f32), "ln_bwd: scaled bf16 copy requires the f32 output");
   if (split == 0) split = M;
-  const int rpb = 32;
+  static const int rpb_env = getenv("SIMVG_LN_RPB") ? atoi(getenv("SIMVG_LN_RPB")) : 32;
+  const int rpb = rpb_env;
   const int blocks0 = cdiv(split, rpb), blocks1 = cdiv(M - split, rpb);
   const dim3 grid(blocks0 + blocks1), block(256);
   const size_t shm = (size_t)2 * D * sizeof(float);
@@ -251,6 +374,19 @@ extern "C" int simvg_ln_bwd(const void* dy_bf16, int dy_is_f32, int lddy, const 
                        (const float*)x, ldx, mean, rstd, gamma, group_stride, dgamma, dbeta, (bf16_t*)dx_bf16, lddxb,
                        (const bf16_t*)gelu_u_bf16, ldu, dres, dx_f32, lddxf, (bf16_t*)dx_scaled_bf16, lddxs, row_scale,
                        rps0, rps1, M, D, split, rpb, blocks0);
+    SIMVG_LAUNCH_CHECK();
+    return SIMVG_OK;
+  }
+  if (D >= 2048) {
+    const int nitw = (D + 1023) / 1024;
+#define WCALL(T_, N_)                                                                                                   \
+    hipLaunchKernelGGL((ln_bwd_wide_kernel<T_, N_>), grid, block, 0, stream, (const bf16_t*)dy_bf16, lddy, (const T_*)x, \
+                       ldx, mean, rstd, gamma, group_stride, dgamma, dbeta, (bf16_t*)dx_bf16, lddxb,                    \
+                       (const bf16_t*)gelu_u_bf16, ldu, dres, dx_f32, lddxf, (bf16_t*)dx_scaled_bf16, lddxs, row_scale, \
+                       rps0, rps1, M, D, split, rpb, blocks0)
+    if (x_is_bf16) { if (nitw <= 2) WCALL(bf16_t, 2); else if (nitw == 3) WCALL(bf16_t, 3); else WCALL(bf16_t, 4); }
+    else { if (nitw <= 2) WCALL(float, 2); else if (nitw == 3) WCALL(float, 3); else WCALL(float, 4); }
+#undef WCALL
     SIMVG_LAUNCH_CHECK();
     return SIMVG_OK;
   }
