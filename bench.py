@@ -186,9 +186,10 @@ def main():
                    "parallelism": f"dp{world}", "loss_total": round(loss_val, 4)},
         "model_tflops_per_gpu": round(value / world * FLOP_PER_PAIR_FWD_BWD / 1e12, 2),
         "model_mfma_frac": round(value / world * FLOP_PER_PAIR_FWD_BWD / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
-        "roofline": {"kernel": "gemm_nt_kernel (bf16 MFMA 16x16x32, 128x128x64 tile)", "bound": "mfma",
+        "roofline": {"kernel": "gemm_nt_kernel_256 (bf16 MFMA 16x16x32, 256x128x64 tile, 3-stage global_load_lds ring)", "bound": "mfma",
                      "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
+                     "algorithmic_bytes_per_launch": round(g["bytes"] / g["calls"]),
                      "launches": g["calls"], "avg_launch_us": round(g["ms"] / g["calls"] * 1e3, 2),
                      "share_of_step": round(g["ms"] / (dt * 1e3), 4)},
     }

@@ -94,6 +94,12 @@ int simvg_attn_small_bwd(const float* q, int ldq, const float* k, int ldk, const
                          float* dq, int lddq, float* dk, int lddk, float* dv, int lddv, int B, int H, int Lq, int Lk,
                          int kv_rows_per_batch, float scale, simvg_stream_t stream);
 
+/* exact-fp32 forward pieces (precision="fp32" inference mode: the reference computes in fp32, use_fp16=False in all
+ * 53 configs): fp32 im2col and an fp32 encoder attention with the same modality-major row layout as simvg_attn_fwd. */
+int simvg_im2col_f32(const float* img_nchw, float* cols, int B, int S, int P, simvg_stream_t stream);
+int simvg_attn_f32_fwd(const float* qkv, int ldqkv, float* out, int ldo, const unsigned char* pad, int B, int H, int Nv,
+                       int Nt, int D, float scale, simvg_stream_t stream);
+
 /* ---- matcher + criterion (no host synchronisation) ------------------------------------------------------
  * detrex HungarianMatcher (ce_cost; cost_class 1, cost_bbox 5, cost_giou 2 at tgqs_kd_detr_head.py:132-137) with the
  * LSAP solved on the device instead of SciPy on the host; prepare_soft_targets (tgqs_kd_detr_head.py:207-268,

@@ -53,6 +53,8 @@ _SIGS = {
     "simvg_criterion": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                         c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float,
                         c_void_p],
+    "simvg_im2col_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "simvg_attn_f32_fwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
     "simvg_probe_mfma": [c_void_p, c_void_p, c_void_p, c_void_p],
     "simvg_probe_tr16": [c_void_p, c_void_p, c_void_p],
     "simvg_probe_glds": [c_void_p, c_void_p, c_void_p, c_void_p],

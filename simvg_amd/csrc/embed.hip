@@ -14,6 +14,21 @@
 
 namespace {
 
+__global__ __launch_bounds__(256) void im2col_f32_kernel(const float* __restrict__ img, float* __restrict__ cols,
+                                                         int B, int S, int P, long total4) {
+  const int G = S / P, K = 3 * P * P;
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total4; t += (long)gridDim.x * 256) {
+    const long e = t * 4;
+    const int x = (int)(e % S);
+    const long r = e / S;
+    const int y = (int)(r % S);
+    const long bc = r / S;
+    const int c = (int)(bc % 3), b = (int)(bc / 3);
+    const int py = y / P, ky = y - py * P, px = x / P, kx = x - px * P;
+    *(f32x4_t*)(cols + ((long)b * G * G + py * G + px) * K + c * P * P + ky * P + kx) = *(const f32x4_t*)(img + e);
+  }
+}
+
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, bf16_t* __restrict__ cols,
                                                      int B, int S, int P, long total4) {
   const int G = S / P, K = 3 * P * P;
@@ -184,6 +199,15 @@ extern "C" int simvg_im2col(const float* img, void* cols_bf16, int B, int S, int
   const long total4 = (long)B * 3 * S * S / 4;
   const int grid = (int)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
   hipLaunchKernelGGL(im2col_kernel, dim3(grid), dim3(256), 0, stream, img, (bf16_t*)cols_bf16, B, S, P, total4);
+  SIMVG_LAUNCH_CHECK();
+  return SIMVG_OK;
+}
+
+extern "C" int simvg_im2col_f32(const float* img, float* cols, int B, int S, int P, hipStream_t stream) {
+  SIMVG_CHECK_ARG(B > 0 && S > 0 && P > 0 && S % P == 0 && P % 4 == 0, "im2col: S must be a multiple of P, P of 4");
+  const long total4 = (long)B * 3 * S * S / 4;
+  const int grid = (int)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
+  hipLaunchKernelGGL(im2col_f32_kernel, dim3(grid), dim3(256), 0, stream, img, cols, B, S, P, total4);
   SIMVG_LAUNCH_CHECK();
   return SIMVG_OK;
 }

@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(SGArgs a) {
       float v = acc[j][r] + bv;
       if (a.addend) v += a.addend[(long)(m % a.add_rows) * a.lda2 + n];
       if (a.act == 2) v = fmaxf(v, 0.f);
+      else if (a.act == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));   // exact mode: libm erf
       float* p = a.C + (long)m * a.ldc + n;
       *p = a.accumulate ? *p + v : v;
     }
@@ -249,7 +250,7 @@ extern "C" int simvg_gemm_f32(const float* A, long sam, long sak, const float* B
                               long ldc, const float* bias, const float* addend, long ld_addend, int addend_rows,
                               int M, int N, int K, int accumulate, int act, hipStream_t stream) {
   SIMVG_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm_f32: empty problem");
-  SIMVG_CHECK_ARG(act == 0 || act == 2, "gemm_f32: act must be 0 (none) or 2 (relu)");
+  SIMVG_CHECK_ARG(act >= 0 && act <= 2, "gemm_f32: act must be 0 (none), 1 (gelu) or 2 (relu)");
   SGArgs a{A, sam, sak, B, sbk, sbn, C, ldc, bias, addend, ld_addend, addend_rows > 0 ? addend_rows : 1, M, N, K,
            accumulate, act};
   hipLaunchKernelGGL(gemm_f32_kernel, dim3(cdiv(N, 64), cdiv(M, 64)), dim3(256), 0, stream, a);
@@ -288,6 +289,92 @@ extern "C" int simvg_attn_small_bwd(const float* q, int ldq, const float* k, int
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
   (void)once;
   hipLaunchKernelGGL(attn_small_bwd_kernel, dim3(B * H), dim3(256), shm, stream, a);
+  SIMVG_LAUNCH_CHECK();
+  return SIMVG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Exact-fp32 encoder attention (precision="fp32" mode: the reference's own arithmetic, fp32 end to end).
+// One workgroup per (sample, head, 16-query chunk); scores for the chunk live in LDS; VALU dot products.
+// Rows are modality-major like the bf16 kernel.  Forward only (inference parity mode).
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct AF32Args {
+  const float* qkv; int ld;   // [M, 3D]
+  float* out; int ldo;        // [M, D]
+  const unsigned char* pad;   // [B, Nt] or null
+  int B, H, Nv, Nt, D;
+  float scale;
+};
+__device__ __forceinline__ long af32_row(const AF32Args& a, int b, int t) {
+  return t < a.Nv ? (long)b * a.Nv + t : (long)a.B * a.Nv + (long)b * a.Nt + (t - a.Nv);
+}
+__global__ __launch_bounds__(256) void attn_f32_fwd_kernel(AF32Args a) {
+  extern __shared__ float sm[];
+  const int N = a.Nv + a.Nt;
+  float* qs = sm;              // [16][64]
+  float* sc = sm + 16 * 64;    // [16][N]
+  const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
+  const int q0 = blockIdx.y * 16;
+  const int nq = min(16, N - q0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int e = tid; e < 16 * 64; e += 256) {
+    const int qi = e >> 6, d = e & 63;
+    qs[e] = qi < nq ? a.qkv[af32_row(a, b, q0 + qi) * a.ld + h * 64 + d] * a.scale : 0.f;
+  }
+  __syncthreads();
+  for (int kk = tid; kk < N; kk += 256) {
+    const float* kp = a.qkv + af32_row(a, b, kk) * a.ld + a.D + h * 64;
+    float kr[64];
+#pragma unroll
+    for (int d = 0; d < 64; d += 4) {
+      const f32x4_t t = *(const f32x4_t*)(kp + d);
+      kr[d] = t[0]; kr[d + 1] = t[1]; kr[d + 2] = t[2]; kr[d + 3] = t[3];
+    }
+    const bool masked = a.pad && kk >= a.Nv && a.pad[b * a.Nt + (kk - a.Nv)];
+    for (int qi = 0; qi < 16; ++qi) {
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < 64; ++d) s = fmaf(qs[qi * 64 + d], kr[d], s);
+      sc[qi * N + kk] = masked ? -INFINITY : s;
+    }
+  }
+  __syncthreads();
+  for (int qi = wave; qi < nq; qi += 4) {
+    float mx = -INFINITY;
+    for (int kk = lane; kk < N; kk += 64) mx = fmaxf(mx, sc[qi * N + kk]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int kk = lane; kk < N; kk += 64) {
+      const float p = expf(sc[qi * N + kk] - mx);
+      sc[qi * N + kk] = p;
+      sum += p;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    for (int kk = lane; kk < N; kk += 64) sc[qi * N + kk] *= inv;
+  }
+  __syncthreads();
+  for (int e = tid; e < nq * 64; e += 256) {
+    const int qi = e >> 6, d = e & 63;
+    float o = 0.f;
+    for (int kk = 0; kk < N; ++kk) o = fmaf(sc[qi * N + kk], a.qkv[af32_row(a, b, kk) * a.ld + 2 * a.D + h * 64 + d], o);
+    a.out[af32_row(a, b, q0 + qi) * a.ldo + h * 64 + d] = o;
+  }
+}
+}  // namespace
+
+extern "C" int simvg_attn_f32_fwd(const float* qkv, int ldqkv, float* out, int ldo, const unsigned char* pad, int B,
+                                  int H, int Nv, int Nt, int D, float scale, hipStream_t stream) {
+  SIMVG_CHECK_ARG(B > 0 && H > 0 && D == H * 64 && Nv + Nt > 0 && Nv + Nt <= 2048 && ldqkv % 4 == 0,
+                  "attn_f32_fwd: need head_dim 64, N <= 2048");
+  AF32Args a{qkv, ldqkv, out, ldo, pad, B, H, Nv, Nt, D, scale};
+  const int N = Nv + Nt;
+  const size_t shm = (size_t)(16 * 64 + 16 * N) * sizeof(float);
+  static bool once = hipFuncSetAttribute((const void*)attn_f32_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         160 * 1024) == hipSuccess;
+  (void)once;
+  hipLaunchKernelGGL(attn_f32_fwd_kernel, dim3(B * H, cdiv(N, 16)), dim3(256), shm, stream, a);
   SIMVG_LAUNCH_CHECK();
   return SIMVG_OK;
 }

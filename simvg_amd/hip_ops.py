@@ -346,3 +346,37 @@ def criterion(logits, boxes, match_idx, tboxes, tlabels, num_boxes, wdist, coef_
                              weights[1], weights[2], _stream())
     _lib.check(rc, "simvg_criterion")
     return out, dlogits, dboxes
+
+
+# ---------------------------------------------------------------------------------------------
+# exact-fp32 forward mode
+# ---------------------------------------------------------------------------------------------
+def im2col_f32(img, P):
+    lib = _lib.load()
+    _chk(img, torch.float32, "img")
+    B, Cc, S, _ = img.shape
+    out = torch.empty(B * (S // P) ** 2, 3 * P * P, device=img.device, dtype=torch.float32)
+    _lib.check(lib.simvg_im2col_f32(_p(img.contiguous()), _p(out), B, S, P, _stream()), "simvg_im2col_f32")
+    return out
+
+
+def attn_f32_fwd(qkv, B, H, Nv, Nt, pad=None):
+    lib = _lib.load()
+    _chk(qkv, torch.float32, "qkv")
+    M, D3 = qkv.shape
+    D = D3 // 3
+    out = torch.empty(M, D, device=qkv.device, dtype=torch.float32)
+    rc = lib.simvg_attn_f32_fwd(_p(qkv), qkv.stride(0), _p(out), out.stride(0), _p(pad), B, H, Nv, Nt, D,
+                                (D // H) ** -0.5, _stream())
+    _lib.check(rc, "simvg_attn_f32_fwd")
+    return out
+
+
+def linear_f32(x, W, b=None, out=None, act=0, accumulate=False):
+    """out[M,N] (+)= x[M,K] W[N,K]^T + b (exact fp32 on MFMA f32); x, W may be strided 2-D views."""
+    M, K = x.shape
+    N = W.shape[0]
+    if out is None:
+        out = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    gemm_f32(x, x.stride(0), x.stride(1), W, W.stride(1), W.stride(0), out, M, N, K, bias=b, act=act, accumulate=accumulate)
+    return out

@@ -40,6 +40,7 @@ class MIXDETRMB(OneStageModel):
     def forward_test(self, img, ref_expr_inds, img_metas, text_attention_mask=None, with_bbox=False, with_mask=False,
                      rescale=False):
         output = self._run(img, ref_expr_inds, img_metas, text_attention_mask)
+        self._last_output = output
         return self._predict(output, img_metas, rescale)
 
     def _predict(self, output, img_metas, rescale):

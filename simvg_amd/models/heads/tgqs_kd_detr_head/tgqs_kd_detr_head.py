@@ -289,10 +289,17 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
         E, nq, H = self.embed_dim, self.num_queries, self.heads
         HW = Nv - 1
         hw = int(round(HW ** 0.5))
-        self._refresh_weights(device)
-        vis, text32, cls32 = SplitEncoderOutput.apply(enc_out, B, Nv, T)
-        # H1: input_proj on all vision rows (the CLS row is carried along and never used as a key)
-        mem = LinearBF16.apply(vis, self._P("input_proj.weight"), self._P("input_proj.bias"), self.wb["ip"], self.wb["ipT"], True)
+        exact = enc_out.dtype == torch.float32      # precision="fp32" inference mode: fp32 memory rows as well
+        C = self.in_channels
+        if exact:
+            vis, text32 = enc_out[:B * Nv], enc_out[B * Nv:]
+            cls32 = vis.view(B, Nv, C)[:, 0]
+            mem = LinearF32.apply(vis, self._P("input_proj.weight").view(E, C), self._P("input_proj.bias"), False)
+        else:
+            self._refresh_weights(device)
+            vis, text32, cls32 = SplitEncoderOutput.apply(enc_out, B, Nv, T)
+            # H1: input_proj on all vision rows (the CLS row is carried along and never used as a key)
+            mem = LinearBF16.apply(vis, self._P("input_proj.weight"), self._P("input_proj.bias"), self.wb["ip"], self.wb["ipT"], True)
         text = self._lin(text32, "input_text_proj")                       # [B*T, E]
         cls = self._lin(cls32, "input_cls_proj")                          # [B, E]
         pos2d, img_kpm = self._image_pos(B, hw, img_metas, device)
@@ -333,7 +340,10 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
         for i in range(self.num_decoder_layers):
             def mem_cross(q, W1, b1, i=i):
                 # K = (mem + pos) Wk^T + bk = mem Wk^T + bk + pos Wk^T ; V = mem Wv^T + bv   (key_pos only on K)
-                kv = LinearBF16.apply(mem, W1[E:], b1[E:], self.wb[f"kv{i}"], self.wb[f"kvT{i}"], False)   # [B*Nv, 2E] fp32
+                if exact:
+                    kv = LinearF32.apply(mem, W1[E:], b1[E:], False)
+                else:
+                    kv = LinearBF16.apply(mem, W1[E:], b1[E:], self.wb[f"kv{i}"], self.wb[f"kvT{i}"], False)   # [B*Nv, 2E] fp32
                 posk = LinearF32.apply(pos2d.reshape(-1, E), W1[E:2 * E], None, False).view(-1, HW, E)
                 pos_full = F.pad(posk, (0, 0, 1, 0))                        # zero row for the (unused) CLS key
                 k_full = (kv.view(B, Nv, 2 * E)[:, :, :E] + pos_full).reshape(B * Nv, E)

@@ -77,6 +77,7 @@ class BEIT3(nn.Module):
         self.ln_eps = 1e-5
         self.drop_path_probs = [float(v) for v in np.linspace(0, dpr, self.L)] if dpr > 0 else [0.0] * self.L
         self.vision_embed_proj_interpolate = vision_embed_proj_interpolate
+        self.precision = "bf16"     # "bf16": MFMA bf16 operands (training + inference); "fp32": exact forward-only mode
         self._build_parameters()
         self._arena = None
         self._ws = {}
@@ -269,6 +270,57 @@ class BEIT3(nn.Module):
         ws["ctx"] = (B, T, ids, pad_u8, dp)
         return ws["out"], ws
 
+    # ------------------------------------------------------------------ engine: exact fp32 forward (inference)
+    def set_precision(self, precision):
+        """"bf16" (default) or "fp32": the reference's own arithmetic (use_fp16=False in every config) end to end in
+        fp32 on v_mfma_f32_16x16x4_f32 / VALU -- ~1/16 of the bf16 MFMA rate, forward only; used to show that the
+        kernels' logic is exact and that the bf16 deviation is operand rounding."""
+        assert precision in ("bf16", "fp32")
+        self.precision = precision
+        return self
+
+    def _engine_forward_fp32(self, img, ids, pad_u8):
+        A = self._arena
+        V, prm = A.views, A.params
+        B, T = ids.shape
+        D, F_, L, H, P = self.D, self.F, self.L, self.H, self.patch_size
+        Nv = self.np + 1
+        Mv = B * Nv
+        M = Mv + B * T
+        eps = self.ln_eps
+
+        def ln(x, gk, bk):
+            return ops.ln_fwd(x, V[gk], V[bk], split=Mv, eps=eps, out_bf16=False, out_f32=True, save_stats=False)[1]
+
+        def mw(x, wk, bk, out=None, act=0, accumulate=False):
+            W, b = V[wk], V[bk]
+            if out is None:
+                out = torch.empty(M, W.shape[1], device=x.device, dtype=torch.float32)
+            for g, (lo, hi) in enumerate(((0, Mv), (Mv, M))):
+                if hi > lo:
+                    ops.linear_f32(x[lo:hi], W[g], b[g], out=out[lo:hi], act=act, accumulate=accumulate)
+            return out
+
+        cols = ops.im2col_f32(img, P)
+        patch = ops.linear_f32(cols, prm["beit3.vision_embed.proj.weight"].data.view(D, 3 * P * P),
+                               prm["beit3.vision_embed.proj.bias"].data)
+        x = ops.embed_fwd(patch, prm["beit3.vision_embed.cls_token"].data, prm["beit3.encoder.embed_positions.A.weight"].data,
+                          prm["beit3.encoder.embed_positions.B.weight"].data, prm["beit3.text_embed.weight"].data,
+                          ids, pad_u8, B, self.np, T)
+        for i in range(L):
+            h = ln(x, f"ln1g{i}", f"ln1b{i}")
+            qkv = mw(h, f"wqkv{i}", f"bqkv{i}")
+            o = ops.attn_f32_fwd(qkv, B, H, Nv, T, pad=pad_u8)
+            o2 = ln(o, f"lnig{i}", f"lnib{i}")
+            xm = x.clone()
+            mw(o2, f"wout{i}", f"bout{i}", out=xm, accumulate=True)
+            h2 = ln(xm, f"ln2g{i}", f"ln2b{i}")
+            g = mw(h2, f"w1{i}", f"b1{i}", act=1)
+            g2 = ln(g, f"lnfg{i}", f"lnfb{i}")
+            x = xm.clone()
+            mw(g2, f"w2{i}", f"b2{i}", out=x, accumulate=True)
+        return ln(x, "lnog", "lnob")
+
     # ------------------------------------------------------------------ engine: backward
     def _engine_backward(self, ws, dout, layer_done_cb=None):
         A = self._arena
@@ -348,6 +400,10 @@ class BEIT3(nn.Module):
         if dp_scales is None:
             dp_scales = self._drop_path_scales(B, device)
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if self.precision == "fp32":
+            if need_grad:
+                raise NotImplementedError('precision="fp32" is the exact forward-only mode; train in "bf16"')
+            return self._engine_forward_fp32(img, ids, pad_u8)
         return _EncoderFn.apply(self, img, ids, pad_u8, dp_scales, need_grad, self._anchor)
 
     def split_output(self, out, B, T):
@@ -359,7 +415,7 @@ class BEIT3(nn.Module):
     def forward(self, image, question, padding_mask, **kwargs):
         """Reference API (beit3.py:176-185): -> img_feat [B,np,D], text_feat [B,T,D], cls_feat [B,D] (fp32)."""
         out = self.encode(image, question, padding_mask)
-        img_feat, text_feat, cls_feat = self.split_output(out.float(), *question.shape)
+        img_feat, text_feat, cls_feat = self.split_output(out.float(), question.shape[0], question.shape[1])
         return img_feat, text_feat, cls_feat
 
 

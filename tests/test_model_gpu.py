@@ -136,3 +136,26 @@ def test_train_mode_runs_with_dropout_and_droppath():
     assert torch.isfinite(losses["loss_total"])
     missing = [n for n, p in model.named_parameters() if p.grad is None]
     assert missing == ["vis_enc.beit3.vision_embed.mask_token"], missing
+
+
+@pytest.mark.parametrize("name", ["tiny_nq1", "tiny_nq10_grec", "base_nq1", "base_nq10_grec"])
+def test_exact_fp32_mode_meets_1e3_on_harsh_weights(golden, name):
+    """precision="fp32" (forward-only exact mode, same kernels' logic with fp32 operands): the north_star bound --
+    normalised boxes within 1e-3 L1, pixel boxes within 640e-3 px -- holds on the HARSH fixtures too, i.e. the bf16
+    deviation measured above is operand rounding, not kernel logic."""
+    fx = golden(name)
+    model, batch, cfg = _build(fx)
+    model.eval()
+    model.vis_enc.set_precision("fp32")
+    db = _dev_batch(batch)
+    pred = model(db["img"], db["ref_expr_inds"], db["img_metas"], return_loss=False,
+                 text_attention_mask=db["text_attention_mask"], with_bbox=True, with_mask=False, rescale=False)
+    out = model._last_output
+    for key, fkey in [("outputs_coord_decoder_branch", "dec_boxes"), ("outputs_coord_token_branch", "tok_boxes")]:
+        l1 = float((out[key].detach().float().cpu() - fx[fkey]).abs().sum(-1).max())
+        assert l1 <= 1e-3, (key, l1)
+    for key, fkey in [("outputs_class_decoder_branch", "dec_logits"), ("outputs_class_token_branch", "tok_logits")]:
+        assert _rel(out[key].detach(), fx[fkey]) <= 1e-3, key
+    if not fx["grec"]:
+        for i, key in enumerate(["pred_decoder", "pred_token"]):
+            assert float((pred[i]["pred_bboxes"].float().cpu() - fx[key]).abs().max()) <= fx["img_size"] * 1e-3
