@@ -7,6 +7,8 @@ contiguous all-reduces -- one per encoder layer, issued asynchronously from insi
 moment that layer's wgrads are written (overlapping the remaining backward), then one for the embeddings and one
 for the head.  No per-tensor buckets, no unused-parameter search.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -15,6 +17,8 @@ class GradReducer:
     def __init__(self, model, bucket_bytes=None):
         self.model = model
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        # SIMVG_FORCE_REDUCE=1 exercises the exchange even with a single rank (all-reduce over 1 rank == identity)
+        self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("SIMVG_FORCE_REDUCE") == "1")
         self.pending = []
         self.enc = getattr(model, "vis_enc", None)
         self._done_layers = set()
@@ -23,7 +27,7 @@ class GradReducer:
 
     # called by BEIT3._engine_backward after layer i (i = L-1 .. 0), then with -1 after the embedding stage
     def _on_layer_done(self, i):
-        if self.world == 1:
+        if not self.active:
             return
         A = self.enc._arena
         if i >= 0:
@@ -51,7 +55,7 @@ class GradReducer:
 
     def finish(self):
         """Call after loss.backward(): reduces the head gradients, waits for everything, averages."""
-        if self.world == 1:
+        if not self.active:
             return
         head = [p for n, p in self.model.named_parameters() if not n.startswith("vis_enc.") and p.grad is not None]
         if head:
