@@ -64,7 +64,10 @@ int simvg_ln_bwd(const void* dy, int dy_is_f32, int lddy, const void* x, int x_i
                  const float* rstd, const float* gamma, int group_stride, float* dgamma, float* dbeta,
                  void* dx_bf16, int lddxb, const void* gelu_u_bf16, int ldu, const float* dres,
                  float* dx_f32, int lddxf, void* dx_scaled_bf16, int lddxs, const float* row_scale,
-                 int rows_per_sample0, int rows_per_sample1, int M, int D, int split, simvg_stream_t stream);
+                 int rows_per_sample0, int rows_per_sample1, int M, int D, int split, float* partial_ws /* optional:
+                 >= simvg_ln_bwd_ws_floats() floats -> two-stage dgamma/dbeta reduction instead of atomics */,
+                 simvg_stream_t stream);
+long simvg_ln_bwd_ws_floats(int M, int D, int split);
 
 /* ---- fused encoder self-attention ----------------------------------------------------------------
  * softmax(scale * Q K^T + key_padding(-inf)) V per (sample, head), head_dim 64, N = Nv+Nt <= 448.

@@ -26,7 +26,7 @@ _SIGS = {
                      c_void_p, c_int, c_int, c_int, c_float, c_void_p],
     "simvg_ln_bwd": [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                      c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
-                     c_int, c_int, c_int, c_int, c_int, c_void_p],
+                     c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "simvg_attn_fwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                        c_float, c_void_p],
     "simvg_attn_bwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
@@ -83,12 +83,14 @@ def load():
     lib.simvg_last_error.restype = C.c_char_p
     lib.simvg_last_error.argtypes = []
     lib.simvg_version.restype = c_int
+    lib.simvg_ln_bwd_ws_floats.restype = c_long
+    lib.simvg_ln_bwd_ws_floats.argtypes = [c_int, c_int, c_int]
     _lib = lib
     return lib
 
 
 def exported_symbols():
-    return sorted(_SIGS) + ["simvg_last_error", "simvg_version"]
+    return sorted(_SIGS) + ["simvg_last_error", "simvg_version", "simvg_ln_bwd_ws_floats"]
 
 
 def check(rc, what):

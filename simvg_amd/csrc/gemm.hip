@@ -267,6 +267,87 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel_256(GemmNTArgs a) {
   gemm_nt_epilogue(a, acc, group, row0, row_end, n0, wm, wn, lane);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Variant: same 256x128 tile / 8 waves / 3-stage ring, but K-tiles of 32 (24 KiB stages, 72 KiB LDS) so that TWO
+// workgroups are resident per CU (16 waves, 4 per SIMD): while one workgroup sits in its wait/barrier the other
+// one owns the MFMA pipe.  LDS rows are 64 B (4 slots of 16 B); slot ^= (row >> 2) & 3 keeps ds_read_b128 of 16
+// consecutive rows conflict-free.
+// ------------------------------------------------------------------------------------------
+constexpr int BK3 = 32;
+constexpr int STAGE3 = (BM2 + BN) * BK3 * 2;   // 24576 B
+
+__device__ __forceinline__ void stage_tile_k32(const bf16_t* base, int ld, int row0, int row_last, int k0, char* lds,
+                                               int wave, int lane, int per_wave) {
+  for (int i = 0; i < per_wave; ++i) {
+    const int inst = wave * per_wave + i;
+    const int r = inst * 16 + (lane >> 2);
+    int row = row0 + r;
+    row = row < row_last ? row : row_last;
+    const int lslot = (lane & 3) ^ ((r >> 2) & 3);
+    const bf16_t* src = base + (long)row * ld + k0 + lslot * 8;
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds + inst * 1024), 16, 0, 0);
+  }
+}
+__device__ __forceinline__ bf16x8_t read_frag_k32(const char* lds, int row, int lslot) {
+  return *(const bf16x8_t*)(lds + row * 64 + ((lslot ^ ((row >> 2) & 3)) << 4));
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_nt_kernel_256k32(GemmNTArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = (a.N + BN - 1) / BN;
+  const int tm0 = (a.split + BM2 - 1) / BM2;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+  const int group = tile_m >= tm0;
+  const int row0 = group ? a.split + (tile_m - tm0) * BM2 : tile_m * BM2;
+  const int row_end = group ? a.M : a.split;
+  const int n0 = tile_n * BN;
+  const bf16_t* W = a.W + (long)group * a.w_gstride;
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int nk = a.K / BK3;
+#define STA(s_) (smem + (s_) * STAGE3)
+#define STB(s_) (smem + (s_) * STAGE3 + BM2 * BK3 * 2)
+#define ISSUE(t_)                                                                         \
+  do {                                                                                    \
+    const int st__ = (t_) % 3;                                                            \
+    stage_tile_k32(a.A, a.lda, row0, row_end - 1, (t_) * BK3, STA(st__), wave, lane, 2);  \
+    stage_tile_k32(W, a.ldw, n0, a.N - 1, (t_) * BK3, STB(st__), wave, lane, 1);          \
+  } while (0)
+  ISSUE(0);
+  if (nk > 1) ISSUE(1);
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk) ISSUE(kt + 2);
+    const char* sA = STA(kt % 3);
+    const char* sB = STB(kt % 3);
+    bf16x8_t fa[4], fb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      fa[i] = read_frag_k32(sA, wm * 64 + i * 16 + (lane & 15), lane >> 4);
+      fb[i] = read_frag_k32(sB, wn * 64 + i * 16 + (lane & 15), lane >> 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+  }
+#undef STA
+#undef STB
+#undef ISSUE
+  gemm_nt_epilogue(a, acc, group, row0, row_end, n0, wm, wn, lane);
+}
+
 // ------------------------------------------------------------------------------------------
 // wgrad: dW[g][n][k] += sum_m dY[m][n] * X[m][k]
 // ------------------------------------------------------------------------------------------
@@ -374,6 +455,88 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs a) {
     }
 }
 
+// wgrad v2: 32-row stages (16 KiB), 3-stage global_load_lds ring with counted vmcnt + raw barrier; 48 KiB of LDS
+// per workgroup -> three workgroups (12 waves) per CU instead of two, and no vmcnt(0) drain per stage.
+__device__ __forceinline__ void stage_tile_m32(const bf16_t* base, int ld, int m0, int m_end, int c0, int ncols,
+                                               char* lds, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int inst = wave * 2 + i;
+    const int r = inst * 4 + (lane >> 4);
+    const int lslot = (lane & 15) ^ ((r & 3) << 1);
+    const int row = m0 + r, col = c0 + lslot * 8;
+    const bf16_t* src = (row < m_end && col < ncols) ? base + (long)row * ld + col : (const bf16_t*)g_zero_page;
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds + inst * 1024), 16, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(256, 3) void gemm_tn_kernel_v2(GemmTNArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave >> 1, wk = wave & 1;
+  const int tiles_k = (a.K + 127) / 128;
+  const int tile_n = blockIdx.x / tiles_k, tile_k = blockIdx.x - tile_n * tiles_k;
+  const int chunk = blockIdx.y;
+  const int group = chunk >= a.chunks0;
+  const int m_begin = group ? a.split + (chunk - a.chunks0) * a.rows_per_chunk : chunk * a.rows_per_chunk;
+  const int g_end = group ? a.M : a.split;
+  const int m_end = min(m_begin + a.rows_per_chunk, g_end);
+  if (m_begin >= m_end) return;
+  const int n0 = tile_n * 128, k0 = tile_k * 128;
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int nt = (m_end - m_begin + 31) / 32;
+#define SY(s_) (smem + (s_) * 16384)
+#define SX(s_) (smem + (s_) * 16384 + 8192)
+#define ISSUE(t_)                                                                                  \
+  do {                                                                                             \
+    const int st__ = (t_) % 3;                                                                     \
+    stage_tile_m32(a.dY, a.lddy, m_begin + (t_) * 32, m_end, n0, a.N, SY(st__), wave, lane);       \
+    stage_tile_m32(a.X, a.ldx, m_begin + (t_) * 32, m_end, k0, a.K, SX(st__), wave, lane);         \
+  } while (0)
+  ISSUE(0);
+  if (nt > 1) ISSUE(1);
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 < nt) ISSUE(t + 2);
+    const char* sy = SY(t % 3);
+    const char* sx = SX(t % 3);
+    bf16x8_t fy[4], fx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      fy[i] = read_frag_tr(sy, 0, wn * 64 + i * 16, lane);
+      fx[i] = read_frag_tr(sx, 0, wk * 64 + i * 16, lane);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], fx[j], acc[i][j], 0, 0, 0);
+  }
+#undef SY
+#undef SX
+#undef ISSUE
+  float* dW = a.dW + (long)group * a.dw_gstride;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + wk * 64 + j * 16 + (lane & 15);
+      if (k >= a.K) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn * 64 + i * 16 + 4 * (lane >> 4) + r;
+        if (n < a.N) atomicAdd(dW + (long)n * a.lddw + k, acc[i][j][r]);
+      }
+    }
+}
+
 // column sums by row group: out[g][n] += sum_{m in group g} Y[m][n]   (bias gradients)
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* Y, int ldy, float* out, int out_gstride,
                                                      int M, int N, int split, int rows_per_chunk, int chunks0) {
@@ -414,7 +577,7 @@ extern "C" int simvg_gemm_nt(const void* A, int lda, const void* W, long w_gstri
                              const float* row_scale, int rows_per_sample0, int rows_per_sample1,
                              int M, int N, int K, int split, int act, hipStream_t stream) {
   SIMVG_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm_nt: empty problem");
-  SIMVG_CHECK_ARG(K % BK == 0, "gemm_nt: K must be a multiple of 64");
+  SIMVG_CHECK_ARG(K % BK == 0, "gemm_nt: K must be a multiple of 64");   // also covers the BK=32 variant
   SIMVG_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0, "gemm_nt: leading dims must keep 16-B alignment");
   SIMVG_CHECK_ARG(split >= 0 && split <= M, "gemm_nt: split out of range");
   SIMVG_CHECK_ARG(act >= 0 && act <= 2, "gemm_nt: act must be 0 (none), 1 (gelu) or 2 (relu)");
@@ -423,8 +586,17 @@ extern "C" int simvg_gemm_nt(const void* A, int lda, const void* W, long w_gstri
                (bf16_t*)aux_preact, ldaux, residual, ldres, row_scale,
                rows_per_sample0 > 0 ? rows_per_sample0 : 1, rows_per_sample1 > 0 ? rows_per_sample1 : 1,
                M, N, K, split, act, getenv("SIMVG_GEMM_FLAGS") ? atoi(getenv("SIMVG_GEMM_FLAGS")) : 0};
-  static const int variant = getenv("SIMVG_GEMM_NT") ? atoi(getenv("SIMVG_GEMM_NT")) : 256;
-  if (variant == 256 && M >= 512) {
+  // auto: short K (<= 1024: QKV, out-proj, fc1, dgrad of fc2) -> BK=32, two workgroups per CU; long K -> BK=64
+  // (measured: profiles/r01_sweeps.md).  SIMVG_GEMM_NT = 128 | 256 | 232 forces one kernel.
+  static const int variant_env = getenv("SIMVG_GEMM_NT") ? atoi(getenv("SIMVG_GEMM_NT")) : 0;
+  const int variant = variant_env ? variant_env : (K <= 1024 ? 232 : 256);
+  if (variant == 232 && M >= 512) {
+    static bool once3 = hipFuncSetAttribute((const void*)gemm_nt_kernel_256k32, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            3 * STAGE3) == hipSuccess;
+    (void)once3;
+    const int tiles = (cdiv(split, BM2) + cdiv(M - split, BM2)) * cdiv(N, BN);
+    hipLaunchKernelGGL(gemm_nt_kernel_256k32, dim3(tiles), dim3(512), 3 * STAGE3, stream, a);
+  } else if (variant == 256 && M >= 512) {
     static bool once = hipFuncSetAttribute((const void*)gemm_nt_kernel_256, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            3 * STAGE2) == hipSuccess;
     (void)once;
@@ -451,10 +623,14 @@ extern "C" int simvg_gemm_tn(const void* dY, int lddy, const void* X, int ldx, f
   const int target_blocks = target_env ? target_env : (tiles <= 48 ? 256 : 768);
   int want = cdiv(target_blocks, tiles);
   int rpc = cdiv(cdiv(M, want), 64) * 64;
-  if (rpc < 256) rpc = 256;
+  if (rpc < 256) rpc = 256;   // multiple of 64 (v1 stages) and of 32 (v2 stages)
   const int chunks0 = cdiv(split, rpc), chunks1 = cdiv(M - split, rpc);
   GemmTNArgs a{(const bf16_t*)dY, lddy, (const bf16_t*)X, ldx, dW, dw_gstride, lddw, M, N, K, split, rpc, chunks0};
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, chunks0 + chunks1), dim3(256), 65536, stream, a);
+  static const int tn_variant = getenv("SIMVG_GEMM_TN") ? atoi(getenv("SIMVG_GEMM_TN")) : 1;   // v2 measured slower (tr-read bound)
+  if (tn_variant == 2)
+    hipLaunchKernelGGL(gemm_tn_kernel_v2, dim3(tiles, chunks0 + chunks1), dim3(256), 3 * 16384, stream, a);
+  else
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, chunks0 + chunks1), dim3(256), 65536, stream, a);
   SIMVG_LAUNCH_CHECK();
   return SIMVG_OK;
 }

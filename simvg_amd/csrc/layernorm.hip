@@ -96,7 +96,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
                                                      bf16_t* __restrict__ out_bf16, int ldob, const bf16_t* __restrict__ gelu_u, int ldu,
                                                      const float* __restrict__ dres, float* __restrict__ out_f32, int ldof,
                                                      bf16_t* __restrict__ out_scaled, int ldos, const float* __restrict__ row_scale,
-                                                     int rps0, int rps1, int M, int D, int split, int rows_per_block, int blocks0) {
+                                                     int rps0, int rps1, int M, int D, int split, int rows_per_block, int blocks0,
+                                                     float* __restrict__ partial) {
   extern __shared__ float red[];  // [2][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int blk = blockIdx.x;
@@ -190,7 +191,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
     }
   }
   __syncthreads();
-  if (r_begin < r_end) {
+  if (partial) {          // two-stage reduction: [block][2][D] partials, summed by ln_param_reduce_kernel
+    float* pp = partial + (long)blk * 2 * D;
+    for (int c = threadIdx.x; c < D; c += 256) { pp[c] = rg[c]; pp[D + c] = rb[c]; }
+  } else if (r_begin < r_end) {
     for (int c = threadIdx.x; c < D; c += 256) {
       atomicAdd(dgamma + (long)g * gstride + c, rg[c]);
       atomicAdd(dbeta + (long)g * gstride + c, rb[c]);
@@ -210,7 +214,8 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const bf16_t* __restri
                                                           bf16_t* __restrict__ out_bf16, int ldob, const bf16_t* __restrict__ gelu_u, int ldu,
                                                           const float* __restrict__ dres, float* __restrict__ out_f32, int ldof,
                                                           bf16_t* __restrict__ out_scaled, int ldos, const float* __restrict__ row_scale,
-                                                          int rps0, int rps1, int M, int D, int split, int rows_per_block, int blocks0) {
+                                                          int rps0, int rps1, int M, int D, int split, int rows_per_block, int blocks0,
+                                                          float* __restrict__ partial) {
   __shared__ float part[2][4][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int blk = blockIdx.x;
@@ -303,7 +308,17 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const bf16_t* __restri
       }
     }
   }
-  if (r_begin < r_end && dgamma) {
+  if (partial) {
+    float* pp = partial + (long)blk * 2 * D;
+#pragma unroll
+    for (int it = 0; it < NITW; ++it) {
+      const int c = (it * 256 + tid) * 4;
+      if (c < D) {
+        *(f32x4_t*)(pp + c) = (f32x4_t){ag[it][0], ag[it][1], ag[it][2], ag[it][3]};
+        *(f32x4_t*)(pp + D + c) = (f32x4_t){ab[it][0], ab[it][1], ab[it][2], ab[it][3]};
+      }
+    }
+  } else if (r_begin < r_end && dgamma) {
 #pragma unroll
     for (int it = 0; it < NITW; ++it) {
       const int c = (it * 256 + tid) * 4;
@@ -315,6 +330,28 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const bf16_t* __restri
         }
       }
     }
+  }
+}
+
+// second stage: dgamma[g][c] += sum over the blocks of group g of partial[blk][0][c] (same for dbeta)
+__global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int gstride, int D, int blocks0,
+                                                              int blocks1) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int which = blockIdx.y & 1, g = blockIdx.y >> 1;
+  const int b0 = g ? blocks0 : 0, b1 = g ? blocks0 + blocks1 : blocks0;
+  __shared__ float red[16][64];
+  float s = 0.f;
+  if (c < D)
+    for (int b = b0 + (threadIdx.x >> 6); b < b1; b += 16) s += partial[((long)b * 2 + which) * D + c];
+  red[threadIdx.x >> 6][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (threadIdx.x < 64 && c < D && b1 > b0) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w][threadIdx.x];
+    float* dst = (which ? dbeta : dgamma) + (long)g * gstride + c;
+    *dst += t;
   }
 }
 
@@ -357,12 +394,14 @@ extern "C" int simvg_ln_bwd(const void* dy_bf16, int dy_is_f32, int lddy, const 
                             void* dx_bf16, int lddxb, const void* gelu_u_bf16, int ldu, const float* dres,
                             float* dx_f32, int lddxf, void* dx_scaled_bf16, int lddxs, const float* row_scale,
                             int rows_per_sample0, int rows_per_sample1, int M, int D, int split,
-                            hipStream_t stream) {
+                            float* partial_ws, hipStream_t stream) {
   SIMVG_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 4096, "ln_bwd: D must be a multiple of 4 and <= 4096");
   SIMVG_CHECK_ARG(dx_bf16 || dx_f32, "ln_bwd: no output");
   SIMVG_CHECK_ARG(!dy_is_f32 || (D <= 256 && !x_is_bf16), "ln_bwd: fp32 dy is only built for the head (D <= 256, fp32 x)");
   SIMVG_CHECK_ARG(!(dx_scaled_bf16 && !dx_f32), "ln_bwd: scaled bf16 copy requires the f32 output");
   if (split == 0) split = M;
+  // partial_ws (optional, >= simvg_ln_bwd_ws_floats(M, D, split) floats): two-stage dgamma/dbeta reduction instead of
+  // global atomics
   static const int rpb_env = getenv("SIMVG_LN_RPB") ? atoi(getenv("SIMVG_LN_RPB")) : 32;
   const int rpb = rpb_env;
   const int blocks0 = cdiv(split, rpb), blocks1 = cdiv(M - split, rpb);
@@ -373,7 +412,10 @@ extern "C" int simvg_ln_bwd(const void* dy_bf16, int dy_is_f32, int lddy, const 
     hipLaunchKernelGGL((ln_bwd_kernel<float, float, 1>), grid, block, shm, stream, (const float*)dy_bf16, lddy,
                        (const float*)x, ldx, mean, rstd, gamma, group_stride, dgamma, dbeta, (bf16_t*)dx_bf16, lddxb,
                        (const bf16_t*)gelu_u_bf16, ldu, dres, dx_f32, lddxf, (bf16_t*)dx_scaled_bf16, lddxs, row_scale,
-                       rps0, rps1, M, D, split, rpb, blocks0);
+                       rps0, rps1, M, D, split, rpb, blocks0, partial_ws);
+    if (partial_ws)
+      hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(D, 64), 4), dim3(1024), 0, stream, partial_ws, dgamma, dbeta,
+                         group_stride, D, blocks0, blocks1);
     SIMVG_LAUNCH_CHECK();
     return SIMVG_OK;
   }
@@ -383,10 +425,13 @@ extern "C" int simvg_ln_bwd(const void* dy_bf16, int dy_is_f32, int lddy, const 
     hipLaunchKernelGGL((ln_bwd_wide_kernel<T_, N_>), grid, block, 0, stream, (const bf16_t*)dy_bf16, lddy, (const T_*)x, \
                        ldx, mean, rstd, gamma, group_stride, dgamma, dbeta, (bf16_t*)dx_bf16, lddxb,                    \
                        (const bf16_t*)gelu_u_bf16, ldu, dres, dx_f32, lddxf, (bf16_t*)dx_scaled_bf16, lddxs, row_scale, \
-                       rps0, rps1, M, D, split, rpb, blocks0)
+                       rps0, rps1, M, D, split, rpb, blocks0, partial_ws)
     if (x_is_bf16) { if (nitw <= 2) WCALL(bf16_t, 2); else if (nitw == 3) WCALL(bf16_t, 3); else WCALL(bf16_t, 4); }
     else { if (nitw <= 2) WCALL(float, 2); else if (nitw == 3) WCALL(float, 3); else WCALL(float, 4); }
 #undef WCALL
+    if (partial_ws)
+      hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(D, 64), 4), dim3(1024), 0, stream, partial_ws, dgamma, dbeta,
+                         group_stride, D, blocks0, blocks1);
     SIMVG_LAUNCH_CHECK();
     return SIMVG_OK;
   }
@@ -395,14 +440,23 @@ extern "C" int simvg_ln_bwd(const void* dy_bf16, int dy_is_f32, int lddy, const 
     hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, bf16_t, N_>), grid, block, shm, stream, (const bf16_t*)dy_bf16, lddy,             \
                        (const bf16_t*)x, ldx, mean, rstd, gamma, group_stride, dgamma, dbeta, (bf16_t*)dx_bf16, lddxb,  \
                        (const bf16_t*)gelu_u_bf16, ldu, dres, dx_f32, lddxf, (bf16_t*)dx_scaled_bf16, lddxs, row_scale, \
-                       rps0, rps1, M, D, split, rpb, blocks0);                                                          \
+                       rps0, rps1, M, D, split, rpb, blocks0, partial_ws);                                                          \
   else                                                                                                                  \
     hipLaunchKernelGGL((ln_bwd_kernel<float, bf16_t, N_>), grid, block, shm, stream, (const bf16_t*)dy_bf16, lddy,              \
                        (const float*)x, ldx, mean, rstd, gamma, group_stride, dgamma, dbeta, (bf16_t*)dx_bf16, lddxb,   \
                        (const bf16_t*)gelu_u_bf16, ldu, dres, dx_f32, lddxf, (bf16_t*)dx_scaled_bf16, lddxs, row_scale, \
-                       rps0, rps1, M, D, split, rpb, blocks0)
+                       rps0, rps1, M, D, split, rpb, blocks0, partial_ws)
   LN_DISPATCH_NIT(D, CALL);
 #undef CALL
+  if (partial_ws)
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(D, 64), 4), dim3(1024), 0, stream, partial_ws, dgamma, dbeta,
+                       group_stride, D, blocks0, blocks1);
   SIMVG_LAUNCH_CHECK();
   return SIMVG_OK;
+}
+
+extern "C" long simvg_ln_bwd_ws_floats(int M, int D, int split) {
+  if (split == 0) split = M;
+  const int rpb = 32;
+  return (long)(cdiv(split, rpb) + cdiv(M - split, rpb)) * 2 * D;
 }

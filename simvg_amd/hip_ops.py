@@ -150,9 +150,24 @@ def ln_fwd(x, gamma, beta, split=0, eps=1e-5, out_bf16=True, out_f32=False, save
     return y, y32, mean, rstd
 
 
+_ln_ws = {}
+
+
+def _ln_workspace(M, D, split, device):
+    n = int(_lib.load().simvg_ln_bwd_ws_floats(M, D, split))
+    key = (str(device), n)
+    t = _ln_ws.get(key)
+    if t is None:
+        t = torch.empty(n, device=device, dtype=torch.float32)
+        _ln_ws[key] = t
+    return t
+
+
 def ln_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, split=0, dx_bf16=None, gelu_u=None, dres=None, dx_f32=None,
            dx_scaled=None, row_scale=None, rows_per_sample=(1, 1)):
     lib = _lib.load()
+    # two-stage dgamma/dbeta reduction pays for wide rows only (measured: profiles/r01_sweeps.md)
+    ws = _ln_workspace(dy.shape[0], dy.shape[1], split, dy.device) if (dy.shape[0] >= 1024 and dy.shape[1] >= 2048) else None
     _chk(dy, None, "dy")
     M, D = dy.shape
     gs = gamma.stride(0) if gamma.dim() == 2 else 0
@@ -163,7 +178,7 @@ def ln_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, split=0, dx_bf16=None, gelu_
                           gelu_u.stride(0) if gelu_u is not None else 0, _p(dres), _p(dx_f32),
                           dx_f32.stride(0) if dx_f32 is not None else 0, _p(dx_scaled),
                           dx_scaled.stride(0) if dx_scaled is not None else 0, _p(row_scale),
-                          rows_per_sample[0], rows_per_sample[1], M, D, split, _stream())
+                          rows_per_sample[0], rows_per_sample[1], M, D, split, _p(ws), _stream())
     if t0 is not None:
         nb = dy.element_size() + x.element_size() + (2 if dx_bf16 is not None else 0) + (2 if gelu_u is not None else 0) \
             + (4 if dres is not None else 0) + (4 if dx_f32 is not None else 0) + (2 if dx_scaled is not None else 0)
