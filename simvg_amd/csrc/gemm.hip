@@ -394,8 +394,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave >> 1, wk = wave & 1;
-  const int tiles_k = (a.K + 127) / 128;
-  const int tile_n = blockIdx.x / tiles_k, tile_k = blockIdx.x - tile_n * tiles_k;
+  const int tiles_k = (a.K + 127) / 128, tiles_n = (a.N + 127) / 128;
+  // XCD-aware: each XCD (blockIdx.x % 8) owns a contiguous slab of output tiles along the LARGER of N / K, so its L2
+  // only has to hold 1/8 of the bigger operand's column panels (PMC before: 3.5x the algorithmic bytes fetched)
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  int tile_n, tile_k;
+  if (tiles_n >= tiles_k) { tile_n = wg / tiles_k; tile_k = wg - tile_n * tiles_k; }
+  else { tile_k = wg / tiles_n; tile_n = wg - tile_k * tiles_n; }
   const int chunk = blockIdx.y;
   const int group = chunk >= a.chunks0;
   const int m_begin = group ? a.split + (chunk - a.chunks0) * a.rows_per_chunk : chunk * a.rows_per_chunk;
