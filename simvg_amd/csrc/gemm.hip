@@ -57,12 +57,13 @@ __device__ __forceinline__ bf16x8_t read_frag_k64(const char* lds, int row, int 
 
 // shared epilogue: bias, optional pre-activation copy, GELU/ReLU, DropPath-scaled residual add, vector stores.
 // acc[i][j][r] = C[row0 + wm*64 + i*16 + (lane&15)][n0 + wn*64 + j*16 + 4*(lane>>4) + r]
-__device__ __forceinline__ void gemm_nt_epilogue(const GemmNTArgs& a, f32x4_t (&acc)[4][4], int group, int row0,
+template <int MI>
+__device__ __forceinline__ void gemm_nt_epilogue(const GemmNTArgs& a, f32x4_t (&acc)[MI][4], int group, int row0,
                                                  int row_end, int n0, int wm, int wn, int lane) {
   const float* bias = a.bias ? a.bias + (long)group * a.bias_gstride : nullptr;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = row0 + wm * 64 + i * 16 + (lane & 15);
+  for (int i = 0; i < MI; ++i) {
+    const int m = row0 + wm * (MI * 16) + i * 16 + (lane & 15);
     if (m >= row_end) continue;
     float rs = 1.f;
     if (a.row_scale) {
@@ -125,6 +126,107 @@ __device__ __forceinline__ void gemm_nt_epilogue(const GemmNTArgs& a, f32x4_t (&
   }
 }
 
+// Coalesced epilogue: each wave stages (acc + bias) of 32 x 64 outputs at a time through its own 8.5 KiB slice of
+// the (finished) LDS ring and writes them back row-wise, 16 B per lane: a store instruction covers 8 rows x 128 B
+// (bf16) or 4 rows x 256 B (fp32) instead of 16 rows x 32 B.  Activation, the bf16 pre-activation copy, DropPath
+// scale and the residual add are applied at read-out, so GELU/residual operands are read coalesced as well.
+// Requires N % 8 == 0 (vector path); callers fall back to gemm_nt_epilogue otherwise.
+constexpr int EPI_LD = 68;                       // floats per staged row (64 + 4 pad)
+constexpr int EPI_WAVE_BYTES = 32 * EPI_LD * 4;  // 8704 B per wave
+
+__device__ __forceinline__ void gemm_nt_epilogue_lds(const GemmNTArgs& a, f32x4_t (&acc)[4][4], int group, int row0,
+                                                     int row_end, int n0, int wm, int wn, int wave, int lane,
+                                                     char* smem) {
+  __syncthreads();                                // every wave is done reading the ring
+  float* st = (float*)(smem + wave * EPI_WAVE_BYTES);
+  const float* bias = a.bias ? a.bias + (long)group * a.bias_gstride : nullptr;
+  const int nbase = n0 + wn * 64;
+  float bv[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = nbase + j * 16 + 4 * (lane >> 4);
+    if (bias && n < a.N) {
+      const f32x4_t t = *(const f32x4_t*)(bias + n);
+      bv[j][0] = t[0]; bv[j][1] = t[1]; bv[j][2] = t[2]; bv[j][3] = t[3];
+    } else {
+      bv[j][0] = bv[j][1] = bv[j][2] = bv[j][3] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4_t v = acc[2 * p + ii][j];
+        *(f32x4_t*)(st + (ii * 16 + (lane & 15)) * EPI_LD + j * 16 + 4 * (lane >> 4)) =
+            (f32x4_t){v[0] + bv[j][0], v[1] + bv[j][1], v[2] + bv[j][2], v[3] + bv[j][3]};
+      }
+    // wave-private slice: only this wave's own LDS writes must have landed (no barrier)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int mbase = row0 + wm * 64 + p * 32;
+    if (!a.c_f32) {
+      // bf16 output: lane -> 8 consecutive columns, 8 lanes per row, 8 rows per pass
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int r = it * 8 + (lane >> 3), c = (lane & 7) * 8;
+        const int m = mbase + r, n = nbase + c;
+        if (m >= row_end || n >= a.N) continue;
+        const f32x4_t u0 = *(const f32x4_t*)(st + r * EPI_LD + c), u1 = *(const f32x4_t*)(st + r * EPI_LD + c + 4);
+        float v[8] = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3]};
+        if (a.aux)
+          *(u32x4_t*)(a.aux + (long)m * a.ldaux + n) = (u32x4_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]),
+                                                                 pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+        if (a.act == 1) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = gelu_erf(v[k]);
+        } else if (a.act == 2) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+        if (a.row_scale) {
+          const float rs = a.row_scale[group ? (m - a.split) / a.rps1 : m / a.rps0];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] *= rs;
+        }
+        *(u32x4_t*)((bf16_t*)a.C + (long)m * a.ldc + n) = (u32x4_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]),
+                                                                    pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+      }
+    } else {
+      // fp32 output (+ residual): lane -> 4 consecutive columns, 16 lanes per row, 4 rows per pass
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int r = it * 4 + (lane >> 4), c = (lane & 15) * 4;
+        const int m = mbase + r, n = nbase + c;
+        if (m >= row_end || n >= a.N) continue;
+        const f32x4_t u = *(const f32x4_t*)(st + r * EPI_LD + c);
+        float v[4] = {u[0], u[1], u[2], u[3]};
+        if (a.aux) *(u32x2_t*)(a.aux + (long)m * a.ldaux + n) = (u32x2_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        if (a.act == 1) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = gelu_erf(v[k]);
+        } else if (a.act == 2) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+        float rs = 1.f;
+        if (a.row_scale) rs = a.row_scale[group ? (m - a.split) / a.rps1 : m / a.rps0];
+        if (a.res) {
+          const f32x4_t rv = *(const f32x4_t*)(a.res + (long)m * a.ldres + n);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = rv[k] + rs * v[k];
+        } else if (a.row_scale) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] *= rs;
+        }
+        *(f32x4_t*)((float*)a.C + (long)m * a.ldc + n) = (f32x4_t){v[0], v[1], v[2], v[3]};
+      }
+    }
+    // the next pass overwrites the slice: this wave's reads must have completed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -179,7 +281,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
     __syncthreads();
   }
 
-  gemm_nt_epilogue(a, acc, group, row0, row_end, n0, wm, wn, lane);
+  gemm_nt_epilogue<4>(a, acc, group, row0, row_end, n0, wm, wn, lane);
 }
 
 
@@ -264,7 +366,8 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel_256(GemmNTArgs a) {
 #undef STA
 #undef STB
 #undef ISSUE
-  gemm_nt_epilogue(a, acc, group, row0, row_end, n0, wm, wn, lane);
+  if ((a.N & 7) == 0 && !(a.flags & 32)) { gemm_nt_epilogue_lds(a, acc, group, row0, row_end, n0, wm, wn, wave, lane, smem); return; }
+  gemm_nt_epilogue<4>(a, acc, group, row0, row_end, n0, wm, wn, lane);
 }
 
 
@@ -327,7 +430,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_256k32(GemmNTArgs a) {
     if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (kt + 2 < nk) ISSUE(kt + 2);
+    if (kt + 2 < nk && !(a.flags & 4)) ISSUE(kt + 2);          // flags&4: ablation, no global loads in the loop
     const char* sA = STA(kt % 3);
     const char* sB = STB(kt % 3);
     bf16x8_t fa[4], fb[4];
@@ -336,17 +439,33 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_256k32(GemmNTArgs a) {
       fa[i] = read_frag_k32(sA, wm * 64 + i * 16 + (lane & 15), lane >> 4);
       fb[i] = read_frag_k32(sB, wn * 64 + i * 16 + (lane & 15), lane >> 4);
     }
+    if (a.flags & 8) {                                           // flags&8: ablation, no MFMAs (fragments kept live)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fa[i]), "v"(fb[i]));
+    } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
   }
 #undef STA
 #undef STB
 #undef ISSUE
-  gemm_nt_epilogue(a, acc, group, row0, row_end, n0, wm, wn, lane);
+  if (a.flags & 16) {   // ablation: no epilogue (one conditional dword keeps the accumulators live)
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) t += acc[i][jj][0] + acc[i][jj][1] + acc[i][jj][2] + acc[i][jj][3];
+    if (t == 123.456f) ((float*)a.C)[tid] = t;
+    return;
+  }
+  if ((a.N & 7) == 0 && !(a.flags & 32)) { gemm_nt_epilogue_lds(a, acc, group, row0, row_end, n0, wm, wn, wave, lane, smem); return; }
+  gemm_nt_epilogue<4>(a, acc, group, row0, row_end, n0, wm, wn, lane);
 }
+
 
 // ------------------------------------------------------------------------------------------
 // wgrad: dW[g][n][k] += sum_m dY[m][n] * X[m][k]
@@ -460,88 +579,6 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs a) {
     }
 }
 
-// wgrad v2: 32-row stages (16 KiB), 3-stage global_load_lds ring with counted vmcnt + raw barrier; 48 KiB of LDS
-// per workgroup -> three workgroups (12 waves) per CU instead of two, and no vmcnt(0) drain per stage.
-__device__ __forceinline__ void stage_tile_m32(const bf16_t* base, int ld, int m0, int m_end, int c0, int ncols,
-                                               char* lds, int wave, int lane) {
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int inst = wave * 2 + i;
-    const int r = inst * 4 + (lane >> 4);
-    const int lslot = (lane & 15) ^ ((r & 3) << 1);
-    const int row = m0 + r, col = c0 + lslot * 8;
-    const bf16_t* src = (row < m_end && col < ncols) ? base + (long)row * ld + col : (const bf16_t*)g_zero_page;
-    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds + inst * 1024), 16, 0, 0);
-  }
-}
-
-__global__ __launch_bounds__(256, 3) void gemm_tn_kernel_v2(GemmTNArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wn = wave >> 1, wk = wave & 1;
-  const int tiles_k = (a.K + 127) / 128;
-  const int tile_n = blockIdx.x / tiles_k, tile_k = blockIdx.x - tile_n * tiles_k;
-  const int chunk = blockIdx.y;
-  const int group = chunk >= a.chunks0;
-  const int m_begin = group ? a.split + (chunk - a.chunks0) * a.rows_per_chunk : chunk * a.rows_per_chunk;
-  const int g_end = group ? a.M : a.split;
-  const int m_end = min(m_begin + a.rows_per_chunk, g_end);
-  if (m_begin >= m_end) return;
-  const int n0 = tile_n * 128, k0 = tile_k * 128;
-  f32x4_t acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  const int nt = (m_end - m_begin + 31) / 32;
-#define SY(s_) (smem + (s_) * 16384)
-#define SX(s_) (smem + (s_) * 16384 + 8192)
-#define ISSUE(t_)                                                                                  \
-  do {                                                                                             \
-    const int st__ = (t_) % 3;                                                                     \
-    stage_tile_m32(a.dY, a.lddy, m_begin + (t_) * 32, m_end, n0, a.N, SY(st__), wave, lane);       \
-    stage_tile_m32(a.X, a.ldx, m_begin + (t_) * 32, m_end, k0, a.K, SX(st__), wave, lane);         \
-  } while (0)
-  ISSUE(0);
-  if (nt > 1) ISSUE(1);
-  for (int t = 0; t < nt; ++t) {
-    if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (t + 2 < nt) ISSUE(t + 2);
-    const char* sy = SY(t % 3);
-    const char* sx = SX(t % 3);
-    bf16x8_t fy[4], fx[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      fy[i] = read_frag_tr(sy, 0, wn * 64 + i * 16, lane);
-      fx[i] = read_frag_tr(sx, 0, wk * 64 + i * 16, lane);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], fx[j], acc[i][j], 0, 0, 0);
-  }
-#undef SY
-#undef SX
-#undef ISSUE
-  float* dW = a.dW + (long)group * a.dw_gstride;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int k = k0 + wk * 64 + j * 16 + (lane & 15);
-      if (k >= a.K) continue;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int n = n0 + wn * 64 + i * 16 + 4 * (lane >> 4) + r;
-        if (n < a.N) atomicAdd(dW + (long)n * a.lddw + k, acc[i][j][r]);
-      }
-    }
-}
-
 // column sums by row group: out[g][n] += sum_{m in group g} Y[m][n]   (bias gradients)
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* Y, int ldy, float* out, int out_gstride,
                                                      int M, int N, int split, int rows_per_chunk, int chunks0) {
@@ -601,7 +638,7 @@ extern "C" int simvg_gemm_nt(const void* A, int lda, const void* W, long w_gstri
     (void)once3;
     const int tiles = (cdiv(split, BM2) + cdiv(M - split, BM2)) * cdiv(N, BN);
     hipLaunchKernelGGL(gemm_nt_kernel_256k32, dim3(tiles), dim3(512), 3 * STAGE3, stream, a);
-  } else if (variant == 256 && M >= 512) {
+  } else if (variant != 128 && M >= 512) {
     static bool once = hipFuncSetAttribute((const void*)gemm_nt_kernel_256, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            3 * STAGE2) == hipSuccess;
     (void)once;
@@ -631,11 +668,7 @@ extern "C" int simvg_gemm_tn(const void* dY, int lddy, const void* X, int ldx, f
   if (rpc < 256) rpc = 256;   // multiple of 64 (v1 stages) and of 32 (v2 stages)
   const int chunks0 = cdiv(split, rpc), chunks1 = cdiv(M - split, rpc);
   GemmTNArgs a{(const bf16_t*)dY, lddy, (const bf16_t*)X, ldx, dW, dw_gstride, lddw, M, N, K, split, rpc, chunks0};
-  static const int tn_variant = getenv("SIMVG_GEMM_TN") ? atoi(getenv("SIMVG_GEMM_TN")) : 1;   // v2 measured slower (tr-read bound)
-  if (tn_variant == 2)
-    hipLaunchKernelGGL(gemm_tn_kernel_v2, dim3(tiles, chunks0 + chunks1), dim3(256), 3 * 16384, stream, a);
-  else
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, chunks0 + chunks1), dim3(256), 65536, stream, a);
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, chunks0 + chunks1), dim3(256), 65536, stream, a);
   SIMVG_LAUNCH_CHECK();
   return SIMVG_OK;
 }
