@@ -39,15 +39,16 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) {
   return __uint_as_float(((unsigned int)v) << 16);
 }
-// round-to-nearest-even, NaN preserved (matches torch .to(bfloat16))
+// float -> bf16, round-to-nearest-even (matches torch .to(bfloat16)): native __bf16 conversions, which hipcc lowers to
+// the gfx950 hardware v_cvt_pk_bf16_f32 (one instruction per PAIR instead of ~6 integer ops per value)
+typedef __bf16 hw_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float hw_f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  unsigned int u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+  return __builtin_bit_cast(unsigned short, (__bf16)f);
 }
 __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
-  return (unsigned int)f32_to_bf16(lo) | ((unsigned int)f32_to_bf16(hi) << 16);
+  const hw_bf16x2_t v = __builtin_convertvector((hw_f32x2_t){lo, hi}, hw_bf16x2_t);
+  return __builtin_bit_cast(unsigned int, v);
 }
 // exact-erf GELU (torch F.gelu default) with erf from Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. ~4 orders
 // below the bf16 rounding of the stored result) -- one v_exp + one v_rcp instead of the ~50-instruction libm erff;

@@ -474,7 +474,7 @@ struct GemmTNArgs {
   const bf16_t* dY; int lddy;
   const bf16_t* X; int ldx;
   float* dW; long dw_gstride; int lddw;
-  int M, N, K, split, rows_per_chunk, chunks0;
+  int M, N, K, split, rows_per_chunk, chunks0, flags;
 };
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page[64];  // 256 B of zeros
@@ -565,6 +565,15 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs a) {
     __syncthreads();
   }
   float* dW = a.dW + (long)group * a.dw_gstride;
+  if (a.flags & 1) {   // ablation: no atomics
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (t == 123.456f) dW[tid] = t;
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -667,7 +676,8 @@ extern "C" int simvg_gemm_tn(const void* dY, int lddy, const void* X, int ldx, f
   int rpc = cdiv(cdiv(M, want), 64) * 64;
   if (rpc < 256) rpc = 256;   // multiple of 64 (v1 stages) and of 32 (v2 stages)
   const int chunks0 = cdiv(split, rpc), chunks1 = cdiv(M - split, rpc);
-  GemmTNArgs a{(const bf16_t*)dY, lddy, (const bf16_t*)X, ldx, dW, dw_gstride, lddw, M, N, K, split, rpc, chunks0};
+  GemmTNArgs a{(const bf16_t*)dY, lddy, (const bf16_t*)X, ldx, dW, dw_gstride, lddw, M, N, K, split, rpc, chunks0,
+               getenv("SIMVG_TN_FLAGS") ? atoi(getenv("SIMVG_TN_FLAGS")) : 0};
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, chunks0 + chunks1), dim3(256), 65536, stream, a);
   SIMVG_LAUNCH_CHECK();
   return SIMVG_OK;
