@@ -543,7 +543,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs a) {
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
     const int cur = t & 1;
-    if (t + 1 < nt) {
+    if (t + 1 < nt && !(a.flags & 2)) {
       stage_tile_m64(a.dY, a.lddy, m_begin + (t + 1) * 64, m_end, n0, a.N, ldsY(cur ^ 1), wave, lane);
       stage_tile_m64(a.X, a.ldx, m_begin + (t + 1) * 64, m_end, k0, a.K, ldsX(cur ^ 1), wave, lane);
     }
@@ -555,11 +555,16 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs a) {
         fy[i] = read_frag_tr(ldsY(cur), s * 32, wn * 64 + i * 16, lane);
         fx[i] = read_frag_tr(ldsX(cur), s * 32, wk * 64 + i * 16, lane);
       }
+      if (a.flags & 4) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fy[i]), "v"(fx[i]));
+      } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], fx[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], fx[j], acc[i][j], 0, 0, 0);
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -574,6 +579,109 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs a) {
     if (t == 123.456f) dW[tid] = t;
     return;
   }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + wk * 64 + j * 16 + (lane & 15);
+      if (k >= a.K) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn * 64 + i * 16 + 4 * (lane >> 4) + r;
+        if (n < a.N) atomicAdd(dW + (long)n * a.lddw + k, acc[i][j][r]);
+      }
+    }
+}
+
+// wgrad, 256 (n) x 128 (k) output tile: 8 waves as 4 (n) x 2 (k), each 64x64; 32-row stages {dY [32][256], X [32][128]}
+// = 24 KiB, 3-stage global_load_lds ring with counted vmcnt + raw barrier, 72 KiB LDS -> two workgroups per CU.
+// 87 FLOP per staged byte instead of 65 (the kernel is load-bound: removing the loads saves 40 %).
+__device__ __forceinline__ void stage_rows32(const bf16_t* base, int ld, int m0, int m_end, int c0, int ncols, int width,
+                                             char* lds, int wave, int lane, int per_wave) {
+  // width = tile columns (256 or 128); a 1 KiB wave-instruction covers 1024 / (2*width) rows
+  const int lanes_per_row = width / 8, rows_per_inst = 64 / lanes_per_row;
+  for (int i = 0; i < per_wave; ++i) {
+    const int inst = wave * per_wave + i;
+    const int r = inst * rows_per_inst + lane / lanes_per_row;
+    const int pslot = lane % lanes_per_row;
+    const int lslot = pslot ^ ((r & 3) << 1);
+    const int row = m0 + r, col = c0 + lslot * 8;
+    const bf16_t* src = (row < m_end && col < ncols) ? base + (long)row * ld + col : (const bf16_t*)g_zero_page;
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds + inst * 1024), 16, 0, 0);
+  }
+}
+// transposed fragment from a [32 rows][width cols] stage: lane (i = lane&15 -> column c0+i, g = lane>>4 -> rows 8g..8g+7)
+__device__ __forceinline__ bf16x8_t read_frag_tr_w(const char* lds, int row_bytes, int c0, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  const int col = c0 + 4 * (i & 3);
+  const int lslot = col >> 3, within = (col & 7) * 2;
+  bf16x8_t out;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row = 8 * g + 4 * h + (i >> 2);
+    const bf16x4_t v = lds_read_tr16(lds + row * row_bytes + ((lslot ^ ((row & 3) << 1)) << 4) + within);
+    out[4 * h + 0] = v[0]; out[4 * h + 1] = v[1]; out[4 * h + 2] = v[2]; out[4 * h + 3] = v[3];
+  }
+  return out;
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_tn_kernel_256(GemmTNArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave >> 1, wk = wave & 1;
+  const int tiles_k = (a.K + 127) / 128, tiles_n = (a.N + 255) / 256;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  int tile_n, tile_k;
+  if (tiles_n >= tiles_k) { tile_n = wg / tiles_k; tile_k = wg - tile_n * tiles_k; }
+  else { tile_k = wg / tiles_n; tile_n = wg - tile_k * tiles_n; }
+  const int chunk = blockIdx.y;
+  const int group = chunk >= a.chunks0;
+  const int m_begin = group ? a.split + (chunk - a.chunks0) * a.rows_per_chunk : chunk * a.rows_per_chunk;
+  const int g_end = group ? a.M : a.split;
+  const int m_end = min(m_begin + a.rows_per_chunk, g_end);
+  if (m_begin >= m_end) return;
+  const int n0 = tile_n * 256, k0 = tile_k * 128;
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int nt = (m_end - m_begin + 31) / 32;
+  constexpr int ST = 24576;
+#define SY(s_) (smem + (s_) * ST)
+#define SX(s_) (smem + (s_) * ST + 16384)
+#define ISSUE(t_)                                                                                          \
+  do {                                                                                                     \
+    const int st__ = (t_) % 3;                                                                             \
+    stage_rows32(a.dY, a.lddy, m_begin + (t_) * 32, m_end, n0, a.N, 256, SY(st__), wave, lane, 2);         \
+    stage_rows32(a.X, a.ldx, m_begin + (t_) * 32, m_end, k0, a.K, 128, SX(st__), wave, lane, 1);           \
+  } while (0)
+  ISSUE(0);
+  if (nt > 1) ISSUE(1);
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 < nt) ISSUE(t + 2);
+    const char* sy = SY(t % 3);
+    const char* sx = SX(t % 3);
+    bf16x8_t fy[4], fx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      fy[i] = read_frag_tr_w(sy, 512, wn * 64 + i * 16, lane);
+      fx[i] = read_frag_tr_w(sx, 256, wk * 64 + i * 16, lane);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], fx[j], acc[i][j], 0, 0, 0);
+  }
+#undef SY
+#undef SX
+#undef ISSUE
+  float* dW = a.dW + (long)group * a.dw_gstride;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -667,18 +775,27 @@ extern "C" int simvg_gemm_tn(const void* dY, int lddy, const void* X, int ldx, f
   SIMVG_CHECK_ARG(N % 8 == 0 && K % 8 == 0 && lddy % 8 == 0 && ldx % 8 == 0, "gemm_tn: N, K, ld must be multiples of 8");
   SIMVG_CHECK_ARG(split >= 0 && split <= M, "gemm_tn: split out of range");
   if (split == 0) split = M;
-  const int tiles = cdiv(N, 128) * cdiv(K, 128);
-  // split the contraction (rows) so that the grid fills the chip about twice over
+  static const int tn_variant = getenv("SIMVG_GEMM_TN") ? atoi(getenv("SIMVG_GEMM_TN")) : 256;
+  // 256x128 ring kernel for the wide problems (qkv / fc1 / fc2 wgrad); the small out-proj stays on the 128x128 kernel
+  const bool big = tn_variant == 256 && cdiv(N, 256) * cdiv(K, 128) >= 24;
+  const int tiles = big ? cdiv(N, 256) * cdiv(K, 128) : cdiv(N, 128) * cdiv(K, 128);
   // split the contraction so that tiles x chunks ~ 2-3 blocks per CU (measured sweep, profiles/r01_sweeps.md)
   static const int target_env = getenv("SIMVG_TN_BLOCKS") ? atoi(getenv("SIMVG_TN_BLOCKS")) : 0;
-  const int target_blocks = target_env ? target_env : (tiles <= 48 ? 256 : 768);
+  const int target_blocks = target_env ? target_env : (big ? 384 : (tiles <= 48 ? 256 : 768));
   int want = cdiv(target_blocks, tiles);
   int rpc = cdiv(cdiv(M, want), 64) * 64;
-  if (rpc < 256) rpc = 256;   // multiple of 64 (v1 stages) and of 32 (v2 stages)
+  if (rpc < 256) rpc = 256;   // multiple of 64 (and of the 32-row stages)
   const int chunks0 = cdiv(split, rpc), chunks1 = cdiv(M - split, rpc);
   GemmTNArgs a{(const bf16_t*)dY, lddy, (const bf16_t*)X, ldx, dW, dw_gstride, lddw, M, N, K, split, rpc, chunks0,
                getenv("SIMVG_TN_FLAGS") ? atoi(getenv("SIMVG_TN_FLAGS")) : 0};
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, chunks0 + chunks1), dim3(256), 65536, stream, a);
+  if (big) {
+    static bool once = hipFuncSetAttribute((const void*)gemm_tn_kernel_256, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           3 * 24576) == hipSuccess;
+    (void)once;
+    hipLaunchKernelGGL(gemm_tn_kernel_256, dim3(tiles, chunks0 + chunks1), dim3(512), 3 * 24576, stream, a);
+  } else {
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, chunks0 + chunks1), dim3(256), 65536, stream, a);
+  }
   SIMVG_LAUNCH_CHECK();
   return SIMVG_OK;
 }

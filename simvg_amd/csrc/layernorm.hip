@@ -402,8 +402,9 @@ extern "C" int simvg_ln_bwd(const void* dy_bf16, int dy_is_f32, int lddy, const 
   if (split == 0) split = M;
   // partial_ws (optional, >= simvg_ln_bwd_ws_floats(M, D, split) floats): two-stage dgamma/dbeta reduction instead of
   // global atomics
-  static const int rpb_env = getenv("SIMVG_LN_RPB") ? atoi(getenv("SIMVG_LN_RPB")) : 32;
-  const int rpb = rpb_env;
+  // rows per block: 16 for the wide two-stage kernel, 32 for the wave-per-row kernels (sweep: profiles/r01_sweeps.md)
+  static const int rpb_env = getenv("SIMVG_LN_RPB") ? atoi(getenv("SIMVG_LN_RPB")) : 0;
+  const int rpb = rpb_env ? rpb_env : ((D >= 2048 && partial_ws) ? 16 : 32);
   const int blocks0 = cdiv(split, rpb), blocks1 = cdiv(M - split, rpb);
   const dim3 grid(blocks0 + blocks1), block(256);
   const size_t shm = (size_t)2 * D * sizeof(float);
@@ -457,6 +458,6 @@ extern "C" int simvg_ln_bwd(const void* dy_bf16, int dy_is_f32, int lddy, const 
 
 extern "C" long simvg_ln_bwd_ws_floats(int M, int D, int split) {
   if (split == 0) split = M;
-  const int rpb = 32;
+  const int rpb = getenv("SIMVG_LN_RPB") ? atoi(getenv("SIMVG_LN_RPB")) : (D >= 2048 ? 16 : 32);
   return (long)(cdiv(split, rpb) + cdiv(M - split, rpb)) * 2 * D;
 }
