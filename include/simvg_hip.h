@@ -44,9 +44,10 @@ int simvg_gemm_nt(const void* A_bf16, int lda, const void* W_bf16, long w_group_
                   void* aux_preact_bf16, int ldaux, const float* residual, int ldres,
                   const float* row_scale, int rows_per_sample0, int rows_per_sample1,
                   int M, int N, int K, int split, int act, simvg_stream_t stream);
-/* dW[g][N,K] += dY[M,N]^T . X[M,K]  (weight gradient of the same Linears; fp32 accumulate) */
+/* dW[g][N,K] += dY[M,N]^T . X[M,K]  (weight gradient of the same Linears; fp32 accumulate); optional fused bias
+ * gradient db[g][N] += column sums of dY over the rows of group g (extra streaming blocks of the same launch) */
 int simvg_gemm_tn(const void* dY_bf16, int lddy, const void* X_bf16, int ldx, float* dW, long dw_group_stride,
-                  int lddw, int M, int N, int K, int split, simvg_stream_t stream);
+                  int lddw, float* db, int db_group_stride, int M, int N, int K, int split, simvg_stream_t stream);
 /* out[g][N] += column sums of Y over the rows of group g (bias gradients) */
 int simvg_colsum(const void* Y_bf16, int ldy, float* out, int out_group_stride, int M, int N, int split,
                  simvg_stream_t stream);

@@ -475,6 +475,8 @@ struct GemmTNArgs {
   const bf16_t* X; int ldx;
   float* dW; long dw_gstride; int lddw;
   int M, N, K, split, rows_per_chunk, chunks0, flags;
+  float* db; int db_gstride;     // optional bias gradient db[g][n] += column sums of dY over group g (extra blocks)
+  int tiles;                     // GEMM tiles along blockIdx.x; blocks beyond them are the column-sum blocks
 };
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page[64];  // 256 B of zeros
@@ -509,6 +511,40 @@ __device__ __forceinline__ bf16x8_t read_frag_tr(const char* lds, int ms, int c0
   return out;
 }
 
+// Bias gradient as a horizontal fusion: blocks with blockIdx.x >= a.tiles of the SAME launch each sum 256 columns of dY
+// over their row chunk (pure streaming, no MFMA), so the 49 per-step column-sum launches disappear and their HBM
+// reads overlap the MFMA blocks.  (Doing it inside the GEMM blocks -- an extra MFMA against a ones fragment on the
+// tile_k == 0 blocks -- made those blocks the tail of every launch: wgrad 9 -> 12 ms/step.)
+template <int NT>
+__device__ __forceinline__ void colsum_block(const GemmTNArgs& a, char* smem, int cb, int group, int m_begin, int m_end) {
+  constexpr int RY = NT / 32;
+  float (*red)[256 + 8] = (float (*)[256 + 8])smem;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int n = cb * 256 + tx * 8;
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (n < a.N) {
+    for (int m = m_begin + ty; m < m_end; m += RY) {
+      const u32x4_t v = *(const u32x4_t*)(a.dY + (long)m * a.lddy + n);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        s[2 * q] += __uint_as_float(v[q] << 16);
+        s[2 * q + 1] += __uint_as_float(v[q] & 0xffff0000u);
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) red[ty][tx * 8 + q] = s[q];
+  __syncthreads();
+  const int c = threadIdx.x;
+  if (c < 256) {
+    float t = 0.f;
+#pragma unroll
+    for (int y = 0; y < RY; ++y) t += red[y][c];
+    const int nn = cb * 256 + c;
+    if (nn < a.N) atomicAdd(a.db + (long)group * a.db_gstride + nn, t);
+  }
+}
+
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -516,16 +552,17 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs a) {
   const int tiles_k = (a.K + 127) / 128, tiles_n = (a.N + 127) / 128;
   // XCD-aware: each XCD (blockIdx.x % 8) owns a contiguous slab of output tiles along the LARGER of N / K, so its L2
   // only has to hold 1/8 of the bigger operand's column panels (PMC before: 3.5x the algorithmic bytes fetched)
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  int tile_n, tile_k;
-  if (tiles_n >= tiles_k) { tile_n = wg / tiles_k; tile_k = wg - tile_n * tiles_k; }
-  else { tile_k = wg / tiles_n; tile_n = wg - tile_k * tiles_n; }
   const int chunk = blockIdx.y;
   const int group = chunk >= a.chunks0;
   const int m_begin = group ? a.split + (chunk - a.chunks0) * a.rows_per_chunk : chunk * a.rows_per_chunk;
   const int g_end = group ? a.M : a.split;
   const int m_end = min(m_begin + a.rows_per_chunk, g_end);
   if (m_begin >= m_end) return;
+  if ((int)blockIdx.x >= a.tiles) { colsum_block<256>(a, smem, blockIdx.x - a.tiles, group, m_begin, m_end); return; }
+  const int wg = xcd_remap(blockIdx.x, a.tiles);
+  int tile_n, tile_k;
+  if (tiles_n >= tiles_k) { tile_n = wg / tiles_k; tile_k = wg - tile_n * tiles_k; }
+  else { tile_k = wg / tiles_n; tile_n = wg - tile_k * tiles_n; }
   const int n0 = tile_n * 128, k0 = tile_k * 128;
 
 #define ldsY(c) (smem + (c) * 32768)
@@ -631,16 +668,17 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel_256(GemmTNArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave >> 1, wk = wave & 1;
   const int tiles_k = (a.K + 127) / 128, tiles_n = (a.N + 255) / 256;
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  int tile_n, tile_k;
-  if (tiles_n >= tiles_k) { tile_n = wg / tiles_k; tile_k = wg - tile_n * tiles_k; }
-  else { tile_k = wg / tiles_n; tile_n = wg - tile_k * tiles_n; }
   const int chunk = blockIdx.y;
   const int group = chunk >= a.chunks0;
   const int m_begin = group ? a.split + (chunk - a.chunks0) * a.rows_per_chunk : chunk * a.rows_per_chunk;
   const int g_end = group ? a.M : a.split;
   const int m_end = min(m_begin + a.rows_per_chunk, g_end);
   if (m_begin >= m_end) return;
+  if ((int)blockIdx.x >= a.tiles) { colsum_block<512>(a, smem, blockIdx.x - a.tiles, group, m_begin, m_end); return; }
+  const int wg = xcd_remap(blockIdx.x, a.tiles);
+  int tile_n, tile_k;
+  if (tiles_n >= tiles_k) { tile_n = wg / tiles_k; tile_k = wg - tile_n * tiles_k; }
+  else { tile_k = wg / tiles_n; tile_n = wg - tile_k * tiles_n; }
   const int n0 = tile_n * 256, k0 = tile_k * 128;
   f32x4_t acc[4][4];
 #pragma unroll
@@ -770,7 +808,8 @@ extern "C" int simvg_gemm_nt(const void* A, int lda, const void* W, long w_gstri
 }
 
 extern "C" int simvg_gemm_tn(const void* dY, int lddy, const void* X, int ldx, float* dW, long dw_gstride,
-                             int lddw, int M, int N, int K, int split, hipStream_t stream) {
+                             int lddw, float* db, int db_gstride, int M, int N, int K, int split,
+                             hipStream_t stream) {
   SIMVG_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm_tn: empty problem");
   SIMVG_CHECK_ARG(N % 8 == 0 && K % 8 == 0 && lddy % 8 == 0 && ldx % 8 == 0, "gemm_tn: N, K, ld must be multiples of 8");
   SIMVG_CHECK_ARG(split >= 0 && split <= M, "gemm_tn: split out of range");
@@ -787,14 +826,15 @@ extern "C" int simvg_gemm_tn(const void* dY, int lddy, const void* X, int ldx, f
   if (rpc < 256) rpc = 256;   // multiple of 64 (and of the 32-row stages)
   const int chunks0 = cdiv(split, rpc), chunks1 = cdiv(M - split, rpc);
   GemmTNArgs a{(const bf16_t*)dY, lddy, (const bf16_t*)X, ldx, dW, dw_gstride, lddw, M, N, K, split, rpc, chunks0,
-               getenv("SIMVG_TN_FLAGS") ? atoi(getenv("SIMVG_TN_FLAGS")) : 0};
+               getenv("SIMVG_TN_FLAGS") ? atoi(getenv("SIMVG_TN_FLAGS")) : 0, db, db_gstride, tiles};
+  const int gx = tiles + (db ? cdiv(N, 256) : 0);   // + column-sum blocks (bias gradient)
   if (big) {
     static bool once = hipFuncSetAttribute((const void*)gemm_tn_kernel_256, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            3 * 24576) == hipSuccess;
     (void)once;
-    hipLaunchKernelGGL(gemm_tn_kernel_256, dim3(tiles, chunks0 + chunks1), dim3(512), 3 * 24576, stream, a);
+    hipLaunchKernelGGL(gemm_tn_kernel_256, dim3(gx, chunks0 + chunks1), dim3(512), 3 * 24576, stream, a);
   } else {
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, chunks0 + chunks1), dim3(256), 65536, stream, a);
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(gx, chunks0 + chunks1), dim3(256), 65536, stream, a);
   }
   SIMVG_LAUNCH_CHECK();
   return SIMVG_OK;

@@ -97,8 +97,8 @@ def gemm_nt(a, w, bias=None, out=None, out_dtype=BF16, split=0, act=0, aux_preac
     return out
 
 
-def gemm_tn(dy, x, dw, split=0, dw_group_stride=None):
-    """dw[g][N,K] += dy[M,N]^T @ x[M,K]   (fp32 accumulate into dw)."""
+def gemm_tn(dy, x, dw, split=0, dw_group_stride=None, db=None):
+    """dw[g][N,K] += dy[M,N]^T @ x[M,K]   (fp32 accumulate into dw); db[g][N] += column sums of dy (optional)."""
     lib = _lib.load()
     _chk(dy, BF16, "dy"); _chk(x, BF16, "x"); _chk(dw, torch.float32, "dw")
     M, N = dy.shape
@@ -107,6 +107,7 @@ def gemm_tn(dy, x, dw, split=0, dw_group_stride=None):
         dw_group_stride = dw.stride(0) if dw.dim() == 3 else 0
     t0 = _timer.start("gemm_tn") if _timer is not None else None
     rc = lib.simvg_gemm_tn(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), dw_group_stride, dw.stride(-2),
+                           _p(db), (db.stride(0) if db.dim() == 2 else 0) if db is not None else 0,
                            M, N, K, split, _stream())
     if t0 is not None:
         _timer.stop("gemm_tn", t0, 2.0 * M * N * K, 2.0 * M * (N + K) + 4.0 * N * K)

@@ -74,8 +74,9 @@ class LinearBF16(torch.autograd.Function):
             dx = ops.gemm_nt(dyb, wT)                                                    # [M,K] bf16
         if ctx.needs_input_grad[1]:
             dW = torch.zeros(ctx.shapeW, device=dy.device, dtype=torch.float32)
-            ops.gemm_tn(dyb, x, dW.view(ctx.shapeW[0], -1))
-        if ctx.needs_input_grad[2]:
+            db = torch.zeros(ctx.shapeW[0], device=dy.device, dtype=torch.float32) if ctx.needs_input_grad[2] else None
+            ops.gemm_tn(dyb, x, dW.view(ctx.shapeW[0], -1), db=db)
+        elif ctx.needs_input_grad[2]:
             db = torch.zeros(ctx.shapeW[0], device=dy.device, dtype=torch.float32)
             ops.colsum(dyb, db)
         return dx, dW, db, None, None, None

@@ -340,24 +340,20 @@ class BEIT3(nn.Module):
             s = st["stats"]
             # ---- FFN branch: x_out = x_mid + dp1 * fc2(LN(gelu(fc1(LN(x_mid)))))
             ops.gemm_nt(dyb, self.wb[f"w2T{i}"], out=dF, split=Mv)
-            ops.gemm_tn(dyb, st["g2"], G[f"w2{i}"], split=Mv)
-            ops.colsum(dyb, G[f"b2{i}"], split=Mv)
+            ops.gemm_tn(dyb, st["g2"], G[f"w2{i}"], split=Mv, db=G[f"b2{i}"])
             ops.ln_bwd(dF, st["g"], s["m4"], s["r4"], V[f"lnfg{i}"], G[f"lnfg{i}"], G[f"lnfb{i}"], split=Mv,
                        dx_bf16=dF2, gelu_u=st["u"])
             ops.gemm_nt(dF2, self.wb[f"w1T{i}"], out=dD, split=Mv)
-            ops.gemm_tn(dF2, st["h2"], G[f"w1{i}"], split=Mv)
-            ops.colsum(dF2, G[f"b1{i}"], split=Mv)
+            ops.gemm_tn(dF2, st["h2"], G[f"w1{i}"], split=Mv, db=G[f"b1{i}"])
             ops.ln_bwd(dD, xs[2 * i + 1], s["m3"], s["r3"], V[f"ln2g{i}"], G[f"ln2g{i}"], G[f"ln2b{i}"], split=Mv,
                        dres=dx, dx_f32=dx, dx_scaled=dyb, row_scale=None if dp is None else dp[i][0], rows_per_sample=rps)
             # ---- attention branch: x_mid = x_in + dp0 * out_proj(LN(attn(qkv(LN(x_in)))))
             ops.gemm_nt(dyb, self.wb[f"woutT{i}"], out=dD, split=Mv)
-            ops.gemm_tn(dyb, st["o2"], G[f"wout{i}"], split=Mv)
-            ops.colsum(dyb, G[f"bout{i}"], split=Mv)
+            ops.gemm_tn(dyb, st["o2"], G[f"wout{i}"], split=Mv, db=G[f"bout{i}"])
             ops.ln_bwd(dD, st["o"], s["m2"], s["r2"], V[f"lnig{i}"], G[f"lnig{i}"], G[f"lnib{i}"], split=Mv, dx_bf16=dO)
             ops.attn_bwd(st["qkv"], st["o"], dO, st["lse"], B, H, Nv, T, pad=pad_u8, dqkv=dQKV)
             ops.gemm_nt(dQKV, self.wb[f"wqkvT{i}"], out=dD, split=Mv)
-            ops.gemm_tn(dQKV, st["h"], G[f"wqkv{i}"], split=Mv)
-            ops.colsum(dQKV, G[f"bqkv{i}"], split=Mv)
+            ops.gemm_tn(dQKV, st["h"], G[f"wqkv{i}"], split=Mv, db=G[f"bqkv{i}"])
             ops.ln_bwd(dD, xs[2 * i], s["m1"], s["r1"], V[f"ln1g{i}"], G[f"ln1g{i}"], G[f"ln1b{i}"], split=Mv,
                        dres=dx, dx_f32=dx, dx_scaled=dyb,
                        row_scale=None if (dp is None or i == 0) else dp[i - 1][1], rows_per_sample=rps)
@@ -367,8 +363,8 @@ class BEIT3(nn.Module):
                       A.grad("beit3.encoder.embed_positions.A.weight"), A.grad("beit3.encoder.embed_positions.B.weight"),
                       A.grad("beit3.text_embed.weight"), ids, pad_u8, B, self.np, T)
         P = self.patch_size
-        ops.gemm_tn(ws["dpatch"], ws["cols"], A.grad("beit3.vision_embed.proj.weight").view(D, 3 * P * P))
-        ops.colsum(ws["dpatch"], A.grad("beit3.vision_embed.proj.bias"))
+        ops.gemm_tn(ws["dpatch"], ws["cols"], A.grad("beit3.vision_embed.proj.weight").view(D, 3 * P * P),
+                    db=A.grad("beit3.vision_embed.proj.bias"))
         if layer_done_cb is not None:
             layer_done_cb(-1)
 

@@ -159,7 +159,8 @@ def test_gemm_tn_and_colsum(M, N, K, split):
     ng = 2 if split else 1
     init = torch.randn(ng, N, K, generator=g)
     dw = init.clone().to(DEV)
-    ops.gemm_tn(bf(dy).to(DEV), bf(x).to(DEV), dw, split=split)
+    db_fused = torch.zeros(ng, N, device=DEV)
+    ops.gemm_tn(bf(dy).to(DEV), bf(x).to(DEV), dw, split=split, db=db_fused)
     ref = init.clone().double()
     ref[0] += dy[:sp].double().t() @ x[:sp].double()
     if split:
@@ -169,6 +170,7 @@ def test_gemm_tn_and_colsum(M, N, K, split):
     ops.colsum(bf(dy).to(DEV), db, split=split)
     refb = torch.stack([dy[:sp].double().sum(0)] + ([dy[sp:].double().sum(0)] if split else [])).float()
     assert_close(db, refb, 1e-4, "colsum")
+    assert_close(db_fused, refb, 1e-4, "bias gradient fused into the wgrad")
 
 
 # ------------------------------------------------------------------------------------------
