@@ -10,6 +10,7 @@
 //                        with key_padding_mask and optional attention-dropout mask; fp32, one workgroup per
 //                        (sample, head).  (detrex MultiheadAttention)
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -88,6 +89,70 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(SGArgs a) {
       *p = a.accumulate ? *p + v : v;
     }
   }
+}
+
+// Small-problem variant (the head's M = B*num_queries GEMMs: 64x256x256 and friends).  The 64x64 LDS kernel above puts
+// such a problem on 4 workgroups that each walk the whole K loop serially (21 us for 64x256x256, pure latency).  Here
+// one workgroup owns ONE 16x16 output tile and its 4 waves split K (interleaved 16-k steps); operands go straight from
+// global memory into the MFMA lanes -- the 4 "k slots" of v_mfma_f32_16x16x4_f32 may hold ANY 4 k values as long as A
+// and B agree, so a lane takes 4 CONSECUTIVE k (one 16-B load when that operand is K-contiguous) and 4 MFMAs eat 16 k.
+// Partial tiles are reduced through LDS; same epilogue as above.  64x256x256 -> 64 workgroups x 4 steps per wave.
+__device__ __forceinline__ f32x4_t load_k4(const float* base, long sk, bool vec, bool ok, int k, int K) {
+  f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+  if (!ok) return v;
+  if (vec && k + 4 <= K) return *(const f32x4_t*)(base + k);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (k + i < K) v[i] = base[(long)(k + i) * sk];
+  return v;
+}
+__global__ __launch_bounds__(256) void gemm_f32_small_kernel(SGArgs a) {
+  __shared__ float part[4][256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int m = blockIdx.y * 16 + r, n = blockIdx.x * 16 + r;
+  const bool mok = m < a.M, nok = n < a.N;
+  const float* Ap = a.A + (long)m * a.sam;
+  const float* Bp = a.B + (long)n * a.sbn;
+  const bool avec = a.sak == 1 && (a.sam & 3) == 0 && (((unsigned long)a.A) & 15) == 0;
+  const bool bvec = a.sbk == 1 && (a.sbn & 3) == 0 && (((unsigned long)a.B) & 15) == 0;
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  const int nsteps = (a.K + 15) >> 4;
+  // wave w takes steps w, w+4, ...; two steps in flight (the next pair is loaded before the current pair is consumed)
+  f32x4_t av[2], bv[2], an[2], bn[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int st = wave + 4 * u;
+    av[u] = load_k4(Ap, a.sak, avec, mok && st < nsteps, st * 16 + 4 * g, a.K);
+    bv[u] = load_k4(Bp, a.sbk, bvec, nok && st < nsteps, st * 16 + 4 * g, a.K);
+  }
+  for (int s = wave; s < nsteps; s += 8) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int st = s + 8 + 4 * u;
+      an[u] = load_k4(Ap, a.sak, avec, mok && st < nsteps, st * 16 + 4 * g, a.K);
+      bn[u] = load_k4(Bp, a.sbk, bvec, nok && st < nsteps, st * 16 + 4 * g, a.K);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][i], bv[u][i], acc, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { av[u] = an[u]; bv[u] = bn[u]; }
+  }
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) part[wave][(4 * g + rr) * 16 + r] = acc[rr];
+  __syncthreads();
+  const int ml = tid >> 4, nl = tid & 15;
+  const int mo = blockIdx.y * 16 + ml, no = blockIdx.x * 16 + nl;
+  if (mo >= a.M || no >= a.N) return;
+  float v = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+  if (a.bias) v += a.bias[no];
+  if (a.addend) v += a.addend[(long)(mo % a.add_rows) * a.lda2 + no];
+  if (a.act == 2) v = fmaxf(v, 0.f);
+  else if (a.act == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+  float* p = a.C + (long)mo * a.ldc + no;
+  *p = a.accumulate ? *p + v : v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -253,7 +318,11 @@ extern "C" int simvg_gemm_f32(const float* A, long sam, long sak, const float* B
   SIMVG_CHECK_ARG(act >= 0 && act <= 2, "gemm_f32: act must be 0 (none), 1 (gelu) or 2 (relu)");
   SGArgs a{A, sam, sak, B, sbk, sbn, C, ldc, bias, addend, ld_addend, addend_rows > 0 ? addend_rows : 1, M, N, K,
            accumulate, act};
-  hipLaunchKernelGGL(gemm_f32_kernel, dim3(cdiv(N, 64), cdiv(M, 64)), dim3(256), 0, stream, a);
+  static const int small_env = getenv("SIMVG_GEMM_F32_SMALL") ? atoi(getenv("SIMVG_GEMM_F32_SMALL")) : 32;
+  if (cdiv(N, 64) * cdiv(M, 64) <= small_env)   // too few 64x64 tiles to fill the chip: one workgroup per 16x16 tile
+    hipLaunchKernelGGL(gemm_f32_small_kernel, dim3(cdiv(N, 16), cdiv(M, 16)), dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3(cdiv(N, 64), cdiv(M, 64)), dim3(256), 0, stream, a);
   SIMVG_LAUNCH_CHECK();
   return SIMVG_OK;
 }

@@ -295,10 +295,14 @@ class WeightPrep:
 def gemm_f32(A, sam, sak, Bm, sbk, sbn, C, M, N, K, bias=None, addend=None, addend_rows=0, accumulate=False, act=0):
     """C[M,N] (+)= sum_k A(m,k) B(k,n) with explicit element strides (pointers may be offset views)."""
     lib = _lib.load()
+    name = f"gemm_f32[{M}x{N}x{K}]" if _timer is not None and _timer.only is None else "gemm_f32"
+    e0 = _timer.start(name) if _timer is not None else None
     rc = lib.simvg_gemm_f32(_p(A), sam, sak, _p(Bm), sbk, sbn, _p(C), C.stride(0), _p(bias), _p(addend),
                             addend.stride(0) if addend is not None else 0, addend_rows, M, N, K, int(accumulate), act,
                             _stream())
     _lib.check(rc, "simvg_gemm_f32")
+    if e0 is not None:
+        _timer.stop(name, e0, 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N))
     return C
 
 

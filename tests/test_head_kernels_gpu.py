@@ -17,7 +17,8 @@ def close(got, ref, tol, what=""):
     assert err <= tol * scale, f"{what}: err {err:.3g} scale {scale:.3g}"
 
 
-@pytest.mark.parametrize("M,N,K,relu", [(64, 256, 768, False), (10, 2, 256, False), (640, 2048, 256, True), (1280, 256, 768, False)])
+@pytest.mark.parametrize("M,N,K,relu", [(64, 256, 768, False), (10, 2, 256, False), (640, 2048, 256, True), (1280, 256, 768, False),
+                                        (64, 256, 2048, True), (5, 3, 13, False), (33, 70, 20, True), (2560, 256, 256, False)])
 def test_linear_f32_fwd_bwd(M, N, K, relu):
     from simvg_amd.models.heads.functions import LinearF32
     g = torch.Generator().manual_seed(M + N)
@@ -32,6 +33,21 @@ def test_linear_f32_fwd_bwd(M, N, K, relu):
     y = LinearF32.apply(xd, Wd, bd, relu)
     y.backward(dy.to(DEV))
     close(y, y_ref, 1e-5, "y"); close(xd.grad, xr.grad, 1e-5, "dx"); close(Wd.grad, Wr.grad, 1e-5, "dW"); close(bd.grad, br.grad, 1e-5, "db")
+
+
+def test_linear_f32_strided_unaligned_views():
+    """operands that are column-offset views (base pointer not 16-B aligned, row stride != K) take the scalar-load path"""
+    from simvg_amd import hip_ops as ops
+    g = torch.Generator().manual_seed(5)
+    big_a, big_b = torch.randn(40, 100, generator=g).to(DEV), torch.randn(24, 90, generator=g).to(DEV)
+    A, Bw = big_a[:, 3:3 + 37], big_b[:, 1:1 + 37]          # [40,37], [24,37]
+    out = torch.empty(40, 24, device=DEV)
+    ops.gemm_f32(A, A.stride(0), 1, Bw, 1, Bw.stride(0), out, 40, 24, 37)
+    close(out, A.cpu() @ Bw.cpu().t(), 1e-5, "strided NT")
+    out2 = torch.empty(37, 24, device=DEV)                   # A^T (k strided) x B (n strided)
+    Bk = big_b[:, 5:5 + 40].t()                              # B(k,n) = big_b[n, 5+k]
+    ops.gemm_f32(A, 1, A.stride(0), Bk, 1, big_b.stride(0), out2, 37, 24, 40)
+    close(out2, A.cpu().t() @ big_b[:, 5:45].cpu().t(), 1e-5, "strided TN")
 
 
 @pytest.mark.parametrize("B,Lq,Lk,kv_off", [(3, 1, 400, True), (2, 10, 20, False), (2, 10, 10, False), (4, 7, 400, True)])

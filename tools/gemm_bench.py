@@ -6,7 +6,7 @@ from simvg_amd import hip_ops as ops
 
 M, SPLIT = 26944, 25664
 shapes = [("qkv", 2304, 768), ("out", 768, 768), ("fc1", 3072, 768), ("fc2", 768, 3072)]
-reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 which = sys.argv[2] if len(sys.argv) > 2 else "nt"
 dev = "cuda"
 for name, N, K in shapes:
@@ -16,7 +16,7 @@ for name, N, K in shapes:
     out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     dy = (torch.randn(M, N, device=dev)).to(torch.bfloat16)
     dw = torch.zeros(2, N, K, device=dev)
-    for _ in range(2):
+    for _ in range(30):
         if which == "nt":
             ops.gemm_nt(a, w, bias=bias, out=out, split=SPLIT)
         else:
