@@ -97,8 +97,8 @@ def cpu_baseline(batch_size=2, max_threads=32):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE: 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="per-op HIP-event breakdown on stderr")
@@ -187,7 +187,8 @@ def main():
                    "parallelism": f"dp{world}", "loss_total": round(loss_val, 4)},
         "model_tflops_per_gpu": round(value / world * FLOP_PER_PAIR_FWD_BWD / 1e12, 2),
         "model_mfma_frac": round(value / world * FLOP_PER_PAIR_FWD_BWD / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
-        "roofline": {"kernel": "gemm_nt_kernel_256 (bf16 MFMA 16x16x32, 256x128x64 tile, 3-stage global_load_lds ring)", "bound": "mfma",
+        "roofline": {"kernel": "gemm_nt (bf16 MFMA 16x16x32, 256x128 tile, 3-stage global_load_lds ring; all launches of the "
+                               "BK=32 two-workgroup variant and the BK=64 variant)", "bound": "mfma",
                      "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
                      "algorithmic_bytes_per_launch": round(g["bytes"] / g["calls"]),
