@@ -115,7 +115,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)
     from simvg_amd.models import build_model
     from simvg_amd.dist import GradReducer
-    from simvg_amd.optim import FlatAdam
+    from simvg_amd.core import build_optimizer
     from simvg_amd import hip_ops
 
     torch.manual_seed(1234)
@@ -126,7 +126,14 @@ def main():
     B = a.batch
     batch = synthetic_batch(B, 1000 + rank, device)
     model.vis_enc._ensure_engine(device)
-    opt = FlatAdam(model, lr=5e-4, max_norm=0.15)
+    # the reference's optimizer construction (tools/train.py:78-96 + configs: Adam amsgrad, lr 5e-4, vis_enc lr/10)
+    named = list(model.named_parameters())
+    groups = [{"params": [p for n, p in named if "vis_enc" in n and p.requires_grad], "lr": 5e-5},
+              {"params": [p for n, p in named if "lan_enc" in n and p.requires_grad], "lr": 5e-4},
+              {"params": [p for n, p in named if "lan_enc" not in n and "vis_enc" not in n and p.requires_grad], "lr": 5e-4}]
+    opt = build_optimizer(dict(type="Adam", lr=5e-4, betas=(0.9, 0.98), eps=1e-9, weight_decay=0, amsgrad=True), groups,
+                          model=model)
+    assert type(opt).__name__ == "FlatAdam"
     reducer = GradReducer(model)
 
     def step():
@@ -136,6 +143,7 @@ def main():
         reducer.begin()
         losses["loss_total"].backward()
         reducer.finish()
+        opt.clip_grad_norm(0.15)
         opt.step()
         return losses
 

@@ -723,3 +723,33 @@ force_fp32 = auto_fp16
 def trunc_normal_(tensor, mean=0.0, std=1.0, a=-2.0, b=2.0):
     """timm.models.layers.trunc_normal_ (== torch.nn.init.trunc_normal_ semantics)."""
     return nn.init.trunc_normal_(tensor, mean=mean, std=std, a=a, b=b)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# metric leaves used by the reference's simvg/apis/test.py (mmdet / torchvision are not in this image)
+# ---------------------------------------------------------------------------------------------------------------
+def tv_box_area(boxes):
+    """torchvision.ops.boxes.box_area: (x2 - x1) * (y2 - y1) over [N, 4] xyxy boxes."""
+    return (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
+
+
+def mmdet_bbox_overlaps(bboxes1, bboxes2, mode="iou", is_aligned=False, eps=1e-6):
+    """mmdet 2.x `mmdet/core/bbox/iou_calculators/iou2d_calculator.py::bbox_overlaps`, the branches the reference
+    reaches (mode='iou'; aligned: IoU of row i with row i; union clamped from below by eps)."""
+    assert mode == "iou"
+    area1 = (bboxes1[..., 2] - bboxes1[..., 0]) * (bboxes1[..., 3] - bboxes1[..., 1])
+    area2 = (bboxes2[..., 2] - bboxes2[..., 0]) * (bboxes2[..., 3] - bboxes2[..., 1])
+    if is_aligned:
+        lt = torch.max(bboxes1[..., :2], bboxes2[..., :2])
+        rb = torch.min(bboxes1[..., 2:], bboxes2[..., 2:])
+        wh = (rb - lt).clamp(min=0)
+        overlap = wh[..., 0] * wh[..., 1]
+        union = area1 + area2 - overlap
+    else:
+        lt = torch.max(bboxes1[..., :, None, :2], bboxes2[..., None, :, :2])
+        rb = torch.min(bboxes1[..., :, None, 2:], bboxes2[..., None, :, 2:])
+        wh = (rb - lt).clamp(min=0)
+        overlap = wh[..., 0] * wh[..., 1]
+        union = area1[..., None] + area2[..., None, :] - overlap
+    union = torch.max(union, union.new_tensor([eps]))
+    return overlap / union

@@ -140,6 +140,51 @@ def load():
     return _loaded
 
 
+_apis_loaded = None
+
+
+def load_apis():
+    """Executes the reference's scheduler / optimizer registries, metrics and EMA verbatim (dev container only):
+    -> dict(scheduler=module, optimizer=module, test=module, utils=module).  Stand-ins: mmcv Registry (leaf),
+    mmdet bbox_overlaps and torchvision box_area (leaf restatements), logging / dist helpers (trivial)."""
+    global _apis_loaded
+    if _apis_loaded is not None:
+        return _apis_loaded
+    load()
+    L = leaf
+    import logging
+    for p in ["torchvision", "torchvision.ops", "mmdet.core.bbox", "mmdet.core.bbox.iou_calculators"]:
+        _pkg(p)
+    _mod("torchvision.ops.boxes", box_area=L.tv_box_area)
+    _mod("mmdet.core.bbox.iou_calculators.iou2d_calculator", bbox_overlaps=L.mmdet_bbox_overlaps)
+    _mod("simvg.datasets", extract_data=lambda inputs: {k: v.data[0] for k, v in inputs.items()})   # DataContainer unwrap
+    _mod("simvg.utils", get_root_logger=lambda *a, **k: logging.getLogger("SimVG-ref"), reduce_mean=lambda t: t,
+         is_main=lambda: True)
+    _pkg("simvg.apis")
+    # torch >= 2.7 removed the `verbose=` argument the reference still passes (always False): accept and drop it
+    import inspect
+    import torch.optim.lr_scheduler as _ls
+    for _cls in (_ls.LambdaLR, _ls.CosineAnnealingLR, _ls.CosineAnnealingWarmRestarts):
+        if "verbose" not in inspect.signature(_cls.__init__).parameters:
+            def _wrap(orig):
+                def __init__(self, *a, verbose=False, **k):
+                    orig(self, *a, **k)
+                return __init__
+            _cls.__init__ = _wrap(_cls.__init__)
+    out = {}
+    for key, name, rel in [("scheduler", "simvg.core.scheduler", "simvg/core/scheduler.py"),
+                           ("optimizer", "simvg.core.optimizer", "simvg/core/optimizer.py"),
+                           ("test", "simvg.apis.test", "simvg/apis/test.py"),
+                           ("utils", "simvg.models.utils", "simvg/models/utils.py")]:
+        spec = importlib.util.spec_from_file_location(name, os.path.join(REF_ROOT, rel))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[name] = m
+        spec.loader.exec_module(m)
+        out[key] = m
+    _apis_loaded = out
+    return out
+
+
 def model_cfg(vit_type="base", num_queries=1, img_size=640, patch_size=32):
     """cfg.model of configs/single/ViT-{base,large}/refcoco/refcoco_onestage.py:68-105
     (grefcoco: num_queries=10), with pretrain=None (no checkpoint in this image)."""

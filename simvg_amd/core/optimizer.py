@@ -1,0 +1,119 @@
+"""Optimizer registry -- mirror of the reference's `simvg/core/optimizer.py:1-87` (mmcv Registry wrapping
+torch.optim.{SGD, RMSprop, Adam, AdamW}; `build_optimizer(cfg, params)` fills `params` as a default argument).
+
+MI355X-first addition: `FlatAdam`, the same Adam(amsgrad) arithmetic run over the encoder's FLAT parameter / gradient
+arenas (one tensor) plus the head's parameters, as one fused multi-tensor launch instead of ~600 per-tensor updates.
+Element-wise Adam over a flat view is bit-identical to per-tensor Adam.  `build_optimizer(cfg, params, model=model)`
+selects it for `type="Adam"` when the model carries arenas; the param groups keep the reference's order and learning
+rates (tools/train.py:78-94: vis_enc -> lr_vis_enc, lan_enc -> lr_lan_enc, rest -> lr), so schedulers and the
+`lr:{optimizer.param_groups[0]['lr']}` log field behave as in the reference."""
+import torch
+
+from ..models.builder import Registry
+
+OPTIMIZERS = Registry("OPTIMIZERS")
+
+
+@OPTIMIZERS.register_module()
+class SGD(torch.optim.SGD):
+    def __init__(self, params, lr, momentum=0, dampening=0, weight_decay=0, nesterov=False):
+        super().__init__(params, lr=lr, momentum=momentum, weight_decay=weight_decay, dampening=dampening,
+                         nesterov=nesterov)
+
+
+@OPTIMIZERS.register_module()
+class RMSProp(torch.optim.RMSprop):
+    def __init__(self, params, lr=1e-2, alpha=0.99, eps=1e-8, weight_decay=0, momentum=0, centered=False):
+        super().__init__(params, lr=lr, alpha=alpha, eps=eps, weight_decay=weight_decay, momentum=momentum,
+                         centered=centered)
+
+
+@OPTIMIZERS.register_module()
+class Adam(torch.optim.Adam):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
+        super().__init__(params, lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=amsgrad)
+
+
+@OPTIMIZERS.register_module()
+class AdamW(torch.optim.AdamW):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False):
+        super().__init__(params, lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=amsgrad)
+
+
+@OPTIMIZERS.register_module()
+class FlatAdam(torch.optim.Adam):
+    """Adam over [encoder arena as ONE tensor] + [remaining parameters].  `params` are the reference-style groups
+    (lists of the model's nn.Parameters with an `lr` each); every group whose parameters all live in the encoder arena
+    is replaced by the arena's flat tensor.  `step()` re-attaches the flat gradient; `clip_grad_norm(max_norm)` is the
+    global-norm clip of apis/train.py:81-82 computed over the same set of gradients."""
+
+    def __init__(self, params, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
+        enc = getattr(model, "vis_enc", None)
+        arena = getattr(enc, "_arena", None)
+        if arena is None:
+            raise RuntimeError("FlatAdam needs the encoder arena: move the model to its GPU and call "
+                               "model.vis_enc._ensure_engine(device) (or run one forward) first")
+        self.arena = arena
+        self._model_enc = enc
+        in_arena = {id(p) for p in arena.params.values()}
+        self.flat = torch.nn.Parameter(arena.flat)
+        self.flat.grad = arena.flat_grad
+        groups, self._rest, used_flat = [], [], False
+        for g in params:
+            g = dict(g)
+            ps = list(g["params"])
+            if ps and all(id(p) in in_arena for p in ps):
+                if used_flat:
+                    raise ValueError("the encoder arena can belong to one param group only")
+                frozen = [n for n, p in arena.params.items() if not p.requires_grad]
+                if len(ps) + len(frozen) < len(arena.params) - len(arena.no_grad):
+                    raise ValueError("FlatAdam updates the whole encoder arena; a partially selected encoder group "
+                                     "(freeze_layer >= 0) must use type='Adam'")
+                g["params"], used_flat = [self.flat], True
+            else:
+                if any(id(p) in in_arena for p in ps):
+                    raise ValueError("a param group mixes encoder-arena and other parameters")
+                self._rest += ps
+            groups.append(g)      # empty groups (lan_enc) stay, so group indices match the reference's
+        try:      # single-pass multi-tensor kernel (p, g, m, v, vmax read once) instead of ~10 foreach passes
+            super().__init__(groups, lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=amsgrad,
+                             fused=True)
+        except (RuntimeError, ValueError):
+            super().__init__(groups, lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=amsgrad)
+
+    def zero_grad(self, set_to_none=True):
+        for p in self._rest:
+            p.grad = None
+        for p in self.arena.params.values():
+            p.grad = None      # the arena re-attaches (and zeroes) its gradient views on the next backward
+
+    def clip_grad_norm(self, max_norm):
+        self.flat.grad = self.arena.flat_grad
+        params = [self.flat] + [p for p in self._rest if p.grad is not None]
+        return torch.nn.utils.clip_grad_norm_(params, max_norm)
+
+    def _check_arena(self):
+        enc_arena = getattr(getattr(self, "_model_enc", None), "_arena", None)
+        if enc_arena is not self.arena or not self.arena.intact():
+            raise RuntimeError("the encoder re-created its parameter arena after this optimizer was built (model moved "
+                               "to another device?): rebuild the optimizer")
+
+    def step(self, closure=None):
+        self._check_arena()
+        self.flat.grad = self.arena.flat_grad
+        return super().step(closure)
+
+
+def build_optimizer(cfg, params, model=None):
+    """Reference signature `build_optimizer(cfg, params)`.  With `model=` given, `type="Adam"` resolves to FlatAdam
+    when the model has its encoder arena (same arithmetic, one fused launch); `flat=False` in cfg opts out."""
+    cfg = dict(cfg)
+    flat = cfg.pop("flat", True)
+    if model is not None and flat and cfg.get("type") == "Adam":
+        enc = getattr(model, "vis_enc", None)
+        arena = getattr(enc, "_arena", None)
+        enc_all_trainable = arena is not None and all(
+            p.requires_grad for n, p in arena.params.items() if n not in arena.no_grad)
+        if enc_all_trainable:
+            return OPTIMIZERS.build(dict(cfg, type="FlatAdam"), default_args=dict(params=params, model=model))
+    return OPTIMIZERS.build(cfg, default_args=dict(params=params))

@@ -1,0 +1,123 @@
+"""Data side of the drop-in tools: registry + loader construction with the reference's call shape
+(`simvg/datasets/builder.py:16-58`: `build_dataset(cfg.data.train)`, `build_dataloader(cfg, dataset)`,
+`extract_data(inputs)`), and the one dataset this round ships: `SyntheticRefDataset`, RefCOCO-shaped random pairs
+generated ON THE DEVICE (there are no images / annotation files in this image and no network).
+
+The reference's file-backed datasets + CPU pipelines (RefCOCO* json + mscoco jpg, LargeScaleJitter / Resize /
+Normalize / Pad / sentencepiece) are SURVEY.md section 8 row f-3 (device-side input pipeline) and are not built
+yet: naming one of them raises NotImplementedError that says so.  A config selects the synthetic source either with
+`type="SyntheticRefDataset"` or globally with `--cfg-options data.synthetic=True`, which keeps every other key of a
+reference config (pipelines, annsfile, ...) untouched and simply ignores them."""
+import torch
+from torch.utils.data import DataLoader, Dataset
+from torch.utils.data.distributed import DistributedSampler
+
+from ..models.builder import Registry
+
+DATASETS = Registry("DATASETS")
+PIPELINES = Registry("PIPELINES")
+
+_REFERENCE_DATASETS = ("RefCOCOUNC", "RefCOCOGoogle", "RefCOCOgUMD", "RefCOCOgGoogle", "RefCOCOPlusUNC",
+                       "ReferItGameBerkeley", "Flickr30k", "Mixed", "GRefCOCO", "MixedSeg", "RefClef")
+
+
+@DATASETS.register_module()
+class SyntheticRefDataset(Dataset):
+    """`length` (image, expression, box) triples of RefCOCO shape: 640x640 normalised image noise, XLM-R style ids
+    (<s> tokens </s> pad...) with their padding mask, one xyxy box in pixels (GRefCOCO: `max_targets` boxes, some
+    images with no target).  Sample i is a pure function of (seed, i): every rank / epoch sees reproducible data."""
+
+    def __init__(self, which_set="train", length=256, img_size=640, max_token=20, vocab_size=64010, seed=0,
+                 dataset="RefCOCOUNC", max_targets=1, **ignored):
+        self.which_set, self.length, self.img_size = which_set, int(length), int(img_size)
+        self.max_token, self.vocab_size, self.seed = int(max_token), int(vocab_size), int(seed)
+        self.grec = dataset == "GRefCOCO"
+        self.max_targets = max(int(max_targets), 1) if self.grec else 1
+        self.word_emb, self.num_token = None, -1          # what tools/train.py hands to build_model
+        self.flag = torch.zeros(self.length, dtype=torch.uint8).numpy()   # GroupSampler aspect-ratio groups: one group
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(self.seed * 1000003 + i)
+        S, T = self.img_size, self.max_token
+        img = torch.randn(3, S, S, generator=g)
+        ids = torch.ones(T, dtype=torch.int64)
+        pad = torch.ones(T, dtype=torch.int64)
+        m = int(torch.randint(2, T - 1, (1,), generator=g))
+        ids[0] = 0
+        ids[1:1 + m] = torch.randint(4, self.vocab_size, (m,), generator=g)
+        ids[1 + m] = 2
+        pad[:m + 2] = 0
+        k = 1 if not self.grec else int(torch.randint(0, self.max_targets + 1, (1,), generator=g))
+        n = max(k, 1)
+        xy = torch.rand(n, 2, generator=g) * (S * 0.6)
+        wh = S * 0.05 + torch.rand(n, 2, generator=g) * (S * 0.3)
+        boxes = torch.cat([xy, xy + wh], 1)
+        meta = dict(img_shape=(S, S, 3), pad_shape=(S, S, 3), ori_shape=(S, S, 3), scale_factor=[1.0] * 4,
+                    filename=f"synthetic_{self.which_set}_{i}.jpg", expression="synthetic")
+        if self.grec:
+            if k == 0:
+                boxes = torch.zeros(1, 4)
+            meta["target"] = [dict(category_id=-1 if k == 0 else 1) for _ in range(n)]
+            gt = boxes
+        else:
+            gt = boxes[0]
+        return dict(img=img, ref_expr_inds=ids, text_attention_mask=pad, gt_bbox=gt, img_metas=meta)
+
+
+def _collate(batch):
+    out = dict(img=torch.stack([b["img"] for b in batch]),
+               ref_expr_inds=torch.stack([b["ref_expr_inds"] for b in batch]),
+               text_attention_mask=torch.stack([b["text_attention_mask"] for b in batch]),
+               img_metas=[b["img_metas"] for b in batch])
+    gts = [b["gt_bbox"] for b in batch]
+    out["gt_bbox"] = torch.stack(gts) if all(g.dim() == 1 for g in gts) else gts
+    return out
+
+
+def build_dataset(cfg, default_args=None):
+    cfg = dict(cfg)
+    typ = cfg.get("type")
+    if typ in _REFERENCE_DATASETS and not cfg.pop("synthetic", False):
+        raise NotImplementedError(
+            f"dataset type {typ!r} reads annotation json + jpg files through the reference's CPU pipeline; the device-side "
+            "input pipeline is SURVEY.md section 8 row f-3 and is not built yet.  Use type='SyntheticRefDataset' or pass "
+            "--cfg-options data.synthetic=True to run the reference config on synthetic pairs of the same shape.")
+    if typ in _REFERENCE_DATASETS:
+        keep = {k: cfg[k] for k in ("which_set", "length", "img_size", "max_token", "seed", "max_targets") if k in cfg}
+        cfg = dict(type="SyntheticRefDataset", dataset=typ, **keep)
+    cfg.pop("synthetic", None)
+    return DATASETS.build(cfg, default_args=default_args)
+
+
+def build_dataloader(cfg, dataset):
+    sampler, shuffle = None, False
+    train = dataset.which_set == "train"
+    if cfg.distributed:
+        sampler = DistributedSampler(dataset, cfg.world_size, cfg.rank, shuffle=train, seed=cfg.seed or 0)
+    elif train:
+        shuffle = True
+    g = torch.Generator()
+    g.manual_seed(cfg.seed or 0)
+    return DataLoader(dataset, batch_size=cfg.data.samples_per_gpu, sampler=sampler, shuffle=shuffle, generator=g,
+                      num_workers=0, pin_memory=False, collate_fn=_collate, drop_last=False)
+
+
+def extract_data(inputs, device=None):
+    """dict of batch entries -> what the model's forward takes, tensors on `device` (the reference's version unwraps
+    mmcv DataContainers and scatters to the current GPU, `datasets/utils.py:38-52`)."""
+    assert isinstance(inputs, dict)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    out = {}
+    for key, value in inputs.items():
+        if hasattr(value, "data") and not isinstance(value, torch.Tensor):      # DataContainer-like
+            value = value.data[0] if getattr(value, "cpu_only", False) or not isinstance(value.data, torch.Tensor) else value.data
+        if isinstance(value, torch.Tensor):
+            value = value.to(device, non_blocking=True)
+        elif isinstance(value, (list, tuple)) and value and all(isinstance(v, torch.Tensor) for v in value):
+            value = [v.to(device, non_blocking=True) for v in value]
+        out[key] = value
+    return out

@@ -57,7 +57,7 @@ def _trunc_normal(shape, std=0.02):
 class BEIT3(nn.Module):
     def __init__(self, img_size=384, patch_size=32, vit_type="base", drop_path_rate=0.1, vocab_size=64010,
                  norm_layer=None, freeze_layer=-1, vision_embed_proj_interpolate=False, pretrain=None,
-                 encoder_cfg=None):
+                 encoder_cfg=None, precision="bf16"):
         super().__init__()
         if encoder_cfg is not None:           # explicit geometry (tests); not a reference config
             geo = dict(encoder_cfg)
@@ -77,7 +77,8 @@ class BEIT3(nn.Module):
         self.ln_eps = 1e-5
         self.drop_path_probs = [float(v) for v in np.linspace(0, dpr, self.L)] if dpr > 0 else [0.0] * self.L
         self.vision_embed_proj_interpolate = vision_embed_proj_interpolate
-        self.precision = "bf16"     # "bf16": MFMA bf16 operands (training + inference); "fp32": exact forward-only mode
+        assert precision in ("bf16", "fp32")
+        self.precision = precision  # "bf16": MFMA bf16 operands (training + inference); "fp32": exact forward-only mode
         self._build_parameters()
         self._arena = None
         self._ws = {}
@@ -162,6 +163,9 @@ class BEIT3(nn.Module):
         return g
 
     def _ensure_engine(self, device):
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:      # "cuda" and "cuda:<current>" are the same place: a
+            device = torch.device("cuda", torch.cuda.current_device())   # rebuilt arena would orphan optimizer / EMA views
         if self._arena is not None and self._arena.device == device and self._arena.intact():
             return
         named = {n: p for n, p in self.named_parameters()}
@@ -188,10 +192,19 @@ class BEIT3(nn.Module):
     def _refresh_weights(self):
         # training: the optimizer rewrites the arena every step -> always refresh (one launch, ~1.4 GB of traffic);
         # eval: refresh only when the arena's version counter moved (load_state_dict, in-place edits)
-        v = self._arena.flat._version
-        if self.training or v != self._prep_version:
+        if self.training:
+            self._prep.run()
+            self._prep_version = None
+            return
+        # (p.data views do not share the flat tensor's version counter, so the parameters' own counters are summed too)
+        v = (self._arena.flat._version, sum(p._version for p in self._arena.params.values()))
+        if v != self._prep_version:
             self._prep.run()
             self._prep_version = v
+
+    def mark_weights_dirty(self):
+        """Force the next forward to rebuild the bf16 weight copies (after writing the arena behind autograd's back)."""
+        self._prep_version = -1
 
     def layer_param_names(self, i):
         pre = f"beit3.encoder.layers.{i}."

@@ -1,0 +1,135 @@
+"""GPU tests of the drop-in tools on the real HIP model: `tools/train.py` for two epochs on
+synthetic pairs (tiny encoder geometry), resume, `tools/test.py` on the written checkpoint with the EMA double pass;
+FlatAdam over the arenas == per-tensor torch Adam; fused EMA over the arena == the reference formula."""
+import glob
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+CFG = os.path.join(HERE, "cfg_fixture", "tiny_train.py")
+
+
+def _tiny_model(seed=0):
+    from simvg_amd.config import Config
+    from simvg_amd.models import build_model
+    torch.manual_seed(seed)
+    cfg = Config.fromfile(CFG)
+    model = build_model(cfg.model).to("cuda")
+    model.vis_enc._ensure_engine(torch.device("cuda"))
+    return cfg, model
+
+
+def _batch(cfg, B=4, seed=5):
+    from simvg_amd.datasets import build_dataset, _collate, extract_data
+    ds = build_dataset(dict(cfg.data.train, seed=seed))
+    return extract_data(_collate([ds[i] for i in range(B)]), torch.device("cuda"))
+
+
+def test_train_tool_end_to_end_then_resume_then_test_tool(tmp_path):
+    import train as train_tool
+    import test as test_tool
+    work = str(tmp_path / "run")
+    train_tool.main([CFG, "--work-dir", work])
+    runs = sorted(glob.glob(os.path.join(work, "*")))
+    assert len(runs) == 1
+    files = sorted(os.listdir(runs[0]))
+    assert "latest.pth" in files and any(f.endswith("_train_log.txt") for f in files) and any(f.endswith("tiny_train.py") for f in files)
+    ck = torch.load(os.path.join(runs[0], "latest.pth"), map_location="cpu", weights_only=False)
+    assert ck["epoch"] == 1 and "ema_state_dict" in ck and not next(iter(ck["state_dict"])).startswith("module.")
+    assert ck["lr"] == pytest.approx(5e-5 * 0.1)          # group 0 = vis_enc at lr/10; epoch index 1: 1 + 1 >= decay step 2
+    log = open(glob.glob(os.path.join(runs[0], "*_train_log.txt"))[0]).read()
+    assert "train-epoch[1]-[2/6]" in log and "train-epoch[2]-[6/6]" in log and "decoderAcc:" in log and "tokenAcc:" in log
+    assert "val - epoch [2]-[2/2]" in log and "Evaluating dataset using ema: val" in log and "saved epoch 2 checkpoint" in log
+    first = float(log.split("train-epoch[1]-[2/6]")[1].split("total:")[1].split("]")[0])
+    last = float(log.split("train-epoch[2]-[6/6]")[1].split("total:")[1].split("]")[0])
+    assert last < first, (first, last)                     # the loss goes down on the fixed synthetic set
+    # resume: nothing left to train (max_epoch reached) but the state must load into model, EMA, optimizer, scheduler
+    train_tool.main([CFG, "--work-dir", str(tmp_path / "resume"), "--resume-from", os.path.join(runs[0], "latest.pth"),
+                     "--cfg-options", "scheduler_config.max_epoch=3"])
+    r2 = glob.glob(os.path.join(str(tmp_path / "resume"), "*"))[0]
+    ck2 = torch.load(os.path.join(r2, "latest.pth"), map_location="cpu", weights_only=False)
+    assert ck2["epoch"] == 2 and ck2["lr"] == pytest.approx(5e-5 * 0.1)
+    # evaluation tool: val / testA / testB, each with and without the EMA weights
+    res = test_tool.main([CFG, "--load-from", os.path.join(runs[0], "latest.pth")])
+    assert set(res) == {"val", "val_ema", "testA", "testA_ema", "testB", "testB_ema"}
+    assert all(0.0 <= v[0] <= 100.0 for v in res.values())
+
+
+def test_flat_adam_equals_per_tensor_adam_and_clip():
+    from simvg_amd.core import build_optimizer
+    cfg, model = _tiny_model(1)
+    ref_params = {n: p.detach().clone() for n, p in model.named_parameters()}
+    batch = _batch(cfg)
+    named = list(model.named_parameters())
+    groups = [{"params": [p for n, p in named if "vis_enc" in n], "lr": 5e-5}, {"params": [], "lr": 5e-4},
+              {"params": [p for n, p in named if "vis_enc" not in n], "lr": 5e-4}]
+    ocfg = dict(type="Adam", lr=5e-4, betas=(0.9, 0.98), eps=1e-9, weight_decay=0, amsgrad=True)
+    opt = build_optimizer(ocfg, groups, model=model)
+    assert type(opt).__name__ == "FlatAdam" and [g["lr"] for g in opt.param_groups] == [5e-5, 5e-4, 5e-4]
+    model.eval()                                           # no dropout / DropPath: identical gradients for both runs
+    grads_seq = []
+    for _ in range(3):
+        losses, _ = model(**batch, rescale=False)
+        opt.zero_grad()
+        losses["loss_total"].backward()
+        grads_seq.append({n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in model.named_parameters()})
+        norm = opt.clip_grad_norm(0.15)
+        opt.step()
+    flat_result = {n: p.detach().clone() for n, p in model.named_parameters()}
+    # replay the SAME gradients through per-tensor torch Adam + torch clip on plain copies
+    copies = {n: torch.nn.Parameter(v.clone()) for n, v in ref_params.items()}
+    plain = torch.optim.Adam([{"params": [copies[n] for n, _ in named if "vis_enc" in n], "lr": 5e-5},
+                              {"params": [copies[n] for n, _ in named if "vis_enc" not in n], "lr": 5e-4}],
+                             lr=5e-4, betas=(0.9, 0.98), eps=1e-9, amsgrad=True)
+    for gs in grads_seq:
+        for n, p in copies.items():
+            p.grad = None if gs[n] is None else gs[n].clone()
+        torch.nn.utils.clip_grad_norm_([p for p in copies.values() if p.grad is not None], 0.15)
+        plain.step()
+    assert float(norm) > 0
+    worst = max(float((flat_result[n] - copies[n].detach()).abs().max()) for n in copies)
+    moved = max(float((flat_result[n] - ref_params[n]).abs().max()) for n in copies)
+    top = sorted(((float((flat_result[n] - copies[n].detach()).abs().max()), n) for n in copies), reverse=True)[:4]
+    assert moved > 1e-5 and worst <= 2.5e-7, (worst, moved, top)   # fused vs foreach Adam: <= 1 ulp at |w| ~ 1
+
+
+def test_fused_ema_on_the_arena_matches_the_reference_formula():
+    from simvg_amd.models.utils import ExponentialMovingAverage
+    cfg, model = _tiny_model(2)
+    ema = ExponentialMovingAverage(model, 0.999)
+    assert ema._flat_shadow is not None and len(ema._flat_keys) > 20
+    shadow_ref = {k: v.clone() for k, v in model.state_dict().items()}
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for step in range(12):
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(torch.randn(p.shape, generator=g, device="cuda") * 1e-2)
+        decay = min(0.999, (step + 1) / (step + 10))
+        for k, v in model.state_dict().items():
+            shadow_ref[k] = decay * shadow_ref[k] + (1 - decay) * v if v.is_floating_point() else shadow_ref[k]
+        ema.update_params()
+    assert ema.shadow.keys() == shadow_ref.keys()
+    for k in shadow_ref:
+        assert torch.allclose(ema.shadow[k], shadow_ref[k], rtol=1e-5, atol=1e-6), k
+    # apply_shadow must reach the encoder's bf16 weight copies: eval output with the shadow == a fresh model loaded with it
+    batch = _batch(cfg)
+    model.eval()
+    with torch.no_grad():
+        live = model(**{k: v for k, v in batch.items() if k != "gt_bbox"}, return_loss=False, rescale=False)[0]["pred_bboxes"].clone()
+        ema.apply_shadow()
+        shadow_out = model(**{k: v for k, v in batch.items() if k != "gt_bbox"}, return_loss=False, rescale=False)[0]["pred_bboxes"].clone()
+        ema.restore()
+        back = model(**{k: v for k, v in batch.items() if k != "gt_bbox"}, return_loss=False, rescale=False)[0]["pred_bboxes"].clone()
+    _, fresh = _tiny_model(9)
+    fresh.load_state_dict(ema.shadow, strict=True)
+    fresh.eval()
+    with torch.no_grad():
+        fresh_out = fresh(**{k: v for k, v in batch.items() if k != "gt_bbox"}, return_loss=False, rescale=False)[0]["pred_bboxes"]
+    assert torch.equal(back, live)
+    assert torch.allclose(shadow_out, fresh_out, atol=1e-4) and not torch.allclose(shadow_out, live, atol=1e-3)

@@ -1,10 +1,10 @@
 """Print the parity error breakdown of the HIP model vs the reference fixtures (GPU box)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tests.test_model_gpu import _build, _dev_batch
 
-GOLD = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+GOLD = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden")
 for name in sys.argv[1:] or ["tiny_nq1", "tiny_nq10_grec", "base_nq1", "base_nq10_grec", "large_nq1"]:
     fx = torch.load(os.path.join(GOLD, name + ".pt"), weights_only=False)
     model, batch, cfg = _build(fx)

@@ -1,6 +1,6 @@
 """GEMM micro-benchmark for profiling: the four encoder shapes at B=64 (M = 26944, split 25664)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from simvg_amd import hip_ops as ops
 

@@ -1,6 +1,6 @@
 """fc2-shaped NT GEMM (N=768, K=3072) at several M: how much does tile-count quantisation cost?"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from simvg_amd import hip_ops as ops
 N, K = int(os.environ.get("N", 768)), int(os.environ.get("K", 3072))

@@ -1,13 +1,13 @@
 #!/bin/bash
-# PMC passes for the GEMM micro-benchmark (separate passes: TCC has 4 slots, SQ 8).  Usage: tools/pmc_gemm.sh nt|tn
+# PMC passes for the GEMM micro-benchmark (separate passes: TCC has 4 slots, SQ 8).  Usage: tools/dev/pmc_gemm.sh nt|tn
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 W=${1:-nt}
-python tools/gemm_bench.py 5 $W
+python tools/dev/gemm_bench.py 5 $W
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16"; do
   i=$((i+1))
   rm -rf /tmp/pmc$i
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pmc$i -o p -- python tools/gemm_bench.py 1 $W > /tmp/pmc$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pmc$i -o p -- python tools/dev/gemm_bench.py 1 $W > /tmp/pmc$i.log 2>&1
   python - <<PY
 import csv, glob, collections
 f = glob.glob("/tmp/pmc$i/*counter_collection.csv")

@@ -1,4 +1,4 @@
-"""Condense a rocprofv3 kernel_stats.csv: python tools/prof_summary.py stats.csv steps [out.csv] [header...]"""
+"""Condense a rocprofv3 kernel_stats.csv: python tools/dev/prof_summary.py stats.csv steps [out.csv] [header...]"""
 import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 steps = int(sys.argv[2])
