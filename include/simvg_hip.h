@@ -58,9 +58,12 @@ int simvg_colsum(const void* Y_bf16, int ldy, float* out, int out_group_stride, 
  * decoder norms of heads/tgqs_kd_detr_head/transformer.py:119-132. */
 int simvg_ln_fwd(const void* x, int x_is_bf16, int ldx, const float* gamma, const float* beta, int group_stride,
                  void* y_bf16, int ldy, float* y_f32, int ldy32, float* mean, float* rstd,
-                 int M, int D, int split, float eps, simvg_stream_t stream);
+                 int M, int D, int split, float eps, int x_is_gelu_preact /* x = fc1 pre-activation u: normalise
+                 gelu(u), recomputed in registers -- torchscale FeedForwardNetwork: ffn_layernorm(gelu(fc1(x))) */,
+                 simvg_stream_t stream);
 /* dx = LN'(dy); outputs: bf16 dx (optionally * GELU'(u), fusing the activation backward of fc1), and/or
- * fp32 (dres + dx) = the residual-stream gradient, with an optional bf16 copy * row_scale (DropPath). */
+ * fp32 (dres + dx) = the residual-stream gradient, with an optional bf16 copy * row_scale (DropPath).
+ * gelu_u_bf16 == x (same pointer): x is the pre-activation and the LayerNorm input gelu(u) is recomputed. */
 int simvg_ln_bwd(const void* dy, int dy_is_f32, int lddy, const void* x, int x_is_bf16, int ldx, const float* mean,
                  const float* rstd, const float* gamma, int group_stride, float* dgamma, float* dbeta,
                  void* dx_bf16, int lddxb, const void* gelu_u_bf16, int ldu, const float* dres,

@@ -24,7 +24,7 @@ _SIGS = {
                       c_void_p],
     "simvg_colsum": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "simvg_ln_fwd": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
-                     c_void_p, c_int, c_int, c_int, c_float, c_void_p],
+                     c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p],
     "simvg_ln_bwd": [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                      c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
                      c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],

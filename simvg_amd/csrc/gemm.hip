@@ -134,7 +134,8 @@ __device__ __forceinline__ void gemm_nt_epilogue(const GemmNTArgs& a, f32x4_t (&
 constexpr int EPI_LD = 68;                       // floats per staged row (64 + 4 pad)
 constexpr int EPI_WAVE_BYTES = 32 * EPI_LD * 4;  // 8704 B per wave
 
-__device__ __forceinline__ void gemm_nt_epilogue_lds(const GemmNTArgs& a, f32x4_t (&acc)[4][4], int group, int row0,
+template <int MI>
+__device__ __forceinline__ void gemm_nt_epilogue_lds(const GemmNTArgs& a, f32x4_t (&acc)[MI][4], int group, int row0,
                                                      int row_end, int n0, int wm, int wn, int wave, int lane,
                                                      char* smem) {
   __syncthreads();                                // every wave is done reading the ring
@@ -153,7 +154,7 @@ __device__ __forceinline__ void gemm_nt_epilogue_lds(const GemmNTArgs& a, f32x4_
     }
   }
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
+  for (int p = 0; p < MI / 2; ++p) {
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
@@ -164,7 +165,7 @@ __device__ __forceinline__ void gemm_nt_epilogue_lds(const GemmNTArgs& a, f32x4_
       }
     // wave-private slice: only this wave's own LDS writes must have landed (no barrier)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const int mbase = row0 + wm * 64 + p * 32;
+    const int mbase = row0 + wm * (MI * 16) + p * 32;
     if (!a.c_f32) {
       // bf16 output: lane -> 8 consecutive columns, 8 lanes per row, 8 rows per pass
 #pragma unroll
@@ -366,10 +367,77 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel_256(GemmNTArgs a) {
 #undef STA
 #undef STB
 #undef ISSUE
-  if ((a.N & 7) == 0 && !(a.flags & 32)) { gemm_nt_epilogue_lds(a, acc, group, row0, row_end, n0, wm, wn, wave, lane, smem); return; }
+  if ((a.N & 7) == 0 && !(a.flags & 32)) { gemm_nt_epilogue_lds<4>(a, acc, group, row0, row_end, n0, wm, wn, wave, lane, smem); return; }
   gemm_nt_epilogue<4>(a, acc, group, row0, row_end, n0, wm, wn, lane);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// 256x256x64 tile for the wide-N problems (QKV, fc1, dgrad of fc2: N >= 2304): 8 waves as 2 (M) x 4 (N), each
+// 128x64 = acc[8][4] (128 accumulator VGPRs), two 64 KiB LDS buffers, one rendezvous per k-tile with the loads of
+// tile t+1 in flight under the 64 MFMAs of tile t.  128 FLOP per staged byte (256x128: 85): the L2->LDS path
+// (global_load_lds issue ~16+ cycles per KiB) and the LDS reads drop to half of the MFMA time.
+// ------------------------------------------------------------------------------------------
+constexpr int BMQ = 256, BNQ = 256;
+constexpr int STAGEQ = (BMQ + BNQ) * BK * 2;   // 65536 B
+
+__global__ __launch_bounds__(512) void gemm_nt_kernel_256sq(GemmNTArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int tiles_n = (a.N + BNQ - 1) / BNQ;
+  const int tm0 = (a.split + BMQ - 1) / BMQ;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+  const int group = tile_m >= tm0;
+  const int row0 = group ? a.split + (tile_m - tm0) * BMQ : tile_m * BMQ;
+  const int row_end = group ? a.M : a.split;
+  const int n0 = tile_n * BNQ;
+  const bf16_t* W = a.W + (long)group * a.w_gstride;
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = a.K / BK;
+#define STA(s_) (smem + (s_) * STAGEQ)
+#define STB(s_) (smem + (s_) * STAGEQ + BMQ * BK * 2)
+#define ISSUE(t_)                                                                                  \
+  do {                                                                                             \
+    const int st__ = (t_) & 1;                                                                     \
+    stage_tile_k64_n(a.A, a.lda, row0, row_end - 1, (t_) * BK, STA(st__), wave, lane, 4);          \
+    stage_tile_k64_n(W, a.ldw, n0, a.N - 1, (t_) * BK, STB(st__), wave, lane, 4);                  \
+  } while (0)
+
+  ISSUE(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's share of tile kt has landed
+    __builtin_amdgcn_s_barrier();                        // everyone's has, and everyone is past compute(kt-1)
+    if (kt + 1 < nk) ISSUE(kt + 1);
+    const char* sA = STA(kt & 1);
+    const char* sB = STB(kt & 1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8_t fa[8], fb[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = read_frag_k64(sB, wn * 64 + j * 16 + (lane & 15), s * 4 + (lane >> 4));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) fa[i] = read_frag_k64(sA, wm * 128 + i * 16 + (lane & 15), s * 4 + (lane >> 4));
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+  }
+#undef STA
+#undef STB
+#undef ISSUE
+  gemm_nt_epilogue_lds<8>(a, acc, group, row0, row_end, n0, wm, wn, wave, lane, smem);
+}
 
 // ------------------------------------------------------------------------------------------
 // Variant: same 256x128 tile / 8 waves / 3-stage ring, but K-tiles of 32 (24 KiB stages, 72 KiB LDS) so that TWO
@@ -462,7 +530,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_256k32(GemmNTArgs a) {
     if (t == 123.456f) ((float*)a.C)[tid] = t;
     return;
   }
-  if ((a.N & 7) == 0 && !(a.flags & 32)) { gemm_nt_epilogue_lds(a, acc, group, row0, row_end, n0, wm, wn, wave, lane, smem); return; }
+  if ((a.N & 7) == 0 && !(a.flags & 32)) { gemm_nt_epilogue_lds<4>(a, acc, group, row0, row_end, n0, wm, wn, wave, lane, smem); return; }
   gemm_nt_epilogue<4>(a, acc, group, row0, row_end, n0, wm, wn, lane);
 }
 
@@ -787,7 +855,13 @@ extern "C" int simvg_gemm_nt(const void* A, int lda, const void* W, long w_gstri
   // (measured: profiles/r01_sweeps.md).  SIMVG_GEMM_NT = 128 | 256 | 232 forces one kernel.
   static const int variant_env = getenv("SIMVG_GEMM_NT") ? atoi(getenv("SIMVG_GEMM_NT")) : 0;
   const int variant = variant_env ? variant_env : (K <= 1024 ? 232 : 256);
-  if (variant == 232 && M >= 512) {
+  if ((variant == 2562 || (!variant_env && N >= 2304)) && (N & 7) == 0 && M >= 2048) {
+    static bool onceq = hipFuncSetAttribute((const void*)gemm_nt_kernel_256sq, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            2 * STAGEQ) == hipSuccess;
+    (void)onceq;
+    const int tiles = (cdiv(split, BMQ) + cdiv(M - split, BMQ)) * cdiv(N, BNQ);
+    hipLaunchKernelGGL(gemm_nt_kernel_256sq, dim3(tiles), dim3(512), 2 * STAGEQ, stream, a);
+  } else if (variant == 232 && M >= 512) {
     static bool once3 = hipFuncSetAttribute((const void*)gemm_nt_kernel_256k32, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             3 * STAGE3) == hipSuccess;
     (void)once3;

@@ -34,7 +34,10 @@ template <typename TIn, int NIT>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIn* __restrict__ x, int ldx, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, int gstride, bf16_t* __restrict__ y,
                                                      int ldy, float* __restrict__ y32, int ldy32, float* __restrict__ mean,
-                                                     float* __restrict__ rstd, int M, int D, int split, float eps) {
+                                                     float* __restrict__ rstd, int M, int D, int split, float eps,
+                                                     int gelu_in) {
+  // gelu_in: x holds the fc1 PRE-activation u and the LayerNorm input is gelu(u), recomputed here (the activation is
+  // never stored: one [M, F] bf16 write per layer less in the fc1 GEMM, one read less in the backward)
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -47,6 +50,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIn* __restrict__ x, 
     const int c = (it * 64 + lane) * 4;
     if (c < D) {
       Ld4<TIn>::ld(xr + c, v[it]);
+      if (gelu_in) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[it][k] = gelu_erf(v[it][k]);
+      }
       s += (v[it][0] + v[it][1]) + (v[it][2] + v[it][3]);
     } else {
       v[it][0] = v[it][1] = v[it][2] = v[it][3] = 0.f;
@@ -100,6 +107,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
                                                      float* __restrict__ partial) {
   extern __shared__ float red[];  // [2][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool x_is_u = gelu_u != nullptr && (const void*)gelu_u == (const void*)x;
   const int blk = blockIdx.x;
   const int g = blk >= blocks0;
   const int r_begin = g ? split + (blk - blocks0) * rows_per_block : blk * rows_per_block;
@@ -119,7 +127,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
   const float invD = 1.f / (float)D;
   for (int row = r_begin + wave; row < r_end; row += 4) {
     const float mu = mean[row], rs = rstd[row];
-    float xh[NIT][4], dyv[NIT][4];
+    float xh[NIT][4], dyv[NIT][4], gp[NIT][4];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -128,6 +136,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
         float xv[4];
         Ld4<TIn>::ld(x + (long)row * ldx + c, xv);
         Ld4<TDy>::ld(dy + (long)row * lddy + c, dyv[it]);
+        if (x_is_u) {     // x is the GELU pre-activation: LN input g = u*Phi(u), and keep GELU'(u) for the output
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            float cdf, pdf;
+            gelu_parts(xv[k], cdf, pdf);
+            gp[it][k] = fmaf(xv[k], pdf, cdf);
+            xv[k] *= cdf;
+          }
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           xh[it][k] = (xv[k] - mu) * rs;
@@ -153,7 +170,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
 #pragma unroll
         for (int k = 0; k < 4; ++k) dx[k] = rs * (dyv[it][k] * gv[it][k] - c1 - xh[it][k] * c2);
         if (out_bf16) {
-          if (gelu_u) {
+          if (x_is_u) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dx[k] *= gp[it][k];
+          } else if (gelu_u) {
             float u[4];
             Ld4<bf16_t>::ld(gelu_u + (long)row * ldu + c, u);
 #pragma unroll
@@ -218,6 +238,7 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const bf16_t* __restri
                                                           float* __restrict__ partial) {
   __shared__ float part[2][4][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool x_is_u = gelu_u != nullptr && (const void*)gelu_u == (const void*)x;
   const int blk = blockIdx.x;
   const int g = blk >= blocks0;
   const int r_begin = g ? split + (blk - blocks0) * rows_per_block : blk * rows_per_block;
@@ -244,7 +265,7 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const bf16_t* __restri
     for (int it = 0; it < NITW; ++it) {
       const int c = (it * 256 + tid) * 4;
       if (c < D) {
-        Ld4<TIn>::ld(x + (long)row * ldx + c, xq[it]);
+        if (!x_is_u) Ld4<TIn>::ld(x + (long)row * ldx + c, xq[it]);
         Ld4<bf16_t>::ld(dy + (long)row * lddy + c, dq[it]);
         if (gelu_u) Ld4<bf16_t>::ld(gelu_u + (long)row * ldu + c, uq[it]);
       }
@@ -262,8 +283,14 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const bf16_t* __restri
       for (int k = 0; k < 4; ++k) {
         const bool in = c < D;
         dyv[it][k] = in ? dq[it][k] : 0.f;
-        uv[it][k] = uq[it][k];
-        xh[it][k] = in ? (xq[it][k] - mu) * rs : 0.f;
+        float xval = xq[it][k];
+        if (gelu_u) {       // uv <- GELU'(u); with x == u the LayerNorm input g = u*Phi(u) is recomputed as well
+          float cdf, pdf;
+          gelu_parts(uq[it][k], cdf, pdf);
+          uv[it][k] = fmaf(uq[it][k], pdf, cdf);
+          if (x_is_u) xval = uq[it][k] * cdf;
+        }
+        xh[it][k] = in ? (xval - mu) * rs : 0.f;
         const float dg = dyv[it][k] * gv[it][k];
         s1 += dg;
         s2 += dg * xh[it][k];
@@ -289,7 +316,7 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const bf16_t* __restri
         if (out_bf16) {
           if (gelu_u) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) dx[k] *= gelu_erf_grad(uv[it][k]);
+            for (int k = 0; k < 4; ++k) dx[k] *= uv[it][k];
           }
           st4_bf16(out_bf16 + (long)row * ldob + c, dx);
         }
@@ -370,7 +397,8 @@ __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __re
 
 extern "C" int simvg_ln_fwd(const void* x, int x_is_bf16, int ldx, const float* gamma, const float* beta,
                             int group_stride, void* y_bf16, int ldy, float* y_f32, int ldy32, float* mean,
-                            float* rstd, int M, int D, int split, float eps, hipStream_t stream) {
+                            float* rstd, int M, int D, int split, float eps, int x_is_gelu_preact,
+                            hipStream_t stream) {
   SIMVG_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 4096, "ln_fwd: D must be a multiple of 4 and <= 4096");
   SIMVG_CHECK_ARG(ldx % 4 == 0 && (y_bf16 == nullptr || ldy % 4 == 0), "ln_fwd: leading dims must be multiples of 4");
   SIMVG_CHECK_ARG(y_bf16 || y_f32, "ln_fwd: no output");
@@ -379,10 +407,12 @@ extern "C" int simvg_ln_fwd(const void* x, int x_is_bf16, int ldx, const float* 
 #define CALL(N_)                                                                                                   \
   if (x_is_bf16)                                                                                                   \
     hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, N_>), grid, block, 0, stream, (const bf16_t*)x, ldx, gamma, beta,    \
-                       group_stride, (bf16_t*)y_bf16, ldy, y_f32, ldy32, mean, rstd, M, D, split, eps);            \
+                       group_stride, (bf16_t*)y_bf16, ldy, y_f32, ldy32, mean, rstd, M, D, split, eps,             \
+                       x_is_gelu_preact);                                                                          \
   else                                                                                                             \
     hipLaunchKernelGGL((ln_fwd_kernel<float, N_>), grid, block, 0, stream, (const float*)x, ldx, gamma, beta,      \
-                       group_stride, (bf16_t*)y_bf16, ldy, y_f32, ldy32, mean, rstd, M, D, split, eps)
+                       group_stride, (bf16_t*)y_bf16, ldy, y_f32, ldy32, mean, rstd, M, D, split, eps,             \
+                       x_is_gelu_preact)
   LN_DISPATCH_NIT(D, CALL);
 #undef CALL
   SIMVG_LAUNCH_CHECK();

@@ -129,8 +129,10 @@ def colsum(y, out, split=0, out_group_stride=None):
     return out
 
 
-def ln_fwd(x, gamma, beta, split=0, eps=1e-5, out_bf16=True, out_f32=False, save_stats=True, y=None, y32=None):
-    """gamma/beta: [D] or [2,D] fp32.  Returns (y_bf16|None, y_f32|None, mean, rstd)."""
+def ln_fwd(x, gamma, beta, split=0, eps=1e-5, out_bf16=True, out_f32=False, save_stats=True, y=None, y32=None,
+           gelu_in=False):
+    """gamma/beta: [D] or [2,D] fp32.  Returns (y_bf16|None, y_f32|None, mean, rstd).  gelu_in: x is the fc1
+    pre-activation, LayerNorm(gelu(x)) is computed."""
     lib = _lib.load()
     _chk(x, None, "x")
     M, D = x.shape
@@ -144,7 +146,7 @@ def ln_fwd(x, gamma, beta, split=0, eps=1e-5, out_bf16=True, out_f32=False, save
     t0 = _timer.start("ln_fwd") if _timer is not None else None
     rc = lib.simvg_ln_fwd(_p(x), int(x.dtype == BF16), x.stride(0), _p(gamma), _p(beta), gs, _p(y),
                           y.stride(0) if y is not None else 0, _p(y32), y32.stride(0) if y32 is not None else 0,
-                          _p(mean), _p(rstd), M, D, split, eps, _stream())
+                          _p(mean), _p(rstd), M, D, split, eps, int(gelu_in), _stream())
     if t0 is not None:
         _timer.stop("ln_fwd", t0, 0.0, float(M) * D * (x.element_size() + (2 if y is not None else 0) + (4 if y32 is not None else 0)))
     _lib.check(rc, "simvg_ln_fwd")

@@ -233,7 +233,7 @@ class BEIT3(nn.Module):
         ws["layer"] = []
         for _ in range(nl):
             ws["layer"].append(dict(h=bf(M, D), qkv=bf(M, 3 * D), o=bf(M, D), lse=None, o2=bf(M, D), h2=bf(M, D),
-                                    u=bf(M, F_), g=bf(M, F_), g2=bf(M, F_), stats={}))
+                                    u=bf(M, F_), g2=bf(M, F_), stats={}))
         if save:
             ws.update(dx=f32(M, D), dyb=bf(M, D), dF=bf(M, F_), dF2=bf(M, F_), dD=bf(M, D), dO=bf(M, D),
                       dQKV=bf(M, 3 * D), dpatch=bf(B * self.np, D))
@@ -272,9 +272,10 @@ class BEIT3(nn.Module):
             ops.gemm_nt(st["o2"], self.wb[f"wout{i}"], bias=V[f"bout{i}"], out=x_mid, split=Mv, residual=x_in,
                         row_scale=None if dp is None else dp[i][0], rows_per_sample=rps)
             _, _, s["m3"], s["r3"] = ops.ln_fwd(x_mid, V[f"ln2g{i}"], V[f"ln2b{i}"], split=Mv, eps=eps, y=st["h2"], save_stats=save)
-            ops.gemm_nt(st["h2"], self.wb[f"w1{i}"], bias=V[f"b1{i}"], out=st["g"], split=Mv, act=1,
-                        aux_preact=st["u"] if save else None)
-            _, _, s["m4"], s["r4"] = ops.ln_fwd(st["g"], V[f"lnfg{i}"], V[f"lnfb{i}"], split=Mv, eps=eps, y=st["g2"], save_stats=save)
+            # fc1 stores only its pre-activation u; ffn_layernorm recomputes gelu(u) in registers (forward and backward)
+            ops.gemm_nt(st["h2"], self.wb[f"w1{i}"], bias=V[f"b1{i}"], out=st["u"], split=Mv)
+            _, _, s["m4"], s["r4"] = ops.ln_fwd(st["u"], V[f"lnfg{i}"], V[f"lnfb{i}"], split=Mv, eps=eps, y=st["g2"], save_stats=save,
+                                                gelu_in=True)
             ops.gemm_nt(st["g2"], self.wb[f"w2{i}"], bias=V[f"b2{i}"], out=x_out, split=Mv, residual=x_mid,
                         row_scale=None if dp is None else dp[i][1], rows_per_sample=rps)
         x_last = xs[2 * L] if save else xs[(2 * L) % 3]
@@ -354,8 +355,8 @@ class BEIT3(nn.Module):
             # ---- FFN branch: x_out = x_mid + dp1 * fc2(LN(gelu(fc1(LN(x_mid)))))
             ops.gemm_nt(dyb, self.wb[f"w2T{i}"], out=dF, split=Mv)
             ops.gemm_tn(dyb, st["g2"], G[f"w2{i}"], split=Mv, db=G[f"b2{i}"])
-            ops.ln_bwd(dF, st["g"], s["m4"], s["r4"], V[f"lnfg{i}"], G[f"lnfg{i}"], G[f"lnfb{i}"], split=Mv,
-                       dx_bf16=dF2, gelu_u=st["u"])
+            ops.ln_bwd(dF, st["u"], s["m4"], s["r4"], V[f"lnfg{i}"], G[f"lnfg{i}"], G[f"lnfb{i}"], split=Mv,
+                       dx_bf16=dF2, gelu_u=st["u"])      # x == gelu_u: LN input gelu(u) and GELU'(u) recomputed from u
             ops.gemm_nt(dF2, self.wb[f"w1T{i}"], out=dD, split=Mv)
             ops.gemm_tn(dF2, st["h2"], G[f"w1{i}"], split=Mv, db=G[f"b1{i}"])
             ops.ln_bwd(dD, xs[2 * i + 1], s["m3"], s["r3"], V[f"ln2g{i}"], G[f"ln2g{i}"], G[f"ln2b{i}"], split=Mv,

@@ -106,7 +106,8 @@ def test_probe_glds_lane_linear():
 # GEMMs
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,N,K,split", [(300, 192, 128, 200), (1684, 768, 768, 1604), (257, 64, 64, 0),
-                                         (1684, 3072, 768, 1604), (640, 768, 3072, 512)])
+                                         (1684, 3072, 768, 1604), (640, 768, 3072, 512),
+                                         (2370, 2304, 768, 2100), (2112, 3072, 128, 0)])    # 256x256 tile path
 @pytest.mark.parametrize("mode", ["plain", "bias_gelu_aux", "residual_scale_f32", "relu_f32"])
 def test_gemm_nt(M, N, K, split, mode):
     ops = _ops()
@@ -222,6 +223,33 @@ def test_layernorm_fwd_bwd(M, D, split, xdtype):
     ur = u.clone().requires_grad_(True)
     F.gelu(ur).backward(xr.grad)
     assert_close(dxb, ur.grad, 1e-2, "ln bwd * gelu'")
+
+
+@pytest.mark.parametrize("M,D,split", [(90, 3072, 61), (37, 256, 0), (33, 4096, 9)])
+def test_layernorm_of_recomputed_gelu(M, D, split):
+    """ffn_layernorm(gelu(u)) with only the pre-activation u stored: forward recomputes gelu(u), backward recomputes
+    gelu(u) AND gelu'(u) from the same u (x == gelu_u) -- reference: torchscale FeedForwardNetwork.forward."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + D)
+    u = (torch.randn(M, D, generator=g) * 1.5).to(torch.bfloat16).float()
+    ng = 2 if split else 1
+    gamma, beta = 1 + 0.2 * torch.randn(ng, D, generator=g), 0.1 * torch.randn(ng, D, generator=g)
+    sp = split if split else M
+    ur = u.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    a = F.gelu(ur)
+    y_ref = torch.cat([F.layer_norm(a[:sp], (D,), gr[0], br[0], 1e-5), F.layer_norm(a[sp:], (D,), gr[-1], br[-1], 1e-5)], 0)
+    ud = bf(u).to(DEV)
+    y, y32, mean, rstd = ops.ln_fwd(ud, gamma.to(DEV), beta.to(DEV), split=split, out_bf16=True, out_f32=True, gelu_in=True)
+    assert_close(y32, y_ref, 2e-5, "ln(gelu(u)) fwd")
+    dy = rnd_bf16(M, D, gen=g)
+    y_ref.backward(dy)
+    dgamma, dbeta = torch.zeros(ng, D, device=DEV), torch.zeros(ng, D, device=DEV)
+    dxb = torch.empty(M, D, device=DEV, dtype=torch.bfloat16)
+    ops.ln_bwd(bf(dy).to(DEV), ud, mean, rstd, gamma.to(DEV), dgamma, dbeta, split=split, dx_bf16=dxb, gelu_u=ud)
+    assert_close(dxb, ur.grad, 1e-2, "d/du of ln(gelu(u))")
+    assert_close(dgamma, gr.grad, 1e-4, "dgamma")
+    assert_close(dbeta, br.grad, 1e-4, "dbeta")
 
 
 # ------------------------------------------------------------------------------------------

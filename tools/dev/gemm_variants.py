@@ -24,3 +24,4 @@ for rep in range(3):
   run("split 2 groups", lambda: ops.gemm_nt(a, w, out=out, split=SPLIT))
   run("split+bias", lambda: ops.gemm_nt(a, w, bias=bias, out=out, split=SPLIT))
   run("split+bias+res f32 out", lambda: ops.gemm_nt(a, w, bias=bias, out=outf, split=SPLIT, residual=res))
+  run("split+bias+gelu+aux", lambda: ops.gemm_nt(a, w, bias=bias, out=out, split=SPLIT, act=1, aux_preact=outf.view(torch.bfloat16)[:, :N]))
