@@ -174,7 +174,11 @@ def main():
     pairs = world * B * a.steps
     value = pairs / dt
     summ = timer.summary()
-    g = summ["gemm_nt"]
+    g = dict(calls=0, ms=0.0, flops=0.0, bytes=0.0)     # every gemm_nt launch (--breakdown keys them per shape)
+    for k, d in summ.items():
+        if k.startswith("gemm_nt"):
+            for f in g:
+                g[f] += d[f]
     ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "gemm_nt_hbm_traffic.json")
@@ -208,7 +212,7 @@ def main():
         for k, d in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
             tf = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["flops"] else 0.0
             gb = d["bytes"] / (d["ms"] * 1e-3) / 1e9
-            print(f"[breakdown] {k:10s} calls/step {d['calls'] / a.steps:7.1f}  ms/step {d['ms'] / a.steps:8.3f} "
+            print(f"[breakdown] {k:34s} calls/step {d['calls'] / a.steps:7.1f}  ms/step {d['ms'] / a.steps:8.3f} "
                   f"({100 * d['ms'] / tot:5.1f} %)  {tf:8.1f} TFLOP/s  {gb:8.1f} GB/s(algorithmic)", file=sys.stderr)
     if world == 1 and not a.no_cpu_baseline:
         try:

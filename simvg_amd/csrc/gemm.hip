@@ -154,15 +154,17 @@ __device__ __forceinline__ void gemm_nt_epilogue_lds(const GemmNTArgs& a, f32x4_
     }
   }
 #pragma unroll
-  for (int p = 0; p < MI / 2; ++p) {
+  for (int p = 0; p < (MI + 1) / 2; ++p) {
 #pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
+    for (int ii = 0; ii < 2; ++ii) {
+      if (2 * p + ii >= MI) continue;      // odd MI: the last pass stages 16 rows only
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const f32x4_t v = acc[2 * p + ii][j];
         *(f32x4_t*)(st + (ii * 16 + (lane & 15)) * EPI_LD + j * 16 + 4 * (lane >> 4)) =
             (f32x4_t){v[0] + bv[j][0], v[1] + bv[j][1], v[2] + bv[j][2], v[3] + bv[j][3]};
       }
+    }
     // wave-private slice: only this wave's own LDS writes must have landed (no barrier)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const int mbase = row0 + wm * (MI * 16) + p * 32;
@@ -172,7 +174,7 @@ __device__ __forceinline__ void gemm_nt_epilogue_lds(const GemmNTArgs& a, f32x4_
       for (int it = 0; it < 4; ++it) {
         const int r = it * 8 + (lane >> 3), c = (lane & 7) * 8;
         const int m = mbase + r, n = nbase + c;
-        if (m >= row_end || n >= a.N) continue;
+        if (m >= row_end || n >= a.N || 2 * p + (r >> 4) >= MI) continue;
         const f32x4_t u0 = *(const f32x4_t*)(st + r * EPI_LD + c), u1 = *(const f32x4_t*)(st + r * EPI_LD + c + 4);
         float v[8] = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3]};
         if (a.aux)
@@ -199,7 +201,7 @@ __device__ __forceinline__ void gemm_nt_epilogue_lds(const GemmNTArgs& a, f32x4_
       for (int it = 0; it < 8; ++it) {
         const int r = it * 4 + (lane >> 4), c = (lane & 15) * 4;
         const int m = mbase + r, n = nbase + c;
-        if (m >= row_end || n >= a.N) continue;
+        if (m >= row_end || n >= a.N || 2 * p + (r >> 4) >= MI) continue;
         const f32x4_t u = *(const f32x4_t*)(st + r * EPI_LD + c);
         float v[4] = {u[0], u[1], u[2], u[3]};
         if (a.aux) *(u32x2_t*)(a.aux + (long)m * a.ldaux + n) = (u32x2_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
@@ -378,10 +380,27 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel_256(GemmNTArgs a) {
 // tile t+1 in flight under the 64 MFMAs of tile t.  128 FLOP per staged byte (256x128: 85): the L2->LDS path
 // (global_load_lds issue ~16+ cycles per KiB) and the LDS reads drop to half of the MFMA time.
 // ------------------------------------------------------------------------------------------
-constexpr int BMQ = 256, BNQ = 256;
-constexpr int STAGEQ = (BMQ + BNQ) * BK * 2;   // 65536 B
+constexpr int BNQ = 256;
 
+// [n_inst * 8 rows][64 k] tile, wave w stages instructions w, w+8, ... (n_inst need not be a multiple of 8)
+__device__ __forceinline__ void stage_rows_k64(const bf16_t* base, int ld, int row0, int row_last, int k0, char* lds,
+                                               int wave, int lane, int n_inst) {
+  for (int inst = wave; inst < n_inst; inst += 8) {
+    const int r = inst * 8 + (lane >> 3);
+    int row = row0 + r;
+    row = row < row_last ? row : row_last;
+    const int lslot = (lane & 7) ^ (r & 7);
+    const bf16_t* src = base + (long)row * ld + k0 + lslot * 8;
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds + inst * 1024), 16, 0, 0);
+  }
+}
+
+// MI = 16-row blocks per wave along M: tile = (32*MI) x 256.  MI = 8 (256x256) for N >= 2304; MI = 5 (160x256) for the
+// N = 768 problems, whose 256x128 tiling gave 636 tiles = 2.48 rounds on 256 CUs: 160x256 gives 507 = 1.98 rounds.
+template <int MI>
 __global__ __launch_bounds__(512) void gemm_nt_kernel_256sq(GemmNTArgs a) {
+  constexpr int BMQ = 32 * MI;
+  constexpr int STAGEQ = (BMQ + BNQ) * BK * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -396,9 +415,9 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel_256sq(GemmNTArgs a) {
   const int n0 = tile_n * BNQ;
   const bf16_t* W = a.W + (long)group * a.w_gstride;
 
-  f32x4_t acc[8][4];
+  f32x4_t acc[MI][4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
@@ -408,8 +427,8 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel_256sq(GemmNTArgs a) {
 #define ISSUE(t_)                                                                                  \
   do {                                                                                             \
     const int st__ = (t_) & 1;                                                                     \
-    stage_tile_k64_n(a.A, a.lda, row0, row_end - 1, (t_) * BK, STA(st__), wave, lane, 4);          \
-    stage_tile_k64_n(W, a.ldw, n0, a.N - 1, (t_) * BK, STB(st__), wave, lane, 4);                  \
+    stage_rows_k64(a.A, a.lda, row0, row_end - 1, (t_) * BK, STA(st__), wave, lane, BMQ / 8);      \
+    stage_rows_k64(W, a.ldw, n0, a.N - 1, (t_) * BK, STB(st__), wave, lane, BNQ / 8);              \
   } while (0)
 
   ISSUE(0);
@@ -421,13 +440,13 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel_256sq(GemmNTArgs a) {
     const char* sB = STB(kt & 1);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf16x8_t fa[8], fb[4];
+      bf16x8_t fa[MI], fb[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) fb[j] = read_frag_k64(sB, wn * 64 + j * 16 + (lane & 15), s * 4 + (lane >> 4));
 #pragma unroll
-      for (int i = 0; i < 8; ++i) fa[i] = read_frag_k64(sA, wm * 128 + i * 16 + (lane & 15), s * 4 + (lane >> 4));
+      for (int i = 0; i < MI; ++i) fa[i] = read_frag_k64(sA, wm * (MI * 16) + i * 16 + (lane & 15), s * 4 + (lane >> 4));
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
@@ -436,7 +455,7 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel_256sq(GemmNTArgs a) {
 #undef STA
 #undef STB
 #undef ISSUE
-  gemm_nt_epilogue_lds<8>(a, acc, group, row0, row_end, n0, wm, wn, wave, lane, smem);
+  gemm_nt_epilogue_lds<MI>(a, acc, group, row0, row_end, n0, wm, wn, wave, lane, smem);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -545,6 +564,7 @@ struct GemmTNArgs {
   int M, N, K, split, rows_per_chunk, chunks0, flags;
   float* db; int db_gstride;     // optional bias gradient db[g][n] += column sums of dY over group g (extra blocks)
   int tiles;                     // GEMM tiles along blockIdx.x; blocks beyond them are the column-sum blocks
+  int cs_split;                  // row slices per chunk for the column-sum blocks
 };
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page[64];  // 256 B of zeros
@@ -585,18 +605,37 @@ __device__ __forceinline__ bf16x8_t read_frag_tr(const char* lds, int ms, int c0
 // tile_k == 0 blocks -- made those blocks the tail of every launch: wgrad 9 -> 12 ms/step.)
 template <int NT>
 __device__ __forceinline__ void colsum_block(const GemmTNArgs& a, char* smem, int cb, int group, int m_begin, int m_end) {
+  // cb = column block (256 columns) * cs_split + row slice: a GEMM chunk's rows are cut into cs_split slices so that a
+  // column-sum block never walks more than ~512 rows (one long serial walk per chunk made these blocks the tail of
+  // the out-proj wgrad: 157 us in situ vs 82 us without them); 4 independent 16-B loads in flight per thread
   constexpr int RY = NT / 32;
   float (*red)[256 + 8] = (float (*)[256 + 8])smem;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int n = cb * 256 + tx * 8;
+  const int col_block = cb / a.cs_split, slice = cb - col_block * a.cs_split;
+  const int rows = (m_end - m_begin + a.cs_split - 1) / a.cs_split;
+  const int r0 = m_begin + slice * rows, r1 = min(r0 + rows, m_end);
+  const int n = col_block * 256 + tx * 8;
   float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (n < a.N) {
-    for (int m = m_begin + ty; m < m_end; m += RY) {
+    int m = r0 + ty;
+    for (; m + 3 * RY < r1; m += 4 * RY) {
+      u32x4_t v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = *(const u32x4_t*)(a.dY + (long)(m + q * RY) * a.lddy + n);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s[2 * e] += __uint_as_float(v[q][e] << 16);
+          s[2 * e + 1] += __uint_as_float(v[q][e] & 0xffff0000u);
+        }
+    }
+    for (; m < r1; m += RY) {
       const u32x4_t v = *(const u32x4_t*)(a.dY + (long)m * a.lddy + n);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        s[2 * q] += __uint_as_float(v[q] << 16);
-        s[2 * q + 1] += __uint_as_float(v[q] & 0xffff0000u);
+      for (int e = 0; e < 4; ++e) {
+        s[2 * e] += __uint_as_float(v[e] << 16);
+        s[2 * e + 1] += __uint_as_float(v[e] & 0xffff0000u);
       }
     }
   }
@@ -608,8 +647,8 @@ __device__ __forceinline__ void colsum_block(const GemmTNArgs& a, char* smem, in
     float t = 0.f;
 #pragma unroll
     for (int y = 0; y < RY; ++y) t += red[y][c];
-    const int nn = cb * 256 + c;
-    if (nn < a.N) atomicAdd(a.db + (long)group * a.db_gstride + nn, t);
+    const int nn = col_block * 256 + c;
+    if (nn < a.N && r0 < r1) atomicAdd(a.db + (long)group * a.db_gstride + nn, t);
   }
 }
 
@@ -855,12 +894,22 @@ extern "C" int simvg_gemm_nt(const void* A, int lda, const void* W, long w_gstri
   // (measured: profiles/r01_sweeps.md).  SIMVG_GEMM_NT = 128 | 256 | 232 forces one kernel.
   static const int variant_env = getenv("SIMVG_GEMM_NT") ? atoi(getenv("SIMVG_GEMM_NT")) : 0;
   const int variant = variant_env ? variant_env : (K <= 1024 ? 232 : 256);
-  if ((variant == 2562 || (!variant_env && N >= 2304)) && (N & 7) == 0 && M >= 2048) {
-    static bool onceq = hipFuncSetAttribute((const void*)gemm_nt_kernel_256sq, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            2 * STAGEQ) == hipSuccess;
+  // wide-N tiles (N a multiple of 256, big M): 256x256 for N >= 2304; 160x256 for N = 768 (tile-count quantisation,
+  // see the kernel).  SIMVG_GEMM_NT = 2568 / 2565 forces one of them, 256 / 232 / 128 the older kernels.
+  const bool wide_ok = (N % 256) == 0 && M >= 2048;
+  const int wide_mi = variant_env == 2568 ? 8 : variant_env == 2565 ? 5 : variant_env ? 0 : (N >= 2304 ? 8 : (N == 768 ? 5 : 0));
+  if (wide_ok && wide_mi == 8) {
+    constexpr int SM = 2 * (256 + BNQ) * BK * 2;
+    static bool onceq = hipFuncSetAttribute((const void*)gemm_nt_kernel_256sq<8>, hipFuncAttributeMaxDynamicSharedMemorySize, SM) == hipSuccess;
     (void)onceq;
-    const int tiles = (cdiv(split, BMQ) + cdiv(M - split, BMQ)) * cdiv(N, BNQ);
-    hipLaunchKernelGGL(gemm_nt_kernel_256sq, dim3(tiles), dim3(512), 2 * STAGEQ, stream, a);
+    const int tiles = (cdiv(split, 256) + cdiv(M - split, 256)) * cdiv(N, BNQ);
+    hipLaunchKernelGGL(gemm_nt_kernel_256sq<8>, dim3(tiles), dim3(512), SM, stream, a);
+  } else if (wide_ok && wide_mi == 5) {
+    constexpr int SM = 2 * (160 + BNQ) * BK * 2;
+    static bool onceq5 = hipFuncSetAttribute((const void*)gemm_nt_kernel_256sq<5>, hipFuncAttributeMaxDynamicSharedMemorySize, SM) == hipSuccess;
+    (void)onceq5;
+    const int tiles = (cdiv(split, 160) + cdiv(M - split, 160)) * cdiv(N, BNQ);
+    hipLaunchKernelGGL(gemm_nt_kernel_256sq<5>, dim3(tiles), dim3(512), SM, stream, a);
   } else if (variant == 232 && M >= 512) {
     static bool once3 = hipFuncSetAttribute((const void*)gemm_nt_kernel_256k32, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             3 * STAGE3) == hipSuccess;
@@ -900,8 +949,8 @@ extern "C" int simvg_gemm_tn(const void* dY, int lddy, const void* X, int ldx, f
   if (rpc < 256) rpc = 256;   // multiple of 64 (and of the 32-row stages)
   const int chunks0 = cdiv(split, rpc), chunks1 = cdiv(M - split, rpc);
   GemmTNArgs a{(const bf16_t*)dY, lddy, (const bf16_t*)X, ldx, dW, dw_gstride, lddw, M, N, K, split, rpc, chunks0,
-               getenv("SIMVG_TN_FLAGS") ? atoi(getenv("SIMVG_TN_FLAGS")) : 0, db, db_gstride, tiles};
-  const int gx = tiles + (db ? cdiv(N, 256) : 0);   // + column-sum blocks (bias gradient)
+               getenv("SIMVG_TN_FLAGS") ? atoi(getenv("SIMVG_TN_FLAGS")) : 0, db, db_gstride, tiles, cdiv(rpc, 512)};
+  const int gx = tiles + (db ? cdiv(N, 256) * a.cs_split : 0);   // + column-sum blocks (bias gradient)
   if (big) {
     static bool once = hipFuncSetAttribute((const void*)gemm_tn_kernel_256, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            3 * 24576) == hipSuccess;

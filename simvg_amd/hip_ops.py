@@ -85,14 +85,17 @@ def gemm_nt(a, w, bias=None, out=None, out_dtype=BF16, split=0, act=0, aux_preac
         _chk(bias, torch.float32, "bias")
         if bias_group_stride is None:
             bias_group_stride = bias.stride(0) if bias.dim() == 2 else 0
-    t0 = _timer.start("gemm_nt") if _timer is not None else None
+    tname = "gemm_nt"
+    if _timer is not None and _timer.only is None:      # --breakdown: one line per shape / epilogue
+        tname = f"gemm_nt[{M}x{N}x{K}{'+res' if residual is not None else ''}{'+f32' if out.dtype == torch.float32 else ''}]"
+    t0 = _timer.start(tname) if _timer is not None else None
     rc = lib.simvg_gemm_nt(_p(a), a.stride(0), _p(w), w_group_stride, w.stride(-2), _p(bias), bias_group_stride or 0,
                            _p(out), out.stride(0), int(out.dtype == torch.float32),
                            _p(aux_preact), aux_preact.stride(0) if aux_preact is not None else 0,
                            _p(residual), residual.stride(0) if residual is not None else 0,
                            _p(row_scale), rows_per_sample[0], rows_per_sample[1], M, N, K, split, act, _stream())
     if t0 is not None:
-        _timer.stop("gemm_nt", t0, 2.0 * M * N * K, 2.0 * (M * K + N * K) + out.element_size() * M * N)
+        _timer.stop(tname, t0, 2.0 * M * N * K, 2.0 * (M * K + N * K) + out.element_size() * M * N)
     _lib.check(rc, "simvg_gemm_nt")
     return out
 
@@ -105,12 +108,13 @@ def gemm_tn(dy, x, dw, split=0, dw_group_stride=None, db=None):
     K = x.shape[1]
     if dw_group_stride is None:
         dw_group_stride = dw.stride(0) if dw.dim() == 3 else 0
-    t0 = _timer.start("gemm_tn") if _timer is not None else None
+    tname = f"gemm_tn[{M}x{N}x{K}]" if _timer is not None and _timer.only is None else "gemm_tn"
+    t0 = _timer.start(tname) if _timer is not None else None
     rc = lib.simvg_gemm_tn(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), dw_group_stride, dw.stride(-2),
                            _p(db), (db.stride(0) if db.dim() == 2 else 0) if db is not None else 0,
                            M, N, K, split, _stream())
     if t0 is not None:
-        _timer.stop("gemm_tn", t0, 2.0 * M * N * K, 2.0 * M * (N + K) + 4.0 * N * K)
+        _timer.stop(tname, t0, 2.0 * M * N * K, 2.0 * M * (N + K) + 4.0 * N * K)
     _lib.check(rc, "simvg_gemm_tn")
     return dw
 
