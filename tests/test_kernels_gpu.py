@@ -151,7 +151,7 @@ def test_gemm_nt(M, N, K, split, mode):
 
 
 @pytest.mark.parametrize("M,N,K,split", [(300, 192, 128, 200), (1684, 768, 768, 1604), (5000, 128, 256, 0),
-                                         (1684, 3072, 768, 1604), (1684, 768, 3072, 1604)])
+                                         (1684, 3072, 768, 1604), (1684, 768, 3072, 1604), (3000, 2304, 768, 2500)])
 def test_gemm_tn_and_colsum(M, N, K, split):
     ops = _ops()
     g = torch.Generator().manual_seed(7 * M + N)
