@@ -142,6 +142,17 @@ int simvg_weight_prep(const void* descs_dev, int n_desc, int total_tiles, simvg_
 int simvg_cast_f32_to_bf16(const float* src, void* dst_bf16, long n, simvg_stream_t stream);
 int simvg_cast_bf16_to_f32(const void* src_bf16, float* dst, long n, simvg_stream_t stream);
 
+/* ---- optimizer step over a flat fp32 arena (csrc/optim.hip) ------------------------------------------------------
+ * Replaces torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step of apis/train.py:81-83 (core/optimizer.py:52-68)
+ * for the encoder arena: out_accum += sum(x^2) (the arena's share of the global gradient norm), then ONE pass
+ *   g' = g * min(1, max_norm / (*total_norm + 1e-6));  Adam (L2 weight decay, amsgrad when max_exp_avg_sq != NULL):
+ *   p -= step_size * m / (sqrt(vmax) / bias_correction2_sqrt + eps),  step_size = lr / (1 - beta1^t).
+ * total_norm is a DEVICE scalar (no host sync); NULL = no clipping. */
+int simvg_sumsq(const float* x, long n, float* out_accum, simvg_stream_t stream);
+int simvg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, long n,
+                    float step_size, float bias_correction2_sqrt, float beta1, float beta2, float eps, float weight_decay,
+                    const float* total_norm, float max_norm, simvg_stream_t stream);
+
 /* ---- hardware-semantics probes (tests/test_kernels_gpu.py) ---------------------------------------- */
 int simvg_probe_mfma(const void* a_bf16, const void* b_bf16, float* out, simvg_stream_t stream);
 int simvg_probe_tr16(const int* byte_addr, void* out_i16, simvg_stream_t stream);

@@ -44,8 +44,10 @@ class AdamW(torch.optim.AdamW):
 class FlatAdam(torch.optim.Adam):
     """Adam over [encoder arena as ONE tensor] + [remaining parameters].  `params` are the reference-style groups
     (lists of the model's nn.Parameters with an `lr` each); every group whose parameters all live in the encoder arena
-    is replaced by the arena's flat tensor.  `step()` re-attaches the flat gradient; `clip_grad_norm(max_norm)` is the
-    global-norm clip of apis/train.py:81-82 computed over the same set of gradients."""
+    is replaced by the arena's flat tensor.  The arena is updated by ONE HIP kernel (`simvg_adam_step`: clip scale + Adam
+    amsgrad, 36 B per parameter), the head's ~120 tensors by torch's fused multi-tensor Adam; the optimizer state keeps
+    torch's keys (`step`, `exp_avg`, `exp_avg_sq`, `max_exp_avg_sq`), so `state_dict()` round-trips.
+    `clip_grad_norm(max_norm)` is the global-norm clip of apis/train.py:81-82 over the same set of gradients."""
 
     def __init__(self, params, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
         enc = getattr(model, "vis_enc", None)
@@ -58,6 +60,7 @@ class FlatAdam(torch.optim.Adam):
         in_arena = {id(p) for p in arena.params.values()}
         self.flat = torch.nn.Parameter(arena.flat)
         self.flat.grad = arena.flat_grad
+        self._clip = None
         groups, self._rest, used_flat = [], [], False
         for g in params:
             g = dict(g)
@@ -86,11 +89,7 @@ class FlatAdam(torch.optim.Adam):
             p.grad = None
         for p in self.arena.params.values():
             p.grad = None      # the arena re-attaches (and zeroes) its gradient views on the next backward
-
-    def clip_grad_norm(self, max_norm):
-        self.flat.grad = self.arena.flat_grad
-        params = [self.flat] + [p for p in self._rest if p.grad is not None]
-        return torch.nn.utils.clip_grad_norm_(params, max_norm)
+        self._clip = None
 
     def _check_arena(self):
         enc_arena = getattr(getattr(self, "_model_enc", None), "_arena", None)
@@ -98,10 +97,51 @@ class FlatAdam(torch.optim.Adam):
             raise RuntimeError("the encoder re-created its parameter arena after this optimizer was built (model moved "
                                "to another device?): rebuild the optimizer")
 
-    def step(self, closure=None):
+    def clip_grad_norm(self, max_norm):
+        """Global-norm clip (apis/train.py:81-82) without a host sync: the head's gradients are scaled now; the arena's
+        share of the scale is applied inside the fused Adam kernel of the following step() (its gradient buffer is left
+        unscaled -- it is zeroed by the next backward anyway).  Returns the total norm (device scalar)."""
+        from .. import hip_ops as ops
         self._check_arena()
-        self.flat.grad = self.arena.flat_grad
-        return super().step(closure)
+        rest = [p.grad for p in self._rest if p.grad is not None]
+        sq = torch.zeros(1, device=self.arena.flat.device, dtype=torch.float32)
+        ops.sumsq_accum(self.arena.flat_grad, sq)
+        if rest:
+            norms = torch.stack(torch._foreach_norm(rest))
+            sq = sq + (norms * norms).sum()
+        total = sq.sqrt()
+        if rest:
+            coef = torch.clamp(max_norm / (total + 1e-6), max=1.0).reshape(())
+            torch._foreach_mul_(rest, coef)
+        self._clip = (total, float(max_norm))
+        return total.reshape(())
+
+    def step(self, closure=None):
+        from .. import hip_ops as ops
+        self._check_arena()
+        group = next(g for g in self.param_groups if any(p is self.flat for p in g["params"]))
+        st = self.state[self.flat]
+        if len(st) == 0:
+            st["step"] = torch.tensor(0.0)
+            st["exp_avg"] = torch.zeros_like(self.arena.flat)
+            st["exp_avg_sq"] = torch.zeros_like(self.arena.flat)
+            if group["amsgrad"]:
+                st["max_exp_avg_sq"] = torch.zeros_like(self.arena.flat)
+        st["step"] += 1
+        t = int(st["step"])
+        b1, b2 = group["betas"]
+        lr = float(group["lr"])
+        total, max_norm = self._clip if self._clip is not None else (None, 0.0)
+        ops.adam_step(self.arena.flat, self.arena.flat_grad, st["exp_avg"], st["exp_avg_sq"], st.get("max_exp_avg_sq"),
+                      lr / (1.0 - b1 ** t), (1.0 - b2 ** t) ** 0.5, b1, b2, group["eps"], group["weight_decay"],
+                      total_norm=total, max_norm=max_norm)
+        self._clip = None
+        # the remaining (head) parameters: the framework's fused multi-tensor Adam; the flat parameter is hidden from it
+        self.flat.grad = None
+        try:
+            return super().step(closure)
+        finally:
+            self.flat.grad = self.arena.flat_grad
 
 
 def build_optimizer(cfg, params, model=None):

@@ -1,0 +1,89 @@
+// Fused optimizer step over a FLAT fp32 parameter arena (gfx950): global-norm clip scale + Adam (amsgrad optional) in
+// ONE pass -- 5 streams read (p, g, m, v, vmax), 4 written: 36 B per parameter, against ~9 foreach passes / the
+// chunked multi-tensor kernel of the framework optimizer (measured 2.2 ms + 0.7 ms clip for the 108 M parameters of
+// ViT-B SimVG; this kernel is HBM-bound at ~0.9 ms).
+//
+// Replaces, for the encoder arena, torch.nn.utils.clip_grad_norm_(model.parameters(), 0.15) + torch.optim.Adam.step()
+// of the reference's apis/train.py:81-83 / core/optimizer.py:52-68 (betas (0.9, 0.98), eps 1e-9, amsgrad=True,
+// weight_decay 0 in every config).  Same arithmetic as torch's Adam, in fp32:
+//   g' = g * min(1, max_norm / (total_norm + 1e-6))            (clip_grad_norm_)
+//   g' += wd * p                                                (L2 weight decay, Adam not AdamW)
+//   m  = m + (1 - b1) * (g' - m)                                (exp_avg.lerp_)
+//   v  = b2 * v + (1 - b2) * g' * g'
+//   vmax = max(vmax, v);  denom = sqrt(vmax) / sqrt(1 - b2^t) + eps
+//   p  = p - (lr / (1 - b1^t)) * m / denom
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n4, float* __restrict__ out) {
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const f32x4_t v = ((const f32x4_t*)g)[i];
+    s += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+  }
+  __shared__ float red[4];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+}
+
+struct AdamArgs {
+  float* p; const float* g; float* m; float* v; float* vmax;
+  long n4;
+  float step_size, bc2_sqrt, beta1, beta2, eps, weight_decay;
+  const float* total_norm; float max_norm;     // clip (total_norm == nullptr: no clip)
+  int amsgrad;
+};
+
+__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
+  float coef = 1.f;
+  if (a.total_norm) coef = fminf(a.max_norm / (*a.total_norm + 1e-6f), 1.f);
+  const float w1 = 1.f - a.beta1, w2 = 1.f - a.beta2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.n4; i += (long)gridDim.x * 256) {
+    f32x4_t p = ((f32x4_t*)a.p)[i];
+    const f32x4_t g = ((const f32x4_t*)a.g)[i];
+    f32x4_t m = ((f32x4_t*)a.m)[i], v = ((f32x4_t*)a.v)[i];
+    f32x4_t vm = a.amsgrad ? ((f32x4_t*)a.vmax)[i] : v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float gk = g[k] * coef;
+      if (a.weight_decay != 0.f) gk = fmaf(a.weight_decay, p[k], gk);
+      m[k] = m[k] + w1 * (gk - m[k]);
+      v[k] = a.beta2 * v[k] + w2 * gk * gk;
+      float d2 = v[k];
+      if (a.amsgrad) { vm[k] = fmaxf(vm[k], v[k]); d2 = vm[k]; }
+      const float denom = sqrtf(d2) / a.bc2_sqrt + a.eps;
+      p[k] = p[k] - a.step_size * (m[k] / denom);
+    }
+    ((f32x4_t*)a.p)[i] = p;
+    ((f32x4_t*)a.m)[i] = m;
+    ((f32x4_t*)a.v)[i] = v;
+    if (a.amsgrad) ((f32x4_t*)a.vmax)[i] = vm;
+  }
+}
+
+}  // namespace
+
+extern "C" int simvg_sumsq(const float* x, long n, float* out_accum, hipStream_t stream) {
+  SIMVG_CHECK_ARG(x && out_accum && n > 0 && n % 4 == 0, "sumsq: n must be a positive multiple of 4");
+  const long n4 = n / 4;
+  const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, stream, x, n4, out_accum);
+  SIMVG_LAUNCH_CHECK();
+  return SIMVG_OK;
+}
+
+extern "C" int simvg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq,
+                               long n, float step_size, float bias_correction2_sqrt, float beta1, float beta2, float eps,
+                               float weight_decay, const float* total_norm, float max_norm, hipStream_t stream) {
+  SIMVG_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n > 0 && n % 4 == 0, "adam_step: n must be a positive multiple of 4");
+  SIMVG_CHECK_ARG(bias_correction2_sqrt > 0.f, "adam_step: bias_correction2_sqrt must be > 0");
+  AdamArgs a{param, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, n / 4, step_size, bias_correction2_sqrt, beta1, beta2, eps,
+             weight_decay, total_norm, max_norm, max_exp_avg_sq != nullptr};
+  const int grid = (int)((a.n4 + 255) / 256 < 4096 ? (a.n4 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, stream, a);
+  SIMVG_LAUNCH_CHECK();
+  return SIMVG_OK;
+}

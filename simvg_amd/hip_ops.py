@@ -406,3 +406,22 @@ def linear_f32(x, W, b=None, out=None, act=0, accumulate=False):
         out = torch.empty(M, N, device=x.device, dtype=torch.float32)
     gemm_f32(x, x.stride(0), x.stride(1), W, W.stride(1), W.stride(0), out, M, N, K, bias=b, act=act, accumulate=accumulate)
     return out
+
+
+def sumsq_accum(x, out):
+    """out[0] += sum(x^2) over a contiguous fp32 tensor (numel % 4 == 0)."""
+    lib = _lib.load()
+    _chk(x, torch.float32, "x")
+    _lib.check(lib.simvg_sumsq(_p(x), x.numel(), _p(out), _stream()), "simvg_sumsq")
+    return out
+
+
+def adam_step(p, g, m, v, vmax, step_size, bc2_sqrt, beta1, beta2, eps, weight_decay=0.0, total_norm=None, max_norm=0.0):
+    """fused clip-scale + Adam(amsgrad if vmax is given) over flat fp32 tensors, in place."""
+    lib = _lib.load()
+    t0 = _timer.start("adam") if _timer is not None else None
+    rc = lib.simvg_adam_step(_p(p), _p(g), _p(m), _p(v), _p(vmax), p.numel(), step_size, bc2_sqrt, beta1, beta2, eps,
+                             weight_decay, _p(total_norm), max_norm, _stream())
+    if t0 is not None:
+        _timer.stop("adam", t0, 0.0, 36.0 * p.numel())
+    _lib.check(rc, "simvg_adam_step")
