@@ -14,7 +14,7 @@ for cname in ["FETCH_SIZE", "WRITE_SIZE"]:
     agg = collections.defaultdict(lambda: [0.0, set()])
     for r in csv.DictReader(open(f[0])):
         k = r["Kernel_Name"]
-        key = "gemm_nt_kernel_256" if "gemm_nt_kernel_256" in k else ("gemm_nt_kernel" if "gemm_nt_kernel" in k else ("gemm_tn_kernel" if "gemm_tn" in k else None))
+        key = "gemm_nt" if "gemm_nt_kernel" in k else ("gemm_tn" if "gemm_tn_kernel" in k else None)   # all variants of each
         if key is None or r["Counter_Name"] != cname: continue
         agg[key][0] += float(r["Counter_Value"]); agg[key][1].add(r["Dispatch_Id"])
     res[cname] = {k: (v[0], len(v[1])) for k, v in agg.items()}
