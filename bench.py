@@ -147,21 +147,25 @@ def main():
         opt.step()
         return losses
 
-    for _ in range(a.warmup):
-        step()
-    timer = hip_ops.KernelTimer(only=None if a.breakdown else {"gemm_nt"}) if rank == 0 else None
-    hip_ops.set_timer(timer)
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        losses = step()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    hip_ops.set_timer(None)
+    # the step runs on a non-default HIP stream (what `train_model` does as well): required for the hipGraph replay of
+    # the head, see simvg_amd/graphs.py.  The roofline events are recorded on that same stream.
+    from simvg_amd.graphs import train_stream
+    with torch.cuda.stream(train_stream(device)):
+        for _ in range(a.warmup):
+            step()
+        timer = hip_ops.KernelTimer(only=None if a.breakdown else {"gemm_nt"}) if rank == 0 else None
+        hip_ops.set_timer(timer)
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            losses = step()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        hip_ops.set_timer(None)
     if use_dist:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

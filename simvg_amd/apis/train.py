@@ -38,6 +38,17 @@ def _reducer_of(model):
 
 
 def train_model(epoch, cfg, model, model_ema, optimizer, loader):
+    device = next(model.parameters()).device
+    if device.type == "cuda":      # non-default stream: precondition of the head's hipGraph replay (simvg_amd/graphs.py)
+        from ..graphs import train_stream
+        with torch.cuda.stream(train_stream(device)):
+            out = _train_epoch(epoch, cfg, model, model_ema, optimizer, loader)
+        torch.cuda.current_stream(device).wait_stream(train_stream(device))
+        return out
+    return _train_epoch(epoch, cfg, model, model_ema, optimizer, loader)
+
+
+def _train_epoch(epoch, cfg, model, model_ema, optimizer, loader):
     from ..datasets import extract_data
     model.train()
     if cfg.distributed and hasattr(getattr(loader, "sampler", None), "set_epoch"):

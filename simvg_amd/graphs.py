@@ -1,0 +1,115 @@
+"""hipGraph replay of the launch-bound part of the training step: the decoder head + matcher + criterion.
+
+The head is ~650 small launches forward and ~700 backward (exact-fp32 GEMMs on M = B*num_queries rows, small attention,
+LayerNorms, matcher, criterion, glue): ~4 ms of GPU work that costs ~13 ms of Python / autograd dispatch per step, so
+the MI355X idles while the CPU feeds it (step time at B=2 is a flat 21.5 ms).  `torch.cuda.make_graphed_callables`
+captures the head's forward and backward once per input signature into two hipGraphs; a training step then replays
+them with two launches.  The encoder (150 large launches per direction) stays eager.
+
+What makes the capture legal:
+  * everything data-dependent that needs the host -- target packing, the loss normalisers and their RCCL all-reduce --
+    happens BEFORE the graphed region (`head.prepare_targets`); the region itself contains no collective, no host copy,
+    no synchronisation (the matcher and the criterion run on the device);
+  * dropout / attention-dropout masks come from PyTorch's graph-safe Philox generator (fresh masks on every replay);
+  * the bf16 weight refresh of the head's memory projections is part of the captured forward, so replays always see
+    the current master weights.
+A signature = (shapes, dtypes, per-image `img_shape`s, train/eval mode).  Anything else (first steps, a ragged last
+batch, GRefCOCO-style variable metas) runs eagerly; a failed capture disables the feature with a warning.
+
+Stream rule: the training step must run on a NON-default HIP stream (`with torch.cuda.stream(simvg_amd.graphs.
+train_stream()):` -- bench.py, `train_model` and the tests do).  The autograd engine waits, at the end of every backward,
+on the stream each parameter's gradient accumulator was created on; accumulators created by an eager step on the legacy
+default stream make the captured backward touch that stream, which is illegal during a global capture (this HIP runtime
+dies in hipStreamEndCapture instead of reporting it).  A model that has ever run a training forward on the default
+stream therefore never captures -- it silently stays eager.
+"""
+import warnings
+
+import torch
+
+
+_train_streams = {}
+
+
+def train_stream(device=None):
+    """The (per-device, process-wide) non-default stream training steps should run on -- see the stream rule above."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    s = _train_streams.get(device.index)
+    if s is None:
+        s = torch.cuda.Stream(device=device)
+        _train_streams[device.index] = s
+    return s
+
+
+class _HeadStep(torch.nn.Module):
+    """enc_out, text mask, packed targets -> (5 losses, 4 prediction tensors); parameters = the head's."""
+
+    def __init__(self, head, B, Nv, T, img_metas):
+        super().__init__()
+        self.head = head
+        self.geo = (B, Nv, T)
+        self.img_metas = img_metas
+
+    def forward(self, enc_out, text_mask, tboxes, tlabels, tcount, nums):
+        B, Nv, T = self.geo
+        out = self.head.forward_fused(enc_out, B, Nv, T, self.img_metas, text_mask)
+        losses, _ = self.head.loss_from_targets(out, tboxes, tlabels, tcount, nums)
+        t, d = out["token_branch_output"], out["decoder_branch_output"]
+        return (losses["loss_dgt"], losses["loss_tgt"], losses["loss_kd"], losses["loss_distill_w"], losses["loss_total"],
+                t["pred_logits"], t["pred_boxes"], d["pred_logits"], d["pred_boxes"])
+
+
+LOSS_KEYS = ("loss_dgt", "loss_tgt", "loss_kd", "loss_distill_w", "loss_total")
+
+
+class HeadGraphs:
+    """Per-signature cache of graphed head steps; `run()` returns (losses dict, output dict for `_predict`) or None
+    when the step must run eagerly."""
+
+    def __init__(self, head, warm_steps=3):
+        self.head = head
+        self.warm_steps = warm_steps
+        self.seen = {}
+        self.graphs = {}
+        self.disabled = False
+        self.default_stream_seen = False
+
+    @staticmethod
+    def _signature(enc_out, text_mask, tboxes, img_metas, training):
+        return (tuple(enc_out.shape), enc_out.dtype, tuple(text_mask.shape), text_mask.dtype, tuple(tboxes.shape),
+                tuple(tuple(m["img_shape"][:2]) for m in img_metas), bool(training))
+
+    def run(self, enc_out, B, Nv, T, img_metas, text_mask, targets):
+        if self.disabled or not torch.is_grad_enabled() or not enc_out.requires_grad:
+            return None
+        if torch.cuda.current_stream(enc_out.device) == torch.cuda.default_stream(enc_out.device):
+            self.default_stream_seen = True      # gradient accumulators now live on the legacy stream: never capture
+        if self.default_stream_seen:
+            return None
+        tboxes, tlabels, tcount, nums = targets
+        sig = self._signature(enc_out, text_mask, tboxes, img_metas, self.head.training)
+        g = self.graphs.get(sig)
+        if g is None:
+            n = self.seen.get(sig, 0)
+            self.seen[sig] = n + 1
+            if n < self.warm_steps:          # lazily created workspaces / constants must exist before the capture
+                return None
+            try:
+                mod = _HeadStep(self.head, B, Nv, T, [dict(m) for m in img_metas])
+                mod.train(self.head.training)
+                sample = (enc_out.detach().clone().requires_grad_(True), text_mask.clone(), tboxes.clone(),
+                          tlabels.clone(), tcount.clone(), nums.clone())
+                g = torch.cuda.make_graphed_callables(mod, sample, num_warmup_iters=2, allow_unused_input=True)
+            except Exception as e:      # noqa: BLE001 -- any capture problem: stay eager, say so once
+                warnings.warn(f"simvg_amd: head hipGraph capture failed ({type(e).__name__}: {e}); running eagerly")
+                self.disabled = True
+                torch.cuda.synchronize()
+                return None
+            self.graphs[sig] = g
+        outs = g(enc_out, text_mask, tboxes, tlabels, tcount, nums)
+        losses = dict(zip(LOSS_KEYS, outs[:5]))
+        output = dict(token_branch_output={"pred_logits": outs[5], "pred_boxes": outs[6]},
+                      decoder_branch_output={"pred_logits": outs[7], "pred_boxes": outs[8]})
+        return losses, output

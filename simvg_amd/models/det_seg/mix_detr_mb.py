@@ -6,6 +6,8 @@ Mirror of `simvg/models/det_seg/mix_detr_mb.py:13-190` (registered in MODELS; `f
 bf16 layout (no `[B,C,h,w]` transpose copy, `mix_detr_mb.py:52` of the reference), and the post-processing of
 `get_predictions` (detectron2 Boxes.scale / clip / nonempty + argmax) is vectorised on the device.
 """
+import os
+
 import torch
 
 from .. import builder
@@ -14,9 +16,13 @@ from .base import OneStageModel
 
 @builder.MODELS.register_module()
 class MIXDETRMB(OneStageModel):
-    def __init__(self, word_emb, num_token, vis_enc, lan_enc, head, fusion):
+    def __init__(self, word_emb, num_token, vis_enc, lan_enc, head, fusion, head_graph=True):
         super().__init__(word_emb, num_token, vis_enc, lan_enc, head, fusion)
         self.patch_size = vis_enc["patch_size"]
+        # replay the launch-bound head (+ matcher + criterion) forward/backward as two hipGraphs once a training input
+        # signature has repeated (simvg_amd/graphs.py); `head_graph=False` (or SIMVG_HEAD_GRAPH=0) keeps it eager
+        self.head_graph = bool(head_graph) and os.environ.get("SIMVG_HEAD_GRAPH", "1") != "0"
+        self._head_graphs = None
 
     def extract_visual_language(self, img, ref_expr_inds, text_attention_mask=None):
         return self.vis_enc(img, ref_expr_inds, text_attention_mask)
@@ -29,9 +35,23 @@ class MIXDETRMB(OneStageModel):
 
     def forward_train(self, img, ref_expr_inds, img_metas, text_attention_mask=None, gt_bbox=None,
                       gt_mask_vertices=None, rescale=False):
-        output = self._run(img, ref_expr_inds, img_metas, text_attention_mask)
-        losses_dict, detail = self.head.loss(output, gt_bbox, img_metas)
-        self._last_output, self._last_detail = output, detail     # debugging / parity tests
+        B, T = ref_expr_inds.shape
+        Nv = self.vis_enc.np + 1
+        enc_out = self.vis_enc.encode(img, ref_expr_inds, text_attention_mask)
+        targets = self.head.prepare_targets(gt_bbox, img_metas, enc_out.device)
+        graphed = None
+        if self.head_graph and self.training and text_attention_mask is not None and enc_out.dtype == torch.bfloat16:
+            if self._head_graphs is None:
+                from ...graphs import HeadGraphs
+                self._head_graphs = HeadGraphs(self.head)
+            graphed = self._head_graphs.run(enc_out, B, Nv, T, img_metas, text_attention_mask, targets)
+        if graphed is not None:
+            losses_dict, output = graphed
+            self._last_output, self._last_detail = output, None
+        else:
+            output = self.head.forward_fused(enc_out, B, Nv, T, img_metas, text_attention_mask)
+            losses_dict, detail = self.head.loss_from_targets(output, *targets)
+            self._last_output, self._last_detail = output, detail     # debugging / parity tests
         with torch.no_grad():
             predictions = self._predict(output, img_metas, rescale)
         return losses_dict, predictions

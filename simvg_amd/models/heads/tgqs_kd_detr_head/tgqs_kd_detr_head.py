@@ -365,7 +365,7 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
             token_features=tok.view(1, B, nq, E), decoder_features=hs)
 
     # ------------------------------------------------------------------ targets + losses (:207-268, 456-572)
-    def _pack_targets(self, gt_bbox, img_metas, device):
+    def _pack_targets(self, gt_bbox, img_metas, device, return_counts=False):
         """GT -> normalised cxcywh target arrays (prepare_soft_targets :215-234; drops category_id == -1 entries).
         Counts / indices come from host metadata (shapes, img_metas); the boxes themselves stay where they are
         (CPU or HBM) and are packed with device ops -- no device-to-host synchronisation."""
@@ -393,20 +393,39 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
             cx = torch.stack([(t[:, 0] + t[:, 2]) / 2, (t[:, 1] + t[:, 3]) / 2, t[:, 2] - t[:, 0], t[:, 3] - t[:, 1]], -1)
             boxes[torch.tensor(dst, dtype=torch.long).to(device, non_blocking=True)] = cx
         count = torch.tensor(counts, dtype=torch.int32).to(device, non_blocking=True)
-        return boxes.view(B, TM, 4), torch.zeros(B, TM, dtype=torch.int32, device=device), count
+        out = (boxes.view(B, TM, 4), torch.zeros(B, TM, dtype=torch.int32, device=device), count)
+        return out + (counts,) if return_counts else out
+
+    def prepare_targets(self, gt_bbox, img_metas, device):
+        """Everything the criterion needs that is known BEFORE the forward: packed targets and the two loss normalisers
+        num_boxes = max(sum_ranks(k) / world, 1) (criterion.py:245-249, C3) for the GT target set (k = #GT boxes) and
+        for the pseudo-target set of the KD term (k = #matched queries = min(num_queries, #GT) per image).  Keeping this
+        outside `loss_from_targets` leaves the latter free of collectives and host copies (CUDA-graph capturable)."""
+        tboxes, tlabels, tcount, counts = self._pack_targets(gt_bbox, img_metas, device, return_counts=True)
+        n_gt = float(sum(counts))
+        n_kd = float(sum(min(self.num_queries, c) for c in counts))
+        key = ("nums", str(device), n_gt, n_kd)
+        nums = self._const.get(key)
+        if nums is None:
+            nums = torch.tensor([n_gt, n_kd], dtype=torch.float32).to(device)
+            if len(self._const) < 4096:
+                self._const[key] = nums
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            nums = nums.clone()
+            torch.distributed.all_reduce(nums)
+            nums = nums / torch.distributed.get_world_size()
+        return tboxes, tlabels, tcount, nums
 
     def loss(self, output, gt_bbox, img_metas):
+        tboxes, tlabels, tcount, nums = self.prepare_targets(gt_bbox, img_metas, output["outputs_class_decoder_branch"].device)
+        return self.loss_from_targets(output, tboxes, tlabels, tcount, nums)
+
+    def loss_from_targets(self, output, tboxes, tlabels, tcount, nums):
         dl, dbx = output["outputs_class_decoder_branch"], output["outputs_coord_decoder_branch"]
         tl, tbx = output["outputs_class_token_branch"][-1:], output["outputs_coord_token_branch"][-1:]
-        device = dl.device
-        tboxes, tlabels, tcount = self._pack_targets(gt_bbox, img_metas, device)
         dl_d, dbx_d = dl.detach().contiguous(), dbx.detach().contiguous()
         m_dec = ops.match(dl_d, dbx_d, tboxes, tlabels, tcount, self.cost)
         pboxes, plabels, pcount, pweight, scal = ops.soft_targets(dl_d[-1], dbx_d[-1], m_dec[-1], tboxes, tcount)
-        nums = scal[1:3].clone()
-        if torch.distributed.is_available() and torch.distributed.is_initialized():   # criterion.py:245-249 (C3), fused
-            torch.distributed.all_reduce(nums)
-            nums = nums / torch.distributed.get_world_size()
         wd = scal[0:1]
         bw = self.branch_loss_weight
         loss_dgt, t_dec = Criterion.apply(dl, dbx, m_dec, tboxes, tlabels, nums[0:1], None, 0, float(bw["decoder"]),
@@ -421,7 +440,8 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
         losses = dict(loss_dgt=loss_dgt, loss_tgt=loss_tgt, loss_kd=loss_kd, loss_distill_w=wd[0],
                       loss_total=loss_dgt + loss_tgt + loss_kd)
         detail = dict(match_dec=m_dec, match_tok_gt=m_tg, match_tok_kd=m_kd, terms_dec=t_dec, terms_tok_gt=t_tg,
-                      terms_tok_kd=t_kd, targets=(tboxes, tcount), targets_pred=(pboxes, pcount, pweight))
+                      terms_tok_kd=t_kd, targets=(tboxes, tcount), targets_pred=(pboxes, pcount, pweight),
+                      device_counts=scal[1:3])
         return losses, detail
 
     # ------------------------------------------------------------------ reference entry points

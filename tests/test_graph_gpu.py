@@ -1,0 +1,98 @@
+"""hipGraph replay of the head (simvg_amd/graphs.py) must be the same computation as the eager head: losses, predictions
+and every parameter gradient, on replay after replay with changing inputs and weights."""
+import copy
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+
+def _no_dropout(model):
+    model.head.attn_dropout = 0.0
+    model.head.ffn_dropout = 0.0
+    model.vis_enc.drop_path_probs = [0.0] * model.vis_enc.L
+
+
+def test_graphed_head_equals_eager_over_several_steps():
+    """ONE model, every step run twice on identical weights and inputs -- eager head, then (once the signature has
+    repeated) the replayed hipGraphs -- so that the comparison is not polluted by two trajectories drifting apart
+    through bf16 rounding flips; the weights move between steps so that a stale captured copy would show."""
+    from test_tools_gpu import _tiny_model, _batch
+    from simvg_amd.graphs import train_stream
+    cfg, model = _tiny_model(3)
+    _no_dropout(model)
+    model.train()
+    used_graph = []
+    torch.cuda.set_stream(train_stream())          # the stream rule of simvg_amd/graphs.py
+    try:
+        for step in range(7):
+            batch = _batch(cfg, B=4, seed=20 + step)
+            res = []
+            for graph in (False, True):
+                model.head_graph = graph
+                model.zero_grad(set_to_none=True)
+                losses, preds = model(**batch, rescale=False)
+                losses["loss_total"].backward()
+                res.append(({k: v.detach().clone() for k, v in losses.items()}, [p["pred_bboxes"].clone() for p in preds],
+                            {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}))
+                del losses, preds
+            used_graph.append(len(model._head_graphs.graphs) > 0)
+            (l0, p0, g0), (l1, p1, g1) = res
+            for k in l0:
+                assert torch.allclose(l0[k].float(), l1[k].float(), rtol=1e-5, atol=1e-6), (step, k, float(l0[k]), float(l1[k]))
+            for a, b in zip(p0, p1):
+                assert torch.allclose(a, b, rtol=1e-5, atol=1e-4), step
+            assert g0.keys() == g1.keys()
+            for n in g0:
+                ref = g0[n].float()
+                tol = 1e-3 * float(ref.abs().max()) + 1e-7     # fp32 atomics order in the wgrad / LN reductions
+                assert float((ref - g1[n].float()).abs().max()) <= tol, (step, n)
+            with torch.no_grad():
+                for n, p in model.named_parameters():
+                    if n in g0:
+                        p.add_(g0[n], alpha=-1e-3)
+            model.vis_enc.mark_weights_dirty()
+    finally:
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(torch.cuda.default_stream())
+    assert not used_graph[0] and used_graph[-1] and not model._head_graphs.disabled
+
+
+def test_graphed_head_draws_fresh_dropout_masks_and_falls_back_on_new_shapes():
+    from test_tools_gpu import _tiny_model, _batch
+    cfg, model = _tiny_model(4)
+    model.vis_enc.drop_path_probs = [0.0] * model.vis_enc.L
+    model.train()
+    batch = _batch(cfg, B=4, seed=1)
+    vals = []
+    from simvg_amd.graphs import train_stream
+    torch.cuda.set_stream(train_stream())
+    for _ in range(7):
+        model.zero_grad(set_to_none=True)
+        losses, _ = model(**batch, rescale=False)
+        losses["loss_total"].backward()
+        vals.append(float(losses["loss_total"]))
+    assert len(model._head_graphs.graphs) == 1
+    assert len(set(round(v, 6) for v in vals[4:])) > 1      # same input, replayed graph: dropout masks differ per replay
+    small = _batch(cfg, B=2, seed=2)                        # another signature: eager for its first steps, no error
+    losses, _ = model(**small, rescale=False)
+    assert torch.isfinite(losses["loss_total"]) and len(model._head_graphs.graphs) == 1
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(torch.cuda.default_stream())
+
+
+def test_default_stream_training_never_captures():
+    from test_tools_gpu import _tiny_model, _batch
+    cfg, model = _tiny_model(5)
+    model.train()
+    batch = _batch(cfg, B=4, seed=1)
+    for _ in range(6):
+        model.zero_grad(set_to_none=True)
+        losses, _ = model(**batch, rescale=False)
+        losses["loss_total"].backward()
+    assert model._head_graphs.default_stream_seen and not model._head_graphs.graphs
