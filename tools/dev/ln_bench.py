@@ -16,15 +16,15 @@ for D, xdt in [(3072, torch.bfloat16), (768, torch.float32), (768, torch.bfloat1
     dres = torch.randn(M, D, device=dev)
     def run():
         if D == 3072:
-            ops.ln_bwd(dy, x, mean, rstd, g, None if os.environ.get('NOATOM') else dg, db, split=SPLIT, dx_bf16=dxb, gelu_u=None if os.environ.get('NOGELU') else u)
+            ops.ln_bwd(dy, u, mean, rstd, g, dg, db, split=SPLIT, dx_bf16=dxb, gelu_u=None if os.environ.get('NOGELU') else u)   # x == u: GELU recompute path
         elif xdt == torch.float32:
             ops.ln_bwd(dy, x, mean, rstd, g, dg, db, split=SPLIT, dres=dres, dx_f32=dxf, dx_scaled=dxb)
         else:
             ops.ln_bwd(dy, x, mean, rstd, g, dg, db, split=SPLIT, dx_bf16=dxb)
-    for _ in range(3): run()
+    for _ in range(30): run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(10): run()
+    for _ in range(20): run()
     e1.record(); torch.cuda.synchronize()
-    print(f"ln_bwd D={D} x={xdt}: {e0.elapsed_time(e1) / 10 * 1e3:.1f} us", flush=True)
+    print(f"ln_bwd D={D} x={xdt}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us", flush=True)
