@@ -1,0 +1,88 @@
+"""Full-size (BASELINE.json configs[1]: ViT-B/32, 640x640, 20 tokens, B = 64) size-independent properties of the HIP
+path -- the oracle finishes only small cases in seconds, so at this size the checks are structural:
+
+  * batch independence: forward_test on 64 pairs == forward_test on the two halves (tile edges, row-group boundaries of
+    the multiway GEMMs, attention workgroup indexing, head batching) -- bit-exact;
+  * batch-permutation equivariance: permuting the pairs permutes the boxes -- bit-exact (every output element is the
+    same dot product in the same k order whatever tile its row lands in);
+  * determinism of the forward (no atomics in it): two runs are bit-identical;
+  * linearity of the backward in the loss scale: grad(2 L) == 2 grad(L) up to the fp32 atomics' summation order;
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+@pytest.fixture(scope="module")
+def full():
+    import bench
+    from simvg_amd.models import build_model
+    torch.manual_seed(7)
+    model = build_model(bench.model_cfg()).to("cuda")
+    model.vis_enc._ensure_engine(torch.device("cuda"))
+    batch = bench.synthetic_batch(64, 99, torch.device("cuda"))
+    return model, batch
+
+
+def _test_inputs(batch, idx=None):
+    sel = (lambda t: t) if idx is None else (lambda t: t[idx])
+    metas = batch["img_metas"] if idx is None else [batch["img_metas"][int(i)] for i in idx]
+    return dict(img=sel(batch["img"]), ref_expr_inds=sel(batch["ref_expr_inds"]), img_metas=metas,
+                text_attention_mask=sel(batch["text_attention_mask"]), return_loss=False, rescale=False)
+
+
+def _boxes(model, **kw):
+    with torch.no_grad():
+        out = model(**kw)
+    return out[0]["pred_bboxes"].clone(), out[1]["pred_bboxes"].clone()
+
+
+def test_full_size_forward_is_deterministic_batch_independent_and_permutation_equivariant(full):
+    model, batch = full
+    model.eval()
+    d0, t0 = _boxes(model, **_test_inputs(batch))
+    d1, t1 = _boxes(model, **_test_inputs(batch))
+    assert torch.equal(d0, d1) and torch.equal(t0, t1)                       # determinism
+    assert torch.isfinite(d0).all() and (d0[:, 2] >= d0[:, 0]).all() and (d0[:, 3] >= d0[:, 1]).all()
+    assert float(d0.min()) >= 0.0 and float(d0.max()) <= 640.0               # clipped to the image
+    lo, hi = torch.arange(0, 32, device="cuda"), torch.arange(32, 64, device="cuda")
+    dl, tl = _boxes(model, **_test_inputs(batch, lo))
+    dh, th = _boxes(model, **_test_inputs(batch, hi))
+    assert torch.equal(torch.cat([dl, dh]), d0) and torch.equal(torch.cat([tl, th]), t0)     # batch independence
+    perm = torch.randperm(64, generator=torch.Generator().manual_seed(3)).to("cuda")
+    dp, tp = _boxes(model, **_test_inputs(batch, perm))
+    assert torch.equal(dp, d0[perm]) and torch.equal(tp, t0[perm])            # permutation equivariance
+    odd = torch.arange(0, 37, device="cuda")                                  # ragged batch: 37 pairs (partial tiles)
+    do, to = _boxes(model, **_test_inputs(batch, odd))
+    assert torch.equal(do, d0[:37]) and torch.equal(to, t0[:37])
+
+
+def test_full_size_backward_is_linear_in_the_loss_scale(full):
+    model, batch = full
+    model.eval()                     # no dropout / DropPath: the two passes see the same function
+    grads = []
+    for scale in (1.0, 2.0):
+        model.zero_grad(set_to_none=True)
+        losses, _ = model(img=batch["img"], ref_expr_inds=batch["ref_expr_inds"], img_metas=batch["img_metas"],
+                          text_attention_mask=batch["text_attention_mask"], gt_bbox=batch["gt_bbox"], rescale=False)
+        (losses["loss_total"] * scale).backward()
+        grads.append({n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+    g1, g2 = grads
+    assert g1.keys() == g2.keys() and len(g1) > 300
+    worst = 0.0
+    for n in g1:
+        ref = 2.0 * g1[n].float()
+        den = float(ref.abs().max())
+        if den == 0.0:
+            assert float(g2[n].abs().max()) == 0.0, n
+            continue
+        worst = max(worst, float((g2[n].float() - ref).abs().max()) / den)
+    # dgrad operands are rounded to bf16 AFTER the scale (bf16(2x) == 2 bf16(x) exactly), so only the summation order of
+    # the fp32 atomics differs between the passes
+    assert worst <= 2e-3, worst
