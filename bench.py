@@ -28,7 +28,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FLOP_PER_PAIR_FWD_BWD = 241.33e9     # ViT-B/32 @640, nq=1, forward+backward
+FLOP_PER_PAIR_FWD_BWD = {"base": 241.33e9, "large": 824.33e9}   # /32 @640, forward+backward
 MFMA_BF16_PEAK_TFLOPS = 2500.0       # gfx950 dense bf16 (MI355X_MICROARCH.md)
 
 
@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE: 64)")
+    ap.add_argument("--vit", choices=["base", "large"], default="base", help="encoder size (BASELINE metric: base)")
+    ap.add_argument("--queries", type=int, default=1, help="num_queries (GRefCOCO configs: 10)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="per-op HIP-event breakdown on stderr")
     a = ap.parse_args()
@@ -120,7 +122,7 @@ def main():
     from simvg_amd import hip_ops
 
     torch.manual_seed(1234)
-    model = build_model(model_cfg()).to(device).train()
+    model = build_model(model_cfg(a.queries, a.vit)).to(device).train()
     if use_dist:   # identical replicas
         for p in model.parameters():
             dist.broadcast(p.data, 0)
@@ -197,13 +199,13 @@ def main():
         "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "ViT-B/32 SimVG (MIXDETRMB), synthetic RefCOCO 640x640 + 20-token expr, num_queries=1, "
+        "config": {"workload": f"ViT-{'B' if a.vit == 'base' else 'L'}/32 SimVG (MIXDETRMB), synthetic RefCOCO 640x640 + 20-token expr, num_queries={a.queries}, "
                                "full training step: forward+backward bf16 (fp32 accumulate, fp32 residual/master), "
                                "DropPath+dropout on, clip 0.15, Adam(amsgrad)",
                    "global_batch": world * B, "per_gpu_batch": B, "tokens_per_pair": 421,
                    "parallelism": f"dp{world}", "loss_total": round(loss_val, 4)},
-        "model_tflops_per_gpu": round(value / world * FLOP_PER_PAIR_FWD_BWD / 1e12, 2),
-        "model_mfma_frac": round(value / world * FLOP_PER_PAIR_FWD_BWD / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+        "model_tflops_per_gpu": round(value / world * FLOP_PER_PAIR_FWD_BWD[a.vit] / 1e12, 2),
+        "model_mfma_frac": round(value / world * FLOP_PER_PAIR_FWD_BWD[a.vit] / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
         "roofline": {"kernel": "gemm_nt (bf16 MFMA 16x16x32; every launch: 256x256x64 tiles for N >= 2304, 160x256x64 for "
                                "N = 768, global_load_lds double buffer, LDS-staged coalesced epilogue)", "bound": "mfma",
                      "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -219,7 +221,7 @@ def main():
             gb = d["bytes"] / (d["ms"] * 1e-3) / 1e9
             print(f"[breakdown] {k:34s} calls/step {d['calls'] / a.steps:7.1f}  ms/step {d['ms'] / a.steps:8.3f} "
                   f"({100 * d['ms'] / tot:5.1f} %)  {tf:8.1f} TFLOP/s  {gb:8.1f} GB/s(algorithmic)", file=sys.stderr)
-    if world == 1 and not a.no_cpu_baseline:
+    if world == 1 and not a.no_cpu_baseline and a.vit == "base" and a.queries == 1:
         try:
             out["cpu_baseline"] = cpu_baseline()
         except Exception as e:   # the oracle is a checker; never let it take the GPU number down

@@ -897,7 +897,14 @@ extern "C" int simvg_gemm_nt(const void* A, int lda, const void* W, long w_gstri
   // wide-N tiles (N a multiple of 256, big M): 256x256 for N >= 2304; 160x256 for N = 768 (tile-count quantisation,
   // see the kernel).  SIMVG_GEMM_NT = 2568 / 2565 forces one of them, 256 / 232 / 128 the older kernels.
   const bool wide_ok = (N % 256) == 0 && M >= 2048;
-  const int wide_mi = variant_env == 2568 ? 8 : variant_env == 2565 ? 5 : variant_env ? 0 : (N >= 2304 ? 8 : (N == 768 ? 5 : 0));
+  // pick the M extent by tile-count quantisation on the 256 CUs: cost = rounds x rows per tile (ViT-B: N >= 2304 -> 256
+  // rows, N = 768 -> 160 rows; ViT-L: N = 1024 at B = 32 -> 256 rows in one round)
+  auto tile_cost = [&](int bm) {
+    const long tiles = (long)(cdiv(split, bm) + cdiv(M - split, bm)) * cdiv(N, BNQ);
+    return (double)cdiv((int)tiles, 256) * bm * (bm == 160 ? 1.04 : 1.0);     // 160-row tiles: slightly less reuse
+  };
+  const int auto_mi = tile_cost(256) <= tile_cost(160) ? 8 : 5;
+  const int wide_mi = variant_env == 2568 ? 8 : variant_env == 2565 ? 5 : variant_env ? 0 : auto_mi;
   if (wide_ok && wide_mi == 8) {
     constexpr int SM = 2 * (256 + BNQ) * BK * 2;
     static bool onceq = hipFuncSetAttribute((const void*)gemm_nt_kernel_256sq<8>, hipFuncAttributeMaxDynamicSharedMemorySize, SM) == hipSuccess;
