@@ -19,7 +19,7 @@ class GradReducer:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         # SIMVG_FORCE_REDUCE=1 exercises the exchange even with a single rank (all-reduce over 1 rank == identity)
         self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("SIMVG_FORCE_REDUCE") == "1")
-        self.pending = []
+        self.pending, self._scale, self._head = [], [], None
         self.enc = getattr(model, "vis_enc", None)
         self._done_layers = set()
         if self.enc is not None:
@@ -29,6 +29,9 @@ class GradReducer:
     def _on_layer_done(self, i):
         if not self.active:
             return
+        # the head's backward is complete before the encoder's starts (the encoder output is upstream of every head
+        # node): its gradients go first, as ONE packed message, and travel under the whole encoder backward
+        self._launch_head()
         A = self.enc._arena
         if i >= 0:
             lo, hi = A.slice_of(self.enc.layer_param_names(i))
@@ -50,25 +53,30 @@ class GradReducer:
             self.pending.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
             self._scale.append(t)
 
+    def _launch_head(self):
+        if self._head is not None:
+            return
+        grads = [p.grad for n, p in self.model.named_parameters() if not n.startswith("vis_enc.") and p.grad is not None]
+        if not grads:
+            self._head = ([], None)
+            return
+        flat = torch.cat([g.reshape(-1) for g in grads])           # one batched copy kernel (torch.cat over a list)
+        self._head = (grads, flat)
+        self._launch(flat)
+
     def begin(self):
-        self.pending, self._scale = [], []
+        self.pending, self._scale, self._head = [], [], None
 
     def finish(self):
-        """Call after loss.backward(): reduces the head gradients, waits for everything, averages."""
+        """Call after loss.backward(): waits for every message, averages, scatters the head gradients back."""
         if not self.active:
             return
-        head = [p for n, p in self.model.named_parameters() if not n.startswith("vis_enc.") and p.grad is not None]
-        if head:
-            flat = torch.cat([p.grad.reshape(-1) for p in head])
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-            flat.div_(self.world)
-            off = 0
-            for p in head:
-                n = p.numel()
-                p.grad.copy_(flat[off:off + n].view_as(p.grad))
-                off += n
+        self._launch_head()              # models without an encoder hook (or a frozen encoder) reduce the head here
         for w in self.pending:
             w.wait()
         for t in self._scale:
             t.div_(self.world)
-        self.pending, self._scale = [], []
+        grads, flat = self._head
+        if grads:
+            torch._foreach_copy_(grads, [v.view_as(g) for g, v in zip(grads, flat.split([g.numel() for g in grads]))])
+        self.pending, self._scale, self._head = [], [], None
