@@ -23,6 +23,7 @@ default stream make the captured backward touch that stream, which is illegal du
 dies in hipStreamEndCapture instead of reporting it).  A model that has ever run a training forward on the default
 stream therefore never captures -- it silently stays eager.
 """
+import time
 import warnings
 
 import torch
@@ -97,6 +98,11 @@ class HeadGraphs:
             if n < self.warm_steps:          # lazily created workspaces / constants must exist before the capture
                 return None
             try:
+                if torch.distributed.is_available() and torch.distributed.is_initialized():
+                    # drain every RCCL operation and give the process group's watchdog thread (100 ms poll) time to retire
+                    # them: an event query from that thread while this thread captures in global mode would abort the capture
+                    torch.cuda.synchronize()
+                    time.sleep(0.5)
                 mod = _HeadStep(self.head, B, Nv, T, [dict(m) for m in img_metas])
                 mod.train(self.head.training)
                 sample = (enc_out.detach().clone().requires_grad_(True), text_mask.clone(), tboxes.clone(),
