@@ -27,7 +27,7 @@ struct GemmNTArgs {
   bf16_t* aux; int ldaux;
   const float* res; int ldres;
   const float* row_scale; int rps0, rps1;
-  int M, N, K, split, act, flags;
+  int M, N, K, split, act;
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel_256(GemmNTArgs a) {
 #undef STA
 #undef STB
 #undef ISSUE
-  if ((a.N & 7) == 0 && !(a.flags & 32)) { gemm_nt_epilogue_lds<4>(a, acc, group, row0, row_end, n0, wm, wn, wave, lane, smem); return; }
+  if ((a.N & 7) == 0) { gemm_nt_epilogue_lds<4>(a, acc, group, row0, row_end, n0, wm, wn, wave, lane, smem); return; }
   gemm_nt_epilogue<4>(a, acc, group, row0, row_end, n0, wm, wn, lane);
 }
 
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_256k32(GemmNTArgs a) {
     if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (kt + 2 < nk && !(a.flags & 4)) ISSUE(kt + 2);          // flags&4: ablation, no global loads in the loop
+    if (kt + 2 < nk) ISSUE(kt + 2);
     const char* sA = STA(kt % 3);
     const char* sB = STB(kt % 3);
     bf16x8_t fa[4], fb[4];
@@ -526,30 +526,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_256k32(GemmNTArgs a) {
       fa[i] = read_frag_k32(sA, wm * 64 + i * 16 + (lane & 15), lane >> 4);
       fb[i] = read_frag_k32(sB, wn * 64 + i * 16 + (lane & 15), lane >> 4);
     }
-    if (a.flags & 8) {                                           // flags&8: ablation, no MFMAs (fragments kept live)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fa[i]), "v"(fb[i]));
-    } else {
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-    }
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
   }
 #undef STA
 #undef STB
 #undef ISSUE
-  if (a.flags & 16) {   // ablation: no epilogue (one conditional dword keeps the accumulators live)
-    float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) t += acc[i][jj][0] + acc[i][jj][1] + acc[i][jj][2] + acc[i][jj][3];
-    if (t == 123.456f) ((float*)a.C)[tid] = t;
-    return;
-  }
-  if ((a.N & 7) == 0 && !(a.flags & 32)) { gemm_nt_epilogue_lds<4>(a, acc, group, row0, row_end, n0, wm, wn, wave, lane, smem); return; }
+  if ((a.N & 7) == 0) { gemm_nt_epilogue_lds<4>(a, acc, group, row0, row_end, n0, wm, wn, wave, lane, smem); return; }
   gemm_nt_epilogue<4>(a, acc, group, row0, row_end, n0, wm, wn, lane);
 }
 
@@ -561,7 +547,7 @@ struct GemmTNArgs {
   const bf16_t* dY; int lddy;
   const bf16_t* X; int ldx;
   float* dW; long dw_gstride; int lddw;
-  int M, N, K, split, rows_per_chunk, chunks0, flags;
+  int M, N, K, split, rows_per_chunk, chunks0;
   float* db; int db_gstride;     // optional bias gradient db[g][n] += column sums of dY over group g (extra blocks)
   int tiles;                     // GEMM tiles along blockIdx.x; blocks beyond them are the column-sum blocks
   int cs_split;                  // row slices per chunk for the column-sum blocks
@@ -687,7 +673,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs a) {
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
     const int cur = t & 1;
-    if (t + 1 < nt && !(a.flags & 2)) {
+    if (t + 1 < nt) {
       stage_tile_m64(a.dY, a.lddy, m_begin + (t + 1) * 64, m_end, n0, a.N, ldsY(cur ^ 1), wave, lane);
       stage_tile_m64(a.X, a.ldx, m_begin + (t + 1) * 64, m_end, k0, a.K, ldsX(cur ^ 1), wave, lane);
     }
@@ -699,30 +685,16 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs a) {
         fy[i] = read_frag_tr(ldsY(cur), s * 32, wn * 64 + i * 16, lane);
         fx[i] = read_frag_tr(ldsX(cur), s * 32, wk * 64 + i * 16, lane);
       }
-      if (a.flags & 4) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fy[i]), "v"(fx[i]));
-      } else {
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], fx[j], acc[i][j], 0, 0, 0);
-      }
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], fx[j], acc[i][j], 0, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
   float* dW = a.dW + (long)group * a.dw_gstride;
-  if (a.flags & 1) {   // ablation: no atomics
-    float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-    if (t == 123.456f) dW[tid] = t;
-    return;
-  }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -889,7 +861,7 @@ extern "C" int simvg_gemm_nt(const void* A, int lda, const void* W, long w_gstri
   GemmNTArgs a{(const bf16_t*)A, lda, (const bf16_t*)W, w_gstride, ldw, bias, bias_gstride, C, ldc, c_is_f32,
                (bf16_t*)aux_preact, ldaux, residual, ldres, row_scale,
                rows_per_sample0 > 0 ? rows_per_sample0 : 1, rows_per_sample1 > 0 ? rows_per_sample1 : 1,
-               M, N, K, split, act, getenv("SIMVG_GEMM_FLAGS") ? atoi(getenv("SIMVG_GEMM_FLAGS")) : 0};
+               M, N, K, split, act};
   // auto: short K (<= 1024: QKV, out-proj, fc1, dgrad of fc2) -> BK=32, two workgroups per CU; long K -> BK=64
   // (measured: profiles/r01_sweeps.md).  SIMVG_GEMM_NT = 128 | 256 | 232 forces one kernel.
   static const int variant_env = getenv("SIMVG_GEMM_NT") ? atoi(getenv("SIMVG_GEMM_NT")) : 0;
@@ -956,7 +928,7 @@ extern "C" int simvg_gemm_tn(const void* dY, int lddy, const void* X, int ldx, f
   if (rpc < 256) rpc = 256;   // multiple of 64 (and of the 32-row stages)
   const int chunks0 = cdiv(split, rpc), chunks1 = cdiv(M - split, rpc);
   GemmTNArgs a{(const bf16_t*)dY, lddy, (const bf16_t*)X, ldx, dW, dw_gstride, lddw, M, N, K, split, rpc, chunks0,
-               getenv("SIMVG_TN_FLAGS") ? atoi(getenv("SIMVG_TN_FLAGS")) : 0, db, db_gstride, tiles, cdiv(rpc, 512)};
+               db, db_gstride, tiles, cdiv(rpc, 512)};
   const int gx = tiles + (db ? cdiv(N, 256) * a.cs_split : 0);   // + column-sum blocks (bias gradient)
   if (big) {
     static bool once = hipFuncSetAttribute((const void*)gemm_tn_kernel_256, hipFuncAttributeMaxDynamicSharedMemorySize,
