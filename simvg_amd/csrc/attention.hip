@@ -98,6 +98,7 @@ __global__ __launch_bounds__(768) void attn_fwd_kernel(AttnArgs a) {
   fill_key_bias(a, b, N, npad, bias);
   __syncthreads();
 
+  const float sc2 = a.scale * 1.44269504088896340736f;
   for (int qb = wave; qb < nkt; qb += nwaves) {
     const int tq = qb * 16 + j;
     const bf16_t* qp = a.qkv + tok_row(a, b, tq < N ? tq : N - 1) * a.ld + h * HD + 8 * g;
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(768) void attn_fwd_kernel(AttnArgs a) {
         const f32x4_t kb = *(const f32x4_t*)(bias + kt * 16 + 4 * g);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          acc[r] = acc[r] * a.scale + kb[r];
+          acc[r] = acc[r] * sc2 + kb[r];        // log2 domain: scale * log2(e) folded in; kb is 0 or -inf
           mx = fmaxf(mx, acc[r]);
         }
         s[kt] = acc;
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(768) void attn_fwd_kernel(AttnArgs a) {
       if (kt < nkt) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = __expf(s[kt][r] - mx);
+          const float p = __builtin_amdgcn_exp2f(s[kt][r] - mx);     // bare v_exp_f32
           s[kt][r] = p;
           sum += p;
         }
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(768) void attn_fwd_kernel(AttnArgs a) {
       for (int dt = 0; dt < 4; ++dt)
         *(u32x2_t*)(op + dt * 16) = (u32x2_t){pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv),
                                              pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv)};
-      if (g == 0 && a.lse) a.lse[(long)blockIdx.x * N + tq] = mx + __logf(sum);
+      if (g == 0 && a.lse) a.lse[(long)blockIdx.x * N + tq] = (mx + __log2f(sum)) * 0.69314718055994530942f;   // natural log
     }
   }
 }
@@ -186,6 +187,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnArgs a) {
   fill_key_bias(a, b, N, npad, bias);
   __syncthreads();
 
+  const float sc2 = a.scale * 1.44269504088896340736f;
   for (int qb = wave; qb < nkt; qb += nwaves) {
     const int tq = qb * 16 + j;
     const long row = tok_row(a, b, tq < N ? tq : N - 1);
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnArgs a) {
     }
     dl += __shfl_xor(dl, 16, 64);
     dl += __shfl_xor(dl, 32, 64);
-    const float lse = a.lse[(long)blockIdx.x * N + (tq < N ? tq : N - 1)];
+    const float lse2 = a.lse[(long)blockIdx.x * N + (tq < N ? tq : N - 1)] * 1.44269504088896340736f;
     if (tq < N && g == 0) a.delta[(long)blockIdx.x * N + tq] = dl;
 
     u32x2_t dsb[MAX_KT];
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnArgs a) {
         float ds[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = __expf(sa[r] * a.scale + kb[r] - lse);
+          const float p = __builtin_amdgcn_exp2f(sa[r] * sc2 + kb[r] - lse2);
           ds[r] = p * (dp[r] - dl);
         }
         dsb[kt] = (u32x2_t){pack_bf16x2(ds[0], ds[1]), pack_bf16x2(ds[2], ds[3])};
@@ -270,11 +272,12 @@ __global__ __launch_bounds__(768) void attn_bwd_dkv_kernel(AttnArgs a) {
   load_head_to_lds(a, a.qkv, a.ld, h * HD, b, N, npad, ldsQ);
   load_head_to_lds(a, a.dout, a.lddo, h * HD, b, N, npad, ldsDO);
   for (int q = threadIdx.x; q < npad; q += blockDim.x) {
-    lse_s[q] = q < N ? a.lse[(long)blockIdx.x * N + q] : INFINITY;   // exp(.. - inf) = 0 for pad rows
+    lse_s[q] = q < N ? a.lse[(long)blockIdx.x * N + q] * 1.44269504088896340736f : INFINITY;   // log2 domain; exp2(.. - inf) = 0 for pad rows
     dl_s[q] = q < N ? a.delta[(long)blockIdx.x * N + q] : 0.f;
   }
   __syncthreads();
 
+  const float sc2 = a.scale * 1.44269504088896340736f;
   for (int kb = wave; kb < nkt; kb += nwaves) {
     const int tk = kb * 16 + j;
     const long row = tok_row(a, b, tk < N ? tk : N - 1);
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dkv_kernel(AttnArgs a) {
         const f32x4_t d4 = *(const f32x4_t*)(dl_s + qt * 16 + 4 * g);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pr = __expf(sa[r] * a.scale + kbias - l4[r]);
+          const float pr = __builtin_amdgcn_exp2f(sa[r] * sc2 + kbias - l4[r]);
           p[hh][r] = pr;
           ds[hh][r] = pr * (dp[r] - d4[r]);
         }
