@@ -142,6 +142,18 @@ int simvg_weight_prep(const void* descs_dev, int n_desc, int total_tiles, simvg_
 int simvg_cast_f32_to_bf16(const float* src, void* dst_bf16, long n, simvg_stream_t stream);
 int simvg_cast_bf16_to_f32(const void* src_bf16, float* dst, long n, simvg_stream_t stream);
 
+/* ---- device-side image pre-processing (csrc/preprocess.hip) --------------------------------------------------------
+ * Replaces the pixel work of simvg/datasets/pipelines/transforms.py (LargeScaleJitter :221-342 -> mmcv.imrescale + crop,
+ * Resize :59-80 -> mmcv.imresize, Normalize :146-158 -> mmcv.imnormalize, Pad :193-205 -> mmcv.impad_to_multiple) and the
+ * HWC->CHW transpose of formatting.py:62-70, on interleaved 8-bit BGR images resident in HBM.
+ * resize_u8 produces the [out_h, out_w] window at (win_y0, win_x0) of the image resized to [full_h, full_w] with OpenCV's
+ * 8-bit INTER_LINEAR arithmetic (window == full image for a plain resize; rescale-then-crop in one pass otherwise).
+ * normalize_pad_u8 writes fp32 planes [3, pad_h, pad_w]: (x - mean) * (1 / std), optional BGR->RGB, zeros outside. */
+int simvg_resize_u8(const void* src_hwc, int src_h, int src_w, long src_row_bytes, void* dst_hwc, long dst_row_bytes,
+                    int out_h, int out_w, int full_h, int full_w, int win_y0, int win_x0, simvg_stream_t stream);
+int simvg_normalize_pad_u8(const void* src_hwc, long src_row_bytes, int h, int w, float* dst_chw, int pad_h, int pad_w,
+                           const float* mean3_host, const float* std3_host, int to_rgb, simvg_stream_t stream);
+
 /* ---- optimizer step over a flat fp32 arena (csrc/optim.hip) ------------------------------------------------------
  * Replaces torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step of apis/train.py:81-83 (core/optimizer.py:52-68)
  * for the encoder arena: out_accum += sum(x^2) (the arena's share of the global gradient norm), then ONE pass

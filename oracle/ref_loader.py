@@ -185,6 +185,37 @@ def load_apis():
     return out
 
 
+_pipes_loaded = None
+
+
+def load_pipelines():
+    """Executes the reference's image transforms (simvg/datasets/pipelines/transforms.py: Resize, Normalize, Pad,
+    LargeScaleJitter) verbatim on top of the restated mmcv / OpenCV leaves of oracle/pipeline_cpu.py."""
+    global _pipes_loaded
+    if _pipes_loaded is not None:
+        return _pipes_loaded
+    load()
+    from . import pipeline_cpu as P
+    mm = sys.modules["mmcv"]
+    for k in ("imrescale", "imresize", "imnormalize", "impad", "impad_to_multiple", "rescale_size", "is_list_of"):
+        setattr(mm, k, getattr(P, k))
+    sys.modules["mmcv.utils"].to_2tuple = P.to_2tuple
+    mm.utils = sys.modules["mmcv.utils"]
+    ds = sys.modules.get("simvg.datasets")
+    if ds is None:
+        ds = _pkg("simvg.datasets")
+    ds.__path__ = []
+    _mod("simvg.datasets.builder", PIPELINES=leaf.Registry("PIPELINES"), DATASETS=leaf.Registry("DATASETS"))
+    _pkg("simvg.datasets.pipelines")
+    name = "simvg.datasets.pipelines.transforms"
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF_ROOT, "simvg/datasets/pipelines/transforms.py"))
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m
+    spec.loader.exec_module(m)
+    _pipes_loaded = m
+    return m
+
+
 def model_cfg(vit_type="base", num_queries=1, img_size=640, patch_size=32):
     """cfg.model of configs/single/ViT-{base,large}/refcoco/refcoco_onestage.py:68-105
     (grefcoco: num_queries=10), with pretrain=None (no checkpoint in this image)."""

@@ -40,6 +40,8 @@ _SIGS = {
     "simvg_weight_prep": [c_void_p, c_int, c_int, c_void_p],
     "simvg_cast_f32_to_bf16": [c_void_p, c_void_p, c_long, c_void_p],
     "simvg_cast_bf16_to_f32": [c_void_p, c_void_p, c_long, c_void_p],
+    "simvg_resize_u8": [c_void_p, c_int, c_int, c_long, c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "simvg_normalize_pad_u8": [c_void_p, c_long, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
     "simvg_sumsq": [c_void_p, c_long, c_void_p, c_void_p],
     "simvg_adam_step": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float, c_float, c_float,
                         c_float, c_void_p, c_float, c_void_p],

@@ -3,9 +3,10 @@
 `extract_data(inputs)`), and the one dataset this round ships: `SyntheticRefDataset`, RefCOCO-shaped random pairs
 generated ON THE DEVICE (there are no images / annotation files in this image and no network).
 
-The reference's file-backed datasets + CPU pipelines (RefCOCO* json + mscoco jpg, LargeScaleJitter / Resize /
-Normalize / Pad / sentencepiece) are SURVEY.md section 8 row f-3 (device-side input pipeline) and are not built
-yet: naming one of them raises NotImplementedError that says so.  A config selects the synthetic source either with
+The image transforms of the reference's pipeline (LargeScaleJitter / Resize / Normalize / Pad / DefaultFormatBundle /
+CollectData) exist as device-side classes in `simvg_amd.datasets.pipelines`.  The
+file-backed part -- annotation json, JPEG decode, the XLM-R sentencepiece model -- needs artefacts that are not in this
+image: naming one of the reference's dataset types raises NotImplementedError that says so.  A config selects the synthetic source either with
 `type="SyntheticRefDataset"` or globally with `--cfg-options data.synthetic=True`, which keeps every other key of a
 reference config (pipelines, annsfile, ...) untouched and simply ignores them."""
 import torch
@@ -67,6 +68,9 @@ class SyntheticRefDataset(Dataset):
         return dict(img=img, ref_expr_inds=ids, text_attention_mask=pad, gt_bbox=gt, img_metas=meta)
 
 
+from . import pipelines as _pipelines   # noqa: E402,F401  (registers the device-side transforms in PIPELINES)
+
+
 def _collate(batch):
     out = dict(img=torch.stack([b["img"] for b in batch]),
                ref_expr_inds=torch.stack([b["ref_expr_inds"] for b in batch]),
@@ -82,8 +86,8 @@ def build_dataset(cfg, default_args=None):
     typ = cfg.get("type")
     if typ in _REFERENCE_DATASETS and not cfg.pop("synthetic", False):
         raise NotImplementedError(
-            f"dataset type {typ!r} reads annotation json + jpg files through the reference's CPU pipeline; the device-side "
-            "input pipeline is SURVEY.md section 8 row f-3 and is not built yet.  Use type='SyntheticRefDataset' or pass "
+            f"dataset type {typ!r} reads annotation json + jpg files through the reference's CPU pipeline; the file-bound "
+            "part of the input pipeline (json / JPEG / sentencepiece artefacts) is not available in this build.  Use type='SyntheticRefDataset' or pass "
             "--cfg-options data.synthetic=True to run the reference config on synthetic pairs of the same shape.")
     if typ in _REFERENCE_DATASETS:
         keep = {k: cfg[k] for k in ("which_set", "length", "img_size", "max_token", "seed", "max_targets") if k in cfg}

@@ -1,0 +1,249 @@
+"""Device-side data pipeline: the reference's transform classes (`simvg/datasets/pipelines/transforms.py`,
+`formatting.py`) with the same names, constructor arguments, result-dict keys, random-number consumption and box
+arithmetic -- but `results["img"]` is a uint8 [H, W, 3] tensor in HBM and every pixel operation is a HIP kernel
+(`csrc/preprocess.hip`).  SURVEY.md section 8 row f-3.
+
+What is taken over verbatim in behaviour (pinned by `tests/golden/pipeline_golden.pt`, recorded from the reference's own
+classes):  Resize (single scale, keep_ratio False/True), Normalize, Pad (size / size_divisor / pad_to_square),
+LargeScaleJitter including its crop search, its "escape" branch (image and boxes left untouched, img_shape overwritten)
+and its clipping of boxes to the crop.  LargeScaleJitter never materialises the rescaled image: rescale + crop is one
+windowed resize.  `DeviceFormat` = Normalize + Pad + DefaultFormatBundle's HWC->CHW transpose in one kernel.
+
+Not here (host-side, file-bound, or dependent on artefacts that are not in this image): `LoadImageAnnotationsFromFile`
+(JPEG decode, the XLM-R sentencepiece model `beit3.spm`), mask transforms."""
+import math
+import random
+
+import numpy
+import torch
+
+from .. import hip_ops as ops
+from . import PIPELINES
+
+
+def _scale_size(size, scale):
+    w, h = size
+    if isinstance(scale, (float, int)):
+        scale = (scale, scale)
+    return int(w * float(scale[0]) + 0.5), int(h * float(scale[1]) + 0.5)
+
+
+def rescale_size(old_size, scale, return_scale=False):
+    """mmcv.rescale_size: number -> that factor; (long, short) tuple -> largest factor that fits both edges."""
+    w, h = old_size
+    if isinstance(scale, (float, int)):
+        if scale <= 0:
+            raise ValueError(f"Invalid scale {scale}, must be positive.")
+        scale_factor = scale
+    elif isinstance(scale, tuple):
+        scale_factor = min(max(scale) / max(h, w), min(scale) / min(h, w))
+    else:
+        raise TypeError(f"Scale must be a number or tuple of int, but got {type(scale)}")
+    new_size = _scale_size((w, h), scale_factor)
+    return (new_size, scale_factor) if return_scale else new_size
+
+
+def _shape(img):
+    return (int(img.shape[0]), int(img.shape[1]), int(img.shape[2]))
+
+
+@PIPELINES.register_module()
+class Resize:
+    def __init__(self, img_scale=None, keep_ratio=True, interpolation="bilinear", backend="cv2"):
+        if img_scale is None:
+            self.img_scale = None
+        else:
+            self.img_scale = img_scale if isinstance(img_scale, list) else [img_scale]
+            assert all(isinstance(s, tuple) for s in self.img_scale)
+        if interpolation != "bilinear":
+            raise NotImplementedError("only bilinear resizing is built (every reference config uses it)")
+        self.keep_ratio = keep_ratio
+
+    def __call__(self, results):
+        scale = self.img_scale[0] if len(self.img_scale) == 1 else self.img_scale[numpy.random.randint(len(self.img_scale))]
+        results["scale"] = scale
+        img = results["img"]
+        h, w = img.shape[:2]
+        if self.keep_ratio:
+            new_w, new_h = rescale_size((w, h), scale)
+            img = ops.resize_u8(img, (new_h, new_w))
+            oh, ow = results["ori_shape"][:2]
+            w_scale, h_scale = new_w / ow, new_h / oh
+        else:
+            img = ops.resize_u8(img, (scale[1], scale[0]))
+            w_scale, h_scale = scale[0] / w, scale[1] / h
+        scale_factor = numpy.array([w_scale, h_scale, w_scale, h_scale], dtype=numpy.float32)
+        results["img"] = img
+        results["img_shape"] = _shape(img)
+        results["pad_shape"] = _shape(img)
+        results["scale_factor"] = scale_factor
+        results["keep_ratio"] = self.keep_ratio
+        if results["with_bbox"]:
+            gt_bbox = results["gt_bbox"]
+            results["gt_bbox"] = [b * scale_factor for b in gt_bbox] if isinstance(gt_bbox, list) else gt_bbox * scale_factor
+        if results.get("with_mask"):
+            raise NotImplementedError("mask transforms are outside this hot path")
+        return results
+
+
+@PIPELINES.register_module()
+class Normalize:
+    """Records the normalisation; the arithmetic is fused into `DeviceFormat` (one pass with padding and the CHW
+    transpose).  Called on its own it produces the normalised fp32 HWC image like the reference."""
+
+    def __init__(self, mean, std, to_rgb=True):
+        self.mean = numpy.array(mean, dtype=numpy.float32)
+        self.std = numpy.array(std, dtype=numpy.float32)
+        self.to_rgb = to_rgb
+
+    def __call__(self, results):
+        results["img_norm_cfg"] = dict(mean=self.mean, std=self.std, to_rgb=self.to_rgb)
+        results["_pending_normalize"] = True
+        return results
+
+
+@PIPELINES.register_module()
+class Pad:
+    def __init__(self, size=None, size_divisor=None, pad_to_square=False, pad_to_square_size=(640, 640), pad_val=0):
+        self.size, self.size_divisor, self.pad_val = size, size_divisor, pad_val
+        self.pad_to_square, self.pad_to_square_size = pad_to_square, pad_to_square_size
+        if pad_to_square:
+            assert size is None and size_divisor is None, "The size and size_divisor must be None when pad2square is True"
+        else:
+            assert size is not None or size_divisor is not None, "only one of size and size_divisor should be valid"
+            assert size is None or size_divisor is None
+        if pad_val != 0:
+            raise NotImplementedError("only zero padding is built (every reference config uses it)")
+
+    def __call__(self, results):
+        if self.pad_to_square:
+            self.size = self.pad_to_square_size
+        h, w, c = _shape(results["img"])
+        if self.size is not None:
+            ph, pw = self.size
+        else:
+            ph = int(math.ceil(h / self.size_divisor)) * self.size_divisor
+            pw = int(math.ceil(w / self.size_divisor)) * self.size_divisor
+        results["pad_shape"] = (ph, pw, c)
+        results["pad_fixed_size"] = self.size
+        results["pad_size_divisor"] = self.size_divisor
+        return results
+
+
+@PIPELINES.register_module()
+class LargeScaleJitter:
+    def __init__(self, out_max_size=640, jitter_min=0.3, jitter_max=1.4, min_iou_thr=0.3, crop_iou_thr=[0.5, 0.6, 0.7, 0.8, 0.9]):
+        self.out_max_size, self.jitter_min, self.jitter_max = out_max_size, jitter_min, jitter_max
+        self.crop_iou_thr, self.min_iou_thr, self.jitter_times = crop_iou_thr, min_iou_thr, 100
+
+    @staticmethod
+    def _bbox_overlaps(crop_bbox, gt_bbox):
+        lt = numpy.maximum(crop_bbox[:2], gt_bbox[:2])
+        rb = numpy.minimum(crop_bbox[2:], gt_bbox[2:])
+        wh = rb - lt
+        return wh[0] * wh[1] / ((gt_bbox[2] - gt_bbox[0]) * (gt_bbox[3] - gt_bbox[1]))
+
+    def __call__(self, results):
+        img = results["img"]
+        h, w = results["ori_shape"][:2]
+        if results.get("with_mask"):
+            raise NotImplementedError("mask transforms are outside this hot path")
+        with_bbox = results["with_bbox"]
+        rand_scale = self.jitter_min + random.random() * (self.jitter_max - self.jitter_min)
+        scale = rand_scale * (self.out_max_size / max(h, w))
+        new_w, new_h = rescale_size((int(img.shape[1]), int(img.shape[0])), scale)
+        window = None                                     # (y0, x0, h, w) inside the rescaled image
+        if with_bbox:
+            gt_bbox = results["gt_bbox"]
+            factor = numpy.array([new_w / w, new_h / h, new_w / w, new_h / h])
+            gt_bbox = [box * factor for box in gt_bbox] if isinstance(gt_bbox, list) else gt_bbox * factor
+        cur_h, cur_w = new_h, new_w
+        if rand_scale > 1.0:
+            w_out, h_out = rescale_size((w, h), (self.out_max_size, self.out_max_size))
+            flag, best_idx, best_iou, history = False, -1, 0, []
+            for i, iou_thr in enumerate(self.crop_iou_thr[::-1]):
+                if not flag:
+                    for it in range(self.jitter_times):
+                        offset = (random.random() * (new_w - w_out), random.random() * (new_h - h_out))
+                        crop_bbox = numpy.array([offset[0], offset[1], offset[0] + w_out, offset[1] + h_out])
+                        iou = self._bbox_overlaps(crop_bbox, gt_bbox) if with_bbox else 0.0
+                        history.append(crop_bbox)
+                        if iou > best_iou:
+                            best_iou, best_idx = iou, i * self.jitter_times + it
+                        if iou >= iou_thr:
+                            flag = True
+                            break
+            if not flag:
+                if best_iou < self.min_iou_thr:           # "escape, do nothing": image and boxes stay as they were
+                    results["img_shape"] = (new_h, new_w, int(img.shape[2]))
+                    results["pad_shape"] = (new_h, new_w, int(img.shape[2]))
+                    results["scale_factor"] = numpy.array([1.0, 1.0, 1.0, 1.0])
+                    results["keep_ratio"] = True
+                    return results
+                crop_bbox = history[best_idx]
+            crop_bbox = crop_bbox.astype(numpy.uint32)
+            window = (int(crop_bbox[1]), int(crop_bbox[0]), int(crop_bbox[3] - crop_bbox[1]), int(crop_bbox[2] - crop_bbox[0]))
+            cur_h, cur_w = window[2], window[3]
+            assert cur_h == h_out and cur_w == w_out
+            if with_bbox:
+                gt_bbox = gt_bbox - numpy.array([offset[0], offset[1], offset[0], offset[1]])
+        if with_bbox:
+            gt_bbox[0::2] = numpy.clip(gt_bbox[0::2], 0, cur_w - 1)
+            gt_bbox[1::2] = numpy.clip(gt_bbox[1::2], 0, cur_h - 1)
+            assert gt_bbox[0] >= 0 and gt_bbox[1] >= 0 and gt_bbox[2] <= cur_w and gt_bbox[3] <= cur_h
+            results["gt_bbox"] = gt_bbox
+        img = ops.resize_u8(img, (new_h, new_w), window)   # rescale (+ crop) in one pass
+        results["img"] = img
+        results["img_shape"] = _shape(img)
+        results["pad_shape"] = _shape(img)
+        results["scale_factor"] = numpy.array([cur_w / w, cur_h / h, cur_w / w, cur_h / h])
+        results["keep_ratio"] = True
+        return results
+
+
+@PIPELINES.register_module()
+class DefaultFormatBundle:
+    """formatting.py:18-104: image -> fp32 CHW tensor (here: normalisation + padding + transpose in ONE kernel, straight
+    from the uint8 image), ids / mask / boxes -> tensors."""
+
+    def __call__(self, results):
+        img = results["img"]
+        if img.dtype != torch.uint8:
+            raise TypeError("DefaultFormatBundle (device) expects the uint8 HWC image; Normalize / Pad only record their settings")
+        cfg = results.get("img_norm_cfg") if results.pop("_pending_normalize", False) else None
+        ph, pw = results.get("pad_shape", _shape(img))[:2]
+        results.setdefault("pad_shape", _shape(img))
+        results.setdefault("scale_factor", 1.0)
+        if cfg is None:
+            cfg = dict(mean=numpy.zeros(3, dtype=numpy.float32), std=numpy.ones(3, dtype=numpy.float32), to_rgb=False)
+            results.setdefault("img_norm_cfg", cfg)
+        results["img"] = ops.normalize_pad_u8(img, cfg["mean"], cfg["std"], cfg["to_rgb"], (ph, pw))
+        for key in ("ref_expr_inds", "text_attention_mask"):
+            if key in results:
+                results[key] = torch.as_tensor(numpy.asarray(results[key]))
+        if results.get("with_bbox"):
+            results["gt_bbox"] = torch.as_tensor(numpy.asarray(results["gt_bbox"]))
+        return results
+
+
+@PIPELINES.register_module()
+class CollectData:
+    def __init__(self, keys, meta_keys=("filename", "expression", "ori_shape", "img_shape", "pad_shape", "scale_factor")):
+        self.keys, self.meta_keys = keys, meta_keys
+
+    def __call__(self, results):
+        data = {k: results[k] for k in self.keys}
+        data["img_metas"] = {k: results[k] for k in self.meta_keys if k in results}
+        return data
+
+
+class Compose:
+    def __init__(self, transforms):
+        self.transforms = [PIPELINES.build(t) if isinstance(t, dict) else t for t in transforms]
+
+    def __call__(self, results):
+        for t in self.transforms:
+            results = t(results)
+            if results is None:
+                return None
+        return results

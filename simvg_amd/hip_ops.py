@@ -425,3 +425,36 @@ def adam_step(p, g, m, v, vmax, step_size, bc2_sqrt, beta1, beta2, eps, weight_d
     if t0 is not None:
         _timer.stop("adam", t0, 0.0, 36.0 * p.numel())
     _lib.check(rc, "simvg_adam_step")
+
+
+def resize_u8(src, full_hw, window=None):
+    """src [H, W, 3] uint8 (HBM) -> window (y0, x0, h, w) of the image resized to full_hw = (h, w) with OpenCV's 8-bit
+    INTER_LINEAR arithmetic; window=None: the whole resized image."""
+    import ctypes
+    lib = _lib.load()
+    _chk(src, torch.uint8, "src")
+    assert src.dim() == 3 and src.shape[2] == 3 and src.stride(2) == 1 and src.stride(1) == 3
+    fh, fw = int(full_hw[0]), int(full_hw[1])
+    y0, x0, oh, ow = (0, 0, fh, fw) if window is None else [int(v) for v in window]
+    dst = torch.empty(oh, ow, 3, device=src.device, dtype=torch.uint8)
+    rc = lib.simvg_resize_u8(_p(src), src.shape[0], src.shape[1], src.stride(0), _p(dst), dst.stride(0), oh, ow, fh, fw,
+                             y0, x0, _stream())
+    _lib.check(rc, "simvg_resize_u8")
+    return dst
+
+
+def normalize_pad_u8(src, mean, std, to_rgb, pad_hw, out=None):
+    """src [h, w, 3] uint8 (HBM) -> fp32 [3, pad_h, pad_w]: optional BGR->RGB, (x - mean) * (1 / std), zero padding."""
+    import ctypes
+    lib = _lib.load()
+    _chk(src, torch.uint8, "src")
+    assert src.dim() == 3 and src.shape[2] == 3 and src.stride(2) == 1 and src.stride(1) == 3
+    ph, pw = int(pad_hw[0]), int(pad_hw[1])
+    if out is None:
+        out = torch.empty(3, ph, pw, device=src.device, dtype=torch.float32)
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    sd = (ctypes.c_float * 3)(*[float(v) for v in std])
+    rc = lib.simvg_normalize_pad_u8(_p(src), src.stride(0), src.shape[0], src.shape[1], _p(out), ph, pw, m, sd, int(bool(to_rgb)),
+                                    _stream())
+    _lib.check(rc, "simvg_normalize_pad_u8")
+    return out
