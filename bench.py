@@ -154,6 +154,17 @@ def main():
     # the head, see simvg_amd/graphs.py.  The roofline events are recorded on that same stream.
     from simvg_amd.graphs import train_stream
     with torch.cuda.stream(train_stream(device)):
+        # set-up, not warm-up: the head's hipGraphs are captured once its input signature has been seen four times
+        # (lazy workspaces must exist first); do that here so that the capture (~0.7 s) can never land in the timed
+        # steps whatever --warmup is.  No optimizer step: the weights the warm-up starts from are untouched.
+        for _ in range(4):
+            losses, _ = model(batch["img"], batch["ref_expr_inds"], batch["img_metas"], return_loss=True,
+                              text_attention_mask=batch["text_attention_mask"], gt_bbox=batch["gt_bbox"], rescale=False)
+            opt.zero_grad()
+            reducer.begin()
+            losses["loss_total"].backward()
+            reducer.finish()
+        opt.zero_grad()
         for _ in range(a.warmup):
             step()
         timer = hip_ops.KernelTimer(only=None if a.breakdown else {"gemm_nt"}) if rank == 0 else None
