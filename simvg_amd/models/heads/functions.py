@@ -116,8 +116,13 @@ class SmallAttention(torch.autograd.Function):
         q, k, v, P, kpm, drop = ctx.saved_tensors
         B, H, Lq, Lk, kv_rows = ctx.geo
         dq = torch.empty_like(q)
-        dk = torch.zeros_like(k)     # rows the kernel does not own (e.g. the CLS key) must read as zero
-        dv = torch.zeros_like(v)
+        # the kernel writes rows b*kv_rows + [0, Lk) of dk / dv; only the rows it does not own (the CLS key between two
+        # samples' patch keys) are cleared -- not a 26 MB fill per cross-attention layer
+        dk, dv = torch.empty_like(k), torch.empty_like(v)
+        stride_rows = kv_rows if kv_rows else Lk
+        for j in range(Lk, stride_rows):
+            dk[j::stride_rows].zero_()
+            dv[j::stride_rows].zero_()
         ops.attn_small_bwd(q, k, v, P, dout.contiguous(), dq, dk, dv, B, H, Lq, Lk, kpm=kpm, drop=drop, kv_rows=kv_rows)
         return dq, dk, dv, None, None, None, None, None, None, None
 
