@@ -86,3 +86,35 @@ def test_full_size_backward_is_linear_in_the_loss_scale(full):
     # dgrad operands are rounded to bf16 AFTER the scale (bf16(2x) == 2 bf16(x) exactly), so only the summation order of
     # the fp32 atomics differs between the passes
     assert worst <= 2e-3, worst
+
+
+def test_other_geometry_512px_15_tokens_batch_independence_and_training_step():
+    """the reference's 512x512 / max_token 15 dataset bases (configs/_base_/datasets/detection/*.py): 257 + 15 tokens"""
+    import bench
+    from simvg_amd.models import build_model
+    torch.manual_seed(11)
+    cfg = bench.model_cfg()
+    cfg["vis_enc"]["img_size"] = 512
+    cfg["head"]["text_max_token"] = 15
+    model = build_model(cfg).to("cuda")
+    B, S, T = 12, 512, 15
+    g = torch.Generator().manual_seed(5)
+    img = torch.randn(B, 3, S, S, generator=g).cuda()
+    ids = torch.randint(4, 64010, (B, T), generator=g).cuda()
+    ids[:, 0] = 0
+    pad = torch.zeros(B, T, dtype=torch.int64).cuda()
+    pad[:, 9:] = 1
+    metas = [dict(img_shape=(S, S, 3), pad_shape=(S, S, 3), ori_shape=(S, S, 3), scale_factor=[1.0] * 4) for _ in range(B)]
+    model.eval()
+    kw = dict(return_loss=False, rescale=False)
+    with torch.no_grad():
+        full = model(img=img, ref_expr_inds=ids, img_metas=metas, text_attention_mask=pad, **kw)[0]["pred_bboxes"].clone()
+        part = torch.cat([model(img=img[i:i + 5], ref_expr_inds=ids[i:i + 5], img_metas=metas[i:i + 5],
+                                text_attention_mask=pad[i:i + 5], **kw)[0]["pred_bboxes"] for i in (0, 5, 10)])
+    assert torch.equal(full, part) and torch.isfinite(full).all() and float(full.max()) <= 512.0
+    model.train()
+    gt = torch.tensor([[30.0, 40.0, 300.0, 350.0]]).repeat(B, 1).cuda()
+    losses, _ = model(img=img, ref_expr_inds=ids, img_metas=metas, text_attention_mask=pad, gt_bbox=[b for b in gt], rescale=False)
+    losses["loss_total"].backward()
+    grads = [p.grad for p in model.parameters() if p.grad is not None]
+    assert torch.isfinite(losses["loss_total"]) and len(grads) > 300 and all(torch.isfinite(x).all() for x in grads)
