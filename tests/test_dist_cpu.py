@@ -78,3 +78,58 @@ def test_grad_reducer_world2_gloo():
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert dict(out) == {0: True, 1: True}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the training loop itself under data parallelism: world-2 gloo run of `train_model` == single-process run on the
+# concatenated batches (gradient averaging by GradReducer, reduce_mean'd statistics, sampler.set_epoch)
+# ---------------------------------------------------------------------------------------------------------------------
+def _loop_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import logging
+    from oracle import mock_loop as ML
+    from simvg_amd.apis import train_model
+    from simvg_amd.core import build_optimizer
+    from simvg_amd.utils import get_root_logger
+    cfg = ML.make_cfg("RefCOCOUNC")
+    cfg.distributed, cfg.ema = True, False
+    model = ML.MockVG()
+    opt = build_optimizer(dict(type="Adam", lr=5e-2, betas=(0.9, 0.98), eps=1e-9, weight_decay=0, amsgrad=True),
+                          [{"params": list(model.parameters()), "lr": 5e-2}], model=model)
+    lines = []
+
+    class Cap(logging.Handler):
+        def emit(self, record):
+            lines.append(record.getMessage())
+    lg = get_root_logger()
+    lg.addHandler(Cap())
+    full = ML.batches(4, 8, 300)                                   # 4 global batches of 8 pairs
+    shard = [{k: (v[rank * 4:(rank + 1) * 4] if not isinstance(v, list) else v[rank * 4:(rank + 1) * 4]) for k, v in b.items()}
+             for b in full]
+    means = train_model(0, cfg, model, None, opt, ML.Loader(shard))
+    out[rank] = dict(params={k: v.detach().clone() for k, v in model.state_dict().items()}, means=means, lines=lines)
+    dist.destroy_process_group()
+
+
+def test_train_model_world2_equals_single_process_on_the_global_batch():
+    from oracle import mock_loop as ML
+    from simvg_amd.apis import train_model
+    from simvg_amd.core import build_optimizer
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_loop_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    cfg = ML.make_cfg("RefCOCOUNC")
+    cfg.ema = False
+    model = ML.MockVG()
+    opt = build_optimizer(dict(type="Adam", lr=5e-2, betas=(0.9, 0.98), eps=1e-9, weight_decay=0, amsgrad=True),
+                          [{"params": list(model.parameters()), "lr": 5e-2}], model=model)
+    means = train_model(0, cfg, model, None, opt, ML.Loader(ML.batches(4, 8, 300)))
+    r0, r1 = out[0], out[1]
+    for k, v in model.state_dict().items():
+        assert torch.allclose(r0["params"][k], r1["params"][k], atol=0, rtol=0), k       # replicas stay identical
+        assert torch.allclose(r0["params"][k], v, rtol=2e-5, atol=2e-6), k               # == global-batch training
+    for k in means:                                                                       # reduce_mean'd statistics
+        assert abs(r0["means"][k] - means[k]) <= 1e-5 * max(1.0, abs(means[k])), k
+    assert any(line.startswith("train-epoch[1]-[4/4]") for line in r0["lines"]) and not r1["lines"]   # rank 0 logs only
