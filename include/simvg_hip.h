@@ -106,6 +106,13 @@ int simvg_attn_small_bwd(const float* q, int ldq, const float* k, int ldk, const
 int simvg_im2col_f32(const float* img_nchw, float* cols, int B, int S, int P, simvg_stream_t stream);
 int simvg_attn_f32_fwd(const float* qkv, int ldqkv, float* out, int ldo, const unsigned char* pad, int B, int H, int Nv,
                        int Nt, int D, float scale, simvg_stream_t stream);
+/* exact-fp32 attention backward: dqkv[:, 0:D] (dQ) is written, dqkv[:, D:3D] (dK, dV) is ACCUMULATED (zero it first);
+ * autograd of the reference's torchscale MultiheadAttention core in fp32. */
+int simvg_attn_f32_bwd(const float* qkv, int ldqkv, const float* dout, int lddo, float* dqkv, int lddqkv,
+                       const unsigned char* pad, int B, int H, int Nv, int Nt, int D, float scale, simvg_stream_t stream);
+/* exact-erf GELU, elementwise fp32: out = gelu(u) (dy == NULL) or out = dy * gelu'(u)  (F.gelu of
+ * torchscale FeedForwardNetwork in the exact mode, where pre-activation and activation are both kept in fp32) */
+int simvg_gelu_f32(const float* u, const float* dy_or_null, float* out, long n, simvg_stream_t stream);
 
 /* ---- matcher + criterion (no host synchronisation) ------------------------------------------------------
  * detrex HungarianMatcher (ce_cost; cost_class 1, cost_bbox 5, cost_giou 2 at tgqs_kd_detr_head.py:132-137) with the

@@ -431,6 +431,142 @@ __global__ __launch_bounds__(256) void attn_f32_fwd_kernel(AF32Args a) {
     a.out[af32_row(a, b, q0 + qi) * a.ldo + h * 64 + d] = o;
   }
 }
+
+// exact-fp32 attention backward (precision="fp32" training mode): same decomposition as the forward -- one workgroup per
+// (sample, head, 16-query chunk).  P is recomputed, dS = P o (dO V^T - rowsum(dO o O)) * scale; dQ rows are owned by the
+// workgroup, dK / dV rows are accumulated across the query chunks with fp32 atomics (dqkv's K and V thirds must be
+// zero on entry).  VALU dot products, libm expf: the reference's own arithmetic (torchscale MultiheadAttention).
+struct AF32BwdArgs {
+  const float* qkv; int ld;     // [M, 3D]
+  const float* dout; int lddo;  // [M, D]
+  float* dqkv; int lddq;        // [M, 3D]
+  const unsigned char* pad;
+  int B, H, Nv, Nt, D;
+  float scale;
+};
+__device__ __forceinline__ long af32b_row(const AF32BwdArgs& a, int b, int t) {
+  return t < a.Nv ? (long)b * a.Nv + t : (long)a.B * a.Nv + (long)b * a.Nt + (t - a.Nv);
+}
+__global__ __launch_bounds__(256) void attn_f32_bwd_kernel(AF32BwdArgs a) {
+  extern __shared__ float sm[];
+  const int N = a.Nv + a.Nt;
+  float* qs = sm;                 // [16][64]  q * scale
+  float* dos = qs + 16 * 64;      // [16][64]  dO
+  float* sc = dos + 16 * 64;      // [16][N]   P, then dS
+  float* dp = sc + 16 * N;        // [16][N]   dO V^T
+  float* rs = dp + 16 * N;        // [16]
+  const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
+  const int q0 = blockIdx.y * 16;
+  const int nq = min(16, N - q0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int e = tid; e < 16 * 64; e += 256) {
+    const int qi = e >> 6, d = e & 63;
+    const long r = af32b_row(a, b, q0 + (qi < nq ? qi : 0));
+    qs[e] = qi < nq ? a.qkv[r * a.ld + h * 64 + d] * a.scale : 0.f;
+    dos[e] = qi < nq ? a.dout[r * a.lddo + h * 64 + d] : 0.f;
+  }
+  __syncthreads();
+  for (int kk = tid; kk < N; kk += 256) {
+    const long kr_ = af32b_row(a, b, kk);
+    const float* kp = a.qkv + kr_ * a.ld + a.D + h * 64;
+    const float* vp = a.qkv + kr_ * a.ld + 2 * a.D + h * 64;
+    float kr[64], vr[64];
+#pragma unroll
+    for (int d = 0; d < 64; d += 4) {
+      const f32x4_t t = *(const f32x4_t*)(kp + d), u = *(const f32x4_t*)(vp + d);
+      kr[d] = t[0]; kr[d + 1] = t[1]; kr[d + 2] = t[2]; kr[d + 3] = t[3];
+      vr[d] = u[0]; vr[d + 1] = u[1]; vr[d + 2] = u[2]; vr[d + 3] = u[3];
+    }
+    const bool masked = a.pad && kk >= a.Nv && a.pad[b * a.Nt + (kk - a.Nv)];
+    for (int qi = 0; qi < 16; ++qi) {
+      float s = 0.f, t = 0.f;
+#pragma unroll
+      for (int d = 0; d < 64; ++d) { s = fmaf(qs[qi * 64 + d], kr[d], s); t = fmaf(dos[qi * 64 + d], vr[d], t); }
+      sc[qi * N + kk] = masked ? -INFINITY : s;
+      dp[qi * N + kk] = t;
+    }
+  }
+  __syncthreads();
+  for (int qi = wave; qi < 16; qi += 4) {
+    if (qi >= nq) {       // rows beyond the sequence: contribute nothing
+      for (int kk = lane; kk < N; kk += 64) sc[qi * N + kk] = 0.f;
+      continue;
+    }
+    float mx = -INFINITY;
+    for (int kk = lane; kk < N; kk += 64) mx = fmaxf(mx, sc[qi * N + kk]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int kk = lane; kk < N; kk += 64) {
+      const float p = expf(sc[qi * N + kk] - mx);
+      sc[qi * N + kk] = p;
+      sum += p;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    float r = 0.f;
+    for (int kk = lane; kk < N; kk += 64) {
+      const float p = sc[qi * N + kk] * inv;
+      sc[qi * N + kk] = p;
+      r += p * dp[qi * N + kk];
+    }
+    r = wave_sum(r);
+    if (lane == 0) rs[qi] = r;
+  }
+  __syncthreads();
+  // dV[k] += sum_q P[q][k] dO[q]   (before P is overwritten by dS);  then dS = P (dP - rowsum) * scale
+  for (int kk = tid; kk < N; kk += 256) {
+    float acc[64];
+#pragma unroll
+    for (int d = 0; d < 64; ++d) acc[d] = 0.f;
+    for (int qi = 0; qi < nq; ++qi) {
+      const float p = sc[qi * N + kk];
+#pragma unroll
+      for (int d = 0; d < 64; ++d) acc[d] = fmaf(p, dos[qi * 64 + d], acc[d]);
+    }
+    float* gv = a.dqkv + af32b_row(a, b, kk) * a.lddq + 2 * a.D + h * 64;
+#pragma unroll
+    for (int d = 0; d < 64; ++d) atomicAdd(gv + d, acc[d]);
+  }
+  __syncthreads();
+  for (int e = tid; e < 16 * N; e += 256) {
+    const int qi = e / N;
+    sc[e] = qi < nq ? sc[e] * (dp[e] - rs[qi]) * a.scale : 0.f;       // masked keys: P = 0 -> dS = 0
+  }
+  __syncthreads();
+  // dQ[q][d] = sum_k dS[q][k] K[k][d]
+  for (int e = tid; e < nq * 64; e += 256) {
+    const int qi = e >> 6, d = e & 63;
+    float o = 0.f;
+    for (int kk = 0; kk < N; ++kk) o = fmaf(sc[qi * N + kk], a.qkv[af32b_row(a, b, kk) * a.ld + a.D + h * 64 + d], o);
+    a.dqkv[af32b_row(a, b, q0 + qi) * a.lddq + h * 64 + d] = o;
+  }
+  // dK[k][d] += sum_q dS[q][k] Q[q][d]     (qs holds q * scale and dS already carries one scale: use the raw q)
+  for (int kk = tid; kk < N; kk += 256) {
+    float acc[64];
+#pragma unroll
+    for (int d = 0; d < 64; ++d) acc[d] = 0.f;
+    const float inv_scale = 1.f / a.scale;
+    for (int qi = 0; qi < nq; ++qi) {
+      const float ds = sc[qi * N + kk] * inv_scale;
+#pragma unroll
+      for (int d = 0; d < 64; ++d) acc[d] = fmaf(ds, qs[qi * 64 + d], acc[d]);
+    }
+    float* gk = a.dqkv + af32b_row(a, b, kk) * a.lddq + a.D + h * 64;
+#pragma unroll
+    for (int d = 0; d < 64; ++d) atomicAdd(gk + d, acc[d]);
+  }
+}
+
+// exact-erf GELU (libm) forward / backward, elementwise fp32 (precision="fp32" mode keeps u and g separately)
+__global__ __launch_bounds__(256) void gelu_f32_kernel(const float* __restrict__ u, const float* __restrict__ dy,
+                                                       float* __restrict__ out, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float x = u[i];
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    if (dy) out[i] = dy[i] * (cdf + x * 0.39894228040143267794f * expf(-0.5f * x * x));
+    else out[i] = x * cdf;
+  }
+}
 }  // namespace
 
 extern "C" int simvg_attn_f32_fwd(const float* qkv, int ldqkv, float* out, int ldo, const unsigned char* pad, int B,
@@ -444,6 +580,30 @@ extern "C" int simvg_attn_f32_fwd(const float* qkv, int ldqkv, float* out, int l
                                          160 * 1024) == hipSuccess;
   (void)once;
   hipLaunchKernelGGL(attn_f32_fwd_kernel, dim3(B * H, cdiv(N, 16)), dim3(256), shm, stream, a);
+  SIMVG_LAUNCH_CHECK();
+  return SIMVG_OK;
+}
+
+extern "C" int simvg_attn_f32_bwd(const float* qkv, int ldqkv, const float* dout, int lddo, float* dqkv, int lddqkv,
+                                  const unsigned char* pad, int B, int H, int Nv, int Nt, int D, float scale,
+                                  hipStream_t stream) {
+  SIMVG_CHECK_ARG(B > 0 && H > 0 && D == H * 64 && Nv + Nt > 0 && Nv + Nt <= 1024 && ldqkv % 4 == 0 && lddqkv % 4 == 0,
+                  "attn_f32_bwd: need head_dim 64, N <= 1024");
+  AF32BwdArgs a{qkv, ldqkv, dout, lddo, dqkv, lddqkv, pad, B, H, Nv, Nt, D, scale};
+  const int N = Nv + Nt;
+  const size_t shm = (size_t)(2 * 16 * 64 + 2 * 16 * N + 16) * sizeof(float);
+  static bool once = hipFuncSetAttribute((const void*)attn_f32_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         160 * 1024) == hipSuccess;
+  (void)once;
+  hipLaunchKernelGGL(attn_f32_bwd_kernel, dim3(B * H, cdiv(N, 16)), dim3(256), shm, stream, a);
+  SIMVG_LAUNCH_CHECK();
+  return SIMVG_OK;
+}
+
+extern "C" int simvg_gelu_f32(const float* u, const float* dy_or_null, float* out, long n, hipStream_t stream) {
+  SIMVG_CHECK_ARG(u && out && n > 0, "gelu_f32: empty");
+  const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(gelu_f32_kernel, dim3(grid), dim3(256), 0, stream, u, dy_or_null, out, n);
   SIMVG_LAUNCH_CHECK();
   return SIMVG_OK;
 }

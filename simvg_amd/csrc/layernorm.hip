@@ -429,7 +429,7 @@ extern "C" int simvg_ln_bwd(const void* dy_bf16, int dy_is_f32, int lddy, const 
                             float* partial_ws, hipStream_t stream) {
   SIMVG_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 4096, "ln_bwd: D must be a multiple of 4 and <= 4096");
   SIMVG_CHECK_ARG(dx_bf16 || dx_f32, "ln_bwd: no output");
-  SIMVG_CHECK_ARG(!dy_is_f32 || (D <= 256 && !x_is_bf16), "ln_bwd: fp32 dy is only built for the head (D <= 256, fp32 x)");
+  SIMVG_CHECK_ARG(!dy_is_f32 || !x_is_bf16, "ln_bwd: fp32 dy goes with fp32 x (decoder head, exact-fp32 encoder mode)");
   SIMVG_CHECK_ARG(!(dx_scaled_bf16 && !dx_f32), "ln_bwd: scaled bf16 copy requires the f32 output");
   if (split == 0) split = M;
   // partial_ws (optional, >= simvg_ln_bwd_ws_floats(M, D, split) floats): two-stage dgamma/dbeta reduction instead of
@@ -441,11 +441,14 @@ extern "C" int simvg_ln_bwd(const void* dy_bf16, int dy_is_f32, int lddy, const 
   const dim3 grid(blocks0 + blocks1), block(256);
   const size_t shm = (size_t)2 * D * sizeof(float);
   const int rps0 = rows_per_sample0 > 0 ? rows_per_sample0 : 1, rps1 = rows_per_sample1 > 0 ? rows_per_sample1 : 1;
-  if (dy_is_f32) {
-    hipLaunchKernelGGL((ln_bwd_kernel<float, float, 1>), grid, block, shm, stream, (const float*)dy_bf16, lddy,
-                       (const float*)x, ldx, mean, rstd, gamma, group_stride, dgamma, dbeta, (bf16_t*)dx_bf16, lddxb,
-                       (const bf16_t*)gelu_u_bf16, ldu, dres, dx_f32, lddxf, (bf16_t*)dx_scaled_bf16, lddxs, row_scale,
-                       rps0, rps1, M, D, split, rpb, blocks0, partial_ws);
+  if (dy_is_f32) {      // wave-per-row kernel at every width (the exact mode is a parity mode, not a fast one)
+#define FCALL(N_)                                                                                                       \
+    hipLaunchKernelGGL((ln_bwd_kernel<float, float, N_>), grid, block, shm, stream, (const float*)dy_bf16, lddy,        \
+                       (const float*)x, ldx, mean, rstd, gamma, group_stride, dgamma, dbeta, (bf16_t*)dx_bf16, lddxb,   \
+                       (const bf16_t*)gelu_u_bf16, ldu, dres, dx_f32, lddxf, (bf16_t*)dx_scaled_bf16, lddxs, row_scale, \
+                       rps0, rps1, M, D, split, rpb, blocks0, partial_ws)
+    LN_DISPATCH_NIT(D, FCALL);
+#undef FCALL
     if (partial_ws)
       hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(D, 64), 4), dim3(1024), 0, stream, partial_ws, dgamma, dbeta,
                          group_stride, D, blocks0, blocks1);

@@ -458,3 +458,26 @@ def normalize_pad_u8(src, mean, std, to_rgb, pad_hw, out=None):
                                     _stream())
     _lib.check(rc, "simvg_normalize_pad_u8")
     return out
+
+
+def attn_f32_bwd(qkv, dout, B, H, Nv, Nt, pad=None):
+    """exact-fp32 attention backward -> dqkv [M, 3D] fp32."""
+    lib = _lib.load()
+    _chk(qkv, torch.float32, "qkv"); _chk(dout, torch.float32, "dout")
+    M, D3 = qkv.shape
+    D = D3 // 3
+    dqkv = torch.zeros(M, D3, device=qkv.device, dtype=torch.float32)
+    rc = lib.simvg_attn_f32_bwd(_p(qkv), qkv.stride(0), _p(dout), dout.stride(0), _p(dqkv), dqkv.stride(0), _p(pad), B, H,
+                                Nv, Nt, D, (D // H) ** -0.5, _stream())
+    _lib.check(rc, "simvg_attn_f32_bwd")
+    return dqkv
+
+
+def gelu_f32(u, dy=None):
+    """exact-erf GELU (dy None) or its backward dy * gelu'(u), elementwise fp32."""
+    lib = _lib.load()
+    _chk(u, torch.float32, "u")
+    u = u.contiguous()
+    out = torch.empty_like(u)
+    _lib.check(lib.simvg_gelu_f32(_p(u), _p(dy.contiguous() if dy is not None else None), _p(out), u.numel(), _stream()), "simvg_gelu_f32")
+    return out

@@ -293,7 +293,9 @@ class BEIT3(nn.Module):
         self.precision = precision
         return self
 
-    def _engine_forward_fp32(self, img, ids, pad_u8):
+    def _engine_forward_fp32(self, img, ids, pad_u8, save=False):
+        """Exact mode: the reference's own arithmetic (fp32 operands on v_mfma_f32_16x16x4_f32, fp32 attention, libm erf).
+        With save=True every intermediate the fp32 backward needs is kept (a parity mode: memory is not a concern)."""
         A = self._arena
         V, prm = A.views, A.params
         B, T = ids.shape
@@ -302,9 +304,11 @@ class BEIT3(nn.Module):
         Mv = B * Nv
         M = Mv + B * T
         eps = self.ln_eps
+        saved = dict(ctx=(B, T, ids, pad_u8), layers=[]) if save else None
 
         def ln(x, gk, bk):
-            return ops.ln_fwd(x, V[gk], V[bk], split=Mv, eps=eps, out_bf16=False, out_f32=True, save_stats=False)[1]
+            _, y, m, r = ops.ln_fwd(x, V[gk], V[bk], split=Mv, eps=eps, out_bf16=False, out_f32=True, save_stats=save)
+            return y, (m, r)
 
         def mw(x, wk, bk, out=None, act=0, accumulate=False):
             W, b = V[wk], V[bk]
@@ -321,19 +325,88 @@ class BEIT3(nn.Module):
         x = ops.embed_fwd(patch, prm["beit3.vision_embed.cls_token"].data, prm["beit3.encoder.embed_positions.A.weight"].data,
                           prm["beit3.encoder.embed_positions.B.weight"].data, prm["beit3.text_embed.weight"].data,
                           ids, pad_u8, B, self.np, T)
+        if save:
+            saved["cols"] = cols
         for i in range(L):
-            h = ln(x, f"ln1g{i}", f"ln1b{i}")
+            h, s1 = ln(x, f"ln1g{i}", f"ln1b{i}")
             qkv = mw(h, f"wqkv{i}", f"bqkv{i}")
             o = ops.attn_f32_fwd(qkv, B, H, Nv, T, pad=pad_u8)
-            o2 = ln(o, f"lnig{i}", f"lnib{i}")
+            o2, s2 = ln(o, f"lnig{i}", f"lnib{i}")
             xm = x.clone()
             mw(o2, f"wout{i}", f"bout{i}", out=xm, accumulate=True)
-            h2 = ln(xm, f"ln2g{i}", f"ln2b{i}")
-            g = mw(h2, f"w1{i}", f"b1{i}", act=1)
-            g2 = ln(g, f"lnfg{i}", f"lnfb{i}")
-            x = xm.clone()
-            mw(g2, f"w2{i}", f"b2{i}", out=x, accumulate=True)
-        return ln(x, "lnog", "lnob")
+            h2, s3 = ln(xm, f"ln2g{i}", f"ln2b{i}")
+            if save:
+                u = mw(h2, f"w1{i}", f"b1{i}")
+                g = ops.gelu_f32(u)
+            else:
+                u, g = None, mw(h2, f"w1{i}", f"b1{i}", act=1)
+            g2, s4 = ln(g, f"lnfg{i}", f"lnfb{i}")
+            x_out = xm.clone()
+            mw(g2, f"w2{i}", f"b2{i}", out=x_out, accumulate=True)
+            if save:
+                saved["layers"].append(dict(x=x, h=h, qkv=qkv, o=o, o2=o2, xm=xm, h2=h2, u=u, g=g, g2=g2, s1=s1, s2=s2, s3=s3, s4=s4))
+            x = x_out
+        out, sF = ln(x, "lnog", "lnob")
+        if save:
+            saved["x_last"], saved["sF"] = x, sF
+            return out, saved
+        return out
+
+    def _engine_backward_fp32(self, saved, dout):
+        """fp32 backward of the exact mode: every contraction through the strided exact-fp32 MFMA GEMM (dgrad, wgrad and
+        bias gradient as three calls per Linear and expert), fp32 LayerNorm / attention / GELU backward kernels."""
+        A = self._arena
+        V, G = A.views, A.grad_views
+        B, T, ids, pad_u8 = saved["ctx"]
+        D, L, H, P = self.D, self.L, self.H, self.patch_size
+        Nv = self.np + 1
+        Mv = B * Nv
+        M = Mv + B * T
+        groups = ((0, Mv), (Mv, M))
+        ones = torch.ones(M, device=dout.device)
+
+        def lnb(dy, x, stats, gk, bk, dres=None):
+            dx = torch.empty_like(x)
+            ops.ln_bwd(dy.contiguous(), x, stats[0], stats[1], V[gk], G[gk], G[bk], split=Mv, dres=dres, dx_f32=dx)
+            return dx
+
+        def lin_bwd(dy, x, wk, bk):
+            """-> dx;  G[wk] += dy^T x, G[bk] += 1^T dy, per expert"""
+            W = V[wk]
+            N, K = W.shape[1], W.shape[2]
+            dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)
+            for g, (lo, hi) in enumerate(groups):
+                if hi <= lo:
+                    continue
+                dyg, xg, m = dy[lo:hi], x[lo:hi], hi - lo
+                ops.gemm_f32(dyg, dyg.stride(0), 1, W[g], W[g].stride(0), 1, dx[lo:hi], m, K, N)
+                ops.gemm_f32(dyg, 1, dyg.stride(0), xg, xg.stride(0), xg.stride(1), G[wk][g], N, K, m, accumulate=True)
+                ops.gemm_f32(ones[:m], 0, 1, dyg, dyg.stride(0), 1, G[bk][g].view(1, N), 1, N, m, accumulate=True)
+            return dx
+
+        dx = lnb(dout.float(), saved["x_last"], saved["sF"], "lnog", "lnob")
+        for i in reversed(range(L)):
+            st = saved["layers"][i]
+            dg2 = lin_bwd(dx, st["g2"], f"w2{i}", f"b2{i}")
+            dg = lnb(dg2, st["g"], st["s4"], f"lnfg{i}", f"lnfb{i}")
+            du = ops.gelu_f32(st["u"], dy=dg)
+            dh2 = lin_bwd(du, st["h2"], f"w1{i}", f"b1{i}")
+            dx = lnb(dh2, st["xm"], st["s3"], f"ln2g{i}", f"ln2b{i}", dres=dx)
+            do2 = lin_bwd(dx, st["o2"], f"wout{i}", f"bout{i}")
+            do = lnb(do2, st["o"], st["s2"], f"lnig{i}", f"lnib{i}")
+            dqkv = ops.attn_f32_bwd(st["qkv"], do, B, H, Nv, T, pad=pad_u8)
+            dh = lin_bwd(dqkv, st["h"], f"wqkv{i}", f"bqkv{i}")
+            dx = lnb(dh, st["x"], st["s1"], f"ln1g{i}", f"ln1b{i}", dres=dx)
+        scratch = torch.empty(B * self.np, D, device=dx.device, dtype=BF16)
+        ops.embed_bwd(dx, scratch, A.grad("beit3.vision_embed.cls_token").view(-1),
+                      A.grad("beit3.encoder.embed_positions.A.weight"), A.grad("beit3.encoder.embed_positions.B.weight"),
+                      A.grad("beit3.text_embed.weight"), ids, pad_u8, B, self.np, T)
+        dpatch = dx[:Mv].view(B, Nv, D)[:, 1:].reshape(B * self.np, D).contiguous()
+        cols = saved["cols"]
+        gW = A.grad("beit3.vision_embed.proj.weight").view(D, 3 * P * P)
+        ops.gemm_f32(dpatch, 1, D, cols, cols.stride(0), 1, gW, D, 3 * P * P, dpatch.shape[0], accumulate=True)
+        ops.gemm_f32(ones[:1].expand(dpatch.shape[0]), 0, 1, dpatch, D, 1, A.grad("beit3.vision_embed.proj.bias").view(1, D),
+                     1, D, dpatch.shape[0], accumulate=True)
 
     # ------------------------------------------------------------------ engine: backward
     def _engine_backward(self, ws, dout, layer_done_cb=None):
@@ -411,9 +484,12 @@ class BEIT3(nn.Module):
             dp_scales = self._drop_path_scales(B, device)
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if self.precision == "fp32":
-            if need_grad:
-                raise NotImplementedError('precision="fp32" is the exact forward-only mode; train in "bf16"')
-            return self._engine_forward_fp32(img, ids, pad_u8)
+            if not need_grad:
+                return self._engine_forward_fp32(img, ids, pad_u8)
+            if dp_scales is not None:
+                raise NotImplementedError('precision="fp32" is the exact parity mode and has no DropPath: call .eval() or '
+                                          'build with drop_path_rate=0 (stochastic masks cannot be compared anyway)')
+            return _EncoderFnF32.apply(self, img, ids, pad_u8, self._anchor)
         return _EncoderFn.apply(self, img, ids, pad_u8, dp_scales, need_grad, self._anchor)
 
     def split_output(self, out, B, T):
@@ -427,6 +503,24 @@ class BEIT3(nn.Module):
         out = self.encode(image, question, padding_mask)
         img_feat, text_feat, cls_feat = self.split_output(out.float(), question.shape[0], question.shape[1])
         return img_feat, text_feat, cls_feat
+
+
+class _EncoderFnF32(torch.autograd.Function):
+    """exact-fp32 encoder under autograd (precision="fp32"): fp32 output, fp32 backward into the gradient arena"""
+
+    @staticmethod
+    def forward(ctx, enc, img, ids, pad_u8, anchor):
+        out, saved = enc._engine_forward_fp32(img, ids, pad_u8, save=True)
+        ctx.enc, ctx.saved = enc, saved
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        enc = ctx.enc
+        enc._arena.begin_backward()
+        enc._engine_backward_fp32(ctx.saved, dout.contiguous())
+        ctx.saved = None
+        return (None,) * 5
 
 
 class _EncoderFn(torch.autograd.Function):
