@@ -458,6 +458,72 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel_256sq(GemmNTArgs a) {
   gemm_nt_epilogue_lds<MI>(a, acc, group, row0, row_end, n0, wm, wn, wave, lane, smem);
 }
 
+// 256x256x64 tile with SIXTEEN waves (4 x 4, each 64x64; 4 waves per SIMD, 112 VGPRs): more waves cover the LDS-read and
+// rendezvous latencies of the one-workgroup-per-CU tile and issue the store-heavy epilogues 2x wider, at the price of 33 %
+// more LDS reads per MFMA (still ~50 % of the LDS bandwidth).  fc1 shape 124 vs 134 us, with fp32 residual epilogue
+// 212 vs 275 us (same box, warm).  SIMVG_GEMM_W16=0 selects the 8-wave kernel above.
+__global__ __launch_bounds__(1024) void gemm_nt_kernel_256sq_w16(GemmNTArgs a) {
+  constexpr int MI = 4;
+  constexpr int BMQ = 256;
+  constexpr int STAGEQ = (BMQ + BNQ) * BK * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;   // 4 x 4 waves
+  const int tiles_n = (a.N + BNQ - 1) / BNQ;
+  const int tm0 = (a.split + BMQ - 1) / BMQ;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+  const int group = tile_m >= tm0;
+  const int row0 = group ? a.split + (tile_m - tm0) * BMQ : tile_m * BMQ;
+  const int row_end = group ? a.M : a.split;
+  const int n0 = tile_n * BNQ;
+  const bf16_t* W = a.W + (long)group * a.w_gstride;
+
+  f32x4_t acc[MI][4];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = a.K / BK;
+#define STA(s_) (smem + (s_) * STAGEQ)
+#define STB(s_) (smem + (s_) * STAGEQ + BMQ * BK * 2)
+#define ISSUE(t_)                                                                                  \
+  do {                                                                                             \
+    const int st__ = (t_) & 1;                                                                     \
+    stage_tile_k64_n(a.A, a.lda, row0, row_end - 1, (t_) * BK, STA(st__), wave, lane, 2);          \
+    stage_tile_k64_n(W, a.ldw, n0, a.N - 1, (t_) * BK, STB(st__), wave, lane, 2);                  \
+  } while (0)
+
+  ISSUE(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's share of tile kt has landed
+    __builtin_amdgcn_s_barrier();                        // everyone's has, and everyone is past compute(kt-1)
+    if (kt + 1 < nk) ISSUE(kt + 1);
+    const char* sA = STA(kt & 1);
+    const char* sB = STB(kt & 1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8_t fa[MI], fb[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = read_frag_k64(sB, wn * 64 + j * 16 + (lane & 15), s * 4 + (lane >> 4));
+#pragma unroll
+      for (int i = 0; i < MI; ++i) fa[i] = read_frag_k64(sA, wm * 64 + i * 16 + (lane & 15), s * 4 + (lane >> 4));
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+  }
+#undef STA
+#undef STB
+#undef ISSUE
+  gemm_nt_epilogue_lds<4>(a, acc, group, row0, row_end, n0, wm, wn, wave, lane, smem);
+}
+
+
 // ------------------------------------------------------------------------------------------
 // Variant: same 256x128 tile / 8 waves / 3-stage ring, but K-tiles of 32 (24 KiB stages, 72 KiB LDS) so that TWO
 // workgroups are resident per CU (16 waves, 4 per SIMD): while one workgroup sits in its wait/barrier the other
@@ -884,6 +950,13 @@ extern "C" int simvg_gemm_nt(const void* A, int lda, const void* W, long w_gstri
     static bool onceq = hipFuncSetAttribute((const void*)gemm_nt_kernel_256sq<8>, hipFuncAttributeMaxDynamicSharedMemorySize, SM) == hipSuccess;
     (void)onceq;
     const int tiles = (cdiv(split, 256) + cdiv(M - split, 256)) * cdiv(N, BNQ);
+    static const int w16 = getenv("SIMVG_GEMM_W16") ? atoi(getenv("SIMVG_GEMM_W16")) : 1;
+    if (w16) {
+      constexpr int SMW = 160 * 1024;      // ring 128 KiB; the 16-wave epilogue staging needs 136 KiB
+      static bool oncew = hipFuncSetAttribute((const void*)gemm_nt_kernel_256sq_w16, hipFuncAttributeMaxDynamicSharedMemorySize, SMW) == hipSuccess;
+      (void)oncew;
+      hipLaunchKernelGGL(gemm_nt_kernel_256sq_w16, dim3(tiles), dim3(1024), SMW, stream, a);
+    } else
     hipLaunchKernelGGL(gemm_nt_kernel_256sq<8>, dim3(tiles), dim3(512), SM, stream, a);
   } else if (wide_ok && wide_mi == 5) {
     constexpr int SM = 2 * (160 + BNQ) * BK * 2;
