@@ -997,7 +997,7 @@ extern "C" int simvg_gemm_tn(const void* dY, int lddy, const void* X, int ldx, f
   const int tiles = big ? cdiv(N, 256) * cdiv(K, 128) : cdiv(N, 128) * cdiv(K, 128);
   // split the contraction so that tiles x chunks ~ 2-3 blocks per CU (measured sweep, profiles/r01_sweeps.md)
   static const int target_env = getenv("SIMVG_TN_BLOCKS") ? atoi(getenv("SIMVG_TN_BLOCKS")) : 0;
-  const int target_blocks = target_env ? target_env : (big ? 384 : (tiles <= 48 ? 256 : 768));
+  const int target_blocks = target_env ? target_env : (big ? 384 : (tiles <= 48 ? 384 : 768));
   int want = cdiv(target_blocks, tiles);
   int rpc = cdiv(cdiv(M, want), 64) * 64;
   if (rpc < 256) rpc = 256;   // multiple of 64 (and of the 32-row stages)
