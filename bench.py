@@ -217,8 +217,8 @@ def main():
                    "parallelism": f"dp{world}", "loss_total": round(loss_val, 4)},
         "model_tflops_per_gpu": round(value / world * FLOP_PER_PAIR_FWD_BWD[a.vit] / 1e12, 2),
         "model_mfma_frac": round(value / world * FLOP_PER_PAIR_FWD_BWD[a.vit] / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
-        "roofline": {"kernel": "gemm_nt (bf16 MFMA 16x16x32; every launch: 256x256x64 tiles for N >= 2304, 160x256x64 for "
-                               "N = 768, global_load_lds double buffer, LDS-staged coalesced epilogue)", "bound": "mfma",
+        "roofline": {"kernel": "gemm_nt (bf16 MFMA 16x16x32; every launch: 16-wave 256x256x64 tiles for N >= 2304, 16-wave "
+                               "160x256x64 for N = 768, global_load_lds double buffer, LDS-staged coalesced epilogue)", "bound": "mfma",
                      "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
                      "algorithmic_bytes_per_launch": round(g["bytes"] / g["calls"]),

@@ -134,17 +134,19 @@ __device__ __forceinline__ void gemm_nt_epilogue(const GemmNTArgs& a, f32x4_t (&
 constexpr int EPI_LD = 68;                       // floats per staged row (64 + 4 pad)
 constexpr int EPI_WAVE_BYTES = 32 * EPI_LD * 4;  // 8704 B per wave
 
-template <int MI>
-__device__ __forceinline__ void gemm_nt_epilogue_lds(const GemmNTArgs& a, f32x4_t (&acc)[MI][4], int group, int row0,
+// MI x NJ = 16x16 accumulator blocks of one wave (rows x columns); NJ = 4 everywhere except the 16-wave 160x256 kernel
+template <int MI, int NJ = 4>
+__device__ __forceinline__ void gemm_nt_epilogue_lds(const GemmNTArgs& a, f32x4_t (&acc)[MI][NJ], int group, int row0,
                                                      int row_end, int n0, int wm, int wn, int wave, int lane,
                                                      char* smem) {
   __syncthreads();                                // every wave is done reading the ring
-  float* st = (float*)(smem + wave * EPI_WAVE_BYTES);
+  constexpr int LD = NJ * 16 + 4;                 // floats per staged row (EPI_LD for NJ = 4)
+  float* st = (float*)(smem + wave * (32 * LD * 4));   // wave-private slice (EPI_WAVE_BYTES for NJ = 4)
   const float* bias = a.bias ? a.bias + (long)group * a.bias_gstride : nullptr;
-  const int nbase = n0 + wn * 64;
-  float bv[4][4];
+  const int nbase = n0 + wn * (NJ * 16);
+  float bv[NJ][4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     const int n = nbase + j * 16 + 4 * (lane >> 4);
     if (bias && n < a.N) {
       const f32x4_t t = *(const f32x4_t*)(bias + n);
@@ -159,9 +161,9 @@ __device__ __forceinline__ void gemm_nt_epilogue_lds(const GemmNTArgs& a, f32x4_
     for (int ii = 0; ii < 2; ++ii) {
       if (2 * p + ii >= MI) continue;      // odd MI: the last pass stages 16 rows only
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         const f32x4_t v = acc[2 * p + ii][j];
-        *(f32x4_t*)(st + (ii * 16 + (lane & 15)) * EPI_LD + j * 16 + 4 * (lane >> 4)) =
+        *(f32x4_t*)(st + (ii * 16 + (lane & 15)) * LD + j * 16 + 4 * (lane >> 4)) =
             (f32x4_t){v[0] + bv[j][0], v[1] + bv[j][1], v[2] + bv[j][2], v[3] + bv[j][3]};
       }
     }
@@ -169,13 +171,14 @@ __device__ __forceinline__ void gemm_nt_epilogue_lds(const GemmNTArgs& a, f32x4_
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const int mbase = row0 + wm * (MI * 16) + p * 32;
     if (!a.c_f32) {
-      // bf16 output: lane -> 8 consecutive columns, 8 lanes per row, 8 rows per pass
+      // bf16 output: lane -> 8 consecutive columns, 2*NJ lanes per row (NJ = 4: 8 lanes, 8 rows per pass)
+      constexpr int LPR = NJ * 2, RPP = 64 / LPR;
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int r = it * 8 + (lane >> 3), c = (lane & 7) * 8;
+      for (int it = 0; it < 32 / RPP; ++it) {
+        const int r = it * RPP + lane / LPR, c = (lane % LPR) * 8;
         const int m = mbase + r, n = nbase + c;
         if (m >= row_end || n >= a.N || 2 * p + (r >> 4) >= MI) continue;
-        const f32x4_t u0 = *(const f32x4_t*)(st + r * EPI_LD + c), u1 = *(const f32x4_t*)(st + r * EPI_LD + c + 4);
+        const f32x4_t u0 = *(const f32x4_t*)(st + r * LD + c), u1 = *(const f32x4_t*)(st + r * LD + c + 4);
         float v[8] = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3]};
         if (a.aux)
           *(u32x4_t*)(a.aux + (long)m * a.ldaux + n) = (u32x4_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]),
@@ -196,13 +199,14 @@ __device__ __forceinline__ void gemm_nt_epilogue_lds(const GemmNTArgs& a, f32x4_
                                                                     pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
       }
     } else {
-      // fp32 output (+ residual): lane -> 4 consecutive columns, 16 lanes per row, 4 rows per pass
+      // fp32 output (+ residual): lane -> 4 consecutive columns, 4*NJ lanes per row (NJ = 4: 16 lanes, 4 rows per pass)
+      constexpr int LPR = NJ * 4, RPP = 64 / LPR;
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int r = it * 4 + (lane >> 4), c = (lane & 15) * 4;
+      for (int it = 0; it < 32 / RPP; ++it) {
+        const int r = it * RPP + lane / LPR, c = (lane % LPR) * 4;
         const int m = mbase + r, n = nbase + c;
         if (m >= row_end || n >= a.N || 2 * p + (r >> 4) >= MI) continue;
-        const f32x4_t u = *(const f32x4_t*)(st + r * EPI_LD + c);
+        const f32x4_t u = *(const f32x4_t*)(st + r * LD + c);
         float v[4] = {u[0], u[1], u[2], u[3]};
         if (a.aux) *(u32x2_t*)(a.aux + (long)m * a.ldaux + n) = (u32x2_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
         if (a.act == 1) {
@@ -384,8 +388,8 @@ constexpr int BNQ = 256;
 
 // [n_inst * 8 rows][64 k] tile, wave w stages instructions w, w+8, ... (n_inst need not be a multiple of 8)
 __device__ __forceinline__ void stage_rows_k64(const bf16_t* base, int ld, int row0, int row_last, int k0, char* lds,
-                                               int wave, int lane, int n_inst) {
-  for (int inst = wave; inst < n_inst; inst += 8) {
+                                               int wave, int lane, int n_inst, int nwaves = 8) {
+  for (int inst = wave; inst < n_inst; inst += nwaves) {
     const int r = inst * 8 + (lane >> 3);
     int row = row0 + r;
     row = row < row_last ? row : row_last;
@@ -523,6 +527,65 @@ __global__ __launch_bounds__(1024) void gemm_nt_kernel_256sq_w16(GemmNTArgs a) {
   gemm_nt_epilogue_lds<4>(a, acc, group, row0, row_end, n0, wm, wn, wave, lane, smem);
 }
 
+
+// 160x256x64 tile with sixteen waves: 2 (M) x 8 (N), each 80x32 = acc[5][2] -- the 16-wave layout for the N = 768 problems
+// (160 rows do not split over 4 M-waves).  7 fragment reads per 10 MFMAs (8-wave layout: 9 per 20).
+__global__ __launch_bounds__(1024) void gemm_nt_kernel_160x256_w16(GemmNTArgs a) {
+  constexpr int BMQ = 160;
+  constexpr int STAGEQ = (BMQ + BNQ) * BK * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 3, wn = wave & 7;
+  const int tiles_n = (a.N + BNQ - 1) / BNQ;
+  const int tm0 = (a.split + BMQ - 1) / BMQ;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+  const int group = tile_m >= tm0;
+  const int row0 = group ? a.split + (tile_m - tm0) * BMQ : tile_m * BMQ;
+  const int row_end = group ? a.M : a.split;
+  const int n0 = tile_n * BNQ;
+  const bf16_t* W = a.W + (long)group * a.w_gstride;
+  f32x4_t acc[5][2];
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int nk = a.K / BK;
+#define STA(s_) (smem + (s_) * STAGEQ)
+#define STB(s_) (smem + (s_) * STAGEQ + BMQ * BK * 2)
+#define ISSUE(t_)                                                                                      \
+  do {                                                                                                 \
+    const int st__ = (t_) & 1;                                                                         \
+    stage_rows_k64(a.A, a.lda, row0, row_end - 1, (t_) * BK, STA(st__), wave, lane, BMQ / 8, 16);      \
+    stage_rows_k64(W, a.ldw, n0, a.N - 1, (t_) * BK, STB(st__), wave, lane, BNQ / 8, 16);              \
+  } while (0)
+  ISSUE(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 1 < nk) ISSUE(kt + 1);
+    const char* sA = STA(kt & 1);
+    const char* sB = STB(kt & 1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8_t fa[5], fb[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = read_frag_k64(sB, wn * 32 + j * 16 + (lane & 15), s * 4 + (lane >> 4));
+#pragma unroll
+      for (int i = 0; i < 5; ++i) fa[i] = read_frag_k64(sA, wm * 80 + i * 16 + (lane & 15), s * 4 + (lane >> 4));
+#pragma unroll
+      for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+  }
+#undef STA
+#undef STB
+#undef ISSUE
+  gemm_nt_epilogue_lds<5, 2>(a, acc, group, row0, row_end, n0, wm, wn, wave, lane, smem);
+}
 
 // ------------------------------------------------------------------------------------------
 // Variant: same 256x128 tile / 8 waves / 3-stage ring, but K-tiles of 32 (24 KiB stages, 72 KiB LDS) so that TWO
@@ -963,6 +1026,13 @@ extern "C" int simvg_gemm_nt(const void* A, int lda, const void* W, long w_gstri
     static bool onceq5 = hipFuncSetAttribute((const void*)gemm_nt_kernel_256sq<5>, hipFuncAttributeMaxDynamicSharedMemorySize, SM) == hipSuccess;
     (void)onceq5;
     const int tiles = (cdiv(split, 160) + cdiv(M - split, 160)) * cdiv(N, BNQ);
+    static const int w16s = getenv("SIMVG_GEMM_W16S") ? atoi(getenv("SIMVG_GEMM_W16S")) : 1;
+    if (w16s) {
+      constexpr int SMW = 2 * (160 + BNQ) * BK * 2;     // 104 KiB ring; 16 waves x 32 x 36 x 4 B = 72 KiB of epilogue staging fit
+      static bool oncews = hipFuncSetAttribute((const void*)gemm_nt_kernel_160x256_w16, hipFuncAttributeMaxDynamicSharedMemorySize, SMW) == hipSuccess;
+      (void)oncews;
+      hipLaunchKernelGGL(gemm_nt_kernel_160x256_w16, dim3(tiles), dim3(1024), SMW, stream, a);
+    } else
     hipLaunchKernelGGL(gemm_nt_kernel_256sq<5>, dim3(tiles), dim3(512), SM, stream, a);
   } else if (variant == 232 && M >= 512) {
     static bool once3 = hipFuncSetAttribute((const void*)gemm_nt_kernel_256k32, hipFuncAttributeMaxDynamicSharedMemorySize,
