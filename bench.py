@@ -115,6 +115,8 @@ def main():
     device = torch.device("cuda", local)
     use_dist = world > 1 or os.environ.get("SIMVG_FORCE_REDUCE") == "1"
     if use_dist:
+        if os.environ.get("NCCL_DEBUG") == "VERSION":    # RCCL prints its version banner on STDOUT: keep stdout to the one JSON line
+            os.environ.pop("NCCL_DEBUG")
         dist.init_process_group("nccl", device_id=device)
     from simvg_amd.models import build_model
     from simvg_amd.dist import GradReducer
