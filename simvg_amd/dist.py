@@ -20,6 +20,9 @@ class GradReducer:
         # SIMVG_FORCE_REDUCE=1 exercises the exchange even with a single rank (all-reduce over 1 rank == identity)
         self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("SIMVG_FORCE_REDUCE") == "1")
         self.pending, self._scale, self._head = [], [], None
+        # RCCL averages inside the collective (ncclAvg): no separate 1/world pass over the 640 MB of gradients; gloo (CPU
+        # tests) has no AVG -> SUM, then one division per message
+        self._avg = dist.is_initialized() and dist.get_backend() == "nccl"
         self.enc = getattr(model, "vis_enc", None)
         self._done_layers = set()
         if self.enc is not None:
@@ -50,8 +53,10 @@ class GradReducer:
 
     def _launch(self, t):
         if t.numel():
-            self.pending.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
-            self._scale.append(t)
+            op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+            self.pending.append(dist.all_reduce(t, op=op, async_op=True))
+            if not self._avg:
+                self._scale.append(t)
 
     def _launch_head(self):
         if self._head is not None:
