@@ -133,3 +133,35 @@ def test_train_model_world2_equals_single_process_on_the_global_batch():
     for k in means:                                                                       # reduce_mean'd statistics
         assert abs(r0["means"][k] - means[k]) <= 1e-5 * max(1.0, abs(means[k])), k
     assert any(line.startswith("train-epoch[1]-[4/4]") for line in r0["lines"]) and not r1["lines"]   # rank 0 logs only
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# loss normalisers: num_boxes = clamp(sum_ranks(k) / world, 1) (criterion.py:245-249) is all-reduced BEFORE the head
+# ---------------------------------------------------------------------------------------------------------------------
+def _nums_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from simvg_amd.models import build_head
+    head = build_head(dict(type="TextGuidedQuerySelectKDDETRHead", num_queries=2, text_max_token=20, in_channels=128, embed_dim=256,
+                           decoder_freeze=False, num_classes=1, aux_loss=True, num_encoder_layers=6, num_decoder_layers=3,
+                           only_decoder=True, text_embed_aug=False,
+                           branch_loss_weight={"decoder": 1.0, "balanced_distill": {"token": 2.0, "distill": 1.0}},
+                           distill_type="hard_weighted", prepare_target_mode="score_iou_weighted", share_predicthead=False,
+                           num_token_mlp_layers=1, mlp_aux_loss=False, text_guided_query_generation=True, num_tgqg_layers=2))
+    metas = [dict(img_shape=(64, 64, 3), target=[dict(category_id=1)] * 3), dict(img_shape=(64, 64, 3), target=[dict(category_id=-1)])]
+    if rank == 0:      # 3 targets + a no-target image: k = 3, matched pseudo targets = min(nq = 2, 3) + 0 = 2
+        gt = [torch.tensor([[1.0, 2, 30, 40], [5, 5, 20, 20], [8, 9, 50, 60]]), torch.zeros(1, 4)]
+    else:              # 1 + 1 targets: k = 2, pseudo = 2
+        metas = [dict(img_shape=(64, 64, 3), target=[dict(category_id=1)]), dict(img_shape=(64, 64, 3), target=[dict(category_id=1)])]
+        gt = [torch.tensor([[1.0, 2, 30, 40]]), torch.tensor([[3.0, 3, 9, 9]])]
+    tboxes, tlabels, tcount, nums = head.prepare_targets(gt, metas, torch.device("cpu"))
+    out[rank] = (nums.tolist(), tcount.tolist())
+    dist.destroy_process_group()
+
+
+def test_loss_normalisers_are_averaged_over_ranks_before_the_head():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_nums_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert out[0][0] == out[1][0] == [2.5, 2.0]            # (3 + 2) / 2 GT boxes, (2 + 2) / 2 matched pseudo targets
+    assert out[0][1] == [3, 0] and out[1][1] == [1, 1]
