@@ -141,12 +141,14 @@ struct WeightDesc {      // mirrored by simvg_amd/_lib.py (ctypes)
   bf16_t* dst;           // [rows, cols] bf16 or null
   bf16_t* dst_t;         // [cols, rows] bf16 or null
   int rows, cols;
-  int tile_start;        // first 32x32 tile index of this matrix in the launch
+  int tile_start;        // first 64x64 tile index of this matrix in the launch
   int pad_;
 };
 
+// 64 x 64 tiles, 16-B loads, 8-B stores in both orientations (the 32 x 32 / 2-B-store version ran at 1.3 TB/s: 0.53 ms per
+// step for the 340 MB of GEMM weights); tile_start counts 64 x 64 tiles (hip_ops.WeightPrep).
 __global__ __launch_bounds__(256) void weight_prep_kernel(const WeightDesc* __restrict__ descs, int n) {
-  __shared__ float tile[32][33];
+  __shared__ float tile[64][65];
   int lo = 0, hi = n - 1;
   const int bid = blockIdx.x;
   while (lo < hi) {   // last descriptor with tile_start <= bid
@@ -154,26 +156,46 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const WeightDesc* __re
     if (descs[mid].tile_start <= bid) lo = mid; else hi = mid - 1;
   }
   const WeightDesc d = descs[lo];
-  const int tiles_c = (d.cols + 31) >> 5;
+  const int tiles_c = (d.cols + 63) >> 6;
   const int tl = bid - d.tile_start;
-  const int r0 = (tl / tiles_c) * 32, c0 = (tl % tiles_c) * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int r0 = (tl / tiles_c) * 64, c0 = (tl % tiles_c) * 64;
+  const int tq = threadIdx.x & 15, ty = threadIdx.x >> 4;      // 16 x 4-element groups across, 16 rows down
+  const bool vec = (d.cols & 3) == 0 && (d.rows & 3) == 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int r = r0 + ty + 8 * k, c = c0 + tx;
-    float v = 0.f;
-    if (r < d.rows && c < d.cols) {
-      v = d.src[(long)r * d.cols + c];
-      if (d.dst) d.dst[(long)r * d.cols + c] = f32_to_bf16(v);
+    const int r = r0 + ty + 16 * k, c = c0 + 4 * tq;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (r < d.rows) {
+      if (vec && c + 3 < d.cols) {
+        const f32x4_t t = *(const f32x4_t*)(d.src + (long)r * d.cols + c);
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+        if (d.dst) *(u32x2_t*)(d.dst + (long)r * d.cols + c) = (u32x2_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+      } else {
+        for (int e = 0; e < 4; ++e)
+          if (c + e < d.cols) {
+            v[e] = d.src[(long)r * d.cols + c + e];
+            if (d.dst) d.dst[(long)r * d.cols + c + e] = f32_to_bf16(v[e]);
+          }
+      }
     }
-    tile[ty + 8 * k][tx] = v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tile[ty + 16 * k][4 * tq + e] = v[e];
   }
   if (!d.dst_t) return;
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int c = c0 + ty + 8 * k, r = r0 + tx;
-    if (r < d.rows && c < d.cols) d.dst_t[(long)c * d.rows + r] = f32_to_bf16(tile[tx][ty + 8 * k]);
+    const int c = c0 + ty + 16 * k, r = r0 + 4 * tq;      // one 8-B store of 4 consecutive source rows of column c
+    if (c >= d.cols) continue;
+    const float t0 = tile[4 * tq][ty + 16 * k], t1 = tile[4 * tq + 1][ty + 16 * k], t2 = tile[4 * tq + 2][ty + 16 * k],
+                t3 = tile[4 * tq + 3][ty + 16 * k];
+    if (vec && r + 3 < d.rows) {
+      *(u32x2_t*)(d.dst_t + (long)c * d.rows + r) = (u32x2_t){pack_bf16x2(t0, t1), pack_bf16x2(t2, t3)};
+    } else {
+      const float tt[4] = {t0, t1, t2, t3};
+      for (int e = 0; e < 4; ++e)
+        if (r + e < d.rows) d.dst_t[(long)c * d.rows + r + e] = f32_to_bf16(tt[e]);
+    }
   }
 }
 

@@ -285,7 +285,7 @@ class WeightPrep:
             assert src.is_contiguous() and (dst is None or dst.is_contiguous()) and (dst_t is None or dst_t.is_contiguous())
             arr[i] = _lib.WeightDesc(src.data_ptr(), dst.data_ptr() if dst is not None else None,
                                      dst_t.data_ptr() if dst_t is not None else None, rows, cols, tiles, 0)
-            tiles += ((rows + 31) // 32) * ((cols + 31) // 32)
+            tiles += ((rows + 63) // 64) * ((cols + 63) // 64)
         raw = bytes(arr)
         self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
         self.n, self.tiles = n, tiles

@@ -360,7 +360,7 @@ def test_embed_fwd_bwd():
 def test_weight_prep():
     ops = _ops()
     g = torch.Generator().manual_seed(9)
-    mats = [torch.randn(r, c, generator=g).to(DEV) for r, c in [(70, 33), (128, 256), (5, 300)]]
+    mats = [torch.randn(r, c, generator=g).to(DEV) for r, c in [(70, 33), (128, 256), (5, 300), (132, 200), (768, 3072)]]
     entries = []
     for i, m in enumerate(mats):
         dst = torch.empty_like(m, dtype=torch.bfloat16) if i != 2 else None
