@@ -20,6 +20,8 @@ class GradReducer:
         # SIMVG_FORCE_REDUCE=1 exercises the exchange even with a single rank (all-reduce over 1 rank == identity)
         self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("SIMVG_FORCE_REDUCE") == "1")
         self.pending, self._scale, self._head = [], [], None
+        self._all_ids, self._ids_done, self._text_rows = None, False, None
+        self.last_sparse_rows = 0
         # RCCL averages inside the collective (ncclAvg): no separate 1/world pass over the 640 MB of gradients; gloo (CPU
         # tests) has no AVG -> SUM, then one division per message
         self._avg = dist.is_initialized() and dist.get_backend() == "nccl"
@@ -28,6 +30,8 @@ class GradReducer:
         if self.enc is not None:
             self.enc._grad_ready_hook = self._on_layer_done
 
+    TEXT_TABLE = "beit3.text_embed.weight"
+
     # called by BEIT3._engine_backward after layer i (i = L-1 .. 0), then with -1 after the embedding stage
     def _on_layer_done(self, i):
         if not self.active:
@@ -35,14 +39,21 @@ class GradReducer:
         # the head's backward is complete before the encoder's starts (the encoder output is upstream of every head
         # node): its gradients go first, as ONE packed message, and travel under the whole encoder backward
         self._launch_head()
+        self._gather_ids()
         A = self.enc._arena
         if i >= 0:
             lo, hi = A.slice_of(self.enc.layer_param_names(i))
             self._launch(A.flat_grad[lo:hi])
             self._done_layers.add(i)
         else:
-            # everything that is not a layer slice: embeddings, position tables, final LayerNorm
+            # everything that is not a layer slice: embeddings, position tables, final LayerNorm.  The text table
+            # (64 010 x D: 197 MB for ViT-B, a third of all gradients, and the LAST thing the backward produces) is
+            # exchanged as the rows this step's tokens touch on ANY rank -- all other rows are zero everywhere.
             spans = sorted(A.slice_of(self.enc.layer_param_names(l)) for l in range(self.enc.L))
+            sparse = self._all_ids is not None and self.TEXT_TABLE in A.params
+            if sparse:
+                t_lo = A.offsets[self.TEXT_TABLE]
+                spans = sorted(spans + [(t_lo, t_lo + A.params[self.TEXT_TABLE].numel())])
             cur = 0
             for lo, hi in spans:
                 if lo > cur:
@@ -50,6 +61,34 @@ class GradReducer:
                 cur = max(cur, hi)
             if cur < A.total:
                 self._launch(A.flat_grad[cur:])
+            if sparse:
+                work, ids = self._all_ids
+                if work is not None:
+                    work.wait()
+                ids = ids.reshape(-1)
+                table = A.grad(self.TEXT_TABLE)
+                rows = table.index_select(0, ids)          # duplicates carry the same row: harmless, no unique() / sync
+                self._launch(rows)
+                self._text_rows = (table, ids, rows)
+                self.last_sparse_rows = int(ids.numel())
+
+    def _gather_ids(self):
+        """token ids of every rank for this step (a few KB), gathered asynchronously when the backward starts"""
+        if self._ids_done or self.enc is None:
+            return
+        self._ids_done = True
+        ids = getattr(self.enc, "_last_ids", None)
+        if ids is None or os.environ.get("SIMVG_DENSE_EMBED_REDUCE") == "1" or self.TEXT_TABLE not in self.enc._arena.params:
+            return
+        ids = ids.reshape(-1).contiguous()
+        out = torch.empty(self.world * ids.numel(), dtype=ids.dtype, device=ids.device)
+        if self._avg:      # RCCL
+            work = dist.all_gather_into_tensor(out, ids, async_op=True)
+        else:              # gloo (CPU tests)
+            parts = [torch.empty_like(ids) for _ in range(self.world)]
+            dist.all_gather(parts, ids)
+            out, work = torch.cat(parts), None
+        self._all_ids = (work, out)
 
     def _launch(self, t):
         if t.numel():
@@ -71,6 +110,7 @@ class GradReducer:
 
     def begin(self):
         self.pending, self._scale, self._head = [], [], None
+        self._all_ids, self._ids_done, self._text_rows = None, False, None
 
     def finish(self):
         """Call after loss.backward(): waits for every message, averages, scatters the head gradients back."""
@@ -84,4 +124,8 @@ class GradReducer:
         grads, flat = self._head
         if grads:
             torch._foreach_copy_(grads, [v.view_as(g) for g, v in zip(grads, flat.split([g.numel() for g in grads]))])
+        if self._text_rows is not None:
+            table, ids, rows = self._text_rows
+            table.index_copy_(0, ids, rows)
         self.pending, self._scale, self._head = [], [], None
+        self._all_ids, self._ids_done, self._text_rows = None, False, None

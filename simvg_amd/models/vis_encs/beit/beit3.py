@@ -84,6 +84,7 @@ class BEIT3(nn.Module):
         self._ws = {}
         self._prep_version = -1
         self._anchor = None
+        self._last_ids = None
         if isinstance(pretrain, str):
             from ....checkpoint import load_beit3_pretrain
             load_beit3_pretrain(self, pretrain)
@@ -282,6 +283,7 @@ class BEIT3(nn.Module):
         _, _, mF, rF = ops.ln_fwd(x_last, V["lnog"], V["lnob"], split=Mv, eps=eps, y=ws["out"], save_stats=save)
         ws["final_stats"] = (mF, rF)
         ws["ctx"] = (B, T, ids, pad_u8, dp)
+        self._last_ids = ids          # which text-table rows this step touches (GradReducer exchanges only those)
         return ws["out"], ws
 
     # ------------------------------------------------------------------ engine: exact fp32 forward (inference)

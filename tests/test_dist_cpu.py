@@ -25,12 +25,14 @@ class _FakeEnc(torch.nn.Module):
         self.L = L
         self.beit3 = torch.nn.Module()
         self.beit3.emb = torch.nn.Parameter(torch.zeros(5, D))
+        self.beit3.text_embed = torch.nn.Embedding(50, D)          # exchanged sparsely: only rows of this step's tokens
         self.beit3.encoder = torch.nn.Module()
         self.beit3.encoder.layers = torch.nn.ModuleList([torch.nn.Linear(D, D) for _ in range(L)])
         self.beit3.encoder.layer_norm = torch.nn.LayerNorm(D)
         from simvg_amd.arena import ParamArena
         self._arena = ParamArena(dict(self.named_parameters()), [], "cpu")
         self._grad_ready_hook = None
+        self._last_ids = None
 
     def layer_param_names(self, i):
         return [n for n in self._arena.params if n.startswith(f"beit3.encoder.layers.{i}.")]
@@ -55,6 +57,13 @@ def _worker(rank, world, port, out):
     red.begin()
     A.begin_backward()
     A.flat_grad.copy_(torch.randn(A.total, generator=g))          # this rank's local gradients
+    # text table: rows of THIS rank's tokens carry gradient, every other row is exactly zero (as embed_bwd leaves it)
+    ids = torch.randint(0, 50, (2, 4), generator=g)
+    model.vis_enc._last_ids = ids
+    tg = A.grad("beit3.text_embed.weight")
+    keep = torch.zeros(50, dtype=torch.bool)
+    keep[ids.reshape(-1)] = True
+    tg[~keep] = 0.0
     model.head.weight.grad = torch.randn(2, 8, generator=g)
     model.head.bias.grad = torch.randn(2, generator=g)
     local = (A.flat_grad.clone(), model.head.weight.grad.clone(), model.head.bias.grad.clone())
@@ -68,7 +77,7 @@ def _worker(rank, world, port, out):
     exp_w = sum(x[1] for x in gathered) / world
     ok = (torch.allclose(A.flat_grad, exp_flat, atol=1e-6) and torch.allclose(model.head.weight.grad, exp_w, atol=1e-6)
           and all(torch.equal(p.grad, A.grad(n)) for n, p in A.params.items()))
-    out[rank] = bool(ok)
+    out[rank] = bool(ok) and red.last_sparse_rows == 2 * 8       # the text table went as 2 ranks x 8 token rows
     dist.destroy_process_group()
 
 
