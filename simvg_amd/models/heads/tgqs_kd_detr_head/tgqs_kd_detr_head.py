@@ -16,7 +16,8 @@ import torch.nn.functional as F
 
 from ... import builder
 from .... import hip_ops as ops
-from ..functions import (Criterion, LayerNormF32, LinearBF16, LinearF32, SmallAttention, SplitEncoderOutput)
+from ..functions import (Criterion, CrossAttnBlock, LayerNormF32, LinearBF16, LinearF32, MemCrossAttnBlock, SelfAttnBlock,
+                         SplitEncoderOutput)
 
 
 def _xavier(*shape):
@@ -227,28 +228,27 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
     def _drop_mult(self, shape, device):
         if not self.training or self.attn_dropout == 0:
             return None
-        keep = 1.0 - self.attn_dropout
-        return torch.empty(shape, device=device).bernoulli_(keep).div_(keep)
+        key = ("ones", str(device), tuple(shape))
+        ones = self._const.get(key)
+        if ones is None:
+            ones = self._const[key] = torch.ones(shape, device=device)
+        return F.dropout(ones, self.attn_dropout, True)          # keep-mask / keep, one launch
 
     def _dropout(self, x):
         return F.dropout(x, self.ffn_dropout, self.training) if self.training and self.ffn_dropout > 0 else x
 
     def _decoder_layer(self, L, tgt, qpos, B, nq, cross_kv):
         """BaseTransformerLayer, post-norm order (self_attn, norm, cross_attn, norm, ffn, norm);
-        tgt/qpos [B*nq, E]; cross_kv(q_in) -> attention output [B*nq, E] (before out_proj)."""
+        tgt/qpos [B*nq, E]; cross_kv(query rows, in_proj_weight, in_proj_bias) -> attention output [B*nq, E] (before
+        out_proj)."""
         E, H = self.embed_dim, self.heads
         a0 = L + "attentions.0.attn."
-        qk_in = tgt + qpos
-        W, bias = self._P(a0 + "in_proj_weight"), self._P(a0 + "in_proj_bias")
-        qk = LinearF32.apply(qk_in, W[:2 * E], bias[:2 * E], False)
-        v = LinearF32.apply(tgt, W[2 * E:], bias[2 * E:], False)
-        o = SmallAttention.apply(qk[:, :E], qk[:, E:], v, B, H, nq, nq, None, self._drop_mult((B, H, nq, nq), tgt.device), 0)
+        o = SelfAttnBlock.apply(tgt + qpos, tgt, self._P(a0 + "in_proj_weight"), self._P(a0 + "in_proj_bias"), B, H, nq,
+                                self._drop_mult((B, H, nq, nq), tgt.device))
         o = LinearF32.apply(o, self._P(a0 + "out_proj.weight"), self._P(a0 + "out_proj.bias"), False)
         tgt = self._ln(tgt + o, L + "norms.0")
         a1 = L + "attentions.1.attn."
-        W1, b1 = self._P(a1 + "in_proj_weight"), self._P(a1 + "in_proj_bias")
-        q = LinearF32.apply(tgt + qpos, W1[:E], b1[:E], False)
-        o = cross_kv(q, W1, b1)
+        o = cross_kv(tgt + qpos, self._P(a1 + "in_proj_weight"), self._P(a1 + "in_proj_bias"))
         o = LinearF32.apply(o, self._P(a1 + "out_proj.weight"), self._P(a1 + "out_proj.bias"), False)
         tgt = self._ln(tgt + o, L + "norms.1")
         h = LinearF32.apply(tgt, self._P(L + "ffns.0.layers.0.0.weight"), self._P(L + "ffns.0.layers.0.0.bias"), True)
@@ -316,10 +316,8 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
         tkpm = (text_mask != 0).to(torch.uint8).contiguous()
         tk_in = (text3 + c["tpos"][None]).reshape(B * T, E)
 
-        def text_cross(q, W1, b1):
-            k = LinearF32.apply(tk_in, W1[E:2 * E], b1[E:2 * E], False)
-            v = LinearF32.apply(text, W1[2 * E:], b1[2 * E:], False)
-            return SmallAttention.apply(q, k, v, B, H, nq, T, tkpm, self._drop_mult((B, H, nq, T), device), 0)
+        def text_cross(xq, W1, b1):
+            return CrossAttnBlock.apply(xq, tk_in, text, W1, b1, B, H, nq, T, tkpm, self._drop_mult((B, H, nq, T), device))
 
         tgt = torch.zeros(B * nq, E, device=device)
         pre = "text_guided_query_generation_transformer."
@@ -338,18 +336,11 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
         tgt = torch.zeros(B * nq, E, device=device)
         hs = []
         for i in range(self.num_decoder_layers):
-            def mem_cross(q, W1, b1, i=i):
+            def mem_cross(xq, W1, b1, i=i):
                 # K = (mem + pos) Wk^T + bk = mem Wk^T + bk + pos Wk^T ; V = mem Wv^T + bv   (key_pos only on K)
-                if exact:
-                    kv = LinearF32.apply(mem, W1[E:], b1[E:], False)
-                else:
-                    kv = LinearBF16.apply(mem, W1[E:], b1[E:], self.wb[f"kv{i}"], self.wb[f"kvT{i}"], False)   # [B*Nv, 2E] fp32
-                posk = LinearF32.apply(pos2d.reshape(-1, E), W1[E:2 * E], None, False).view(-1, HW, E)
-                pos_full = F.pad(posk, (0, 0, 1, 0))                        # zero row for the (unused) CLS key
-                k_full = (kv.view(B, Nv, 2 * E)[:, :, :E] + pos_full).reshape(B * Nv, E)
-                # keys of sample b start at row b*Nv + 1: pass views that begin at row 1, batch stride Nv rows
-                return SmallAttention.apply(q, k_full[1:], kv[1:, E:], B, H, nq, HW, img_kpm,
-                                            self._drop_mult((B, H, nq, HW), device), Nv)
+                wb, wbT = (None, None) if exact else (self.wb[f"kv{i}"], self.wb[f"kvT{i}"])
+                return MemCrossAttnBlock.apply(xq, mem, W1, b1, pos2d, wb, wbT, B, H, nq, Nv, img_kpm,
+                                               self._drop_mult((B, H, nq, HW), device))
 
             tgt = self._decoder_layer(f"transformer.decoder.layers.{i}.", tgt, qpos_d, B, nq, mem_cross)
             hs.append(self._ln(tgt, "transformer.decoder.post_norm_layer"))
@@ -383,7 +374,8 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
             if len(keep) > TM:
                 raise ValueError(f"more than {TM} targets in one image")
             if keep:
-                rows.append(tb[keep].to(device=device, dtype=torch.float32, non_blocking=True))
+                sel = tb if len(keep) == int(tb.shape[0]) else tb[keep]       # no gather launch when nothing is dropped
+                rows.append(sel.to(device=device, dtype=torch.float32, non_blocking=True))
                 dst += [b * TM + j for j in range(len(keep))]
                 whwh += [[w, h, w, h]] * len(keep)
             counts.append(len(keep))
