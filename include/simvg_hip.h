@@ -91,6 +91,18 @@ int simvg_attn_bwd(const void* qkv_bf16, int ldqkv, const void* out_bf16, int ld
 int simvg_gemm_f32(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc,
                    const float* bias, const float* addend, long ld_addend, int addend_rows, int M, int N, int K,
                    int accumulate, int act, simvg_stream_t stream);
+/* Up to 8 independent simvg_gemm_f32 problems in ONE launch (e.g. the dgrad, wgrad and bias-gradient GEMMs of one
+ * nn.Linear backward, or the q|k and v projections of an attention): same arithmetic per problem as simvg_gemm_f32.
+ * No problem may read or write another problem's C.  `problems` is a HOST array, consumed before the call returns. */
+typedef struct simvg_gemm_f32_problem {
+  const float* A; long sam, sak;
+  const float* B; long sbk, sbn;
+  float* C; long ldc;
+  const float* bias;
+  const float* addend; long ld_addend; int addend_rows;
+  int M, N, K, accumulate, act;
+} simvg_gemm_f32_problem;
+int simvg_gemm_f32_grouped(const simvg_gemm_f32_problem* problems, int count, simvg_stream_t stream);
 /* torch.nn.MultiheadAttention core (heads of 32) for <= 16 queries: softmax(scale q k^T + key_padding) [* dropout] v
  * (detrex MultiheadAttention wrapper; decoder layers transformer.py:167-186). */
 int simvg_attn_small_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo,

@@ -16,7 +16,14 @@ class WeightDesc(C.Structure):
                 ("tile_start", c_int), ("pad_", c_int)]
 
 
+class GemmF32Problem(C.Structure):      # simvg_gemm_f32_problem
+    _fields_ = [("A", c_void_p), ("sam", c_long), ("sak", c_long), ("B", c_void_p), ("sbk", c_long), ("sbn", c_long),
+                ("C", c_void_p), ("ldc", c_long), ("bias", c_void_p), ("addend", c_void_p), ("ld_addend", c_long),
+                ("addend_rows", c_int), ("M", c_int), ("N", c_int), ("K", c_int), ("accumulate", c_int), ("act", c_int)]
+
+
 _SIGS = {
+    "simvg_gemm_f32_grouped": [c_void_p, c_int, c_void_p],
     "simvg_gemm_nt": [c_void_p, c_int, c_void_p, c_long, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
                       c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                       c_void_p],

@@ -12,6 +12,16 @@
 #include "common.h"
 #include <stdlib.h>
 
+// mirror of include/simvg_hip.h
+struct simvg_gemm_f32_problem {
+  const float* A; long sam, sak;
+  const float* B; long sbk, sbn;
+  float* C; long ldc;
+  const float* bias;
+  const float* addend; long ld_addend; int addend_rows;
+  int M, N, K, accumulate, act;
+};
+
 namespace {
 
 struct SGArgs {
@@ -24,13 +34,15 @@ struct SGArgs {
   int M, N, K, accumulate, act;
 };
 
-__global__ __launch_bounds__(256) void gemm_f32_kernel(SGArgs a) {
+constexpr int SG_LDS_FLOATS = 2 * 32 * 68;
+
+__device__ __forceinline__ void gemm_f32_tile64(const SGArgs& a, int bx, int by, float* smem) {
   // 64x64 tile, K-chunks of 32 staged through LDS, next chunk prefetched into registers while the current one
   // feeds v_mfma_f32_16x16x4_f32 (the head's GEMMs are latency-bound: few blocks, long K loops)
-  __shared__ float As[32][68];
-  __shared__ float Bs[32][68];
+  float (*As)[68] = (float (*)[68])smem;
+  float (*Bs)[68] = (float (*)[68])(smem + 32 * 68);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int m0 = by * 64, n0 = bx * 64;
   f32x4_t acc[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) acc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -106,11 +118,11 @@ __device__ __forceinline__ f32x4_t load_k4(const float* base, long sk, bool vec,
     if (k + i < K) v[i] = base[(long)(k + i) * sk];
   return v;
 }
-__global__ __launch_bounds__(256) void gemm_f32_small_kernel(SGArgs a) {
-  __shared__ float part[4][256];
+__device__ __forceinline__ void gemm_f32_tile16(const SGArgs& a, int bx, int by, float* smem) {
+  float (*part)[256] = (float (*)[256])smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const int m = blockIdx.y * 16 + r, n = blockIdx.x * 16 + r;
+  const int m = by * 16 + r, n = bx * 16 + r;
   const bool mok = m < a.M, nok = n < a.N;
   const float* Ap = a.A + (long)m * a.sam;
   const float* Bp = a.B + (long)n * a.sbn;
@@ -144,7 +156,7 @@ __global__ __launch_bounds__(256) void gemm_f32_small_kernel(SGArgs a) {
   for (int rr = 0; rr < 4; ++rr) part[wave][(4 * g + rr) * 16 + r] = acc[rr];
   __syncthreads();
   const int ml = tid >> 4, nl = tid & 15;
-  const int mo = blockIdx.y * 16 + ml, no = blockIdx.x * 16 + nl;
+  const int mo = by * 16 + ml, no = bx * 16 + nl;
   if (mo >= a.M || no >= a.N) return;
   float v = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
   if (a.bias) v += a.bias[no];
@@ -153,6 +165,38 @@ __global__ __launch_bounds__(256) void gemm_f32_small_kernel(SGArgs a) {
   else if (a.act == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
   float* p = a.C + (long)mo * a.ldc + no;
   *p = a.accumulate ? *p + v : v;
+}
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(SGArgs a) {
+  __shared__ float smem[SG_LDS_FLOATS];
+  gemm_f32_tile64(a, blockIdx.x, blockIdx.y, smem);
+}
+__global__ __launch_bounds__(256) void gemm_f32_small_kernel(SGArgs a) {
+  __shared__ float smem[4 * 256];
+  gemm_f32_tile16(a, blockIdx.x, blockIdx.y, smem);
+}
+
+// Several INDEPENDENT problems in one launch (the dgrad / wgrad / bias-gradient GEMMs of one layer, the q|k and v
+// projections of an attention ...): the head is a chain of ~5 us launches, so what matters is how many there are.
+// blockIdx.x walks the concatenated tile lists; each problem keeps the tile shape the single-problem entry point
+// would have picked for it.
+constexpr int SG_MAX = 8;
+struct SGGroup {
+  SGArgs p[SG_MAX];
+  int start[SG_MAX + 1];      // first linear block of problem i
+  int nx[SG_MAX];             // tiles along N of problem i
+  int small[SG_MAX];
+  int count;
+};
+__global__ __launch_bounds__(256) void gemm_f32_group_kernel(SGGroup g) {
+  __shared__ float smem[SG_LDS_FLOATS];
+  int i = 0;
+  while (i + 1 < g.count && (int)blockIdx.x >= g.start[i + 1]) ++i;
+  const int t = blockIdx.x - g.start[i];
+  const int by = t / g.nx[i], bx = t - by * g.nx[i];
+  const SGArgs a = g.p[i];
+  if (g.small[i]) gemm_f32_tile16(a, bx, by, smem);
+  else gemm_f32_tile64(a, bx, by, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -323,6 +367,32 @@ extern "C" int simvg_gemm_f32(const float* A, long sam, long sak, const float* B
     hipLaunchKernelGGL(gemm_f32_small_kernel, dim3(cdiv(N, 16), cdiv(M, 16)), dim3(256), 0, stream, a);
   else
     hipLaunchKernelGGL(gemm_f32_kernel, dim3(cdiv(N, 64), cdiv(M, 64)), dim3(256), 0, stream, a);
+  SIMVG_LAUNCH_CHECK();
+  return SIMVG_OK;
+}
+
+extern "C" int simvg_gemm_f32_grouped(const simvg_gemm_f32_problem* problems, int count, hipStream_t stream) {
+  SIMVG_CHECK_ARG(problems != nullptr && count > 0 && count <= SG_MAX, "gemm_f32_grouped: 1..8 problems");
+  static const int small_env = getenv("SIMVG_GEMM_F32_SMALL") ? atoi(getenv("SIMVG_GEMM_F32_SMALL")) : 32;
+  SGGroup g;
+  g.count = count;
+  int total = 0;
+  for (int i = 0; i < count; ++i) {
+    const simvg_gemm_f32_problem& q = problems[i];
+    SIMVG_CHECK_ARG(q.M > 0 && q.N > 0 && q.K > 0, "gemm_f32_grouped: empty problem");
+    SIMVG_CHECK_ARG(q.act >= 0 && q.act <= 2, "gemm_f32_grouped: act must be 0 (none), 1 (gelu) or 2 (relu)");
+    g.p[i] = SGArgs{q.A, q.sam, q.sak, q.B, q.sbk, q.sbn, q.C, q.ldc, q.bias, q.addend, q.ld_addend,
+                    q.addend_rows > 0 ? q.addend_rows : 1, q.M, q.N, q.K, q.accumulate, q.act};
+    const int sm = cdiv(q.N, 64) * cdiv(q.M, 64) <= small_env;
+    const int t = sm ? 16 : 64;
+    g.small[i] = sm;
+    g.nx[i] = cdiv(q.N, t);
+    g.start[i] = total;
+    total += cdiv(q.N, t) * cdiv(q.M, t);
+  }
+  for (int i = count; i <= SG_MAX; ++i) g.start[i] = total;
+  for (int i = count; i < SG_MAX; ++i) { g.p[i] = g.p[0]; g.nx[i] = 1; g.small[i] = 1; }
+  hipLaunchKernelGGL(gemm_f32_group_kernel, dim3(total), dim3(256), 0, stream, g);
   SIMVG_LAUNCH_CHECK();
   return SIMVG_OK;
 }

@@ -312,6 +312,37 @@ def gemm_f32(A, sam, sak, Bm, sbk, sbn, C, M, N, K, bias=None, addend=None, adde
     return C
 
 
+def gemm_f32_group(problems):
+    """Independent gemm_f32 problems in ONE launch.  Each problem: dict(A, sam, sak, B, sbk, sbn, C, M, N, K[, bias,
+    addend, addend_rows, accumulate, act]) with the meaning of `gemm_f32`; at most 8 per call (longer lists are split)."""
+    lib = _lib.load()
+    for i in range(0, len(problems), 8):
+        chunk = problems[i:i + 8]
+        arr = (_lib.GemmF32Problem * len(chunk))()
+        for d, q in zip(arr, chunk):
+            ad = q.get("addend")
+            d.A, d.sam, d.sak = q["A"].data_ptr(), q["sam"], q["sak"]
+            d.B, d.sbk, d.sbn = q["B"].data_ptr(), q["sbk"], q["sbn"]
+            d.C, d.ldc = q["C"].data_ptr(), q["C"].stride(0)
+            b = q.get("bias")
+            d.bias = b.data_ptr() if b is not None else None
+            d.addend = ad.data_ptr() if ad is not None else None
+            d.ld_addend = ad.stride(0) if ad is not None else 0
+            d.addend_rows = q.get("addend_rows", 0)
+            d.M, d.N, d.K = q["M"], q["N"], q["K"]
+            d.accumulate, d.act = int(q.get("accumulate", False)), q.get("act", 0)
+        t0 = _timer.start("gemm_f32_group") if _timer is not None else None
+        rc = lib.simvg_gemm_f32_grouped(C.byref(arr), len(chunk), _stream())
+        if t0 is not None:
+            _timer.stop("gemm_f32_group", t0, sum(2.0 * q["M"] * q["N"] * q["K"] for q in chunk), 0.0)
+        _lib.check(rc, "simvg_gemm_f32_grouped")
+
+
+def gp(A, sam, sak, Bm, sbk, sbn, Cm, M, N, K, **kw):
+    """one problem of `gemm_f32_group` (same positional arguments as `gemm_f32`)"""
+    return dict(A=A, sam=sam, sak=sak, B=Bm, sbk=sbk, sbn=sbn, C=Cm, M=M, N=N, K=K, **kw)
+
+
 def attn_small_fwd(q, k, v, B, H, Lq, Lk, kpm=None, drop=None, kv_rows=0):
     lib = _lib.load()
     E = H * 32

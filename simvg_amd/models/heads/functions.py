@@ -41,16 +41,18 @@ class LinearF32(torch.autograd.Function):
         M, K = x.shape
         N = W.shape[0]
         dx = dW = db = None
+        if ctx.needs_input_grad[1]:
+            dW = torch.empty(N, K, device=dy.device, dtype=torch.float32)
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            db = torch.empty(1, N, device=dy.device, dtype=torch.float32)
+        if dW is not None:
+            ops.gemm_f32(dy, 1, N, x, x.stride(0), x.stride(1), dW, N, K, M)        # dW = dy^T x
+        if db is not None:
+            ops.gemm_f32(_ones(M, dy.device), 0, 1, dy, N, 1, db, 1, N, M)          # db = 1^T dy
+            db = db.view(N)
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)
             ops.gemm_f32(dy, N, 1, W, W.stride(0), 1, dx, M, K, N)                      # dx = dy W
-        if ctx.needs_input_grad[1]:
-            dW = torch.empty(N, K, device=dy.device, dtype=torch.float32)
-            ops.gemm_f32(dy, 1, N, x, x.stride(0), x.stride(1), dW, N, K, M)            # dW = dy^T x
-        if ctx.has_b and ctx.needs_input_grad[2]:
-            db = torch.empty(1, N, device=dy.device, dtype=torch.float32)
-            ops.gemm_f32(_ones(M, dy.device), 0, 1, dy, N, 1, db, 1, N, M)              # db = 1^T dy
-            db = db.view(N)
         return dx, dW, db, None
 
 
@@ -161,9 +163,9 @@ class SelfAttnBlock(torch.autograd.Function):
         ops.attn_small_bwd(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], P, dout.contiguous(), dqkv[:, :E], dqkv[:, E:2 * E],
                            dqkv[:, 2 * E:], B, H, L, L, kpm=None, drop=drop, kv_rows=0)
         dW, db = _f32(3 * E, E, device=dev), _f32(1, 3 * E, device=dev)
-        ops.gemm_f32(dqkv, 1, 3 * E, x_qk, E, 1, dW, 2 * E, E, M)                       # dW[:2E] = dqk^T x_qk
-        ops.gemm_f32(dqkv[:, 2 * E:], 1, 3 * E, x_v, E, 1, dW[2 * E:], E, E, M)         # dW[2E:] = dv^T x_v
-        ops.gemm_f32(_ones(M, dev), 0, 1, dqkv, 3 * E, 1, db, 1, 3 * E, M)              # db = 1^T dqkv
+        ops.gemm_f32(dqkv, 1, 3 * E, x_qk, E, 1, dW, 2 * E, E, M)                   # dW[:2E] = dqk^T x_qk
+        ops.gemm_f32(dqkv[:, 2 * E:], 1, 3 * E, x_v, E, 1, dW[2 * E:], E, E, M)     # dW[2E:] = dv^T x_v
+        ops.gemm_f32(_ones(M, dev), 0, 1, dqkv, 3 * E, 1, db, 1, 3 * E, M)          # db = 1^T dqkv
         dx_qk = dx_v = None
         if ctx.needs_input_grad[0]:
             dx_qk = _f32(M, E, device=dev)
@@ -263,29 +265,33 @@ class MemCrossAttnBlock(torch.autograd.Function):
         ops.attn_small_bwd(q, kv[1:, :E], kv[1:, E:], P, dout.contiguous(), dq, dkv[1:, :E], dkv[1:, E:], B, H, Lq, HW,
                            kpm=kpm, drop=drop, kv_rows=Nv)
         dmem = None
-        if mem.dtype == torch.bfloat16:
+        bf = mem.dtype == torch.bfloat16
+        if bf:
             dW = torch.zeros(3 * E, E, device=dev, dtype=torch.float32)                  # gemm_tn accumulates
             db = torch.zeros(1, 3 * E, device=dev, dtype=torch.float32)
-            dkvb = ops.cast_bf16(dkv)
-            if ctx.needs_input_grad[1]:
-                dmem = ops.gemm_nt(dkvb, wbT)                                            # [R, E] bf16
-            ops.gemm_tn(dkvb, mem, dW[E:], db=db[0, E:])
         else:
             dW, db = _f32(3 * E, E, device=dev), _f32(1, 3 * E, device=dev)
+        # the memory-row side: rows [E:] of dW / db
+        if bf:
+            dkvb = ops.cast_bf16(dkv)
+            if ctx.needs_input_grad[1]:
+                dmem = ops.gemm_nt(dkvb, wbT)                                        # [R, E] bf16
+            ops.gemm_tn(dkvb, mem, dW[E:], db=db[0, E:])
+        else:
             if ctx.needs_input_grad[1]:
                 dmem = _f32(R, E, device=dev)
                 ops.gemm_f32(dkv, 2 * E, 1, W[E:], E, 1, dmem, R, E, 2 * E)
             ops.gemm_f32(dkv, 1, 2 * E, mem, mem.stride(0), 1, dW[E:], 2 * E, E, R)
             ops.gemm_f32(_ones(R, dev), 0, 1, dkv, 2 * E, 1, db[:, E:], 1, 2 * E, R)
         dk3 = dkv.view(B, Nv, 2 * E)[:, 1:, :E]
-        dpk = dk3.sum(0) if shared_pos else dk3.reshape(-1, E)                           # d(pos Wk^T)
+        dpk = dk3.sum(0) if shared_pos else dk3.reshape(-1, E)                       # d(pos Wk^T)
         ops.gemm_f32(dpk, 1, E, pos2, E, 1, dW[E:2 * E], E, E, pos2.shape[0], accumulate=True)
-        ops.gemm_f32(dq, 1, E, xq, E, 1, dW, E, E, M)
-        ops.gemm_f32(_ones(M, dev), 0, 1, dq, E, 1, db, 1, E, M)
         dxq = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0]:                                                      # the query-row side: rows [:E]
             dxq = _f32(M, E, device=dev)
             ops.gemm_f32(dq, E, 1, W, E, 1, dxq, M, E, E)
+        ops.gemm_f32(dq, 1, E, xq, E, 1, dW, E, E, M)
+        ops.gemm_f32(_ones(M, dev), 0, 1, dq, E, 1, db, 1, E, M)
         return dxq, dmem, dW, db.view(3 * E), None, None, None, None, None, None, None, None, None
 
 

@@ -126,3 +126,136 @@ def test_matcher_vs_scipy_and_criterion_vs_autograd(L, B, nq):
         suf = "" if l == L - 1 else f"_{l}"
         for j, key in enumerate(["loss_class", "loss_bbox", "loss_giou"]):
             assert abs(float(out[1 + 3 * l + j]) - float(losses[key + suf])) <= 1e-4 * max(1.0, abs(float(losses[key + suf])))
+
+
+def test_gemm_f32_grouped_matches_single_launches():
+    """several independent problems (small-tile and 64x64-tile ones mixed, strided operands, bias / relu / addend /
+    accumulate epilogues) in one launch == the same problems launched one by one, bit for bit"""
+    from simvg_amd import hip_ops as ops
+    g = torch.Generator().manual_seed(11)
+    r = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    x, W, b, dy = r(64, 256), r(768, 256), r(768), r(64, 768)
+    big_x, big_w = r(1280, 256), r(256, 256)
+    add = r(64, 256)
+    acc0 = r(256, 256)
+    ones = torch.ones(64, device=DEV)
+
+    def problems(outs):
+        return [
+            ops.gp(x, 256, 1, W, 1, 256, outs[0], 64, 512, 256, bias=b),                               # q|k projection
+            ops.gp(x, 256, 1, W[512:], 1, 256, outs[0][:, 512:], 64, 256, 256, bias=b[512:], act=2),    # v, column view
+            ops.gp(dy, 1, 768, x, 256, 1, outs[1], 768, 256, 64),                                       # wgrad
+            ops.gp(ones, 0, 1, dy, 768, 1, outs[2], 1, 768, 64),                                        # bias gradient
+            ops.gp(dy, 768, 1, W, 256, 1, outs[3], 64, 256, 768, addend=add, addend_rows=64),           # dgrad + residual
+            ops.gp(big_x, 256, 1, big_w, 1, 256, outs[4], 1280, 256, 256),                              # 64x64-tile problem
+            ops.gp(x, 1, 256, x, 256, 1, outs[5], 256, 256, 64, accumulate=True),                       # C += x^T x
+        ]
+
+    def outs():
+        return [torch.zeros(64, 768, device=DEV), torch.zeros(768, 256, device=DEV), torch.zeros(1, 768, device=DEV),
+                torch.zeros(64, 256, device=DEV), torch.zeros(1280, 256, device=DEV), acc0.clone()]
+
+    one, grp = outs(), outs()
+    for q in problems(one):
+        ops.gemm_f32(q["A"], q["sam"], q["sak"], q["B"], q["sbk"], q["sbn"], q["C"], q["M"], q["N"], q["K"],
+                     bias=q.get("bias"), addend=q.get("addend"), addend_rows=q.get("addend_rows", 0),
+                     accumulate=q.get("accumulate", False), act=q.get("act", 0))
+    ops.gemm_f32_group(problems(grp))
+    for a, c in zip(one, grp):
+        assert torch.equal(a, c)
+    close(grp[1], dy.cpu().t() @ x.cpu(), 1e-5, "wgrad")
+    close(grp[3], dy.cpu() @ W.cpu() + add.cpu(), 1e-5, "dgrad + addend")
+    close(grp[5], acc0.cpu() + x.cpu().t() @ x.cpu(), 1e-5, "accumulate")
+    # more than 8 problems: split into several launches
+    many = [torch.zeros(64, 256, device=DEV) for _ in range(11)]
+    ops.gemm_f32_group([ops.gp(x, 256, 1, big_w, 1, 256, o, 64, 256, 256) for o in many])
+    for o in many:
+        close(o, x.cpu() @ big_w.cpu().t(), 1e-5, "11 problems")
+
+
+def _mha_ref(xq, xk, xv, W, b, B, H, Lq, Lk, kpm=None, dm=None):
+    """nn.MultiheadAttention core in plain fp32 PyTorch: in_proj rows [q | k | v], heads of E/H, scale d^-1/2"""
+    E = xq.shape[1]
+    q = F.linear(xq, W[:E], b[:E]).view(B, Lq, H, E // H).transpose(1, 2) * (E // H) ** -0.5
+    k = F.linear(xk, W[E:2 * E], b[E:2 * E]).view(B, Lk, H, E // H).transpose(1, 2)
+    v = F.linear(xv, W[2 * E:], b[2 * E:]).view(B, Lk, H, E // H).transpose(1, 2)
+    w = q @ k.transpose(-1, -2)
+    if kpm is not None:
+        w = w.masked_fill(kpm.bool()[:, None, None, :], float("-inf"))
+    w = w.softmax(-1)
+    if dm is not None:
+        w = w * dm
+    return (w @ v).transpose(1, 2).reshape(B * Lq, E)
+
+
+@pytest.mark.parametrize("B,L,drop", [(4, 1, False), (3, 10, True)])
+def test_self_attn_block_fwd_bwd(B, L, drop):
+    from simvg_amd.models.heads.functions import SelfAttnBlock
+    H, E = 8, 256
+    g = torch.Generator().manual_seed(7 * B + L)
+    x_qk, x_v = torch.randn(B * L, E, generator=g), torch.randn(B * L, E, generator=g)
+    W, b = torch.randn(3 * E, E, generator=g) * E ** -0.5, torch.randn(3 * E, generator=g) * 0.1
+    dm = (torch.bernoulli(torch.full((B, H, L, L), 0.9), generator=g) / 0.9) if drop else None
+    dout = torch.randn(B * L, E, generator=g)
+    ref_in = [t.clone().requires_grad_(True) for t in (x_qk, x_v, W, b)]
+    _mha_ref(ref_in[0], ref_in[0], ref_in[1], ref_in[2], ref_in[3], B, H, L, L, dm=dm).backward(dout)
+    dev_in = [t.clone().to(DEV).requires_grad_(True) for t in (x_qk, x_v, W, b)]
+    out = SelfAttnBlock.apply(*dev_in, B, H, L, None if dm is None else dm.to(DEV))
+    out.backward(dout.to(DEV))
+    close(out, _mha_ref(x_qk, x_qk, x_v, W, b, B, H, L, L, dm=dm), 1e-5, "out")
+    for name, d, r in zip(("dx_qk", "dx_v", "dW", "db"), dev_in, ref_in):
+        close(d.grad, r.grad, 2e-5, name)
+
+
+def test_cross_attn_block_fwd_bwd():
+    from simvg_amd.models.heads.functions import CrossAttnBlock
+    B, H, E, Lq, Lk = 3, 8, 256, 10, 20
+    g = torch.Generator().manual_seed(3)
+    xq, xk, xv = (torch.randn(B * n, E, generator=g) for n in (Lq, Lk, Lk))
+    W, b = torch.randn(3 * E, E, generator=g) * E ** -0.5, torch.randn(3 * E, generator=g) * 0.1
+    kpm = torch.zeros(B, Lk, dtype=torch.uint8)
+    kpm[1, 12:] = 1
+    dm = torch.bernoulli(torch.full((B, H, Lq, Lk), 0.9), generator=g) / 0.9
+    dout = torch.randn(B * Lq, E, generator=g)
+    ref_in = [t.clone().requires_grad_(True) for t in (xq, xk, xv, W, b)]
+    _mha_ref(*ref_in, B, H, Lq, Lk, kpm=kpm, dm=dm).backward(dout)
+    dev_in = [t.clone().to(DEV).requires_grad_(True) for t in (xq, xk, xv, W, b)]
+    out = CrossAttnBlock.apply(*dev_in, B, H, Lq, Lk, kpm.to(DEV), dm.to(DEV))
+    out.backward(dout.to(DEV))
+    close(out, _mha_ref(xq, xk, xv, W, b, B, H, Lq, Lk, kpm=kpm, dm=dm), 1e-5, "out")
+    for name, d, r in zip(("dxq", "dxk", "dxv", "dW", "db"), dev_in, ref_in):
+        close(d.grad, r.grad, 2e-5, name)
+
+
+@pytest.mark.parametrize("shared_pos", [True, False])
+def test_mem_cross_attn_block_fp32_fwd_bwd(shared_pos):
+    """the exact (fp32-memory) flavour against plain PyTorch: key = memory + key_pos on the patch rows, value = memory,
+    the CLS row of every sample is carried but never attended to"""
+    from simvg_amd.models.heads.functions import MemCrossAttnBlock
+    B, H, E, Lq, HW = 2, 8, 256, 3, 16
+    Nv = HW + 1
+    g = torch.Generator().manual_seed(9)
+    xq, mem = torch.randn(B * Lq, E, generator=g), torch.randn(B * Nv, E, generator=g)
+    pos = torch.randn(HW, E, generator=g) if shared_pos else torch.randn(B, HW, E, generator=g)
+    W, b = torch.randn(3 * E, E, generator=g) * E ** -0.5, torch.randn(3 * E, generator=g) * 0.1
+    kpm = None
+    if not shared_pos:
+        kpm = torch.zeros(B, HW, dtype=torch.uint8)
+        kpm[0, 10:] = 1
+    dout = torch.randn(B * Lq, E, generator=g)
+
+    def ref(xq_, mem_, W_, b_):
+        patches = mem_.view(B, Nv, E)[:, 1:]
+        xk = (patches + (pos[None] if shared_pos else pos)).reshape(B * HW, E)
+        return _mha_ref(xq_, xk, patches.reshape(B * HW, E), W_, b_, B, H, Lq, HW, kpm=kpm)
+
+    ref_in = [t.clone().requires_grad_(True) for t in (xq, mem, W, b)]
+    ref(*ref_in).backward(dout)
+    dev_in = [t.clone().to(DEV).requires_grad_(True) for t in (xq, mem, W, b)]
+    out = MemCrossAttnBlock.apply(dev_in[0], dev_in[1], dev_in[2], dev_in[3], pos.to(DEV), None, None, B, H, Lq, Nv,
+                                  None if kpm is None else kpm.to(DEV), None)
+    out.backward(dout.to(DEV))
+    close(out, ref(xq, mem, W, b), 1e-5, "out")
+    for name, d, r in zip(("dxq", "dmem", "dW", "db"), dev_in, ref_in):
+        close(d.grad, r.grad, 2e-5, name)
+    assert float(dev_in[1].grad.view(B, Nv, E)[:, 0].abs().max()) == 0.0      # CLS rows get no gradient
