@@ -91,7 +91,7 @@ int simvg_attn_bwd(const void* qkv_bf16, int ldqkv, const void* out_bf16, int ld
 int simvg_gemm_f32(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc,
                    const float* bias, const float* addend, long ld_addend, int addend_rows, int M, int N, int K,
                    int accumulate, int act, simvg_stream_t stream);
-/* Up to 8 independent simvg_gemm_f32 problems in ONE launch (e.g. the dgrad, wgrad and bias-gradient GEMMs of one
+/* Up to 12 independent simvg_gemm_f32 problems in ONE launch (e.g. the dgrad, wgrad and bias-gradient GEMMs of one
  * nn.Linear backward, or the q|k and v projections of an attention): same arithmetic per problem as simvg_gemm_f32.
  * No problem may read or write another problem's C.  `problems` is a HOST array, consumed before the call returns. */
 typedef struct simvg_gemm_f32_problem {

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void gemm_f32_small_kernel(SGArgs a) {
 // projections of an attention ...): the head is a chain of ~5 us launches, so what matters is how many there are.
 // blockIdx.x walks the concatenated tile lists; each problem keeps the tile shape the single-problem entry point
 // would have picked for it.
-constexpr int SG_MAX = 8;
+constexpr int SG_MAX = 12;
 struct SGGroup {
   SGArgs p[SG_MAX];
   int start[SG_MAX + 1];      // first linear block of problem i
@@ -372,7 +372,7 @@ extern "C" int simvg_gemm_f32(const float* A, long sam, long sak, const float* B
 }
 
 extern "C" int simvg_gemm_f32_grouped(const simvg_gemm_f32_problem* problems, int count, hipStream_t stream) {
-  SIMVG_CHECK_ARG(problems != nullptr && count > 0 && count <= SG_MAX, "gemm_f32_grouped: 1..8 problems");
+  SIMVG_CHECK_ARG(problems != nullptr && count > 0 && count <= SG_MAX, "gemm_f32_grouped: 1..12 problems");
   static const int small_env = getenv("SIMVG_GEMM_F32_SMALL") ? atoi(getenv("SIMVG_GEMM_F32_SMALL")) : 32;
   SGGroup g;
   g.count = count;

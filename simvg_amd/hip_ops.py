@@ -314,10 +314,10 @@ def gemm_f32(A, sam, sak, Bm, sbk, sbn, C, M, N, K, bias=None, addend=None, adde
 
 def gemm_f32_group(problems):
     """Independent gemm_f32 problems in ONE launch.  Each problem: dict(A, sam, sak, B, sbk, sbn, C, M, N, K[, bias,
-    addend, addend_rows, accumulate, act]) with the meaning of `gemm_f32`; at most 8 per call (longer lists are split)."""
+    addend, addend_rows, accumulate, act]) with the meaning of `gemm_f32`; at most 12 per launch (longer lists are split)."""
     lib = _lib.load()
-    for i in range(0, len(problems), 8):
-        chunk = problems[i:i + 8]
+    for i in range(0, len(problems), 12):
+        chunk = problems[i:i + 12]
         arr = (_lib.GemmF32Problem * len(chunk))()
         for d, q in zip(arr, chunk):
             ad = q.get("addend")

@@ -295,6 +295,246 @@ class MemCrossAttnBlock(torch.autograd.Function):
         return dxq, dmem, dW, db.view(3 * E), None, None, None, None, None, None, None, None, None
 
 
+class LayerCfg:
+    """non-tensor arguments of `DecoderLayerFn` (geometry, cross-attention flavour and its gradient-free operands)"""
+
+    def __init__(self, B, H, nq, kind, Lk, kpm=None, pos=None, wb=None, wbT=None, Nv=0, p_attn=0.0, p_ffn=0.0,
+                 training=False, mask_fn=None):
+        self.B, self.H, self.nq, self.kind, self.Lk = B, H, nq, kind, Lk
+        self.kpm, self.pos, self.wb, self.wbT, self.Nv = kpm, pos, wb, wbT, Nv
+        self.p_attn, self.p_ffn, self.training, self.mask_fn = p_attn, p_ffn, training, mask_fn
+
+
+class DecoderLayerFn(torch.autograd.Function):
+    """One post-norm DETR decoder layer -- self-attention, norm, cross-attention, norm, FFN(ReLU), norm (detrex
+    `BaseTransformerLayer` as configured at heads/tgqs_kd_detr_head/transformer.py:93-131), optionally followed by the
+    decoder's shared post-norm of the layer output (transformer.py:176-183) -- as ONE autograd node with a hand-sequenced
+    backward.  The head is a chain of ~5 us launches on [B*nq, 256] rows, so its cost is the NUMBER of launches:
+      * residual adds ride in GEMM epilogues (`addend`), independent GEMMs (dgrad / wgrad / bias gradient of a Linear,
+        q|k and v projections ...) share one grouped launch, fan-in of gradients is folded into GEMMs
+        (d_tgt = dqkv W_in + d_r1 is one K = 3E contraction; d_qpos = dqk W_qk + dxq);
+      * parameter gradients are written whole; the only fill is one buffer for the LayerNorm (and, with bf16 memory,
+        cross-attention K|V) gradients that are accumulated with atomics.
+    ~20 launches forward and ~25 backward instead of ~26 / ~50 through per-op autograd nodes.
+    kind "text": keys / values from fp32 rows xk, xv [B*Lk, E] (the TGQG layer); kind "mem": from the image memory
+    mem [B*Nv, E] (bf16 -> bf16 MFMA GEMMs with cfg.wb / cfg.wbT, fp32 -> exact), key_pos cfg.pos on the patch rows.
+    Returns (layer output, post-normed layer output | None)."""
+
+    @staticmethod
+    def forward(ctx, tgt, qpos, xk, xv, mem, Ws, bs, Wso, bso, g0, b0, Wc, bc, Wco, bco, g1, b1n, W1, b1, W2, b2, g2, b2n,
+                gP, bP, cfg):
+        dev = tgt.device
+        tgt, qpos = tgt.contiguous(), qpos.contiguous()
+        M, E = tgt.shape
+        Fd = W1.shape[0]
+        B, H, nq = cfg.B, cfg.H, cfg.nq
+        train = cfg.training
+
+        def amask(Lk):
+            return cfg.mask_fn((B, H, nq, Lk), dev) if (train and cfg.p_attn > 0) else None
+
+        def ln(x, g, b):
+            _, y, mean, rstd = ops.ln_fwd(x, g, b, eps=1e-5, out_bf16=False, out_f32=True)
+            return y, mean, rstd
+
+        # ---- self-attention: q = k = tgt + qpos, v = tgt
+        x_qk = tgt + qpos
+        qkv = _f32(M, 3 * E, device=dev)
+        ops.gemm_f32_group([ops.gp(x_qk, E, 1, Ws, 1, E, qkv, M, 2 * E, E, bias=bs),
+                            ops.gp(tgt, E, 1, Ws[2 * E:], 1, E, qkv[:, 2 * E:], M, E, E, bias=bs[2 * E:])])
+        dm0 = amask(nq)
+        o, P0 = ops.attn_small_fwd(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], B, H, nq, nq, kpm=None, drop=dm0, kv_rows=0)
+        r1 = _f32(M, E, device=dev)
+        ops.gemm_f32(o, E, 1, Wso, 1, E, r1, M, E, E, bias=bso, addend=tgt, addend_rows=M)         # tgt + out_proj(o)
+        t1, mean1, rstd1 = ln(r1, g0, b0)
+        # ---- cross-attention: q = t1 + qpos
+        xq = t1 + qpos
+        q = _f32(M, E, device=dev)
+        if cfg.kind == "text":
+            xk, xv = xk.contiguous(), xv.contiguous()
+            R, Lk = xk.shape[0], cfg.Lk
+            kv = _f32(R, 2 * E, device=dev)
+            ops.gemm_f32_group([ops.gp(xq, E, 1, Wc, 1, E, q, M, E, E, bias=bc),
+                                ops.gp(xk, E, 1, Wc[E:], 1, E, kv, R, E, E, bias=bc[E:]),
+                                ops.gp(xv, E, 1, Wc[2 * E:], 1, E, kv[:, E:], R, E, E, bias=bc[2 * E:])])
+            dm1 = amask(Lk)
+            o2, P1 = ops.attn_small_fwd(q, kv[:, :E], kv[:, E:], B, H, nq, Lk, kpm=cfg.kpm, drop=dm1, kv_rows=0)
+            pos2 = None
+        else:
+            Nv = cfg.Nv
+            HW, R = Nv - 1, B * Nv
+            pos2 = cfg.pos.reshape(-1, E)
+            posk = _f32(pos2.shape[0], E, device=dev)
+            probs = [ops.gp(xq, E, 1, Wc, 1, E, q, M, E, E, bias=bc),
+                     ops.gp(pos2, E, 1, Wc[E:], 1, E, posk, pos2.shape[0], E, E)]
+            if mem.dtype == torch.bfloat16:
+                kv = ops.gemm_nt(mem, cfg.wb, bias=bc[E:], out_dtype=torch.float32)                  # [B*Nv, 2E]
+            else:
+                kv = _f32(R, 2 * E, device=dev)
+                probs.append(ops.gp(mem, mem.stride(0), 1, Wc[E:], 1, E, kv, R, 2 * E, E, bias=bc[E:]))
+            ops.gemm_f32_group(probs)
+            kv.view(B, Nv, 2 * E)[:, 1:, :E].add_(posk.view(-1, HW, E))                              # key_pos, patch keys only
+            dm1 = amask(HW)
+            # keys of sample b start at row b*Nv + 1: views that begin at row 1, batch stride Nv rows
+            o2, P1 = ops.attn_small_fwd(q, kv[1:, :E], kv[1:, E:], B, H, nq, HW, kpm=cfg.kpm, drop=dm1, kv_rows=Nv)
+        r2 = _f32(M, E, device=dev)
+        ops.gemm_f32(o2, E, 1, Wco, 1, E, r2, M, E, E, bias=bco, addend=t1, addend_rows=M)
+        t2, mean2, rstd2 = ln(r2, g1, b1n)
+        # ---- FFN: Linear, ReLU, dropout, Linear, dropout, + identity
+        h1 = _f32(M, Fd, device=dev)
+        ops.gemm_f32(t2, E, 1, W1, 1, E, h1, M, Fd, E, bias=b1, act=2)
+        r3 = _f32(M, E, device=dev)
+        if train and cfg.p_ffn > 0:
+            h1d, m1 = torch.native_dropout(h1, cfg.p_ffn, True)
+            h2 = _f32(M, E, device=dev)
+            ops.gemm_f32(h1d, Fd, 1, W2, 1, Fd, h2, M, E, Fd, bias=b2)
+            h2d, m2 = torch.native_dropout(h2, cfg.p_ffn, True)
+            torch.add(t2, h2d, out=r3)
+        else:
+            h1d, m1, m2 = h1, None, None
+            ops.gemm_f32(h1, Fd, 1, W2, 1, Fd, r3, M, E, Fd, bias=b2, addend=t2, addend_rows=M)
+        t3, mean3, rstd3 = ln(r3, g2, b2n)
+        hs = meanP = rstdP = None
+        if gP is not None:
+            hs, meanP, rstdP = ln(t3, gP, bP)
+        ctx.save_for_backward(tgt, x_qk, qkv, P0, dm0, o, r1, mean1, rstd1, xq, q, kv, P1, dm1, o2, r2, mean2, rstd2, t2,
+                              h1, h1d, m1, m2, r3, mean3, rstd3, t3, meanP, rstdP, xk, xv, mem, pos2,
+                              Ws, Wso, g0, Wc, Wco, g1, W1, W2, g2, gP)
+        ctx.cfg = cfg
+        ctx.set_materialize_grads(False)
+        return t3, hs
+
+    @staticmethod
+    def backward(ctx, d_t3, d_hs):
+        (tgt, x_qk, qkv, P0, dm0, o, r1, mean1, rstd1, xq, q, kv, P1, dm1, o2, r2, mean2, rstd2, t2, h1, h1d, m1, m2, r3,
+         mean3, rstd3, t3, meanP, rstdP, xk, xv, mem, pos2, Ws, Wso, g0, Wc, Wco, g1, W1, W2, g2, gP) = ctx.saved_tensors
+        cfg = ctx.cfg
+        dev = tgt.device
+        M, E = tgt.shape
+        Fd = W1.shape[0]
+        B, H, nq = cfg.B, cfg.H, cfg.nq
+        need = ctx.needs_input_grad
+        ones = _ones(M, dev)
+        mem_bf = cfg.kind == "mem" and mem.dtype == torch.bfloat16
+        # the one fill of this backward: LayerNorm gradients (atomics) and, with bf16 memory, the cross-attention in_proj
+        # gradient that the bf16 wgrad kernel accumulates into
+        z = torch.zeros(8 * E + (3 * E * E + 3 * E if mem_bf else 0), device=dev, dtype=torch.float32)
+        dg2, db2n, dg1, db1n, dg0, db0, dgP, dbP = (z[i * E:(i + 1) * E] for i in range(8))
+        if d_t3 is not None:
+            d_t3 = d_t3.contiguous()
+        if gP is not None and d_hs is not None:
+            dx = _f32(M, E, device=dev)
+            ops.ln_bwd(d_hs.contiguous(), t3, meanP, rstdP, gP, dgP, dbP, dres=d_t3, dx_f32=dx)
+            d_t3 = dx
+        else:
+            dgP = dbP = None
+        if d_t3 is None:
+            d_t3 = torch.zeros(M, E, device=dev, dtype=torch.float32)
+        # ---- FFN
+        d_r3 = _f32(M, E, device=dev)
+        ops.ln_bwd(d_t3, r3, mean3, rstd3, g2, dg2, db2n, dx_f32=d_r3)
+        scale = 1.0 / (1.0 - cfg.p_ffn) if m2 is not None else 1.0
+        d_h2 = torch.ops.aten.native_dropout_backward(d_r3, m2, scale) if m2 is not None else d_r3
+        d_h1 = _f32(M, Fd, device=dev)
+        dW2, db2 = _f32(E, Fd, device=dev), _f32(1, E, device=dev)
+        ops.gemm_f32_group([ops.gp(d_h2, E, 1, W2, Fd, 1, d_h1, M, Fd, E),
+                            ops.gp(d_h2, 1, E, h1d, Fd, 1, dW2, E, Fd, M),
+                            ops.gp(ones, 0, 1, d_h2, E, 1, db2, 1, E, M)])
+        if m1 is not None:
+            d_h1 = torch.ops.aten.native_dropout_backward(d_h1, m1, scale)
+        d_h1 = torch.ops.aten.threshold_backward(d_h1, h1, 0.0)
+        d_t2 = _f32(M, E, device=dev)
+        dW1, db1 = _f32(Fd, E, device=dev), _f32(1, Fd, device=dev)
+        ops.gemm_f32_group([ops.gp(d_h1, Fd, 1, W1, E, 1, d_t2, M, E, Fd, addend=d_r3, addend_rows=M),
+                            ops.gp(d_h1, 1, Fd, t2, E, 1, dW1, Fd, E, M),
+                            ops.gp(ones, 0, 1, d_h1, Fd, 1, db1, 1, Fd, M)])
+        # ---- cross-attention
+        d_r2 = _f32(M, E, device=dev)
+        ops.ln_bwd(d_t2, r2, mean2, rstd2, g1, dg1, db1n, dx_f32=d_r2)
+        d_o2 = _f32(M, E, device=dev)
+        dWco, dbco = _f32(E, E, device=dev), _f32(1, E, device=dev)
+        ops.gemm_f32_group([ops.gp(d_r2, E, 1, Wco, E, 1, d_o2, M, E, E),
+                            ops.gp(d_r2, 1, E, o2, E, 1, dWco, E, E, M),
+                            ops.gp(ones, 0, 1, d_r2, E, 1, dbco, 1, E, M)])
+        dq, dxq, d_t1 = _f32(M, E, device=dev), _f32(M, E, device=dev), _f32(M, E, device=dev)
+        dxk = dxv = dmem = None
+        if cfg.kind == "text":
+            R, Lk = xk.shape[0], cfg.Lk
+            dkv = _f32(R, 2 * E, device=dev)
+            ops.attn_small_bwd(q, kv[:, :E], kv[:, E:], P1, d_o2, dq, dkv[:, :E], dkv[:, E:], B, H, nq, Lk, kpm=cfg.kpm,
+                               drop=dm1, kv_rows=0)
+            dWc, dbc = _f32(3 * E, E, device=dev), _f32(1, 3 * E, device=dev)
+            probs = [ops.gp(dq, E, 1, Wc, E, 1, dxq, M, E, E),
+                     ops.gp(dq, E, 1, Wc, E, 1, d_t1, M, E, E, addend=d_r2, addend_rows=M),
+                     ops.gp(dq, 1, E, xq, E, 1, dWc, E, E, M),
+                     ops.gp(dkv, 1, 2 * E, xk, E, 1, dWc[E:], E, E, R),
+                     ops.gp(dkv[:, E:], 1, 2 * E, xv, E, 1, dWc[2 * E:], E, E, R),
+                     ops.gp(ones, 0, 1, dq, E, 1, dbc, 1, E, M),
+                     ops.gp(_ones(R, dev), 0, 1, dkv, 2 * E, 1, dbc[:, E:], 1, 2 * E, R)]
+            if need[2]:
+                dxk = _f32(R, E, device=dev)
+                probs.append(ops.gp(dkv, 2 * E, 1, Wc[E:], E, 1, dxk, R, E, E))
+            if need[3]:
+                dxv = _f32(R, E, device=dev)
+                probs.append(ops.gp(dkv[:, E:], 2 * E, 1, Wc[2 * E:], E, 1, dxv, R, E, E))
+            ops.gemm_f32_group(probs)
+        else:
+            Nv = cfg.Nv
+            HW, R = Nv - 1, B * Nv
+            dkv = _f32(R, 2 * E, device=dev)
+            dkv.view(B, Nv, 2 * E)[:, 0].zero_()                                         # CLS rows: not keys, no gradient
+            ops.attn_small_bwd(q, kv[1:, :E], kv[1:, E:], P1, d_o2, dq, dkv[1:, :E], dkv[1:, E:], B, H, nq, HW, kpm=cfg.kpm,
+                               drop=dm1, kv_rows=Nv)
+            if mem_bf:
+                dWc, dbc = z[8 * E:8 * E + 3 * E * E].view(3 * E, E), z[8 * E + 3 * E * E:].view(1, 3 * E)
+            else:
+                dWc, dbc = _f32(3 * E, E, device=dev), _f32(1, 3 * E, device=dev)
+            probs = [ops.gp(dq, E, 1, Wc, E, 1, dxq, M, E, E),
+                     ops.gp(dq, E, 1, Wc, E, 1, d_t1, M, E, E, addend=d_r2, addend_rows=M),
+                     ops.gp(dq, 1, E, xq, E, 1, dWc, E, E, M),
+                     ops.gp(ones, 0, 1, dq, E, 1, dbc, 1, E, M)]
+            if mem_bf:
+                ops.gemm_f32_group(probs)
+                dkvb = ops.cast_bf16(dkv)
+                if need[4]:
+                    dmem = ops.gemm_nt(dkvb, cfg.wbT)                                    # [R, E] bf16
+                ops.gemm_tn(dkvb, mem, dWc[E:], db=dbc[0, E:])
+            else:
+                if need[4]:
+                    dmem = _f32(R, E, device=dev)
+                    probs.append(ops.gp(dkv, 2 * E, 1, Wc[E:], E, 1, dmem, R, E, 2 * E))
+                probs.append(ops.gp(dkv, 1, 2 * E, mem, mem.stride(0), 1, dWc[E:], 2 * E, E, R))
+                probs.append(ops.gp(_ones(R, dev), 0, 1, dkv, 2 * E, 1, dbc[:, E:], 1, 2 * E, R))
+                ops.gemm_f32_group(probs)
+            dk3 = dkv.view(B, Nv, 2 * E)[:, 1:, :E]
+            dpk = dk3.sum(0) if cfg.pos.dim() == 2 else dk3.reshape(-1, E)               # d(pos Wk^T)
+            ops.gemm_f32(dpk, 1, E, pos2, E, 1, dWc[E:2 * E], E, E, pos2.shape[0], accumulate=True)
+        # ---- self-attention
+        d_r1 = _f32(M, E, device=dev)
+        ops.ln_bwd(d_t1, r1, mean1, rstd1, g0, dg0, db0, dx_f32=d_r1)
+        d_o = _f32(M, E, device=dev)
+        dWso, dbso = _f32(E, E, device=dev), _f32(1, E, device=dev)
+        ops.gemm_f32_group([ops.gp(d_r1, E, 1, Wso, E, 1, d_o, M, E, E),
+                            ops.gp(d_r1, 1, E, o, E, 1, dWso, E, E, M),
+                            ops.gp(ones, 0, 1, d_r1, E, 1, dbso, 1, E, M)])
+        dqkv = _f32(M, 3 * E, device=dev)
+        ops.attn_small_bwd(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], P0, d_o, dqkv[:, :E], dqkv[:, E:2 * E], dqkv[:, 2 * E:],
+                           B, H, nq, nq, kpm=None, drop=dm0, kv_rows=0)
+        d_qpos = _f32(M, E, device=dev)
+        dWs, dbs = _f32(3 * E, E, device=dev), _f32(1, 3 * E, device=dev)
+        probs = [ops.gp(dqkv, 3 * E, 1, Ws, E, 1, d_qpos, M, E, 2 * E, addend=dxq, addend_rows=M),   # dqk W_qk + dxq
+                 ops.gp(dqkv, 1, 3 * E, x_qk, E, 1, dWs, 2 * E, E, M),
+                 ops.gp(dqkv[:, 2 * E:], 1, 3 * E, tgt, E, 1, dWs[2 * E:], E, E, M),
+                 ops.gp(ones, 0, 1, dqkv, 3 * E, 1, dbs, 1, 3 * E, M)]
+        d_tgt = None
+        if need[0]:
+            d_tgt = _f32(M, E, device=dev)                                               # dqkv W_in (K = 3E) + d_r1
+            probs.append(ops.gp(dqkv, 3 * E, 1, Ws, E, 1, d_tgt, M, E, 3 * E, addend=d_r1, addend_rows=M))
+        ops.gemm_f32_group(probs)
+        return (d_tgt, d_qpos, dxk, dxv, dmem, dWs, dbs.view(3 * E), dWso, dbso.view(E), dg0, db0, dWc, dbc.view(3 * E), dWco,
+                dbco.view(E), dg1, db1n, dW1, db1.view(Fd), dW2, db2.view(E), dg2, db2n, dgP, dbP, None)
+
+
 class Criterion(torch.autograd.Function):
     """SetCriterion value + analytic gradients in one launch; `coef_mode`/`coef` carry the branch weight."""
 

@@ -16,8 +16,7 @@ import torch.nn.functional as F
 
 from ... import builder
 from .... import hip_ops as ops
-from ..functions import (Criterion, CrossAttnBlock, LayerNormF32, LinearBF16, LinearF32, MemCrossAttnBlock, SelfAttnBlock,
-                         SplitEncoderOutput)
+from ..functions import (Criterion, DecoderLayerFn, LayerCfg, LayerNormF32, LinearBF16, LinearF32, SplitEncoderOutput)
 
 
 def _xavier(*shape):
@@ -237,23 +236,24 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
     def _dropout(self, x):
         return F.dropout(x, self.ffn_dropout, self.training) if self.training and self.ffn_dropout > 0 else x
 
-    def _decoder_layer(self, L, tgt, qpos, B, nq, cross_kv):
-        """BaseTransformerLayer, post-norm order (self_attn, norm, cross_attn, norm, ffn, norm);
-        tgt/qpos [B*nq, E]; cross_kv(query rows, in_proj_weight, in_proj_bias) -> attention output [B*nq, E] (before
-        out_proj)."""
-        E, H = self.embed_dim, self.heads
-        a0 = L + "attentions.0.attn."
-        o = SelfAttnBlock.apply(tgt + qpos, tgt, self._P(a0 + "in_proj_weight"), self._P(a0 + "in_proj_bias"), B, H, nq,
-                                self._drop_mult((B, H, nq, nq), tgt.device))
-        o = LinearF32.apply(o, self._P(a0 + "out_proj.weight"), self._P(a0 + "out_proj.bias"), False)
-        tgt = self._ln(tgt + o, L + "norms.0")
-        a1 = L + "attentions.1.attn."
-        o = cross_kv(tgt + qpos, self._P(a1 + "in_proj_weight"), self._P(a1 + "in_proj_bias"))
-        o = LinearF32.apply(o, self._P(a1 + "out_proj.weight"), self._P(a1 + "out_proj.bias"), False)
-        tgt = self._ln(tgt + o, L + "norms.1")
-        h = LinearF32.apply(tgt, self._P(L + "ffns.0.layers.0.0.weight"), self._P(L + "ffns.0.layers.0.0.bias"), True)
-        h = LinearF32.apply(self._dropout(h), self._P(L + "ffns.0.layers.1.weight"), self._P(L + "ffns.0.layers.1.bias"), False)
-        return self._ln(tgt + self._dropout(h), L + "norms.2")
+    _LAYER_KEYS = ("attentions.0.attn.in_proj_weight", "attentions.0.attn.in_proj_bias", "attentions.0.attn.out_proj.weight",
+                   "attentions.0.attn.out_proj.bias", "norms.0.weight", "norms.0.bias",
+                   "attentions.1.attn.in_proj_weight", "attentions.1.attn.in_proj_bias", "attentions.1.attn.out_proj.weight",
+                   "attentions.1.attn.out_proj.bias", "norms.1.weight", "norms.1.bias",
+                   "ffns.0.layers.0.0.weight", "ffns.0.layers.0.0.bias", "ffns.0.layers.1.weight", "ffns.0.layers.1.bias",
+                   "norms.2.weight", "norms.2.bias")
+
+    def _decoder_layer(self, L, tgt, qpos, cfg, xk=None, xv=None, mem=None, post=None):
+        """BaseTransformerLayer, post-norm order (self_attn, norm, cross_attn, norm, ffn, norm) as one autograd node;
+        tgt / qpos [B*nq, E]; `post` = key prefix of a LayerNorm applied to the layer output (the decoder's shared
+        post_norm_layer) -> returns (layer output, post-normed output | None)."""
+        params = [self._P(L + k) for k in self._LAYER_KEYS]
+        gP, bP = (self._P(post + ".weight"), self._P(post + ".bias")) if post else (None, None)
+        return DecoderLayerFn.apply(tgt, qpos, xk, xv, mem, *params, gP, bP, cfg)
+
+    def _layer_cfg(self, B, kind, Lk, **kw):
+        return LayerCfg(B, self.heads, self.num_queries, kind, Lk, p_attn=self.attn_dropout, p_ffn=self.ffn_dropout,
+                        training=self.training, mask_fn=self._drop_mult, **kw)
 
     def _constants(self, device, T, hw):
         key = (str(device), T, hw)
@@ -316,14 +316,14 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
         tkpm = (text_mask != 0).to(torch.uint8).contiguous()
         tk_in = (text3 + c["tpos"][None]).reshape(B * T, E)
 
-        def text_cross(xq, W1, b1):
-            return CrossAttnBlock.apply(xq, tk_in, text, W1, b1, B, H, nq, T, tkpm, self._drop_mult((B, H, nq, T), device))
-
         tgt = torch.zeros(B * nq, E, device=device)
         pre = "text_guided_query_generation_transformer."
+        cfg_t = self._layer_cfg(B, "text", T, kpm=tkpm)
+        g = None
         for i in range(self.num_tgqg_layers):
-            tgt = self._decoder_layer(f"{pre}layers.{i}.", tgt, qpos, B, nq, text_cross)
-        g = self._ln(tgt, pre + "post_norm_layer")
+            last = i == self.num_tgqg_layers - 1
+            tgt, g = self._decoder_layer(f"{pre}layers.{i}.", tgt, qpos, cfg_t, xk=tk_in, xv=text,
+                                         post=pre + "post_norm_layer" if last else None)
         query_embed = g.view(B, nq, E) + filt[:, None, :] + qe[None]
         tok = (query_embed + cls[:, None, :]).reshape(B * nq, E)                      # Q5
         # ---- token branch (:411-420)
@@ -336,14 +336,12 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
         tgt = torch.zeros(B * nq, E, device=device)
         hs = []
         for i in range(self.num_decoder_layers):
-            def mem_cross(xq, W1, b1, i=i):
-                # K = (mem + pos) Wk^T + bk = mem Wk^T + bk + pos Wk^T ; V = mem Wv^T + bv   (key_pos only on K)
-                wb, wbT = (None, None) if exact else (self.wb[f"kv{i}"], self.wb[f"kvT{i}"])
-                return MemCrossAttnBlock.apply(xq, mem, W1, b1, pos2d, wb, wbT, B, H, nq, Nv, img_kpm,
-                                               self._drop_mult((B, H, nq, HW), device))
-
-            tgt = self._decoder_layer(f"transformer.decoder.layers.{i}.", tgt, qpos_d, B, nq, mem_cross)
-            hs.append(self._ln(tgt, "transformer.decoder.post_norm_layer"))
+            # K = (mem + pos) Wk^T + bk = mem Wk^T + bk + pos Wk^T ; V = mem Wv^T + bv   (key_pos only on K)
+            wb, wbT = (None, None) if exact else (self.wb[f"kv{i}"], self.wb[f"kvT{i}"])
+            cfg_m = self._layer_cfg(B, "mem", HW, kpm=img_kpm, pos=pos2d, wb=wb, wbT=wbT, Nv=Nv)
+            tgt, h = self._decoder_layer(f"transformer.decoder.layers.{i}.", tgt, qpos_d, cfg_m, mem=mem,
+                                         post="transformer.decoder.post_norm_layer")
+            hs.append(h)
         hs = torch.stack(hs).view(self.num_decoder_layers, B, nq, E)
         dec_logits = self._lin(hs, "class_embed_decoder")
         db = self._lin(self._lin(hs, "bbox_embed_decoder.layers.0", relu=True), "bbox_embed_decoder.layers.1", relu=True)
