@@ -45,29 +45,38 @@ def train_stream(device=None):
 
 
 class _HeadStep(torch.nn.Module):
-    """enc_out, text mask, packed targets -> (5 losses, 4 prediction tensors); parameters = the head's."""
+    """enc_out, text mask, packed targets -> (loss_total, 4 logged loss terms, 4 prediction tensors[, post-processed boxes
+    and classes of both branches]); parameters = the head's.  Only `loss_total` is differentiable: the other outputs are
+    detached, so the replayed backward takes one incoming gradient instead of materialising zeros for eight."""
 
-    def __init__(self, head, B, Nv, T, img_metas):
+    def __init__(self, head, B, Nv, T, img_metas, predict_fn=None):
         super().__init__()
         self.head = head
         self.geo = (B, Nv, T)
         self.img_metas = img_metas
+        self.predict_fn = predict_fn
 
     def forward(self, enc_out, text_mask, tboxes, tlabels, tcount, nums):
         B, Nv, T = self.geo
         out = self.head.forward_fused(enc_out, B, Nv, T, self.img_metas, text_mask)
         losses, _ = self.head.loss_from_targets(out, tboxes, tlabels, tcount, nums)
         t, d = out["token_branch_output"], out["decoder_branch_output"]
-        return (losses["loss_dgt"], losses["loss_tgt"], losses["loss_kd"], losses["loss_distill_w"], losses["loss_total"],
-                t["pred_logits"], t["pred_boxes"], d["pred_logits"], d["pred_boxes"])
+        res = (losses["loss_total"], losses["loss_dgt"].detach(), losses["loss_tgt"].detach(), losses["loss_kd"].detach(),
+               losses["loss_distill_w"].detach(), t["pred_logits"].detach(), t["pred_boxes"].detach(),
+               d["pred_logits"].detach(), d["pred_boxes"].detach())
+        if self.predict_fn is not None:
+            with torch.no_grad():      # get_predictions of both branches rides in the forward graph (no eager launches)
+                dec, tok = self.predict_fn(out, self.img_metas)
+            res = res + (dec["pred_bboxes"], dec["predict_classes"], tok["pred_bboxes"], tok["predict_classes"])
+        return res
 
 
-LOSS_KEYS = ("loss_dgt", "loss_tgt", "loss_kd", "loss_distill_w", "loss_total")
+LOSS_KEYS = ("loss_total", "loss_dgt", "loss_tgt", "loss_kd", "loss_distill_w")
 
 
 class HeadGraphs:
-    """Per-signature cache of graphed head steps; `run()` returns (losses dict, output dict for `_predict`) or None
-    when the step must run eagerly."""
+    """Per-signature cache of graphed head steps; `run()` returns (losses dict, output dict for `_predict`, predictions or
+    None) or None when the step must run eagerly."""
 
     def __init__(self, head, warm_steps=3):
         self.head = head
@@ -82,7 +91,9 @@ class HeadGraphs:
         return (tuple(enc_out.shape), enc_out.dtype, tuple(text_mask.shape), text_mask.dtype, tuple(tboxes.shape),
                 tuple(tuple(m["img_shape"][:2]) for m in img_metas), bool(training))
 
-    def run(self, enc_out, B, Nv, T, img_metas, text_mask, targets):
+    def run(self, enc_out, B, Nv, T, img_metas, text_mask, targets, predict_fn=None, sig_extra=()):
+        """`predict_fn(output, img_metas) -> [decoder prediction dict, token prediction dict]` (tensor-only, sync-free
+        post-processing) is captured with the forward when given; the third return value is then its result."""
         if self.disabled or not torch.is_grad_enabled() or not enc_out.requires_grad:
             return None
         if torch.cuda.current_stream(enc_out.device) == torch.cuda.default_stream(enc_out.device):
@@ -90,7 +101,7 @@ class HeadGraphs:
         if self.default_stream_seen:
             return None
         tboxes, tlabels, tcount, nums = targets
-        sig = self._signature(enc_out, text_mask, tboxes, img_metas, self.head.training)
+        sig = self._signature(enc_out, text_mask, tboxes, img_metas, self.head.training) + (predict_fn is not None,) + tuple(sig_extra)
         g = self.graphs.get(sig)
         if g is None:
             n = self.seen.get(sig, 0)
@@ -103,7 +114,7 @@ class HeadGraphs:
                     # them: an event query from that thread while this thread captures in global mode would abort the capture
                     torch.cuda.synchronize()
                     time.sleep(0.5)
-                mod = _HeadStep(self.head, B, Nv, T, [dict(m) for m in img_metas])
+                mod = _HeadStep(self.head, B, Nv, T, [dict(m) for m in img_metas], predict_fn)
                 mod.train(self.head.training)
                 sample = (enc_out.detach().clone().requires_grad_(True), text_mask.clone(), tboxes.clone(),
                           tlabels.clone(), tcount.clone(), nums.clone())
@@ -118,4 +129,8 @@ class HeadGraphs:
         losses = dict(zip(LOSS_KEYS, outs[:5]))
         output = dict(token_branch_output={"pred_logits": outs[5], "pred_boxes": outs[6]},
                       decoder_branch_output={"pred_logits": outs[7], "pred_boxes": outs[8]})
-        return losses, output
+        preds = None
+        if len(outs) > 9:
+            preds = [dict(pred_bboxes=outs[9], pred_masks=None, predict_classes=outs[10]),
+                     dict(pred_bboxes=outs[11], pred_masks=None, predict_classes=outs[12])]
+        return losses, output, preds

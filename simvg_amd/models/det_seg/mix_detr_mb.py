@@ -23,6 +23,7 @@ class MIXDETRMB(OneStageModel):
         # signature has repeated (simvg_amd/graphs.py); `head_graph=False` (or SIMVG_HEAD_GRAPH=0) keeps it eager
         self.head_graph = bool(head_graph) and os.environ.get("SIMVG_HEAD_GRAPH", "1") != "0"
         self._head_graphs = None
+        self._pp_const = {}
 
     def extract_visual_language(self, img, ref_expr_inds, text_attention_mask=None):
         return self.vis_enc(img, ref_expr_inds, text_attention_mask)
@@ -44,16 +45,24 @@ class MIXDETRMB(OneStageModel):
             if self._head_graphs is None:
                 from ...graphs import HeadGraphs
                 self._head_graphs = HeadGraphs(self.head)
-            graphed = self._head_graphs.run(enc_out, B, Nv, T, img_metas, text_attention_mask, targets)
+            # the single-box post-processing is sync-free tensor code: it is captured with the head's forward
+            grec = img_metas[0].get("target", None) is not None
+            fn = None
+            if not grec and self.head.num_queries == 1 and not rescale:
+                fn = (lambda out, metas: self._predict(out, metas, False))
+            graphed = self._head_graphs.run(enc_out, B, Nv, T, img_metas, text_attention_mask, targets, predict_fn=fn,
+                                              sig_extra=(bool(rescale),))
+        predictions = None
         if graphed is not None:
-            losses_dict, output = graphed
+            losses_dict, output, predictions = graphed
             self._last_output, self._last_detail = output, None
         else:
             output = self.head.forward_fused(enc_out, B, Nv, T, img_metas, text_attention_mask)
             losses_dict, detail = self.head.loss_from_targets(output, *targets)
             self._last_output, self._last_detail = output, detail     # debugging / parity tests
-        with torch.no_grad():
-            predictions = self._predict(output, img_metas, rescale)
+        if predictions is None:
+            with torch.no_grad():
+                predictions = self._predict(output, img_metas, rescale)
         return losses_dict, predictions
 
     @torch.no_grad()
@@ -69,17 +78,27 @@ class MIXDETRMB(OneStageModel):
         dec = fn(output["decoder_branch_output"], img_metas, rescale=rescale)
         return [dec, tok]   # index 0 = decoder branch, 1 = token branch (mix_detr_mb.py:69,123)
 
+    def _shape_consts(self, img_metas, device, rescale):
+        """[w, h, w, h] per image (and the scale factors when rescaling) as device tensors, cached per batch geometry: no
+        host-to-device copy in the steady state (and none inside a hipGraph capture)."""
+        key = (str(device), tuple(tuple(m["img_shape"][:2]) for m in img_metas),
+               tuple(tuple(float(x) for x in m["scale_factor"]) for m in img_metas) if rescale else None)
+        c = self._pp_const.get(key)
+        if c is None:
+            lim = torch.tensor([[m["img_shape"][1], m["img_shape"][0]] * 2 for m in img_metas], dtype=torch.float32).to(device)
+            sf = torch.tensor([list(m["scale_factor"]) for m in img_metas], dtype=torch.float32).to(device)[:, None, :] \
+                if rescale else None
+            if len(self._pp_const) >= 64:
+                self._pp_const.clear()
+            c = self._pp_const[key] = (lim, sf)
+        return c
+
     def _boxes(self, output, img_metas, rescale):
         box_cls, box_pred = output["pred_logits"].float(), output["pred_boxes"].float()
-        image_sizes = [m["img_shape"] for m in img_metas]
-        scores, labels, xyxy = self.head.inference(box_cls, box_pred, image_sizes)
-        lim = torch.tensor([[s[1], s[0], s[1], s[0]] for s in image_sizes], dtype=xyxy.dtype, device=xyxy.device)[:, None, :]
-        xyxy = torch.minimum(xyxy.clamp(min=0), lim)                      # detector_postprocess: clip to the image
+        lim, sf = self._shape_consts(img_metas, box_pred.device, rescale)
+        scores, labels, xyxy = self.head.inference(box_cls, box_pred, None, wh=lim)
+        xyxy = torch.minimum(xyxy.clamp(min=0), lim[:, None, :])          # detector_postprocess: clip to the image
         keep = ((xyxy[..., 2] - xyxy[..., 0]) > 0) & ((xyxy[..., 3] - xyxy[..., 1]) > 0)   # Boxes.nonempty()
-        if rescale:
-            sf = torch.tensor([m["scale_factor"] for m in img_metas], dtype=xyxy.dtype, device=xyxy.device)[:, None, :]
-        else:
-            sf = None
         return scores, labels, xyxy, keep, sf
 
     def get_predictions(self, output, img_metas, rescale=False):

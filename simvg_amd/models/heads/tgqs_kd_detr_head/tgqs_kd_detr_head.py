@@ -452,11 +452,13 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
         enc_out, B, Nv, T = self._encode_inputs(x_mm, cls_feat, text_feat)
         return self.forward_fused(enc_out, B, Nv, T, img_metas, text_mask)
 
-    def inference(self, box_cls, box_pred, image_sizes):
+    def inference(self, box_cls, box_pred, image_sizes, wh=None):
         """head.inference (:577-604): softmax, drop the no-object column, cxcywh -> xyxy * (w, h).
-        Returns (scores [B,nq], labels [B,nq], boxes_xyxy [B,nq,4]) instead of detectron2 Instances."""
+        Returns (scores [B,nq], labels [B,nq], boxes_xyxy [B,nq,4]) instead of detectron2 Instances.
+        `wh`: optional precomputed [B,4] device tensor of (w, h, w, h) per image (then `image_sizes` is not read)."""
         scores, labels = F.softmax(box_cls, dim=-1)[:, :, :-1].max(-1)
         cx, cy, w, h = box_pred.unbind(-1)
         xyxy = torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h], -1)
-        wh = torch.tensor([[s[1], s[0], s[1], s[0]] for s in image_sizes], dtype=xyxy.dtype, device=xyxy.device)
+        if wh is None:
+            wh = torch.tensor([[s[1], s[0], s[1], s[0]] for s in image_sizes], dtype=xyxy.dtype, device=xyxy.device)
         return scores, labels, xyxy * wh[:, None, :]
