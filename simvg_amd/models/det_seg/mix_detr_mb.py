@@ -16,12 +16,16 @@ from .base import OneStageModel
 
 @builder.MODELS.register_module()
 class MIXDETRMB(OneStageModel):
-    def __init__(self, word_emb, num_token, vis_enc, lan_enc, head, fusion, head_graph=True):
+    def __init__(self, word_emb, num_token, vis_enc, lan_enc, head, fusion, head_graph=False):
         super().__init__(word_emb, num_token, vis_enc, lan_enc, head, fusion)
         self.patch_size = vis_enc["patch_size"]
-        # replay the launch-bound head (+ matcher + criterion) forward/backward as two hipGraphs once a training input
-        # signature has repeated (simvg_amd/graphs.py); `head_graph=False` (or SIMVG_HEAD_GRAPH=0) keeps it eager
-        self.head_graph = bool(head_graph) and os.environ.get("SIMVG_HEAD_GRAPH", "1") != "0"
+        # optional: replay the head (+ matcher + criterion) forward / backward as two hipGraphs once a training input
+        # signature has repeated (simvg_amd/graphs.py).  Off by default: since the head's launch count was cut to ~45 per
+        # decoder layer the eager head keeps the host ahead of the GPU at every batch size, while replaying the backward
+        # graph blocks the host until the stream has drained (measured: profiles/r01_sweeps.md).  `head_graph=True` in the
+        # model cfg or SIMVG_HEAD_GRAPH=1 turns it on, SIMVG_HEAD_GRAPH=0 forces it off.
+        env = os.environ.get("SIMVG_HEAD_GRAPH")
+        self.head_graph = (bool(head_graph) or env == "1") and env != "0"
         self._head_graphs = None
         self._pp_const = {}
 

@@ -67,6 +67,7 @@ def test_graphed_head_draws_fresh_dropout_masks_and_falls_back_on_new_shapes():
     from test_tools_gpu import _tiny_model, _batch
     cfg, model = _tiny_model(4)
     model.vis_enc.drop_path_probs = [0.0] * model.vis_enc.L
+    model.head_graph = True
     model.train()
     batch = _batch(cfg, B=4, seed=1)
     vals = []
@@ -89,6 +90,7 @@ def test_graphed_head_draws_fresh_dropout_masks_and_falls_back_on_new_shapes():
 def test_default_stream_training_never_captures():
     from test_tools_gpu import _tiny_model, _batch
     cfg, model = _tiny_model(5)
+    model.head_graph = True
     model.train()
     batch = _batch(cfg, B=4, seed=1)
     for _ in range(6):
