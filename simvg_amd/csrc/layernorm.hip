@@ -362,6 +362,108 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const bf16_t* __restri
   }
 }
 
+// The hot instance of the wide backward -- ffn_layernorm of the encoder: x == gelu_u (bf16 fc1 pre-activation), bf16 dy,
+// bf16 dx, two-stage dgamma / dbeta.  Same 4-waves-per-row scheme as above, but the kernel is latency-bound (one row of
+// loads in flight per block is ~12 KB; measured 2.5 TB/s), so rows are prefetched TWO ahead and kept as raw bf16 pairs
+// (2 VGPRs per 4 values instead of 4) until they are consumed: twice the bytes in flight for the same registers.
+template <int NITW>
+__global__ __launch_bounds__(256) void ln_bwd_ffn_kernel(const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ u, int ldu,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ gamma, int gstride,
+                                                         bf16_t* __restrict__ out, int ldo, int M, int D, int split,
+                                                         int rows_per_block, int blocks0, float* __restrict__ partial) {
+  __shared__ float part[2][4][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int blk = blockIdx.x;
+  const int g = blk >= blocks0;
+  const int r_begin = g ? split + (blk - blocks0) * rows_per_block : blk * rows_per_block;
+  const int r_end = min(r_begin + rows_per_block, g ? M : split);
+  const float* gm = gamma + (long)g * gstride;
+  float gv[NITW][4], ag[NITW][4], ab[NITW][4];
+#pragma unroll
+  for (int it = 0; it < NITW; ++it) {
+    const int c = (it * 256 + tid) * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { ag[it][k] = 0.f; ab[it][k] = 0.f; gv[it][k] = 0.f; }
+    if (c < D) {
+      const f32x4_t t = *(const f32x4_t*)(gm + c);
+      gv[it][0] = t[0]; gv[it][1] = t[1]; gv[it][2] = t[2]; gv[it][3] = t[3];
+    }
+  }
+  const float invD = 1.f / (float)D;
+  u32x2_t dq[2][NITW], uq[2][NITW];
+  auto fetch = [&](int row, int slot) {
+#pragma unroll
+    for (int it = 0; it < NITW; ++it) {
+      const int c = (it * 256 + tid) * 4;
+      if (c < D) {
+        dq[slot][it] = *(const u32x2_t*)(dy + (long)row * lddy + c);
+        uq[slot][it] = *(const u32x2_t*)(u + (long)row * ldu + c);
+      }
+    }
+  };
+  if (r_begin < r_end) fetch(r_begin, 0);
+  if (r_begin + 1 < r_end) fetch(r_begin + 1, 1);
+  auto row_body = [&](int row, int par) {
+    const float mu = mean[row], rs = rstd[row];
+    float xh[NITW][4], dyv[NITW][4], uv[NITW][4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < NITW; ++it) {
+      const int c = (it * 256 + tid) * 4;
+      const bool in = c < D;
+      const u32x2_t dr = dq[par][it], ur = uq[par][it];
+      const float dv[4] = {__uint_as_float(dr[0] << 16), __uint_as_float(dr[0] & 0xffff0000u),
+                           __uint_as_float(dr[1] << 16), __uint_as_float(dr[1] & 0xffff0000u)};
+      const float uu[4] = {__uint_as_float(ur[0] << 16), __uint_as_float(ur[0] & 0xffff0000u),
+                           __uint_as_float(ur[1] << 16), __uint_as_float(ur[1] & 0xffff0000u)};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        dyv[it][k] = in ? dv[k] : 0.f;
+        float cdf, pdf;
+        gelu_parts(uu[k], cdf, pdf);
+        uv[it][k] = fmaf(uu[k], pdf, cdf);                      // GELU'(u)
+        xh[it][k] = in ? (uu[k] * cdf - mu) * rs : 0.f;         // LayerNorm input g = u * Phi(u), normalised
+        const float dg = dyv[it][k] * gv[it][k];
+        s1 += dg;
+        s2 += dg * xh[it][k];
+        ag[it][k] += dyv[it][k] * xh[it][k];
+        ab[it][k] += dyv[it][k];
+      }
+    }
+    if (row + 2 < r_end) fetch(row + 2, par);
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == 0) { part[par][wave][0] = s1; part[par][wave][1] = s2; }
+    __syncthreads();
+    const float c1 = ((part[par][0][0] + part[par][1][0]) + (part[par][2][0] + part[par][3][0])) * invD;
+    const float c2 = ((part[par][0][1] + part[par][1][1]) + (part[par][2][1] + part[par][3][1])) * invD;
+#pragma unroll
+    for (int it = 0; it < NITW; ++it) {
+      const int c = (it * 256 + tid) * 4;
+      if (c < D) {
+        float dx[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dx[k] = rs * (dyv[it][k] * gv[it][k] - c1 - xh[it][k] * c2) * uv[it][k];
+        st4_bf16(out + (long)row * ldo + c, dx);
+      }
+    }
+  };
+  // two rows per trip so that the prefetch slot is a compile-time index (a runtime-indexed register array would go
+  // to scratch)
+  int row = r_begin;
+  for (; row + 1 < r_end; row += 2) { row_body(row, 0); row_body(row + 1, 1); }
+  if (row < r_end) row_body(row, 0);
+  float* pp = partial + (long)blk * 2 * D;
+#pragma unroll
+  for (int it = 0; it < NITW; ++it) {
+    const int c = (it * 256 + tid) * 4;
+    if (c < D) {
+      *(f32x4_t*)(pp + c) = (f32x4_t){ag[it][0], ag[it][1], ag[it][2], ag[it][3]};
+      *(f32x4_t*)(pp + D + c) = (f32x4_t){ab[it][0], ab[it][1], ab[it][2], ab[it][3]};
+    }
+  }
+}
+
 // second stage: dgamma[g][c] += sum over the blocks of group g of partial[blk][0][c] (same for dbeta)
 __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, int gstride, int D, int blocks0,
@@ -473,9 +575,17 @@ extern "C" int simvg_ln_bwd(const void* dy_bf16, int dy_is_f32, int lddy, const 
                        ldx, mean, rstd, gamma, group_stride, dgamma, dbeta, (bf16_t*)dx_bf16, lddxb,                    \
                        (const bf16_t*)gelu_u_bf16, ldu, dres, dx_f32, lddxf, (bf16_t*)dx_scaled_bf16, lddxs, row_scale, \
                        rps0, rps1, M, D, split, rpb, blocks0, partial_ws)
-    if (x_is_bf16) { if (nitw <= 2) WCALL(bf16_t, 2); else if (nitw == 3) WCALL(bf16_t, 3); else WCALL(bf16_t, 4); }
+    static const int ffn_env = getenv("SIMVG_LN_FFN") ? atoi(getenv("SIMVG_LN_FFN")) : 1;
+    const bool ffn = ffn_env && x_is_bf16 && gelu_u_bf16 && gelu_u_bf16 == x && dx_bf16 && !dx_f32 && !dres && partial_ws &&
+                     (nitw == 3 || nitw == 4);
+#define FCALL_FFN(N_)                                                                                                   \
+    hipLaunchKernelGGL((ln_bwd_ffn_kernel<N_>), grid, block, 0, stream, (const bf16_t*)dy_bf16, lddy, (const bf16_t*)x,  \
+                       ldx, mean, rstd, gamma, group_stride, (bf16_t*)dx_bf16, lddxb, M, D, split, rpb, blocks0, partial_ws)
+    if (ffn) { if (nitw == 3) FCALL_FFN(3); else FCALL_FFN(4); }
+    else if (x_is_bf16) { if (nitw <= 2) WCALL(bf16_t, 2); else if (nitw == 3) WCALL(bf16_t, 3); else WCALL(bf16_t, 4); }
     else { if (nitw <= 2) WCALL(float, 2); else if (nitw == 3) WCALL(float, 3); else WCALL(float, 4); }
 #undef WCALL
+#undef FCALL_FFN
     if (partial_ws)
       hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(D, 64), 4), dim3(1024), 0, stream, partial_ws, dgamma, dbeta,
                          group_stride, D, blocks0, blocks1);
