@@ -224,6 +224,137 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
   }
 }
 
+// Narrow rows (one wave per row) with a software prefetch: the generic kernel above issues a row's loads when it needs
+// them and relies on occupancy alone (measured 1.7 - 3.4 TB/s); here every wave keeps its NEXT row in flight in raw
+// form (two register slots, rows alternate between them) while it works on the current one.  Instances: the residual
+// stream (fp32 x, + dres, fp32 dx and the bf16 copy for the next GEMM) and the attention sub-LayerNorm (bf16 x, bf16 dx).
+template <typename TIn, bool RES, int NIT>
+__global__ __launch_bounds__(256) void ln_bwd_pf_kernel(const bf16_t* __restrict__ dy, int lddy, const TIn* __restrict__ x, int ldx,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const float* __restrict__ gamma, int gstride,
+                                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                        bf16_t* __restrict__ out_bf16, int ldob,
+                                                        const float* __restrict__ dres, float* __restrict__ out_f32, int ldof,
+                                                        bf16_t* __restrict__ out_scaled, int ldos, const float* __restrict__ row_scale,
+                                                        int rps0, int rps1, int M, int D, int split, int rows_per_block, int blocks0) {
+  extern __shared__ float red[];  // [2][D]
+  constexpr bool XF = sizeof(TIn) == 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int blk = blockIdx.x;
+  const int g = blk >= blocks0;
+  const int r_begin = g ? split + (blk - blocks0) * rows_per_block : blk * rows_per_block;
+  const int r_end = min(r_begin + rows_per_block, g ? M : split);
+  const float* gm = gamma + (long)g * gstride;
+  float gv[NIT][4], ag[NIT][4], ab[NIT][4];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = (it * 64 + lane) * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { ag[it][k] = 0.f; ab[it][k] = 0.f; gv[it][k] = 0.f; }
+    if (c < D) {
+      const f32x4_t t = *(const f32x4_t*)(gm + c);
+      gv[it][0] = t[0]; gv[it][1] = t[1]; gv[it][2] = t[2]; gv[it][3] = t[3];
+    }
+  }
+  const float invD = 1.f / (float)D;
+  f32x4_t xf[2][XF ? NIT : 1], rq[2][RES ? NIT : 1];
+  u32x2_t xb[2][XF ? 1 : NIT], dq[2][NIT];
+  auto fetch = [&](int row, int slot) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = (it * 64 + lane) * 4;
+      if (c < D) {
+        if constexpr (XF) xf[slot][it] = *(const f32x4_t*)((const float*)x + (long)row * ldx + c);
+        else xb[slot][it] = *(const u32x2_t*)((const bf16_t*)x + (long)row * ldx + c);
+        dq[slot][it] = *(const u32x2_t*)(dy + (long)row * lddy + c);
+        if constexpr (RES) rq[slot][it] = *(const f32x4_t*)(dres + (long)row * ldof + c);
+      }
+    }
+  };
+  auto body = [&](int row, int slot) {
+    const float mu = mean[row], rs = rstd[row];
+    float xh[NIT][4], dyv[NIT][4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = (it * 64 + lane) * 4;
+      if (c < D) {
+        float xv[4];
+        if constexpr (XF) { const f32x4_t t = xf[slot][it]; xv[0] = t[0]; xv[1] = t[1]; xv[2] = t[2]; xv[3] = t[3]; }
+        else {
+          const u32x2_t t = xb[slot][it];
+          xv[0] = __uint_as_float(t[0] << 16); xv[1] = __uint_as_float(t[0] & 0xffff0000u);
+          xv[2] = __uint_as_float(t[1] << 16); xv[3] = __uint_as_float(t[1] & 0xffff0000u);
+        }
+        const u32x2_t d = dq[slot][it];
+        dyv[it][0] = __uint_as_float(d[0] << 16); dyv[it][1] = __uint_as_float(d[0] & 0xffff0000u);
+        dyv[it][2] = __uint_as_float(d[1] << 16); dyv[it][3] = __uint_as_float(d[1] & 0xffff0000u);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          xh[it][k] = (xv[k] - mu) * rs;
+          const float dg = dyv[it][k] * gv[it][k];
+          s1 += dg;
+          s2 += dg * xh[it][k];
+          ag[it][k] += dyv[it][k] * xh[it][k];
+          ab[it][k] += dyv[it][k];
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { xh[it][k] = 0.f; dyv[it][k] = 0.f; }
+      }
+    }
+    const float c1 = wave_sum(s1) * invD, c2 = wave_sum(s2) * invD;
+    float scl = 1.f;
+    if (RES && out_scaled && row_scale) scl = row_scale[g ? (row - split) / rps1 : row / rps0];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = (it * 64 + lane) * 4;
+      if (c < D) {
+        float dx[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dx[k] = rs * (dyv[it][k] * gv[it][k] - c1 - xh[it][k] * c2);
+        if constexpr (RES) {
+          const f32x4_t t = rq[slot][it];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) dx[k] += t[k];
+          *(f32x4_t*)(out_f32 + (long)row * ldof + c) = (f32x4_t){dx[0], dx[1], dx[2], dx[3]};
+          if (out_scaled) {
+            float t2[4] = {dx[0] * scl, dx[1] * scl, dx[2] * scl, dx[3] * scl};
+            st4_bf16(out_scaled + (long)row * ldos + c, t2);
+          }
+        } else {
+          st4_bf16(out_bf16 + (long)row * ldob + c, dx);
+        }
+      }
+    }
+    if (row + 8 < r_end) fetch(row + 8, slot);      // this wave's rows are r, r+4, r+8, ...: slots alternate
+  };
+  int row = r_begin + wave;
+  if (row < r_end) fetch(row, 0);
+  if (row + 4 < r_end) fetch(row + 4, 1);
+  for (; row + 4 < r_end; row += 8) { body(row, 0); body(row + 4, 1); }
+  if (row < r_end) body(row, 0);
+  float* rg = red;
+  float* rb = red + D;
+  for (int c = threadIdx.x; c < 2 * D; c += 256) red[c] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = (it * 64 + lane) * 4;
+    if (c < D) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { atomicAdd(&rg[c + k], ag[it][k]); atomicAdd(&rb[c + k], ab[it][k]); }
+    }
+  }
+  __syncthreads();
+  if (r_begin < r_end) {
+    for (int c = threadIdx.x; c < D; c += 256) {
+      atomicAdd(dgamma + (long)g * gstride + c, rg[c]);
+      atomicAdd(dbeta + (long)g * gstride + c, rb[c]);
+    }
+  }
+}
+
 // Wide rows (D >= 2048, e.g. the 3072-wide ffn_layernorm): the 4 waves of a block share ONE row (each lane owns
 // D/1024 float4 column groups), so the row costs 12 instead of 48+ live registers per array and the kernel runs at
 // full occupancy; the two row statistics cross waves through 32 B of LDS (one barrier per row, double-buffered).
@@ -591,6 +722,26 @@ extern "C" int simvg_ln_bwd(const void* dy_bf16, int dy_is_f32, int lddy, const 
                          group_stride, D, blocks0, blocks1);
     SIMVG_LAUNCH_CHECK();
     return SIMVG_OK;
+  }
+  {
+    static const int pf_env = getenv("SIMVG_LN_PF") ? atoi(getenv("SIMVG_LN_PF")) : 1;
+    const bool res = !x_is_bf16 && dres && dx_f32 && !dx_bf16;
+    const bool sub = x_is_bf16 && dx_bf16 && !dx_f32 && !dres;
+    const int nit_pf = (D + 255) / 256;
+    if (pf_env && dy_bf16 && !gelu_u_bf16 && !partial_ws && (nit_pf == 3 || nit_pf == 4) && (res || sub)) {
+#define PFCALL(T_, R_)                                                                                                  \
+      if (nit_pf == 3) PFCALL_N(T_, R_, 3); else PFCALL_N(T_, R_, 4)
+#define PFCALL_N(T_, R_, N_)                                                                                            \
+      hipLaunchKernelGGL((ln_bwd_pf_kernel<T_, R_, N_>), grid, block, shm, stream, (const bf16_t*)dy_bf16, lddy,       \
+                         (const T_*)x, ldx, mean, rstd, gamma, group_stride, dgamma, dbeta, (bf16_t*)dx_bf16, lddxb,    \
+                         dres, dx_f32, lddxf, (bf16_t*)dx_scaled_bf16, lddxs, row_scale, rps0, rps1, M, D, split, rpb,  \
+                         blocks0)
+      if (res) { PFCALL(float, true); } else { PFCALL(bf16_t, false); }
+#undef PFCALL
+#undef PFCALL_N
+      SIMVG_LAUNCH_CHECK();
+      return SIMVG_OK;
+    }
   }
 #define CALL(N_)                                                                                                        \
   if (x_is_bf16)                                                                                                        \
