@@ -9,4 +9,4 @@ cd $repo
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o p -- python bench.py --steps 10 --warmup 5 --no-cpu-baseline "$@" > /tmp/prof_$tag.log 2>&1
 grep '"metric"' /tmp/prof_$tag.log | cut -c1-260
 f=$(find /tmp/prof_$tag -name "*kernel_stats.csv" | head -1)
-python tools/dev/prof_summary.py "$f" 19 gpurun_out/${tag}_stats.csv "rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 5 $* (19 steps incl. 4 set-up steps without optimizer; head replayed as hipGraphs from step 4)"
+python tools/dev/prof_summary.py "$f" 19 gpurun_out/${tag}_stats.csv "rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 5 $* (19 steps incl. 4 set-up steps without optimizer; eager head)"
