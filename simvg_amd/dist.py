@@ -117,6 +117,16 @@ class GradReducer:
         if not self.active:
             return
         self._launch_head()              # models without an encoder hook (or a frozen encoder) reduce the head here
+        # safety net: a head gradient that the autograd engine accumulated only AFTER the early head message was packed
+        # (none with the current graph -- every head node is upstream of the encoder's backward node -- but a silent
+        # omission would desynchronise the replicas) goes in a second message
+        packed = {id(g) for g in self._head[0]}
+        late = [p.grad for n, p in self.model.named_parameters()
+                if not n.startswith("vis_enc.") and p.grad is not None and id(p.grad) not in packed]
+        late_flat = None
+        if late:
+            late_flat = torch.cat([g.reshape(-1) for g in late])
+            self._launch(late_flat)
         for w in self.pending:
             w.wait()
         for t in self._scale:
@@ -124,6 +134,8 @@ class GradReducer:
         grads, flat = self._head
         if grads:
             torch._foreach_copy_(grads, [v.view_as(g) for g, v in zip(grads, flat.split([g.numel() for g in grads]))])
+        if late_flat is not None:
+            torch._foreach_copy_(late, [v.view_as(g) for g, v in zip(late, late_flat.split([g.numel() for g in late]))])
         if self._text_rows is not None:
             table, ids, rows = self._text_rows
             table.index_copy_(0, ids, rows)

@@ -65,17 +65,21 @@ def _worker(rank, world, port, out):
     keep[ids.reshape(-1)] = True
     tg[~keep] = 0.0
     model.head.weight.grad = torch.randn(2, 8, generator=g)
-    model.head.bias.grad = torch.randn(2, generator=g)
-    local = (A.flat_grad.clone(), model.head.weight.grad.clone(), model.head.bias.grad.clone())
+    late_bias = torch.randn(2, generator=g)
+    local = (A.flat_grad.clone(), model.head.weight.grad.clone(), late_bias.clone())
     for i in reversed(range(model.vis_enc.L)):                     # what BEIT3._engine_backward does
         model.vis_enc._grad_ready_hook(i)
+        if i == model.vis_enc.L - 1:
+            model.head.bias.grad = late_bias      # a head gradient that lands AFTER the early head message was packed
     model.vis_enc._grad_ready_hook(-1)
     red.finish()
     gathered = [None] * world
     dist.all_gather_object(gathered, local)
     exp_flat = sum(x[0] for x in gathered) / world
     exp_w = sum(x[1] for x in gathered) / world
+    exp_b = sum(x[2] for x in gathered) / world
     ok = (torch.allclose(A.flat_grad, exp_flat, atol=1e-6) and torch.allclose(model.head.weight.grad, exp_w, atol=1e-6)
+          and torch.allclose(model.head.bias.grad, exp_b, atol=1e-6)
           and all(torch.equal(p.grad, A.grad(n)) for n, p in A.params.items()))
     out[rank] = bool(ok) and red.last_sparse_rows == 2 * 8       # the text table went as 2 ranks x 8 token rows
     dist.destroy_process_group()
