@@ -67,10 +67,10 @@ def synthetic_batch(B, seed, device):
                 gt_bbox=[gt[b] for b in range(B)])
 
 
-def cpu_baseline(batch_size=2, max_threads=32):
+def cpu_baseline(batch_size=8, max_threads=32):
     """The oracle's training step (forward_train + backward + clip + Adam amsgrad) on the host cores.
     Bounded sample: the thread count is capped (eager PyTorch on hundreds of threads is slower, not faster, for the
-    ~1400 small ops of this model -- measured 678 s/step with 256 threads) and one B=2 step is timed."""
+    ~1400 small ops of this model -- measured 678 s/step with 256 threads) and one B=8 step is timed (a few seconds)."""
     from oracle import simvg_cpu as O, weights as W
     torch.set_num_threads(max(1, min(os.cpu_count() or 1, max_threads)))
     cfg = O.make_cfg("base", 1, 640)
