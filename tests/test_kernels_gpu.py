@@ -253,6 +253,61 @@ def test_layernorm_of_recomputed_gelu(M, D, split):
     assert_close(dbeta, br.grad, 1e-4, "dbeta")
 
 
+@pytest.mark.parametrize("M,D,split", [(1500, 3072, 1390), (1037, 4096, 0), (1100, 3072, 0)])
+def test_ffn_layernorm_hot_kernels(M, D, split):
+    """The instances the encoder actually launches at training sizes (M >= 1024 rows, bf16-only outputs): the GELU-fused
+    forward and the two-row-prefetch backward with the two-stage dgamma / dbeta reduction -- ragged row counts and row
+    groups included."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + D)
+    u = (torch.randn(M, D, generator=g) * 1.5 + 0.3).to(torch.bfloat16).float()
+    ng = 2 if split else 1
+    gamma, beta = 1 + 0.2 * torch.randn(ng, D, generator=g), 0.1 * torch.randn(ng, D, generator=g)
+    sp = split if split else M
+    ur = u.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    a = F.gelu(ur)
+    y_ref = torch.cat([F.layer_norm(a[:sp], (D,), gr[0], br[0], 1e-5), F.layer_norm(a[sp:], (D,), gr[-1], br[-1], 1e-5)], 0)
+    ud = bf(u).to(DEV)
+    y, y32, mean, rstd = ops.ln_fwd(ud, gamma.to(DEV), beta.to(DEV), split=split, out_bf16=True, out_f32=False, gelu_in=True)
+    assert y32 is None
+    assert_close(y, y_ref, 1e-2, "ln(gelu(u)) fwd, bf16")
+    ad = a.detach().double()
+    assert_close(mean, ad.mean(1).float(), 1e-5, "row mean")
+    assert_close(rstd, (ad.var(1, unbiased=False) + 1e-5).rsqrt().float(), 1e-5, "row rstd")
+    dy = rnd_bf16(M, D, gen=g)
+    y_ref.backward(dy)
+    dgamma, dbeta = torch.zeros(ng, D, device=DEV), torch.zeros(ng, D, device=DEV)
+    dxb = torch.empty(M, D, device=DEV, dtype=torch.bfloat16)
+    ops.ln_bwd(bf(dy).to(DEV), ud, mean, rstd, gamma.to(DEV), dgamma, dbeta, split=split, dx_bf16=dxb, gelu_u=ud)
+    assert_close(dxb, ur.grad, 1e-2, "d/du of ln(gelu(u))")
+    assert_close(dgamma, gr.grad, 2e-4, "dgamma")
+    assert_close(dbeta, br.grad, 2e-4, "dbeta")
+
+
+@pytest.mark.parametrize("M,D,split", [(1203, 768, 1100), (77, 1024, 0)])
+def test_sub_layernorm_backward_prefetch_kernel(M, D, split):
+    """bf16 x, bf16 dy, bf16 dx only (the attention sub-LayerNorm instance of the prefetching backward)"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M)
+    x = rnd_bf16(M, D, gen=g, scale=2.0)
+    ng = 2 if split else 1
+    gamma, beta = 1 + 0.2 * torch.randn(ng, D, generator=g), 0.1 * torch.randn(ng, D, generator=g)
+    sp = split if split else M
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y_ref = torch.cat([F.layer_norm(xr[:sp], (D,), gr[0], br[0], 1e-5), F.layer_norm(xr[sp:], (D,), gr[-1], br[-1], 1e-5)], 0)
+    xd = bf(x).to(DEV)
+    _, _, mean, rstd = ops.ln_fwd(xd, gamma.to(DEV), beta.to(DEV), split=split, out_bf16=True, out_f32=False)
+    dy = rnd_bf16(M, D, gen=g)
+    y_ref.backward(dy)
+    dgamma, dbeta = torch.zeros(ng, D, device=DEV), torch.zeros(ng, D, device=DEV)
+    dxb = torch.empty(M, D, device=DEV, dtype=torch.bfloat16)
+    ops.ln_bwd(bf(dy).to(DEV), xd, mean, rstd, gamma.to(DEV), dgamma, dbeta, split=split, dx_bf16=dxb)
+    assert_close(dxb, xr.grad, 1e-2, "dx")
+    assert_close(dgamma, gr.grad, 2e-4, "dgamma")
+    assert_close(dbeta, br.grad, 2e-4, "dbeta")
+
+
 # ------------------------------------------------------------------------------------------
 # attention
 # ------------------------------------------------------------------------------------------
