@@ -684,6 +684,13 @@ struct GemmTNArgs {
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page[64];  // 256 B of zeros
 
+// XOR swizzle of the 16-B slots of a staged row (rows are a multiple of 256 B, i.e. bank-aligned).  A transposed
+// fragment read (`ds_read_b64_tr_b16`) is served 32 lanes per LDS cycle: lanes 0-15 take rows r..r+3, lanes 16-31 rows
+// r+8..r+11, each 16 columns wide.  (r & 3) << 1 spreads the 4 rows of a 16-lane group over 8 slots = 32 banks; bit 3
+// of the row moves the second group to the OTHER 32 banks -- without it the two groups met on the same banks and every
+// LDS access of the wgrad kernels was a 2-way conflict (PMC: SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE).
+__device__ __forceinline__ int tn_swz(int r) { return ((r & 3) << 1) ^ (((r >> 3) & 1) << 3); }
+
 // stage [64 m-rows][128 cols] bf16 (256 B rows): 16 wave-instructions (4 rows each), 4 per wave
 __device__ __forceinline__ void stage_tile_m64(const bf16_t* base, int ld, int m0, int m_end, int c0, int ncols,
                                                char* lds, int wave, int lane) {
@@ -691,7 +698,7 @@ __device__ __forceinline__ void stage_tile_m64(const bf16_t* base, int ld, int m
   for (int i = 0; i < 4; ++i) {
     const int inst = wave * 4 + i;
     const int r = inst * 4 + (lane >> 4);
-    const int lslot = (lane & 15) ^ ((r & 3) << 1);
+    const int lslot = (lane & 15) ^ tn_swz(r);
     const int row = m0 + r, col = c0 + lslot * 8;
     const bf16_t* src = (row < m_end && col < ncols) ? base + (long)row * ld + col
                                                       : (const bf16_t*)g_zero_page;
@@ -708,7 +715,7 @@ __device__ __forceinline__ bf16x8_t read_frag_tr(const char* lds, int ms, int c0
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int row = ms + 8 * g + 4 * h + (i >> 2);
-    const bf16x4_t v = lds_read_tr16(lds + row * 256 + ((lslot ^ ((row & 3) << 1)) << 4) + within);
+    const bf16x4_t v = lds_read_tr16(lds + row * 256 + ((lslot ^ tn_swz(row)) << 4) + within);
     out[4 * h + 0] = v[0]; out[4 * h + 1] = v[1]; out[4 * h + 2] = v[2]; out[4 * h + 3] = v[3];
   }
   return out;
@@ -849,7 +856,7 @@ __device__ __forceinline__ void stage_rows32(const bf16_t* base, int ld, int m0,
     const int inst = wave * per_wave + i;
     const int r = inst * rows_per_inst + lane / lanes_per_row;
     const int pslot = lane % lanes_per_row;
-    const int lslot = pslot ^ ((r & 3) << 1);
+    const int lslot = pslot ^ tn_swz(r);
     const int row = m0 + r, col = c0 + lslot * 8;
     const bf16_t* src = (row < m_end && col < ncols) ? base + (long)row * ld + col : (const bf16_t*)g_zero_page;
     __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds + inst * 1024), 16, 0, 0);
@@ -864,7 +871,7 @@ __device__ __forceinline__ bf16x8_t read_frag_tr_w(const char* lds, int row_byte
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int row = 8 * g + 4 * h + (i >> 2);
-    const bf16x4_t v = lds_read_tr16(lds + row * row_bytes + ((lslot ^ ((row & 3) << 1)) << 4) + within);
+    const bf16x4_t v = lds_read_tr16(lds + row * row_bytes + ((lslot ^ tn_swz(row)) << 4) + within);
     out[4 * h + 0] = v[0]; out[4 * h + 1] = v[1]; out[4 * h + 2] = v[2]; out[4 * h + 3] = v[3];
   }
   return out;
