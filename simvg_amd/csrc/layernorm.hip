@@ -7,6 +7,7 @@
 // nn.LayerNorm (transformer.py:47-49,119-121).  Rows [0,split) use gamma/beta group 0 ("A",
 // vision), rows [split,M) group 1 ("B", text).
 #include <stdlib.h>
+#include <algorithm>
 
 #include "common.h"
 
@@ -259,7 +260,11 @@ __global__ __launch_bounds__(256) void ln_bwd_pf_kernel(const bf16_t* __restrict
   const float invD = 1.f / (float)D;
   f32x4_t xf[2][XF ? NIT : 1], rq[2][RES ? NIT : 1];
   u32x2_t xb[2][XF ? 1 : NIT], dq[2][NIT];
+  float mu_q[2], rs_q[2];        // the row statistics travel with the prefetch: loaded at the top of the row they showed up
+                                 // as 24-31 % of the wave cycles in s_waitcnt lgkmcnt (PMC SQ_WAIT_INST_LDS)
   auto fetch = [&](int row, int slot) {
+    mu_q[slot] = mean[row];
+    rs_q[slot] = rstd[row];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int c = (it * 64 + lane) * 4;
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(256) void ln_bwd_pf_kernel(const bf16_t* __restrict
     }
   };
   auto body = [&](int row, int slot) {
-    const float mu = mean[row], rs = rstd[row];
+    const float mu = mu_q[slot], rs = rs_q[slot];
     float xh[NIT][4], dyv[NIT][4];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -523,7 +528,10 @@ __global__ __launch_bounds__(256) void ln_bwd_ffn_kernel(const bf16_t* __restric
   }
   const float invD = 1.f / (float)D;
   u32x2_t dq[2][NITW], uq[2][NITW];
+  float mu_q[2], rs_q[2];
   auto fetch = [&](int row, int slot) {
+    mu_q[slot] = mean[row];
+    rs_q[slot] = rstd[row];
 #pragma unroll
     for (int it = 0; it < NITW; ++it) {
       const int c = (it * 256 + tid) * 4;
@@ -536,7 +544,7 @@ __global__ __launch_bounds__(256) void ln_bwd_ffn_kernel(const bf16_t* __restric
   if (r_begin < r_end) fetch(r_begin, 0);
   if (r_begin + 1 < r_end) fetch(r_begin + 1, 1);
   auto row_body = [&](int row, int par) {
-    const float mu = mean[row], rs = rstd[row];
+    const float mu = mu_q[par], rs = rs_q[par];
     float xh[NITW][4], dyv[NITW][4], uv[NITW][4];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -729,13 +737,19 @@ extern "C" int simvg_ln_bwd(const void* dy_bf16, int dy_is_f32, int lddy, const 
     const bool sub = x_is_bf16 && dx_bf16 && !dx_f32 && !dres;
     const int nit_pf = (D + 255) / 256;
     if (pf_env && dy_bf16 && !gelu_u_bf16 && !partial_ws && (nit_pf == 3 || nit_pf == 4) && (res || sub)) {
+      // rows per block: the whole grid in ONE residency round (2-3 blocks of 4 waves per CU) -- with 32 rows the 842
+      // blocks of a B=64 step took two rounds, the second one a third full (sweep: 32 -> 93.7 / 64.9 us, 53-64 ->
+      // 77.4 / 46.6 us for the residual-stream / sub-LN instance)
+      const int rpb_pf = rpb_env ? rpb_env : std::max(32, (cdiv(M, 480) + 3) / 4 * 4);
+      const int pf_blocks0 = cdiv(split, rpb_pf), pf_blocks1 = cdiv(M - split, rpb_pf);
+      const dim3 pf_grid(pf_blocks0 + pf_blocks1);
 #define PFCALL(T_, R_)                                                                                                  \
       if (nit_pf == 3) PFCALL_N(T_, R_, 3); else PFCALL_N(T_, R_, 4)
 #define PFCALL_N(T_, R_, N_)                                                                                            \
-      hipLaunchKernelGGL((ln_bwd_pf_kernel<T_, R_, N_>), grid, block, shm, stream, (const bf16_t*)dy_bf16, lddy,       \
+      hipLaunchKernelGGL((ln_bwd_pf_kernel<T_, R_, N_>), pf_grid, block, shm, stream, (const bf16_t*)dy_bf16, lddy,    \
                          (const T_*)x, ldx, mean, rstd, gamma, group_stride, dgamma, dbeta, (bf16_t*)dx_bf16, lddxb,    \
-                         dres, dx_f32, lddxf, (bf16_t*)dx_scaled_bf16, lddxs, row_scale, rps0, rps1, M, D, split, rpb,  \
-                         blocks0)
+                         dres, dx_f32, lddxf, (bf16_t*)dx_scaled_bf16, lddxs, row_scale, rps0, rps1, M, D, split,       \
+                         rpb_pf, pf_blocks0)
       if (res) { PFCALL(float, true); } else { PFCALL(bf16_t, false); }
 #undef PFCALL
 #undef PFCALL_N
