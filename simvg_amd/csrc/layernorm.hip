@@ -649,6 +649,8 @@ __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __re
     else { CALL(16); }                                               \
   } while (0)
 
+static inline int ln_wide_rpb(int M) { return std::max(16, cdiv(M, 508)); }
+
 extern "C" int simvg_ln_fwd(const void* x, int x_is_bf16, int ldx, const float* gamma, const float* beta,
                             int group_stride, void* y_bf16, int ldy, float* y_f32, int ldy32, float* mean,
                             float* rstd, int M, int D, int split, float eps, int x_is_gelu_preact,
@@ -686,9 +688,10 @@ extern "C" int simvg_ln_bwd(const void* dy_bf16, int dy_is_f32, int lddy, const 
   if (split == 0) split = M;
   // partial_ws (optional, >= simvg_ln_bwd_ws_floats(M, D, split) floats): two-stage dgamma/dbeta reduction instead of
   // global atomics
-  // rows per block: 16 for the wide two-stage kernel, 32 for the wave-per-row kernels (sweep: profiles/r01_sweeps.md)
+  // rows per block: the wide two-stage kernel gets its grid into one residency round (2 blocks per CU; >= 16 rows),
+  // 32 for the generic wave-per-row kernels (sweeps: profiles/r01_sweeps.md)
   static const int rpb_env = getenv("SIMVG_LN_RPB") ? atoi(getenv("SIMVG_LN_RPB")) : 0;
-  const int rpb = rpb_env ? rpb_env : ((D >= 2048 && partial_ws) ? 16 : 32);
+  const int rpb = rpb_env ? rpb_env : ((D >= 2048 && partial_ws) ? ln_wide_rpb(M) : 32);
   const int blocks0 = cdiv(split, rpb), blocks1 = cdiv(M - split, rpb);
   const dim3 grid(blocks0 + blocks1), block(256);
   const size_t shm = (size_t)2 * D * sizeof(float);
@@ -779,6 +782,6 @@ extern "C" int simvg_ln_bwd(const void* dy_bf16, int dy_is_f32, int lddy, const 
 
 extern "C" long simvg_ln_bwd_ws_floats(int M, int D, int split) {
   if (split == 0) split = M;
-  const int rpb = getenv("SIMVG_LN_RPB") ? atoi(getenv("SIMVG_LN_RPB")) : (D >= 2048 ? 16 : 32);
+  const int rpb = getenv("SIMVG_LN_RPB") ? atoi(getenv("SIMVG_LN_RPB")) : (D >= 2048 ? ln_wide_rpb(M) : 32);
   return (long)(cdiv(split, rpb) + cdiv(M - split, rpb)) * 2 * D;
 }
