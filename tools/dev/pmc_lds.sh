@@ -3,7 +3,7 @@
 filt=$1; shift
 export TMPDIR=/tmp
 rm -rf /tmp/pmc_lds
-rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d /tmp/pmc_lds -o p -- "$@" > /tmp/pmc_lds.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d /tmp/pmc_lds -o p -- "$@" > /tmp/pmc_lds.log 2>&1
 python - "$filt" <<'PY'
 import csv, glob, collections, sys
 f = glob.glob("/tmp/pmc_lds/*counter_collection.csv")
