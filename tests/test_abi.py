@@ -36,6 +36,17 @@ def test_argument_errors_are_reported_not_thrown():
     assert b"multiple of 64" in lib.simvg_last_error()
 
 
+def test_grouped_gemm_rejects_bad_problem_lists():
+    import ctypes as C
+    from simvg_amd import _lib
+    lib = _lib.load()
+    assert lib.simvg_gemm_f32_grouped(None, 0, None) < 0 and b"problems" in lib.simvg_last_error()
+    arr = (_lib.GemmF32Problem * 13)()
+    assert lib.simvg_gemm_f32_grouped(C.byref(arr), 13, None) < 0            # more than 12 problems per launch
+    one = (_lib.GemmF32Problem * 1)()                                         # M = N = K = 0
+    assert lib.simvg_gemm_f32_grouped(C.byref(one), 1, None) < 0 and b"empty problem" in lib.simvg_last_error()
+
+
 def test_product_refuses_cpu_tensors():
     import pytest
     import torch
