@@ -134,167 +134,6 @@ def _f32(*shape, device):
     return torch.empty(*shape, device=device, dtype=torch.float32)
 
 
-class SelfAttnBlock(torch.autograd.Function):
-    """in_proj + attention core of an nn.MultiheadAttention self-attention (detrex `MultiheadAttention`, query = key =
-    x + query_pos, value = x): q|k = x_qk W[:2E]^T + b[:2E], v = x_v W[2E:]^T + b[2E:], softmax(q k^T / sqrt(32)) v per
-    (sample, head).  ONE autograd node: the gradient of the packed in_proj_weight / in_proj_bias is produced whole
-    (row blocks written by their own GEMMs) instead of being assembled from sliced views by ~15 fill / copy / add
-    launches."""
-
-    @staticmethod
-    def forward(ctx, x_qk, x_v, W, b, B, H, L, drop):
-        x_qk, x_v = x_qk.contiguous(), x_v.contiguous()
-        M, E = x_v.shape
-        qkv = _f32(M, 3 * E, device=x_v.device)
-        ops.gemm_f32(x_qk, E, 1, W, 1, E, qkv, M, 2 * E, E, bias=b)
-        ops.gemm_f32(x_v, E, 1, W[2 * E:], 1, E, qkv[:, 2 * E:], M, E, E, bias=b[2 * E:])
-        out, P = ops.attn_small_fwd(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], B, H, L, L, kpm=None, drop=drop, kv_rows=0)
-        ctx.save_for_backward(x_qk, x_v, W, qkv, P, drop)
-        ctx.geo = (B, H, L)
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        x_qk, x_v, W, qkv, P, drop = ctx.saved_tensors
-        B, H, L = ctx.geo
-        M, E = x_v.shape
-        dev = dout.device
-        dqkv = _f32(M, 3 * E, device=dev)
-        ops.attn_small_bwd(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], P, dout.contiguous(), dqkv[:, :E], dqkv[:, E:2 * E],
-                           dqkv[:, 2 * E:], B, H, L, L, kpm=None, drop=drop, kv_rows=0)
-        dW, db = _f32(3 * E, E, device=dev), _f32(1, 3 * E, device=dev)
-        ops.gemm_f32(dqkv, 1, 3 * E, x_qk, E, 1, dW, 2 * E, E, M)                   # dW[:2E] = dqk^T x_qk
-        ops.gemm_f32(dqkv[:, 2 * E:], 1, 3 * E, x_v, E, 1, dW[2 * E:], E, E, M)     # dW[2E:] = dv^T x_v
-        ops.gemm_f32(_ones(M, dev), 0, 1, dqkv, 3 * E, 1, db, 1, 3 * E, M)          # db = 1^T dqkv
-        dx_qk = dx_v = None
-        if ctx.needs_input_grad[0]:
-            dx_qk = _f32(M, E, device=dev)
-            ops.gemm_f32(dqkv, 3 * E, 1, W, E, 1, dx_qk, M, E, 2 * E)
-        if ctx.needs_input_grad[1]:
-            dx_v = _f32(M, E, device=dev)
-            ops.gemm_f32(dqkv[:, 2 * E:], 3 * E, 1, W[2 * E:], E, 1, dx_v, M, E, E)
-        return dx_qk, dx_v, dW, db.view(3 * E), None, None, None, None
-
-
-class CrossAttnBlock(torch.autograd.Function):
-    """in_proj + core of a cross-attention whose keys / values are fp32 rows (the TGQG layer's text cross-attention):
-    q = xq W[:E]^T + b[:E] on B*Lq rows, k = xk W[E:2E]^T + b[E:2E], v = xv W[2E:]^T + b[2E:] on B*Lk rows."""
-
-    @staticmethod
-    def forward(ctx, xq, xk, xv, W, b, B, H, Lq, Lk, kpm, drop):
-        xq, xk, xv = xq.contiguous(), xk.contiguous(), xv.contiguous()
-        M, E = xq.shape
-        R = xk.shape[0]
-        q, kv = _f32(M, E, device=xq.device), _f32(R, 2 * E, device=xq.device)
-        ops.gemm_f32(xq, E, 1, W, 1, E, q, M, E, E, bias=b)
-        ops.gemm_f32(xk, E, 1, W[E:], 1, E, kv, R, E, E, bias=b[E:])
-        ops.gemm_f32(xv, E, 1, W[2 * E:], 1, E, kv[:, E:], R, E, E, bias=b[2 * E:])
-        out, P = ops.attn_small_fwd(q, kv[:, :E], kv[:, E:], B, H, Lq, Lk, kpm=kpm, drop=drop, kv_rows=0)
-        ctx.save_for_backward(xq, xk, xv, W, q, kv, P, kpm, drop)
-        ctx.geo = (B, H, Lq, Lk)
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        xq, xk, xv, W, q, kv, P, kpm, drop = ctx.saved_tensors
-        B, H, Lq, Lk = ctx.geo
-        M, E = xq.shape
-        R = xk.shape[0]
-        dev = dout.device
-        dq, dkv = _f32(M, E, device=dev), _f32(R, 2 * E, device=dev)
-        ops.attn_small_bwd(q, kv[:, :E], kv[:, E:], P, dout.contiguous(), dq, dkv[:, :E], dkv[:, E:], B, H, Lq, Lk,
-                           kpm=kpm, drop=drop, kv_rows=0)
-        dW, db = _f32(3 * E, E, device=dev), _f32(1, 3 * E, device=dev)
-        ops.gemm_f32(dq, 1, E, xq, E, 1, dW, E, E, M)
-        ops.gemm_f32(dkv, 1, 2 * E, xk, E, 1, dW[E:], E, E, R)
-        ops.gemm_f32(dkv[:, E:], 1, 2 * E, xv, E, 1, dW[2 * E:], E, E, R)
-        ops.gemm_f32(_ones(M, dev), 0, 1, dq, E, 1, db, 1, E, M)
-        ops.gemm_f32(_ones(R, dev), 0, 1, dkv, 2 * E, 1, db[:, E:], 1, 2 * E, R)
-        dxq = dxk = dxv = None
-        if ctx.needs_input_grad[0]:
-            dxq = _f32(M, E, device=dev)
-            ops.gemm_f32(dq, E, 1, W, E, 1, dxq, M, E, E)
-        if ctx.needs_input_grad[1]:
-            dxk = _f32(R, E, device=dev)
-            ops.gemm_f32(dkv, 2 * E, 1, W[E:], E, 1, dxk, R, E, E)
-        if ctx.needs_input_grad[2]:
-            dxv = _f32(R, E, device=dev)
-            ops.gemm_f32(dkv[:, E:], 2 * E, 1, W[2 * E:], E, 1, dxv, R, E, E)
-        return dxq, dxk, dxv, dW, db.view(3 * E), None, None, None, None, None, None
-
-
-class MemCrossAttnBlock(torch.autograd.Function):
-    """in_proj + core of a decoder layer's cross-attention over the image memory (transformer.py:134-186 via detrex
-    `MultiheadAttention`: key = memory + key_pos, value = memory).  mem [B*Nv, E] holds every vision row (the CLS row of
-    each sample is carried along and never used as a key); K = mem Wk^T + bk + pos Wk^T, V = mem Wv^T + bv.
-    mem bf16 -> the K|V projection, its dgrad and wgrad run on the bf16 MFMA GEMMs (wb = bf16 W[E:], wbT its transpose);
-    mem fp32 (precision="fp32") -> exact fp32 GEMMs.  pos: [HW, E] shared by the batch or [B, HW, E]."""
-
-    @staticmethod
-    def forward(ctx, xq, mem, W, b, pos, wb, wbT, B, H, Lq, Nv, kpm, drop):
-        xq = xq.contiguous()
-        M, E = xq.shape
-        HW = Nv - 1
-        dev = xq.device
-        q = _f32(M, E, device=dev)
-        ops.gemm_f32(xq, E, 1, W, 1, E, q, M, E, E, bias=b)
-        if mem.dtype == torch.bfloat16:
-            kv = ops.gemm_nt(mem, wb, bias=b[E:], out_dtype=torch.float32)               # [B*Nv, 2E]
-        else:
-            kv = _f32(B * Nv, 2 * E, device=dev)
-            ops.gemm_f32(mem, mem.stride(0), 1, W[E:], 1, E, kv, B * Nv, 2 * E, E, bias=b[E:])
-        pos2 = pos.reshape(-1, E)
-        posk = _f32(pos2.shape[0], E, device=dev)
-        ops.gemm_f32(pos2, E, 1, W[E:], 1, E, posk, pos2.shape[0], E, E)
-        kv.view(B, Nv, 2 * E)[:, 1:, :E].add_(posk.view(-1, HW, E))                      # key_pos on the patch keys only
-        # keys of sample b start at row b*Nv + 1: views that begin at row 1, batch stride Nv rows
-        out, P = ops.attn_small_fwd(q, kv[1:, :E], kv[1:, E:], B, H, Lq, HW, kpm=kpm, drop=drop, kv_rows=Nv)
-        ctx.save_for_backward(xq, mem, W, pos2, wbT, q, kv, P, kpm, drop)
-        ctx.geo = (B, H, Lq, Nv, pos.dim() == 2)
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        xq, mem, W, pos2, wbT, q, kv, P, kpm, drop = ctx.saved_tensors
-        B, H, Lq, Nv, shared_pos = ctx.geo
-        M, E = xq.shape
-        HW, R = Nv - 1, B * Nv
-        dev = dout.device
-        dq, dkv = _f32(M, E, device=dev), _f32(R, 2 * E, device=dev)
-        dkv.view(B, Nv, 2 * E)[:, 0].zero_()                                             # CLS rows: not keys, no gradient
-        ops.attn_small_bwd(q, kv[1:, :E], kv[1:, E:], P, dout.contiguous(), dq, dkv[1:, :E], dkv[1:, E:], B, H, Lq, HW,
-                           kpm=kpm, drop=drop, kv_rows=Nv)
-        dmem = None
-        bf = mem.dtype == torch.bfloat16
-        if bf:
-            dW = torch.zeros(3 * E, E, device=dev, dtype=torch.float32)                  # gemm_tn accumulates
-            db = torch.zeros(1, 3 * E, device=dev, dtype=torch.float32)
-        else:
-            dW, db = _f32(3 * E, E, device=dev), _f32(1, 3 * E, device=dev)
-        # the memory-row side: rows [E:] of dW / db
-        if bf:
-            dkvb = ops.cast_bf16(dkv)
-            if ctx.needs_input_grad[1]:
-                dmem = ops.gemm_nt(dkvb, wbT)                                        # [R, E] bf16
-            ops.gemm_tn(dkvb, mem, dW[E:], db=db[0, E:])
-        else:
-            if ctx.needs_input_grad[1]:
-                dmem = _f32(R, E, device=dev)
-                ops.gemm_f32(dkv, 2 * E, 1, W[E:], E, 1, dmem, R, E, 2 * E)
-            ops.gemm_f32(dkv, 1, 2 * E, mem, mem.stride(0), 1, dW[E:], 2 * E, E, R)
-            ops.gemm_f32(_ones(R, dev), 0, 1, dkv, 2 * E, 1, db[:, E:], 1, 2 * E, R)
-        dk3 = dkv.view(B, Nv, 2 * E)[:, 1:, :E]
-        dpk = dk3.sum(0) if shared_pos else dk3.reshape(-1, E)                       # d(pos Wk^T)
-        ops.gemm_f32(dpk, 1, E, pos2, E, 1, dW[E:2 * E], E, E, pos2.shape[0], accumulate=True)
-        dxq = None
-        if ctx.needs_input_grad[0]:                                                      # the query-row side: rows [:E]
-            dxq = _f32(M, E, device=dev)
-            ops.gemm_f32(dq, E, 1, W, E, 1, dxq, M, E, E)
-        ops.gemm_f32(dq, 1, E, xq, E, 1, dW, E, E, M)
-        ops.gemm_f32(_ones(M, dev), 0, 1, dq, E, 1, db, 1, E, M)
-        return dxq, dmem, dW, db.view(3 * E), None, None, None, None, None, None, None, None, None
-
-
 class LayerCfg:
     """non-tensor arguments of `DecoderLayerFn` (geometry, cross-attention flavour and its gradient-free operands)"""
 

@@ -188,74 +188,74 @@ def _mha_ref(xq, xk, xv, W, b, B, H, Lq, Lk, kpm=None, dm=None):
     return (w @ v).transpose(1, 2).reshape(B * Lq, E)
 
 
-@pytest.mark.parametrize("B,L,drop", [(4, 1, False), (3, 10, True)])
-def test_self_attn_block_fwd_bwd(B, L, drop):
-    from simvg_amd.models.heads.functions import SelfAttnBlock
-    H, E = 8, 256
-    g = torch.Generator().manual_seed(7 * B + L)
-    x_qk, x_v = torch.randn(B * L, E, generator=g), torch.randn(B * L, E, generator=g)
-    W, b = torch.randn(3 * E, E, generator=g) * E ** -0.5, torch.randn(3 * E, generator=g) * 0.1
-    dm = (torch.bernoulli(torch.full((B, H, L, L), 0.9), generator=g) / 0.9) if drop else None
-    dout = torch.randn(B * L, E, generator=g)
-    ref_in = [t.clone().requires_grad_(True) for t in (x_qk, x_v, W, b)]
-    _mha_ref(ref_in[0], ref_in[0], ref_in[1], ref_in[2], ref_in[3], B, H, L, L, dm=dm).backward(dout)
-    dev_in = [t.clone().to(DEV).requires_grad_(True) for t in (x_qk, x_v, W, b)]
-    out = SelfAttnBlock.apply(*dev_in, B, H, L, None if dm is None else dm.to(DEV))
-    out.backward(dout.to(DEV))
-    close(out, _mha_ref(x_qk, x_qk, x_v, W, b, B, H, L, L, dm=dm), 1e-5, "out")
-    for name, d, r in zip(("dx_qk", "dx_v", "dW", "db"), dev_in, ref_in):
-        close(d.grad, r.grad, 2e-5, name)
+def _ref_decoder_layer(tgt, qpos, P, B, H, nq, kind, xk=None, xv=None, mem=None, pos=None, kpm=None, post=None):
+    """post-norm DETR decoder layer in plain fp32 PyTorch (eval mode: no dropout); P = the 18 layer parameters"""
+    (Ws, bs, Wso, bso, g0, b0, Wc, bc, Wco, bco, g1, b1n, W1, b1, W2, b2, g2, b2n) = P
+    E = tgt.shape[1]
+    x_qk = tgt + qpos
+    o = _mha_ref(x_qk, x_qk, tgt, Ws, bs, B, H, nq, nq)
+    t1 = F.layer_norm(tgt + F.linear(o, Wso, bso), (E,), g0, b0, 1e-5)
+    xq = t1 + qpos
+    if kind == "text":
+        Lk = xk.shape[0] // B
+        o2 = _mha_ref(xq, xk, xv, Wc, bc, B, H, nq, Lk, kpm=kpm)
+    else:
+        Nv = mem.shape[0] // B
+        patches = mem.view(B, Nv, E)[:, 1:]
+        keys = (patches + (pos[None] if pos.dim() == 2 else pos)).reshape(-1, E)
+        o2 = _mha_ref(xq, keys, patches.reshape(-1, E), Wc, bc, B, H, nq, Nv - 1, kpm=kpm)
+    t2 = F.layer_norm(t1 + F.linear(o2, Wco, bco), (E,), g1, b1n, 1e-5)
+    t3 = F.layer_norm(t2 + F.linear(F.relu(F.linear(t2, W1, b1)), W2, b2), (E,), g2, b2n, 1e-5)
+    hs = F.layer_norm(t3, (E,), post[0], post[1], 1e-5) if post is not None else None
+    return t3, hs
 
 
-def test_cross_attn_block_fwd_bwd():
-    from simvg_amd.models.heads.functions import CrossAttnBlock
-    B, H, E, Lq, Lk = 3, 8, 256, 10, 20
-    g = torch.Generator().manual_seed(3)
-    xq, xk, xv = (torch.randn(B * n, E, generator=g) for n in (Lq, Lk, Lk))
-    W, b = torch.randn(3 * E, E, generator=g) * E ** -0.5, torch.randn(3 * E, generator=g) * 0.1
-    kpm = torch.zeros(B, Lk, dtype=torch.uint8)
-    kpm[1, 12:] = 1
-    dm = torch.bernoulli(torch.full((B, H, Lq, Lk), 0.9), generator=g) / 0.9
-    dout = torch.randn(B * Lq, E, generator=g)
-    ref_in = [t.clone().requires_grad_(True) for t in (xq, xk, xv, W, b)]
-    _mha_ref(*ref_in, B, H, Lq, Lk, kpm=kpm, dm=dm).backward(dout)
-    dev_in = [t.clone().to(DEV).requires_grad_(True) for t in (xq, xk, xv, W, b)]
-    out = CrossAttnBlock.apply(*dev_in, B, H, Lq, Lk, kpm.to(DEV), dm.to(DEV))
-    out.backward(dout.to(DEV))
-    close(out, _mha_ref(xq, xk, xv, W, b, B, H, Lq, Lk, kpm=kpm, dm=dm), 1e-5, "out")
-    for name, d, r in zip(("dxq", "dxk", "dxv", "dW", "db"), dev_in, ref_in):
-        close(d.grad, r.grad, 2e-5, name)
-
-
-@pytest.mark.parametrize("shared_pos", [True, False])
-def test_mem_cross_attn_block_fp32_fwd_bwd(shared_pos):
-    """the exact (fp32-memory) flavour against plain PyTorch: key = memory + key_pos on the patch rows, value = memory,
-    the CLS row of every sample is carried but never attended to"""
-    from simvg_amd.models.heads.functions import MemCrossAttnBlock
-    B, H, E, Lq, HW = 2, 8, 256, 3, 16
+@pytest.mark.parametrize("kind,nq,shared_pos", [("text", 1, True), ("text", 10, True), ("mem", 3, True), ("mem", 1, False)])
+def test_decoder_layer_node_fwd_bwd(kind, nq, shared_pos):
+    """The whole decoder layer as ONE autograd node (grouped GEMM launches, residuals in epilogues, hand-sequenced
+    backward) against a plain PyTorch layer: both outputs and the gradient of every input and parameter.  fp32 memory for
+    the "mem" flavour (the bf16-memory flavour is covered end to end against the reference model in test_model_gpu)."""
+    from simvg_amd.models.heads.functions import DecoderLayerFn, LayerCfg
+    B, H, E, Fd, T, HW = 3, 8, 256, 512, 20, 16
     Nv = HW + 1
-    g = torch.Generator().manual_seed(9)
-    xq, mem = torch.randn(B * Lq, E, generator=g), torch.randn(B * Nv, E, generator=g)
-    pos = torch.randn(HW, E, generator=g) if shared_pos else torch.randn(B, HW, E, generator=g)
-    W, b = torch.randn(3 * E, E, generator=g) * E ** -0.5, torch.randn(3 * E, generator=g) * 0.1
-    kpm = None
-    if not shared_pos:
-        kpm = torch.zeros(B, HW, dtype=torch.uint8)
-        kpm[0, 10:] = 1
-    dout = torch.randn(B * Lq, E, generator=g)
+    g = torch.Generator().manual_seed(17 + nq)
+    r = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
+    tgt, qpos = r(B * nq, E), r(B * nq, E)
+    P = [r(3 * E, E, sc=E ** -0.5), r(3 * E, sc=0.1), r(E, E, sc=E ** -0.5), r(E, sc=0.1), 1 + r(E, sc=0.1), r(E, sc=0.1),
+         r(3 * E, E, sc=E ** -0.5), r(3 * E, sc=0.1), r(E, E, sc=E ** -0.5), r(E, sc=0.1), 1 + r(E, sc=0.1), r(E, sc=0.1),
+         r(Fd, E, sc=E ** -0.5), r(Fd, sc=0.1), r(E, Fd, sc=Fd ** -0.5), r(E, sc=0.1), 1 + r(E, sc=0.1), r(E, sc=0.1)]
+    post = [1 + r(E, sc=0.1), r(E, sc=0.1)]
+    xk = xv = mem = pos = kpm = None
+    if kind == "text":
+        xk, xv = r(B * T, E), r(B * T, E)
+        kpm = torch.zeros(B, T, dtype=torch.uint8)
+        kpm[1, 12:] = 1
+    else:
+        mem = r(B * Nv, E)
+        pos = r(HW, E) if shared_pos else r(B, HW, E)
+        if not shared_pos:
+            kpm = torch.zeros(B, HW, dtype=torch.uint8)
+            kpm[0, 10:] = 1
+    d_t3, d_hs = r(B * nq, E), r(B * nq, E)
 
-    def ref(xq_, mem_, W_, b_):
-        patches = mem_.view(B, Nv, E)[:, 1:]
-        xk = (patches + (pos[None] if shared_pos else pos)).reshape(B * HW, E)
-        return _mha_ref(xq_, xk, patches.reshape(B * HW, E), W_, b_, B, H, Lq, HW, kpm=kpm)
+    def leaves(ts, dev):
+        return [None if t is None else t.clone().to(dev).requires_grad_(True) for t in ts]
 
-    ref_in = [t.clone().requires_grad_(True) for t in (xq, mem, W, b)]
-    ref(*ref_in).backward(dout)
-    dev_in = [t.clone().to(DEV).requires_grad_(True) for t in (xq, mem, W, b)]
-    out = MemCrossAttnBlock.apply(dev_in[0], dev_in[1], dev_in[2], dev_in[3], pos.to(DEV), None, None, B, H, Lq, Nv,
-                                  None if kpm is None else kpm.to(DEV), None)
-    out.backward(dout.to(DEV))
-    close(out, ref(xq, mem, W, b), 1e-5, "out")
-    for name, d, r in zip(("dxq", "dmem", "dW", "db"), dev_in, ref_in):
-        close(d.grad, r.grad, 2e-5, name)
-    assert float(dev_in[1].grad.view(B, Nv, E)[:, 0].abs().max()) == 0.0      # CLS rows get no gradient
+    ins_c = leaves([tgt, qpos, xk, xv, mem] + P + post, "cpu")
+    t3_ref, hs_ref = _ref_decoder_layer(ins_c[0], ins_c[1], ins_c[5:23], B, H, nq, kind, xk=ins_c[2], xv=ins_c[3], mem=ins_c[4],
+                                        pos=pos, kpm=kpm, post=ins_c[23:25])
+    torch.autograd.backward([t3_ref, hs_ref], [d_t3, d_hs])
+    ins_d = leaves([tgt, qpos, xk, xv, mem] + P + post, DEV)
+    cfg = LayerCfg(B, H, nq, kind, T if kind == "text" else HW, kpm=None if kpm is None else kpm.to(DEV),
+                   pos=None if pos is None else pos.to(DEV), Nv=Nv if kind == "mem" else 0, training=False)
+    t3, hs = DecoderLayerFn.apply(*ins_d, cfg)
+    torch.autograd.backward([t3, hs], [d_t3.to(DEV), d_hs.to(DEV)])
+    close(t3, t3_ref, 2e-5, "layer output"); close(hs, hs_ref, 2e-5, "post-normed output")
+    names = ["tgt", "qpos", "xk", "xv", "mem", "self.in_w", "self.in_b", "self.out_w", "self.out_b", "norm0.w", "norm0.b",
+             "cross.in_w", "cross.in_b", "cross.out_w", "cross.out_b", "norm1.w", "norm1.b", "ffn.w1", "ffn.b1", "ffn.w2",
+             "ffn.b2", "norm2.w", "norm2.b", "post.w", "post.b"]
+    for n, d, c in zip(names, ins_d, ins_c):
+        if c is not None:
+            close(d.grad, c.grad, 1e-4, "grad " + n)
+    if kind == "mem":
+        assert float(ins_d[4].grad.view(B, Nv, E)[:, 0].abs().max()) == 0.0        # CLS rows are not keys: no gradient
