@@ -22,6 +22,7 @@ class GradReducer:
         self.pending, self._scale, self._head = [], [], None
         self._all_ids, self._ids_done, self._text_rows = None, False, None
         self.last_sparse_rows = 0
+        self.last_late = 0          # head gradients that missed the early message in the last step (diagnostic)
         # RCCL averages inside the collective (ncclAvg): no separate 1/world pass over the 640 MB of gradients; gloo (CPU
         # tests) has no AVG -> SUM, then one division per message
         self._avg = dist.is_initialized() and dist.get_backend() == "nccl"
@@ -124,6 +125,7 @@ class GradReducer:
         late = [p.grad for n, p in self.model.named_parameters()
                 if not n.startswith("vis_enc.") and p.grad is not None and id(p.grad) not in packed]
         late_flat = None
+        self.last_late = len(late)
         if late:
             late_flat = torch.cat([g.reshape(-1) for g in late])
             self._launch(late_flat)
