@@ -93,3 +93,25 @@ def test_encoder_base_forward_vs_reference_fixture(golden):
         assert err <= 6e-2 * s["max"], (name, err, s["max"])
     err = float((cls_feat.float().cpu() - fx["cls_feat"]).abs().max())
     assert err <= 6e-2 * float(fx["cls_feat"].abs().max()), ("cls_feat", err)
+
+
+def test_drop_path_masks_are_per_sample_bernoulli_draws():
+    """all layers' DropPath masks come from ONE Bernoulli launch over a [L, 2, B] tensor of per-layer keep probabilities:
+    two independent draws per layer (beit3_base.py:148-149,166-167), values in {0, 1/keep}, keep rate as scheduled"""
+    from oracle import simvg_cpu as O
+    cfg = O.make_cfg("tiny", 1, 128)
+    enc = _build(cfg).to("cuda").train()
+    enc.drop_path_probs = [0.0, 0.3]
+    torch.manual_seed(5)
+    B = 20000
+    dp = enc._drop_path_scales(B, torch.device("cuda", 0))
+    assert dp[0] == (None, None)
+    a, b = dp[1]
+    for m in (a, b):
+        assert m.shape == (B,) and m.is_contiguous()
+        vals = torch.unique(m).cpu()
+        assert vals.numel() == 2 and float(vals[0]) == 0.0 and abs(float(vals[1]) - 1 / 0.7) < 1e-6
+        assert abs(float((m > 0).float().mean()) - 0.7) < 0.02
+    assert 0.3 < float(((a > 0) == (b > 0)).float().mean()) < 0.75      # independent: P(agree) = 0.7^2 + 0.3^2 = 0.58
+    enc.eval()
+    assert enc._drop_path_scales(B, torch.device("cuda", 0)) is None
