@@ -13,13 +13,32 @@
 //   vmax = max(vmax, v);  denom = sqrt(vmax) / sqrt(1 - b2^t) + eps
 //   p  = p - (lr / (1 - b1^t)) * m / denom
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
+template <bool NT> __device__ __forceinline__ f32x4_t ld4(const float* p, long i) {
+  if constexpr (NT) return __builtin_nontemporal_load((const f32x4_t*)p + i);
+  else return ((const f32x4_t*)p)[i];
+}
+template <bool NT> __device__ __forceinline__ void st4(float* p, long i, f32x4_t v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, (f32x4_t*)p + i);
+  else ((f32x4_t*)p)[i] = v;
+}
+
+template <bool NT>
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n4, float* __restrict__ out) {
   float s = 0.f;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-    const f32x4_t v = ((const f32x4_t*)g)[i];
+  const long stride = (long)gridDim.x * 256;
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  // 4 independent 16-B loads in flight per thread: one per trip left the read stream latency-bound
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    const f32x4_t a = ld4<NT>(g, i), b = ld4<NT>(g, i + stride), c = ld4<NT>(g, i + 2 * stride), d = ld4<NT>(g, i + 3 * stride);
+    s += ((a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3])) + ((b[0] * b[0] + b[1] * b[1]) + (b[2] * b[2] + b[3] * b[3]));
+    s += ((c[0] * c[0] + c[1] * c[1]) + (c[2] * c[2] + c[3] * c[3])) + ((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]));
+  }
+  for (; i < n4; i += stride) {
+    const f32x4_t v = ld4<NT>(g, i);
     s += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
   }
   __shared__ float red[4];
@@ -37,21 +56,23 @@ struct AdamArgs {
   int amsgrad;
 };
 
+// (non-temporal loads / stores on the moment streams: no gain at 141 M parameters, -15 % at 370 M -- default policy)
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
+  constexpr bool NT = false;
   float coef = 1.f;
   if (a.total_norm) coef = fminf(a.max_norm / (*a.total_norm + 1e-6f), 1.f);
   const float w1 = 1.f - a.beta1, w2 = 1.f - a.beta2;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.n4; i += (long)gridDim.x * 256) {
-    const f32x4_t g = ((const f32x4_t*)a.g)[i];
-    f32x4_t m = ((f32x4_t*)a.m)[i], v = ((f32x4_t*)a.v)[i];
+    const f32x4_t g = ld4<NT>(a.g, i);
+    f32x4_t m = ld4<NT>(a.m, i), v = ld4<NT>(a.v, i);
     // never-touched parameters (embedding rows of tokens that have not occurred yet: 49 M of ViT-B's 141 M parameters are
     // the 64 010-row text table): g = m = v = 0 makes the update exactly zero and leaves the state unchanged -> skip the
     // remaining 24 B of traffic.  (v = 0 implies vmax = 0; weight decay would move them, so only without it.)
     if (a.weight_decay == 0.f && g[0] == 0.f && g[1] == 0.f && g[2] == 0.f && g[3] == 0.f && m[0] == 0.f && m[1] == 0.f &&
         m[2] == 0.f && m[3] == 0.f && v[0] == 0.f && v[1] == 0.f && v[2] == 0.f && v[3] == 0.f)
       continue;
-    f32x4_t p = ((f32x4_t*)a.p)[i];
-    f32x4_t vm = a.amsgrad ? ((f32x4_t*)a.vmax)[i] : v;
+    f32x4_t p = ld4<NT>(a.p, i);
+    f32x4_t vm = a.amsgrad ? ld4<NT>(a.vmax, i) : v;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float gk = g[k] * coef;
@@ -63,10 +84,10 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
       const float denom = sqrtf(d2) / a.bc2_sqrt + a.eps;
       p[k] = p[k] - a.step_size * (m[k] / denom);
     }
-    ((f32x4_t*)a.p)[i] = p;
-    ((f32x4_t*)a.m)[i] = m;
-    ((f32x4_t*)a.v)[i] = v;
-    if (a.amsgrad) ((f32x4_t*)a.vmax)[i] = vm;
+    ((f32x4_t*)a.p)[i] = p;            // the parameters are re-read by the weight refresh right after: default policy
+    st4<NT>(a.m, i, m);
+    st4<NT>(a.v, i, v);
+    if (a.amsgrad) st4<NT>(a.vmax, i, vm);
   }
 }
 
@@ -76,7 +97,8 @@ extern "C" int simvg_sumsq(const float* x, long n, float* out_accum, hipStream_t
   SIMVG_CHECK_ARG(x && out_accum && n > 0 && n % 4 == 0, "sumsq: n must be a positive multiple of 4");
   const long n4 = n / 4;
   const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
-  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, stream, x, n4, out_accum);
+  // read-once stream: non-temporal loads (5.1 -> 5.5 TB/s standalone; 3.7 TB/s before the 4-way unroll)
+  hipLaunchKernelGGL(sumsq_kernel<true>, dim3(grid), dim3(256), 0, stream, x, n4, out_accum);
   SIMVG_LAUNCH_CHECK();
   return SIMVG_OK;
 }
