@@ -8,12 +8,12 @@ One "step" = one full training step of MIXDETRMB (ViT-B/32 BEiT-3, 640x640 image
 num_queries=1, B = 64 per GPU, train mode: DropPath + decoder dropout) on synthetic RefCOCO-shape data already
 resident in HBM: forward_train (encoder + head + on-device matcher/criterion) -> zero_grad -> backward (+ RCCL
 all-reduce of the gradient arenas when N > 1) -> global-norm clip 0.15 -> Adam(amsgrad) -> bf16 weight refresh.
-Nothing is skipped inside the timed region (the head's forward/backward are replayed as two hipGraphs after the
-warm-up steps -- the same kernels, launched by the GPU front-end instead of Python).  Prints ONE JSON line on rank 0.
+Nothing is skipped inside the timed region.  Prints ONE JSON line on rank 0.
 
 Extra objects in the line:
   roofline     : the dominant kernel (bf16 MFMA GEMM `gemm_nt_kernel`): algorithmic FLOPs of its launches divided by
-                 their HIP-event-measured durations (events recorded on the launch stream during the timed steps).
+                 their HIP-event-measured durations (events recorded on the launch stream during the timed steps; every
+                 launch of every `--roofline-every`-th step, default 4: an event pair costs the stream ~6 us).
   cpu_baseline : the CPU oracle (oracle/simvg_cpu.py, a restatement pinned to the reference) timed on the host
                  cores of the same box on a bounded sample (rank 0, N == 1 only).
 """
@@ -155,12 +155,12 @@ def main():
         opt.step()
         return losses
 
-    # the step runs on a non-default HIP stream (what `train_model` does as well): required for the hipGraph replay of
-    # the head, see simvg_amd/graphs.py.  The roofline events are recorded on that same stream.
+    # the step runs on a non-default HIP stream (what `train_model` does as well; required by the optional hipGraph
+    # replay of the head, SIMVG_HEAD_GRAPH=1, see simvg_amd/graphs.py).  The roofline events are recorded on that stream.
     from simvg_amd.graphs import train_stream
     with torch.cuda.stream(train_stream(device)):
-        # set-up, not warm-up: the head's hipGraphs are captured once its input signature has been seen four times
-        # (lazy workspaces must exist first); do that here so that the capture (~0.7 s) can never land in the timed
+        # set-up, not warm-up: lazily created workspaces / constants (and, with SIMVG_HEAD_GRAPH=1, the capture of the head's
+        # hipGraphs after four steps with the same input signature) happen here so that they can never land in the timed
         # steps whatever --warmup is.  No optimizer step: the weights the warm-up starts from are untouched.
         for _ in range(4):
             losses, _ = model(batch["img"], batch["ref_expr_inds"], batch["img_metas"], return_loss=True,
