@@ -28,12 +28,27 @@ struct GemmNTArgs {
   const float* res; int ldres;
   const float* row_scale; int rps0, rps1;
   int M, N, K, split, act;
+  int gn;     // column-group width of the tile walk (0: rows of all column tiles)
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   // bijective XCD-aware remap: XCD x (= bid % 8) walks a contiguous chunk of the tile space
   const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// Tile walk in column groups: an XCD runs 32 tiles at a time, consecutive in this order.  With all column tiles of a row
+// block next to each other (N = 3072: 12 of them) those 32 tiles touch 3 activation panels and ALL 12 weight panels
+// (5.9 MB against 4 MB of L2 per XCD); walking gn = 6 column tiles over ~5 row blocks touches 6 + 6.
+__device__ __forceinline__ void tile_order(int bid, int tiles_m, int tiles_n, int gn, int& tm, int& tn) {
+  if (gn <= 0 || gn >= tiles_n) { tm = bid / tiles_n; tn = bid - tm * tiles_n; return; }
+  const int per_group = tiles_m * gn;
+  const int g = bid / per_group;
+  const int n_start = g * gn;
+  const int w = min(gn, tiles_n - n_start);
+  const int l = bid - g * per_group;
+  tm = l / w;
+  tn = n_start + (l - tm * w);
 }
 
 // stage one [128 rows][64 k] bf16 tile: 16 wave-instructions of 1 KiB, 4 per wave
@@ -477,7 +492,8 @@ __global__ __launch_bounds__(1024) void gemm_nt_kernel_256sq_w16(GemmNTArgs a) {
   const int tiles_n = (a.N + BNQ - 1) / BNQ;
   const int tm0 = (a.split + BMQ - 1) / BMQ;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+  int tile_m, tile_n;
+  tile_order(bid, (int)gridDim.x / tiles_n, tiles_n, a.gn, tile_m, tile_n);
   const int group = tile_m >= tm0;
   const int row0 = group ? a.split + (tile_m - tm0) * BMQ : tile_m * BMQ;
   const int row_end = group ? a.M : a.split;
@@ -997,7 +1013,13 @@ extern "C" int simvg_gemm_nt(const void* A, int lda, const void* W, long w_gstri
   GemmNTArgs a{(const bf16_t*)A, lda, (const bf16_t*)W, w_gstride, ldw, bias, bias_gstride, C, ldc, c_is_f32,
                (bf16_t*)aux_preact, ldaux, residual, ldres, row_scale,
                rows_per_sample0 > 0 ? rows_per_sample0 : 1, rows_per_sample1 > 0 ? rows_per_sample1 : 1,
-               M, N, K, split, act};
+               M, N, K, split, act, 0};
+  {
+    // column-group width of the tile walk (256sq_w16 kernel): 6 of >= 9 column tiles (fc1-shape fetch 246 -> 190 MB per
+    // launch, qkv 170 -> 160 MB; 4: 206 / 181 MB).  SIMVG_NT_GN = -1 restores the plain row-major walk.
+    static const int gn_env = getenv("SIMVG_NT_GN") ? atoi(getenv("SIMVG_NT_GN")) : 0;
+    a.gn = gn_env < 0 ? 0 : gn_env > 0 ? gn_env : (cdiv(N, BNQ) >= 9 ? 6 : 0);
+  }
   // auto: short K (<= 1024: QKV, out-proj, fc1, dgrad of fc2) -> BK=32, two workgroups per CU; long K -> BK=64
   // (measured: profiles/r01_sweeps.md).  SIMVG_GEMM_NT = 128 | 256 | 232 forces one kernel.
   static const int variant_env = getenv("SIMVG_GEMM_NT") ? atoi(getenv("SIMVG_GEMM_NT")) : 0;
