@@ -696,6 +696,7 @@ struct GemmTNArgs {
   float* db; int db_gstride;     // optional bias gradient db[g][n] += column sums of dY over group g (extra blocks)
   int tiles;                     // GEMM tiles along blockIdx.x; blocks beyond them are the column-sum blocks
   int cs_split;                  // row slices per chunk for the column-sum blocks
+  int gk;                        // group width of the tile walk along the faster dimension (0: plain)
 };
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page[64];  // 256 B of zeros
@@ -908,8 +909,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel_256(GemmTNArgs a) {
   if ((int)blockIdx.x >= a.tiles) { colsum_block<512>(a, smem, blockIdx.x - a.tiles, group, m_begin, m_end); return; }
   const int wg = xcd_remap(blockIdx.x, a.tiles);
   int tile_n, tile_k;
-  if (tiles_n >= tiles_k) { tile_n = wg / tiles_k; tile_k = wg - tile_n * tiles_k; }
-  else { tile_k = wg / tiles_n; tile_n = wg - tile_k * tiles_n; }
+  // an XCD gets ~9 consecutive tiles per row chunk: walk the faster dimension in groups of 3 so that they form a 3 x 3
+  // block (3 dY + 3 X panels) instead of 1.5 x 6 (2 dY + 6 X panels; fc1 wgrad: 12 x 6 tiles)
+  if (tiles_n >= tiles_k) tile_order(wg, tiles_n, tiles_k, a.gk, tile_n, tile_k);
+  else tile_order(wg, tiles_k, tiles_n, a.gk, tile_k, tile_n);
   const int n0 = tile_n * 256, k0 = tile_k * 128;
   f32x4_t acc[4][4];
 #pragma unroll
@@ -1102,7 +1105,11 @@ extern "C" int simvg_gemm_tn(const void* dY, int lddy, const void* X, int ldx, f
   if (rpc < 256) rpc = 256;   // multiple of 64 (and of the 32-row stages)
   const int chunks0 = cdiv(split, rpc), chunks1 = cdiv(M - split, rpc);
   GemmTNArgs a{(const bf16_t*)dY, lddy, (const bf16_t*)X, ldx, dW, dw_gstride, lddw, M, N, K, split, rpc, chunks0,
-               db, db_gstride, tiles, cdiv(rpc, 512)};
+               db, db_gstride, tiles, cdiv(rpc, 512), 0};
+  {
+    static const int gk_env = getenv("SIMVG_TN_GK") ? atoi(getenv("SIMVG_TN_GK")) : 0;
+    a.gk = gk_env < 0 ? 0 : gk_env > 0 ? gk_env : 3;
+  }
   const int gx = tiles + (db ? cdiv(N, 256) * a.cs_split : 0);   // + column-sum blocks (bias gradient)
   if (big) {
     static bool once = hipFuncSetAttribute((const void*)gemm_tn_kernel_256, hipFuncAttributeMaxDynamicSharedMemorySize,
