@@ -1,10 +1,14 @@
-"""hipGraph replay of the launch-bound part of the training step: the decoder head + matcher + criterion.
+"""OPTIONAL hipGraph replay of the launch-bound part of the training step: the decoder head + matcher + criterion
+(`MIXDETRMB(head_graph=True)` or SIMVG_HEAD_GRAPH=1; off by default).
 
-The head is ~650 small launches forward and ~700 backward (exact-fp32 GEMMs on M = B*num_queries rows, small attention,
-LayerNorms, matcher, criterion, glue): ~4 ms of GPU work that costs ~13 ms of Python / autograd dispatch per step, so
-the MI355X idles while the CPU feeds it (step time at B=2 is a flat 21.5 ms).  `torch.cuda.make_graphed_callables`
-captures the head's forward and backward once per input signature into two hipGraphs; a training step then replays
-them with two launches.  The encoder (150 large launches per direction) stays eager.
+History: when the head was ~650 small launches forward and ~700 backward through per-op autograd nodes, Python / autograd
+dispatch cost ~13 ms per step and the MI355X idled while the CPU fed it (a flat 21.5 ms per step at B=2); replaying the
+head as two hipGraphs (`torch.cuda.make_graphed_callables`, one capture per input signature) removed that.  Since the
+decoder layers became single autograd nodes with grouped GEMM launches (~350 launches for the whole head, 5 ms of host time
+per direction) the eager head keeps the host ahead of the GPU at every batch size, and the graphs lose: `hipGraphLaunch` of
+the captured BACKWARD blocks the host until the stream has drained (10 ms inside `CUDAGraph.replay()` per step; the forward
+graph's launch costs 0.07 ms), which throws the host's lead away every step (B=64: 1736 vs 1782 pairs/s; table in
+profiles/r01_sweeps.md).  The machinery stays for hosts that are slower relative to the GPU.
 
 What makes the capture legal:
   * everything data-dependent that needs the host -- target packing, the loss normalisers and their RCCL all-reduce --
