@@ -141,6 +141,14 @@ int simvg_criterion(const float* logits, const float* boxes, const int* match, c
                     const float* num_boxes, const float* weights_distill, float* dlogits, float* dboxes, float* out,
                     int L, int B, int nq, int TM, int coef_mode, float coef, float eos_coef, float w_class, float w_bbox,
                     float w_giou, simvg_stream_t stream);
+/* head.inference (tgqs_kd_detr_head.py:577-604: softmax, drop the no-object column, cxcywh -> xyxy * (w,h,w,h)) +
+ * detectron2 detector_postprocess (clip to the image, Boxes.nonempty) + the per-image selection of
+ * MIXDETRMB.get_predictions (mix_detr_mb.py:127-159: best kept query, box / scale_factor when rescaling) in one launch.
+ * wh [B,4] = (w,h,w,h) per image; scale_factor [B,4] or null; outputs: scores / labels / keep [B,nq], xyxy [B,nq,4]
+ * (clipped, rescaled), best_box [B,4], best_label [B]. */
+int simvg_postprocess(const float* logits, const float* boxes, const float* wh, const float* scale_factor, float* scores,
+                      long long* labels, float* xyxy, unsigned char* keep, float* best_box, long long* best_label, int B,
+                      int num_queries, int num_cols, simvg_stream_t stream);
 
 /* ---- embedding stage -------------------------------------------------------------------------------
  * torchscale VisionEmbedding / TextEmbedding / PositionalEmbedding as wired by BEiT3.forward and

@@ -24,6 +24,8 @@ class GemmF32Problem(C.Structure):      # simvg_gemm_f32_problem
 
 _SIGS = {
     "simvg_gemm_f32_grouped": [c_void_p, c_int, c_void_p],
+    "simvg_postprocess": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                          c_int, c_int, c_int, c_void_p],
     "simvg_gemm_nt": [c_void_p, c_int, c_void_p, c_long, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
                       c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                       c_void_p],

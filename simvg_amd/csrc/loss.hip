@@ -290,6 +290,72 @@ __global__ __launch_bounds__(256) void criterion_kernel(CritArgs a) {
   }
 }
 
+
+// head.inference + detector_postprocess + get_predictions in one launch (tgqs_kd_detr_head.py:577-604, mix_detr_mb.py:127-159
+// and detectron2 Boxes.scale / clip / nonempty): per query softmax over the class columns, score / label =
+// max over all but the last (no-object) column, cxcywh -> xyxy * (w, h, w, h), clip to the image, keep = non-empty box;
+// per image the kept query with the highest score (first on ties; query 0 when none is kept) and its box, divided by the
+// scale factor when rescaling.  One 64-lane block per image, lane = query (num_queries <= 16).
+__global__ __launch_bounds__(64) void postprocess_kernel(const float* __restrict__ logits, const float* __restrict__ boxes,
+                                                          const float* __restrict__ wh, const float* __restrict__ sf,
+                                                          float* __restrict__ scores, long long* __restrict__ labels,
+                                                          float* __restrict__ xyxy, unsigned char* __restrict__ keep,
+                                                          float* __restrict__ best_box, long long* __restrict__ best_label,
+                                                          int nq, int ncol) {
+  const int b = blockIdx.x, q = threadIdx.x;
+  float sc = -2.f;
+  int lab = 0;
+  float bx[4] = {0.f, 0.f, 0.f, 0.f};
+  bool kp = false;
+  if (q < nq) {
+    const float* lg = logits + ((long)b * nq + q) * ncol;
+    float mx = lg[0];
+    for (int c = 1; c < ncol; ++c) mx = fmaxf(mx, lg[c]);
+    float den = 0.f;
+    for (int c = 0; c < ncol; ++c) den += expf(lg[c] - mx);
+    float best = -1.f;
+    for (int c = 0; c < ncol - 1; ++c) {
+      const float p = expf(lg[c] - mx) / den;
+      if (p > best) { best = p; lab = c; }
+    }
+    const float* bp = boxes + ((long)b * nq + q) * 4;
+    const float* w4 = wh + (long)b * 4;
+    const float cx = bp[0], cy = bp[1], w = bp[2], h = bp[3];
+    bx[0] = (cx - 0.5f * w) * w4[0];
+    bx[1] = (cy - 0.5f * h) * w4[1];
+    bx[2] = (cx + 0.5f * w) * w4[2];
+    bx[3] = (cy + 0.5f * h) * w4[3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bx[k] = fminf(fmaxf(bx[k], 0.f), w4[k]);
+    kp = (bx[2] - bx[0]) > 0.f && (bx[3] - bx[1]) > 0.f;
+    if (sf) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) bx[k] = bx[k] / sf[(long)b * 4 + k];
+    }
+    const long o = (long)b * nq + q;
+    scores[o] = best;
+    labels[o] = lab;
+    keep[o] = kp ? 1 : 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xyxy[o * 4 + k] = bx[k];
+    sc = kp ? best : -1.f;          // torch.where(keep, scores, -1).argmax(1)
+  }
+  // first maximum over the queries
+  float v = sc;
+  int idx = q < nq ? q : 1 << 20;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float v2 = __shfl_xor(v, o, 64);
+    const int i2 = __shfl_xor(idx, o, 64);
+    if (v2 > v || (v2 == v && i2 < idx)) { v = v2; idx = i2; }
+  }
+  if (q == idx) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) best_box[(long)b * 4 + k] = bx[k];
+    best_label[b] = lab;
+  }
+}
+
 }  // namespace
 
 extern "C" int simvg_match(const float* logits, const float* boxes, const float* tboxes, const int* tlabels,
@@ -322,6 +388,17 @@ extern "C" int simvg_criterion(const float* logits, const float* boxes, const in
   CritArgs a{logits, boxes, match, tboxes, tlabels, num_boxes, weights_distill, dlogits, dboxes, out, L, B, nq, TM,
              coef_mode, coef, eos_coef, w_class, w_bbox, w_giou};
   hipLaunchKernelGGL(criterion_kernel, dim3(1), dim3(256), 0, stream, a);
+  SIMVG_LAUNCH_CHECK();
+  return SIMVG_OK;
+}
+
+extern "C" int simvg_postprocess(const float* logits, const float* boxes, const float* wh, const float* scale_factor,
+                                 float* scores, long long* labels, float* xyxy, unsigned char* keep, float* best_box,
+                                 long long* best_label, int B, int num_queries, int num_cols, hipStream_t stream) {
+  SIMVG_CHECK_ARG(B > 0 && num_queries > 0 && num_queries <= 16 && num_cols >= 2, "postprocess: num_queries <= 16, >= 2 class columns");
+  SIMVG_CHECK_ARG(logits && boxes && wh && scores && labels && xyxy && keep && best_box && best_label, "postprocess: null buffer");
+  hipLaunchKernelGGL(postprocess_kernel, dim3(B), dim3(64), 0, stream, logits, boxes, wh, scale_factor, scores, labels, xyxy,
+                     keep, best_box, best_label, num_queries, num_cols);
   SIMVG_LAUNCH_CHECK();
   return SIMVG_OK;
 }

@@ -374,6 +374,26 @@ def match(logits, boxes, tboxes, tlabels, tcount, cost=(1.0, 5.0, 2.0)):
     return out
 
 
+def postprocess(logits, boxes, wh, scale_factor=None):
+    """logits [B,nq,C+1], boxes [B,nq,4] cxcywh (fp32), wh [B,4] = (w,h,w,h), scale_factor [B,4] | None ->
+    (scores [B,nq], labels [B,nq] i64, xyxy [B,nq,4], keep [B,nq] bool, best_box [B,4], best_label [B] i64)."""
+    lib = _lib.load()
+    logits, boxes = logits.contiguous().float(), boxes.contiguous().float()
+    B, nq, ncol = logits.shape
+    dev = logits.device
+    scores = torch.empty(B, nq, device=dev, dtype=torch.float32)
+    labels = torch.empty(B, nq, device=dev, dtype=torch.int64)
+    xyxy = torch.empty(B, nq, 4, device=dev, dtype=torch.float32)
+    keep = torch.empty(B, nq, device=dev, dtype=torch.uint8)
+    best_box = torch.empty(B, 4, device=dev, dtype=torch.float32)
+    best_label = torch.empty(B, device=dev, dtype=torch.int64)
+    sf = None if scale_factor is None else scale_factor.reshape(B, 4).contiguous().float()
+    rc = lib.simvg_postprocess(_p(logits), _p(boxes), _p(wh.contiguous()), _p(sf), _p(scores), _p(labels), _p(xyxy), _p(keep),
+                               _p(best_box), _p(best_label), B, nq, ncol, _stream())
+    _lib.check(rc, "simvg_postprocess")
+    return scores, labels, xyxy, keep.view(torch.bool), best_box, best_label
+
+
 def soft_targets(logits, boxes, match_idx, tboxes, tcount):
     lib = _lib.load()
     B, nq, _ = logits.shape

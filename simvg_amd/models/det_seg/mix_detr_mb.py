@@ -4,7 +4,7 @@ Mirror of `simvg/models/det_seg/mix_detr_mb.py:13-190` (registered in MODELS; `f
 `(loss_dict, [pred_decoder, pred_token])`, `forward_test` returns `[pred_decoder, pred_token]`, each a dict with
 `pred_bboxes` / `pred_masks` / `predict_classes`).  The encoder -> head hand-off stays in the modality-major
 bf16 layout (no `[B,C,h,w]` transpose copy, `mix_detr_mb.py:52` of the reference), and the post-processing of
-`get_predictions` (detectron2 Boxes.scale / clip / nonempty + argmax) is vectorised on the device.
+`get_predictions` (detectron2 Boxes.scale / clip / nonempty + argmax) is one HIP kernel (`simvg_postprocess`).
 """
 import os
 
@@ -97,26 +97,19 @@ class MIXDETRMB(OneStageModel):
             c = self._pp_const[key] = (lim, sf)
         return c
 
-    def _boxes(self, output, img_metas, rescale):
-        box_cls, box_pred = output["pred_logits"].float(), output["pred_boxes"].float()
-        lim, sf = self._shape_consts(img_metas, box_pred.device, rescale)
-        scores, labels, xyxy = self.head.inference(box_cls, box_pred, None, wh=lim)
-        xyxy = torch.minimum(xyxy.clamp(min=0), lim[:, None, :])          # detector_postprocess: clip to the image
-        keep = ((xyxy[..., 2] - xyxy[..., 0]) > 0) & ((xyxy[..., 3] - xyxy[..., 1]) > 0)   # Boxes.nonempty()
-        return scores, labels, xyxy, keep, sf
+    def _post(self, output, img_metas, rescale):
+        """one launch (`simvg_postprocess`): scores / labels / clipped (and rescaled) xyxy / keep per query, best kept box and
+        its label per image"""
+        from ... import hip_ops as ops
+        lim, sf = self._shape_consts(img_metas, output["pred_boxes"].device, rescale)
+        return ops.postprocess(output["pred_logits"], output["pred_boxes"], lim, sf)
 
     def get_predictions(self, output, img_metas, rescale=False):
         if output["pred_logits"] is None:
             return dict(pred_bboxes=None, pred_masks=None, predict_classes=None)
-        scores, labels, xyxy, keep, sf = self._boxes(output, img_metas, rescale)
-        best = torch.where(keep, scores, torch.full_like(scores, -1.0)).argmax(1)       # argmax over kept queries
-        idx = best[:, None, None].expand(-1, 1, 4)
-        box = xyxy.gather(1, idx)[:, 0]
-        if sf is not None:
-            box = box / sf[:, 0]
-        B = scores.shape[0]
+        scores, labels, xyxy, keep, box, best_label = self._post(output, img_metas, rescale)
         if scores.shape[1] == 1:
-            cls = labels[:, 0]
+            cls = best_label
         else:   # the reference concatenates the classes of ALL kept queries (mix_detr_mb.py:152,157)
             cls = labels[keep]
         return dict(pred_bboxes=box, pred_masks=None, predict_classes=cls)
@@ -124,9 +117,7 @@ class MIXDETRMB(OneStageModel):
     def get_predictions_grec(self, output, img_metas, rescale=False):
         if output["pred_logits"] is None:
             return dict(pred_bboxes=None, pred_masks=None, predict_classes=None)
-        scores, labels, xyxy, keep, sf = self._boxes(output, img_metas, rescale)
-        if sf is not None:
-            xyxy = xyxy / sf
+        scores, labels, xyxy, keep, _, _ = self._post(output, img_metas, rescale)
         # per image: the kept queries in their original order.  A stable sort brings them to the front of every row and ONE
         # device-to-host copy of the counts replaces the reference's boolean indexing per image and field (3 x B host
         # synchronisations per call): the slices below are views.

@@ -259,3 +259,38 @@ def test_decoder_layer_node_fwd_bwd(kind, nq, shared_pos):
             close(d.grad, c.grad, 1e-4, "grad " + n)
     if kind == "mem":
         assert float(ins_d[4].grad.view(B, Nv, E)[:, 0].abs().max()) == 0.0        # CLS rows are not keys: no gradient
+
+
+@pytest.mark.parametrize("B,nq,ncol,rescale", [(5, 1, 2, False), (4, 10, 2, True), (3, 7, 4, True)])
+def test_postprocess_kernel_vs_torch(B, nq, ncol, rescale):
+    """`simvg_postprocess` against the reference's formulation in plain PyTorch: head.inference (softmax, drop the last
+    column, cxcywh -> xyxy * (w,h,w,h)), detector_postprocess (clip, nonempty), best kept query per image, / scale_factor"""
+    from simvg_amd import hip_ops as ops
+    g = torch.Generator().manual_seed(B * 31 + nq)
+    logits = torch.randn(B, nq, ncol, generator=g) * 2
+    boxes = torch.rand(B, nq, 4, generator=g)
+    boxes[0, 0] = torch.tensor([0.5, 0.5, 0.0, 0.3])            # empty box -> dropped
+    boxes[1, :, 2:] *= 0.0                                       # no query of image 1 survives -> query 0 is reported
+    boxes[2, 0] = torch.tensor([0.95, 0.9, 0.4, 0.5])            # sticks out of the image -> clipped
+    hw = torch.tensor([[480, 640], [640, 640], [333, 500], [640, 427], [512, 512]])[:B]
+    lim = torch.stack([hw[:, 1], hw[:, 0], hw[:, 1], hw[:, 0]], 1).float()
+    sf = (torch.rand(B, 4, generator=g) + 0.5) if rescale else None
+    # torch formulation
+    prob = F.softmax(logits, -1)[:, :, :-1]
+    scores_ref, labels_ref = prob.max(-1)
+    cx, cy, w, h = boxes.unbind(-1)
+    xyxy = torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h], -1) * lim[:, None, :]
+    xyxy = torch.minimum(xyxy.clamp(min=0), lim[:, None, :])
+    keep_ref = ((xyxy[..., 2] - xyxy[..., 0]) > 0) & ((xyxy[..., 3] - xyxy[..., 1]) > 0)
+    best = torch.where(keep_ref, scores_ref, torch.full_like(scores_ref, -1.0)).argmax(1)
+    box_ref = xyxy[torch.arange(B), best]
+    if sf is not None:
+        box_ref, xyxy = box_ref / sf, xyxy / sf[:, None, :]
+    scores, labels, out_xyxy, keep, box, best_label = ops.postprocess(logits.to(DEV), boxes.to(DEV), lim.to(DEV),
+                                                                     None if sf is None else sf.to(DEV))
+    assert torch.equal(keep.cpu(), keep_ref) and not keep_ref[0, 0] and not keep_ref[1].any()
+    assert torch.equal(labels.cpu(), labels_ref)
+    assert torch.equal(out_xyxy.cpu(), xyxy)                     # exact fp32 arithmetic, same operation order
+    assert torch.equal(box.cpu(), box_ref)
+    assert torch.equal(best_label.cpu(), labels_ref[torch.arange(B), best])
+    close(scores, scores_ref, 1e-6, "scores")
