@@ -7,11 +7,41 @@ bf16 layout (no `[B,C,h,w]` transpose copy, `mix_detr_mb.py:52` of the reference
 `get_predictions` (detectron2 Boxes.scale / clip / nonempty + argmax) is one HIP kernel (`simvg_postprocess`).
 """
 import os
+from collections.abc import Sequence
 
 import torch
 
 from .. import builder
 from .base import OneStageModel
+
+
+class KeptInstances(Sequence):
+    """`pred_bboxes` of the GRefCOCO path: per image {"boxes", "scores", "labels"} of the kept queries, as a read-only
+    sequence that is materialised on first access.  The counts per image need ONE device-to-host copy; deferring it keeps
+    forward_train free of host synchronisation, so the host can enqueue the backward while the GPU is still busy with the
+    forward -- by the time the training loop reads the predictions for its metrics the copy no longer stalls anything."""
+
+    def __init__(self, xyxy, scores, labels, keep):
+        # a stable sort brings the kept queries to the front of every row in their original order (what the reference's
+        # boolean indexing per image and field returns); the slices taken later are views
+        order = torch.argsort((~keep).to(torch.uint8), dim=1, stable=True)
+        self._xyxy = xyxy.gather(1, order[..., None].expand(-1, -1, 4))
+        self._scores, self._labels = scores.gather(1, order), labels.gather(1, order)
+        self._kept = keep.sum(1)
+        self._items = None
+
+    def _materialise(self):
+        if self._items is None:
+            counts = self._kept.tolist()
+            self._items = [{"boxes": self._xyxy[b, :c], "scores": self._scores[b, :c], "labels": self._labels[b, :c]}
+                           for b, c in enumerate(counts)]
+        return self._items
+
+    def __len__(self):
+        return int(self._xyxy.shape[0])
+
+    def __getitem__(self, i):
+        return self._materialise()[i]
 
 
 @builder.MODELS.register_module()
@@ -118,12 +148,4 @@ class MIXDETRMB(OneStageModel):
         if output["pred_logits"] is None:
             return dict(pred_bboxes=None, pred_masks=None, predict_classes=None)
         scores, labels, xyxy, keep, _, _ = self._post(output, img_metas, rescale)
-        # per image: the kept queries in their original order.  A stable sort brings them to the front of every row and ONE
-        # device-to-host copy of the counts replaces the reference's boolean indexing per image and field (3 x B host
-        # synchronisations per call): the slices below are views.
-        order = torch.argsort((~keep).to(torch.uint8), dim=1, stable=True)
-        xyxy = xyxy.gather(1, order[..., None].expand(-1, -1, 4))
-        scores, labels = scores.gather(1, order), labels.gather(1, order)
-        counts = keep.sum(1).tolist()
-        res = [{"boxes": xyxy[b, :c], "scores": scores[b, :c], "labels": labels[b, :c]} for b, c in enumerate(counts)]
-        return dict(pred_bboxes=res, pred_masks=None)
+        return dict(pred_bboxes=KeptInstances(xyxy, scores, labels, keep), pred_masks=None)
