@@ -44,6 +44,46 @@ class KeptInstances(Sequence):
         return self._materialise()[i]
 
 
+class KeptLabels:
+    """`predict_classes` for num_queries > 1: the classes of ALL kept queries of the batch, concatenated
+    (mix_detr_mb.py:152,157) -- a tensor whose length is data dependent, i.e. a host synchronisation.  Nothing on the
+    training path reads it, so it is computed on first use; until then this object stands in for the tensor
+    (attribute access, indexing, len() and torch functions resolve to the materialised tensor)."""
+
+    def __init__(self, labels, keep):
+        self._labels, self._keep, self._t = labels, keep, None
+
+    def tensor(self):
+        if self._t is None:
+            self._t = self._labels[self._keep]
+        return self._t
+
+    def __getattr__(self, name):
+        return getattr(self.tensor(), name)
+
+    def __len__(self):
+        return len(self.tensor())
+
+    def __getitem__(self, i):
+        return self.tensor()[i]
+
+    def __iter__(self):
+        return iter(self.tensor())
+
+    def __repr__(self):
+        return "KeptLabels(" + repr(self.tensor()) + ")"
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        def unwrap(x):
+            if isinstance(x, KeptLabels):
+                return x.tensor()
+            if isinstance(x, (list, tuple)):
+                return type(x)(unwrap(y) for y in x)
+            return x
+        return func(*unwrap(args), **{k: unwrap(v) for k, v in (kwargs or {}).items()})
+
+
 @builder.MODELS.register_module()
 class MIXDETRMB(OneStageModel):
     def __init__(self, word_emb, num_token, vis_enc, lan_enc, head, fusion, head_graph=False):
@@ -141,7 +181,7 @@ class MIXDETRMB(OneStageModel):
         if scores.shape[1] == 1:
             cls = best_label
         else:   # the reference concatenates the classes of ALL kept queries (mix_detr_mb.py:152,157)
-            cls = labels[keep]
+            cls = KeptLabels(labels, keep)
         return dict(pred_bboxes=box, pred_masks=None, predict_classes=cls)
 
     def get_predictions_grec(self, output, img_metas, rescale=False):
