@@ -1,10 +1,11 @@
 """Checkpoint API with the reference's signatures (`simvg/utils/checkpoint.py:53-148`): `load_checkpoint`,
 `load_pretrained_checkpoint`, `save_checkpoint` -- `.pth` files interchange with the reference (keys `state_dict`,
 `ema_state_dict`, `optimizer`, `scheduler`, `lr`, `epoch`, `d_acc`, `miou`, `best_d_acc`, `best_miou`, `amp`;
-`module.` prefixes stripped on load).  The optimizer entry is this build's own (FlatAdam keeps one state per arena),
-so an optimizer state written by the reference is skipped with a log line instead of being mis-loaded."""
+`module.` prefixes stripped on load) and the log lines are the reference's.  The optimizer entry is this build's own
+(FlatAdam keeps one state per arena), so an optimizer state written by the reference is skipped with a log line instead
+of being mis-loaded."""
 import copy
-import os.path as osp
+import os
 import shutil
 
 import torch
@@ -12,119 +13,106 @@ import torch
 from .distributed import is_main
 from .logger import get_root_logger
 
+_PREFIX = "module."
+# (checkpoint key, log format) in the order the reference prints them after a load
+_REPORT = (("best_d_acc", "best det acc: {:.2f}\n"), ("best_miou", "best mIoU: {:.2f}\n"),
+           ("d_acc", "loaded det acc: {:.2f}\n"), ("miou", "loaded mIoU: {:.2f}\n"))
+
 
 def is_paral_state(state_dict):
-    return list(state_dict.keys())[0].startswith("module.")
+    """was this state dict written through a DataParallel / DDP wrapper?"""
+    return next(iter(state_dict)).startswith(_PREFIX)
 
 
 def de_parallel(state_dict):
-    return {key[7:]: value for key, value in state_dict.items()}
+    return {k[len(_PREFIX):]: v for k, v in state_dict.items()}
+
+
+def _plain(state_dict):
+    return de_parallel(state_dict) if is_paral_state(state_dict) else state_dict
 
 
 def log_loaded_info(ckpt, load_file):
-    logger = get_root_logger()
-    log_str = f"loaded checkpoint from {load_file}\n"
-    best_d_acc, best_miou = 0.0, 0.0
-    if "lr" in ckpt and ckpt["lr"] is not None and "epoch" in ckpt:
-        log_str += f"epoch: {ckpt['epoch']+1} lr: {ckpt['lr']:.6f}\n"
-    if "best_d_acc" in ckpt:
-        log_str += f"best det acc: {ckpt['best_d_acc']:.2f}\n"
-        best_d_acc = ckpt["best_d_acc"]
-    if "best_miou" in ckpt:
-        log_str += f"best mIoU: {ckpt['best_miou']:.2f}\n"
-        best_miou = ckpt["best_miou"]
-    if "d_acc" in ckpt:
-        log_str += f"loaded det acc: {ckpt['d_acc']:.2f}\n"
-    if "miou" in ckpt:
-        log_str += f"loaded mIoU: {ckpt['miou']:.2f}\n"
-    logger.info(log_str)
-    return best_d_acc, best_miou
+    """one log record describing the loaded file; returns the best scores it carries (0.0 when absent)"""
+    text = [f"loaded checkpoint from {load_file}\n"]
+    if ckpt.get("lr") is not None and "epoch" in ckpt:
+        text.append(f"epoch: {ckpt['epoch']+1} lr: {ckpt['lr']:.6f}\n")
+    text += [fmt.format(ckpt[key]) for key, fmt in _REPORT if key in ckpt]
+    get_root_logger().info("".join(text))
+    return ckpt.get("best_d_acc", 0.0), ckpt.get("best_miou", 0.0)
 
 
-def _device_of(model):
-    return next(model.parameters()).device
+def _read(path, model):
+    return torch.load(path, map_location=next(model.parameters()).device, weights_only=False)
 
 
 def load_pretrained_checkpoint(model, model_ema=None, finetune_from=None, amp=False):
-    """Fine-tuning start: non-strict load of `state_dict`, epoch counter reset (reference :53-83)."""
+    """Fine-tuning start (reference :53-83): non-strict load of `state_dict`, the epoch counter starts over."""
     assert model_ema is None, "We do not use EMA during finetuning."
-    start_epoch, best_d_acc, best_miou = -1, 0.0, 0.0
-    ckpt = torch.load(finetune_from, map_location=_device_of(model), weights_only=False)
-    state = ckpt["state_dict"]
-    if is_paral_state(state):
-        state = de_parallel(state)
-    missing_keys, unexpected_keys = model.load_state_dict(copy.deepcopy(state), strict=False)
+    ckpt = _read(finetune_from, model)
+    missing, unexpected = model.load_state_dict(copy.deepcopy(_plain(ckpt["state_dict"])), strict=False)
+    best = (0.0, 0.0)
     if is_main():
-        logger = get_root_logger()
-        logger.info("missing keys:{}".format(missing_keys))
-        logger.info("unexpected keys:{}".format(unexpected_keys))
-        best_d_acc, best_miou = log_loaded_info(ckpt, finetune_from)
-    return start_epoch, best_d_acc, best_miou
+        log = get_root_logger()
+        log.info("missing keys:{}".format(missing))
+        log.info("unexpected keys:{}".format(unexpected))
+        best = log_loaded_info(ckpt, finetune_from)
+    return (-1,) + tuple(best)
 
 
 def load_checkpoint(model, model_ema=None, resume_from=None, load_from=None, amp=False, optimizer=None, scheduler=None):
-    """-> (start_epoch, best_d_acc, best_miou, strict_ok) (reference :86-120)."""
-    start_epoch, best_d_acc, best_miou = -1, 0.0, 0.0
-    flag = True
-    assert not (resume_from is not None and load_from is not None)
-    load_file = resume_from or load_from
-    ckpt = torch.load(load_file, map_location=_device_of(model), weights_only=False)
-    state = ckpt["state_dict"]
-    ema_state = None
-    if "ema_state_dict" in ckpt:
-        ema_state = ckpt["ema_state_dict"]
-        if is_paral_state(ema_state):
-            ema_state = de_parallel(ema_state)
-    if is_paral_state(state):
-        state = de_parallel(state)
+    """-> (start_epoch, best_d_acc, best_miou, strict_ok) (reference :86-120).  `resume_from` continues a run (epoch,
+    optimizer, scheduler, EMA shadow); `load_from` takes the weights only."""
+    assert resume_from is None or load_from is None
+    path = resume_from if resume_from is not None else load_from
+    ckpt = _read(path, model)
+    weights = _plain(ckpt["state_dict"])
+    strict_ok = True
     try:
-        model.load_state_dict(state, strict=True)
+        model.load_state_dict(weights, strict=True)
     except RuntimeError:
-        model.load_state_dict(state, strict=False)
-        flag = False
-    if model_ema is not None and ema_state is not None:
-        model_ema.shadow = ema_state
-    if optimizer is not None and ckpt.get("optimizer") is not None:
+        strict_ok = False
+        model.load_state_dict(weights, strict=False)
+    if model_ema is not None and "ema_state_dict" in ckpt:
+        model_ema.shadow = _plain(ckpt["ema_state_dict"])
+    for obj, key in ((optimizer, "optimizer"), (scheduler, "scheduler")):
+        if obj is None or ckpt.get(key) is None:
+            continue
         try:
-            optimizer.load_state_dict(ckpt["optimizer"])
-        except (ValueError, KeyError) as e:   # a per-tensor state written by the reference's torch.optim.Adam
-            if is_main():
-                get_root_logger().info(f"optimizer state in {load_file} does not match this optimizer ({e}); skipped")
-    if scheduler is not None and ckpt.get("scheduler") is not None:
-        scheduler.load_state_dict(ckpt["scheduler"])
-    if "epoch" in ckpt and load_from is None and resume_from is not None:
-        start_epoch = ckpt["epoch"]
-    if is_main():
-        best_d_acc, best_miou = log_loaded_info(ckpt, load_file)
-    return start_epoch, best_d_acc, best_miou, flag
+            obj.load_state_dict(ckpt[key])
+        except (ValueError, KeyError) as e:
+            if key != "optimizer":
+                raise
+            if is_main():      # a per-tensor state written by the reference's torch.optim.Adam
+                get_root_logger().info(f"optimizer state in {path} does not match this optimizer ({e}); skipped")
+    start_epoch = ckpt["epoch"] if (resume_from is not None and "epoch" in ckpt) else -1
+    best = log_loaded_info(ckpt, path) if is_main() else (0.0, 0.0)
+    return start_epoch, best[0], best[1], strict_ok
 
 
 def save_checkpoint(work_dir, interval, model, model_ema, optimizer, scheduler, checkpoint):
-    """latest.pth every call, epoch_N.pth every `interval`, det_best / segm_best copies on improvement (:123-148)."""
+    """latest.pth on every call, epoch_N.pth every `interval` epochs, det_best.pth / segm_best.pth when the epoch's
+    score beats the best so far (reference :123-148); `checkpoint` carries epoch / d_acc / miou / best_* / amp."""
     epoch = checkpoint["epoch"] + 1
-    logger = get_root_logger()
     checkpoint.pop("use_fp16", False)
-    checkpoint.update({
-        "state_dict": model.state_dict(),
-        "optimizer": optimizer.state_dict(),
-        "scheduler": scheduler.state_dict(),
-        "lr": optimizer.param_groups[0]["lr"],
-    })
+    checkpoint["state_dict"] = model.state_dict()
+    checkpoint["optimizer"] = optimizer.state_dict()
+    checkpoint["scheduler"] = scheduler.state_dict()
+    checkpoint["lr"] = optimizer.param_groups[0]["lr"]
     if model_ema is not None:
-        checkpoint.update({"ema_state_dict": dict(model_ema.shadow)})
-    latest_path = osp.join(work_dir, "latest.pth")
-    det_best_path = osp.join(work_dir, "det_best.pth")
-    segm_best_path = osp.join(work_dir, "segm_best.pth")
-    torch.save(checkpoint, latest_path)
-    if is_main():
-        logger.info(f"saved epoch {epoch} checkpoint at {latest_path}")
+        checkpoint["ema_state_dict"] = dict(model_ema.shadow)
+
+    def announce(path):
+        if is_main():
+            get_root_logger().info(f"saved epoch {epoch} checkpoint at {path}")
+
+    latest = os.path.join(work_dir, "latest.pth")
+    torch.save(checkpoint, latest)
+    announce(latest)
     if interval > 0 and epoch % interval == 0:
-        torch.save(checkpoint, osp.join(work_dir, f"epoch_{epoch}.pth"))
-    if checkpoint["d_acc"] > checkpoint["best_d_acc"]:
-        shutil.copyfile(latest_path, det_best_path)
-        if is_main():
-            logger.info(f"saved epoch {epoch} checkpoint at {det_best_path}")
-    if checkpoint["miou"] > checkpoint["best_miou"]:
-        shutil.copyfile(latest_path, segm_best_path)
-        if is_main():
-            logger.info(f"saved epoch {epoch} checkpoint at {segm_best_path}")
+        torch.save(checkpoint, os.path.join(work_dir, f"epoch_{epoch}.pth"))
+    for score, best, name in (("d_acc", "best_d_acc", "det_best.pth"), ("miou", "best_miou", "segm_best.pth")):
+        if checkpoint[score] > checkpoint[best]:
+            target = os.path.join(work_dir, name)
+            shutil.copyfile(latest, target)
+            announce(target)

@@ -1,35 +1,44 @@
-"""`simvg/utils/distributed.py:9-27` of the reference: init_dist / is_main / reduce_mean, one process per GPU over
-RCCL (`backend="nccl"` is RCCL on ROCm).  `SIMVG_DIST_BACKEND=gloo` selects gloo for the CPU tests."""
+"""Process-group helpers with the reference's names (`simvg/utils/distributed.py:9-27`: init_dist / get_dist_info /
+is_main / reduce_mean): one process per GPU over RCCL (`backend="nccl"` is RCCL on ROCm).  `SIMVG_DIST_BACKEND=gloo`
+selects gloo (CPU tests, and the two-processes-on-one-GPU test)."""
 import os
 from datetime import timedelta
 
 import torch
-from torch import distributed as dist
+import torch.distributed as dist
+
+_TIMEOUT = timedelta(minutes=3)
+
+
+def _live():
+    return dist.is_available() and dist.is_initialized()
 
 
 def get_dist_info():
-    if dist.is_available() and dist.is_initialized():
-        return dist.get_rank(), dist.get_world_size()
-    return 0, 1
-
-
-def init_dist():
-    backend = os.environ.get("SIMVG_DIST_BACKEND", "nccl")
-    if backend == "nccl":
-        torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
-        dist.init_process_group(backend="nccl", timeout=timedelta(minutes=3),
-                                device_id=torch.device("cuda", int(os.environ["LOCAL_RANK"])))
-    else:
-        dist.init_process_group(backend=backend, timeout=timedelta(minutes=3))
+    """(rank, world_size); (0, 1) outside a process group"""
+    return (dist.get_rank(), dist.get_world_size()) if _live() else (0, 1)
 
 
 def is_main():
-    return get_dist_info()[0] == 0
+    rank, _ = get_dist_info()
+    return rank == 0
+
+
+def init_dist():
+    """Join the group the launcher (torchrun: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*) describes."""
+    backend = os.environ.get("SIMVG_DIST_BACKEND", "nccl")
+    kwargs = dict(backend=backend, timeout=_TIMEOUT)
+    if backend == "nccl":
+        local = int(os.environ["LOCAL_RANK"])
+        torch.cuda.set_device(local)
+        kwargs["device_id"] = torch.device("cuda", local)       # binds the RCCL communicator to this GPU up front
+    dist.init_process_group(**kwargs)
 
 
 def reduce_mean(tensor):
-    if not (dist.is_available() and dist.is_initialized()):
+    """mean over the ranks (a copy; the argument is left alone); identity outside a process group"""
+    if not _live():
         return tensor
-    tensor = tensor.clone()
-    dist.all_reduce(tensor.div_(dist.get_world_size()), op=dist.ReduceOp.SUM)
-    return tensor
+    out = tensor.detach().clone() / dist.get_world_size()
+    dist.all_reduce(out, op=dist.ReduceOp.SUM)
+    return out
