@@ -59,6 +59,8 @@ class KeptLabels:
         return self._t
 
     def __getattr__(self, name):
+        if name.startswith("_"):       # private / dunder look-ups (copy, pickle) must not trigger the materialisation
+            raise AttributeError(name)
         return getattr(self.tensor(), name)
 
     def __len__(self):
