@@ -196,6 +196,8 @@ def main():
         if use_dist:
             dist.destroy_process_group()
         return
+    from simvg_amd import _lib as _simvg_lib
+    _lowp = _simvg_lib.lowp_format()      # "fp16" (default build) or "bf16": the MFMA operand / storage format, fp32 accumulate
     pairs = world * B * a.steps
     value = pairs / dt
     summ = timer.summary()
@@ -216,9 +218,9 @@ def main():
         "metric": "image-text pairs/sec (whole node), RefCOCO 640x640 bs=64/GPU, 1/2/4/8 MI355X",
         "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic",
+        "dtype": _lowp, "data": "synthetic",
         "config": {"workload": f"ViT-{'B' if a.vit == 'base' else 'L'}/32 SimVG (MIXDETRMB), synthetic RefCOCO 640x640 + 20-token expr, num_queries={a.queries}, "
-                               "full training step: forward+backward bf16 (fp32 accumulate, fp32 residual/master), "
+                               f"full training step: forward+backward {_lowp} MFMA operands (fp32 accumulate, fp32 residual/master), "
                                "DropPath+dropout on, clip 0.15, Adam(amsgrad)",
                    "global_batch": world * B, "per_gpu_batch": B, "tokens_per_pair": 421,
                    "parallelism": f"dp{world}", "loss_total": round(loss_val, 4)},

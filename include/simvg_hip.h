@@ -5,7 +5,12 @@
  * never allocates; every call only ENQUEUES on the passed hipStream_t (no hidden synchronisation);
  * return 0 on success, <0 on error (message via simvg_last_error()); no global mutable state besides
  * the thread-local error string.  Matrices are row-major with explicit leading dimensions (elements).
- * "bf16" = raw bfloat16 bits (uint16_t).  Weights keep the reference state_dict layout [out, in].
+ * "lp" = the library's 16-bit operand / storage format as raw bits (uint16_t): IEEE fp16 by default (simvg_lowp_format()
+ * == 1), bfloat16 in a -DSIMVG_LOWP_BF16 build (== 2); accumulation is always fp32.  fp16 is the default because bf16
+ * operand rounding cannot meet the path's parity bound (boxes within 1e-3 L1 of the fp32 reference) on trained-scale
+ * weights; backward tensors therefore carry a caller-chosen power-of-two gradient scale that the
+ * `*_scale` arguments below apply / remove, and every 16-bit store saturates instead of producing inf.
+ * Weights keep the reference state_dict layout [out, in].
  *
  * Row layout of every activation matrix is MODALITY-MAJOR: the vision tokens of all samples first
  * ([B*Nv] rows), then the text tokens ([B*Nt] rows).  `split` = B*Nv is where the multiway "A"
@@ -30,46 +35,51 @@ typedef struct ihipStream_t* simvg_stream_t; /* == hipStream_t */
 /* ---- library ---- */
 int simvg_version(void);
 const char* simvg_last_error(void);
+int simvg_lowp_format(void); /* 1 = IEEE fp16, 2 = bfloat16 */
 
-/* ---- dense contractions (bf16 MFMA, fp32 accumulate) -------------------------------------------
- * C[M,N] = A[M,K] . W[g][N,K]^T (+bias[g][N]) (+act) ; optional pre-activation copy (bf16) ; optional
+/* ---- dense contractions (16-bit MFMA, fp32 accumulate) -------------------------------------------
+ * C[M,N] = alpha * A[M,K] . W[g][N,K]^T (+bias[g][N]) (+act) ; optional pre-activation copy (lp) ; optional
  * fused residual: C = residual + row_scale[sample(m)] * (...), the DropPath + residual_connection of
  * simvg/models/vis_encs/beit/beit3_base.py:146-151,166-169.  act: 0 none, 1 exact-erf GELU, 2 ReLU.
  * Replaces the multiway nn.Linear calls of torchscale MultiheadAttention (q/k/v/out_proj) and
  * FeedForwardNetwork (fc1 -> gelu, fc2) invoked at beit3_base.py:137-145,159, the patch-embed Conv2d
  * (beit3_base.py:461, after simvg_im2col) and the head projections
  * simvg/models/heads/tgqs_kd_detr_head/tgqs_kd_detr_head.py:377-379. */
-int simvg_gemm_nt(const void* A_bf16, int lda, const void* W_bf16, long w_group_stride, int ldw,
+int simvg_gemm_nt(const void* A_lp, int lda, const void* W_lp, long w_group_stride, int ldw,
                   const float* bias, int bias_group_stride, void* C, int ldc, int c_is_f32,
-                  void* aux_preact_bf16, int ldaux, const float* residual, int ldres,
+                  void* aux_preact_lp, int ldaux, const float* residual, int ldres,
                   const float* row_scale, int rows_per_sample0, int rows_per_sample1,
-                  int M, int N, int K, int split, int act, simvg_stream_t stream);
-/* dW[g][N,K] += dY[M,N]^T . X[M,K]  (weight gradient of the same Linears; fp32 accumulate); optional fused bias
- * gradient db[g][N] += column sums of dY over the rows of group g (extra streaming blocks of the same launch) */
-int simvg_gemm_tn(const void* dY_bf16, int lddy, const void* X_bf16, int ldx, float* dW, long dw_group_stride,
-                  int lddw, float* db, int db_group_stride, int M, int N, int K, int split, simvg_stream_t stream);
+                  int M, int N, int K, int split, int act, float alpha, simvg_stream_t stream);
+/* dW[g][N,K] += out_scale * dY[M,N]^T . X[M,K]  (weight gradient of the same Linears; fp32 accumulate); optional fused bias
+ * gradient db[g][N] += out_scale * column sums of dY over the rows of group g (extra streaming blocks of the same
+ * launch).  out_scale = 1 / (gradient scale carried by dY). */
+int simvg_gemm_tn(const void* dY_lp, int lddy, const void* X_lp, int ldx, float* dW, long dw_group_stride,
+                  int lddw, float* db, int db_group_stride, int M, int N, int K, int split, float out_scale,
+                  simvg_stream_t stream);
 /* out[g][N] += column sums of Y over the rows of group g (bias gradients) */
-int simvg_colsum(const void* Y_bf16, int ldy, float* out, int out_group_stride, int M, int N, int split,
+int simvg_colsum(const void* Y_lp, int ldy, float* out, int out_group_stride, int M, int N, int split,
                  simvg_stream_t stream);
 
 /* ---- LayerNorm (multiway gamma/beta by row group) -----------------------------------------------
  * torch.nn.LayerNorm under MultiwayWrapper: beit3_base.py:136 (self_attn_layer_norm), :157
  * (final_layer_norm), :396-397 (encoder.layer_norm), torchscale inner_attn_ln / ffn_layernorm; and the
  * decoder norms of heads/tgqs_kd_detr_head/transformer.py:119-132. */
-int simvg_ln_fwd(const void* x, int x_is_bf16, int ldx, const float* gamma, const float* beta, int group_stride,
-                 void* y_bf16, int ldy, float* y_f32, int ldy32, float* mean, float* rstd,
+int simvg_ln_fwd(const void* x, int x_is_lp, int ldx, const float* gamma, const float* beta, int group_stride,
+                 void* y_lp, int ldy, float* y_f32, int ldy32, float* mean, float* rstd,
                  int M, int D, int split, float eps, int x_is_gelu_preact /* x = fc1 pre-activation u: normalise
                  gelu(u), recomputed in registers -- torchscale FeedForwardNetwork: ffn_layernorm(gelu(fc1(x))) */,
                  simvg_stream_t stream);
-/* dx = LN'(dy); outputs: bf16 dx (optionally * GELU'(u), fusing the activation backward of fc1), and/or
- * fp32 (dres + dx) = the residual-stream gradient, with an optional bf16 copy * row_scale (DropPath).
- * gelu_u_bf16 == x (same pointer): x is the pre-activation and the LayerNorm input gelu(u) is recomputed. */
-int simvg_ln_bwd(const void* dy, int dy_is_f32, int lddy, const void* x, int x_is_bf16, int ldx, const float* mean,
+/* dx = LN'(dy); outputs: lp dx (optionally * GELU'(u), fusing the activation backward of fc1), and/or
+ * fp32 (dres + dx) = the residual-stream gradient, with an optional lp copy * row_scale (DropPath).
+ * gelu_u_lp == x (same pointer): x is the pre-activation and the LayerNorm input gelu(u) is recomputed. */
+int simvg_ln_bwd(const void* dy, int dy_is_f32, int lddy, const void* x, int x_is_lp, int ldx, const float* mean,
                  const float* rstd, const float* gamma, int group_stride, float* dgamma, float* dbeta,
-                 void* dx_bf16, int lddxb, const void* gelu_u_bf16, int ldu, const float* dres,
-                 float* dx_f32, int lddxf, void* dx_scaled_bf16, int lddxs, const float* row_scale,
+                 void* dx_lp, int lddxb, const void* gelu_u_lp, int ldu, const float* dres,
+                 float* dx_f32, int lddxf, void* dx_scaled_lp, int lddxs, const float* row_scale,
                  int rows_per_sample0, int rows_per_sample1, int M, int D, int split, float* partial_ws /* optional:
                  >= simvg_ln_bwd_ws_floats() floats -> two-stage dgamma/dbeta reduction instead of atomics */,
+                 float dy_scale /* multiplies an fp32 dy on load: the entry of a scaled backward (1 otherwise) */,
+                 float param_scale /* multiplies what is added to dgamma / dbeta: 1 / gradient scale of dy */,
                  simvg_stream_t stream);
 long simvg_ln_bwd_ws_floats(int M, int D, int split);
 
@@ -77,10 +87,10 @@ long simvg_ln_bwd_ws_floats(int M, int D, int split);
  * softmax(scale * Q K^T + key_padding(-inf)) V per (sample, head), head_dim 64, N = Nv+Nt <= 448.
  * torchscale MultiheadAttention.forward as called at beit3_base.py:137-145 (bmm, masked_fill, fp32
  * softmax, bmm, head merge).  qkv: [M, 3D] = q | k | v columns.  pad: [B,Nt] bytes, 1 = padded key. */
-int simvg_attn_fwd(const void* qkv_bf16, int ldqkv, void* out_bf16, int ldo, float* lse, const unsigned char* pad,
+int simvg_attn_fwd(const void* qkv_lp, int ldqkv, void* out_lp, int ldo, float* lse, const unsigned char* pad,
                    int B, int H, int Nv, int Nt, int D, float scale, simvg_stream_t stream);
-int simvg_attn_bwd(const void* qkv_bf16, int ldqkv, const void* out_bf16, int ldo, const void* dout_bf16, int lddo,
-                   void* dqkv_bf16, int lddqkv, const float* lse, float* delta_ws, const unsigned char* pad,
+int simvg_attn_bwd(const void* qkv_lp, int ldqkv, const void* out_lp, int ldo, const void* dout_lp, int lddo,
+                   void* dqkv_lp, int lddqkv, const float* lse, float* delta_ws, const unsigned char* pad,
                    int B, int H, int Nv, int Nt, int D, float scale, simvg_stream_t stream);
 
 /* ---- decoder head: exact-fp32 small GEMM, small multi-head attention --------------------------------
@@ -153,21 +163,22 @@ int simvg_postprocess(const float* logits, const float* boxes, const float* wh, 
 /* ---- embedding stage -------------------------------------------------------------------------------
  * torchscale VisionEmbedding / TextEmbedding / PositionalEmbedding as wired by BEiT3.forward and
  * Encoder.forward_embedding (beit3_base.py:461-475,317-334) and the pad zeroing at :367. */
-int simvg_im2col(const float* img_nchw, void* cols_bf16, int B, int S, int P, simvg_stream_t stream);
+int simvg_im2col(const float* img_nchw, void* cols_lp, int B, int S, int P, simvg_stream_t stream);
 int simvg_embed_fwd(const float* patch, int ldp, const float* cls, const float* posA, const float* posB,
                     const float* text_embed, const long long* ids, const unsigned char* pad, float* x, int ldx,
                     int B, int np, int T, int D, simvg_stream_t stream);
-int simvg_embed_bwd(const float* dx, int lddx, void* dpatch_bf16, int lddp, float* dcls, float* dposA, float* dposB,
+int simvg_embed_bwd(const float* dx, int lddx, void* dpatch_lp, int lddp, float* dcls, float* dposA, float* dposB,
                     float* dtext, const long long* ids, const unsigned char* pad, int B, int np, int T, int D,
+                    float param_scale /* on dcls / dposA / dposB / dtext; dpatch keeps the scale of dx */,
                     simvg_stream_t stream);
 
-/* ---- weight preparation (fp32 master -> bf16 compute copies, plain + transposed) ---------------- */
+/* ---- weight preparation (fp32 master -> 16-bit compute copies, plain + transposed) ---------------- */
 typedef struct {
-  const float* src; void* dst_bf16; void* dst_t_bf16; int rows, cols; int tile_start; int pad_;
+  const float* src; void* dst_lp; void* dst_t_lp; int rows, cols; int tile_start; int pad_;
 } simvg_weight_desc;
 int simvg_weight_prep(const void* descs_dev, int n_desc, int total_tiles, simvg_stream_t stream);
-int simvg_cast_f32_to_bf16(const float* src, void* dst_bf16, long n, simvg_stream_t stream);
-int simvg_cast_bf16_to_f32(const void* src_bf16, float* dst, long n, simvg_stream_t stream);
+int simvg_cast_f32_to_lp(const float* src, void* dst_lp, long n, float scale, simvg_stream_t stream);
+int simvg_cast_lp_to_f32(const void* src_lp, float* dst, long n, simvg_stream_t stream);
 
 /* ---- device-side image pre-processing (csrc/preprocess.hip) --------------------------------------------------------
  * Replaces the pixel work of simvg/datasets/pipelines/transforms.py (LargeScaleJitter :221-342 -> mmcv.imrescale + crop,
@@ -193,7 +204,7 @@ int simvg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
                     const float* total_norm, float max_norm, simvg_stream_t stream);
 
 /* ---- hardware-semantics probes (tests/test_kernels_gpu.py) ---------------------------------------- */
-int simvg_probe_mfma(const void* a_bf16, const void* b_bf16, float* out, simvg_stream_t stream);
+int simvg_probe_mfma(const void* a_lp, const void* b_lp, float* out, simvg_stream_t stream);
 int simvg_probe_tr16(const int* byte_addr, void* out_i16, simvg_stream_t stream);
 int simvg_probe_glds(const void* src_i16, const int* perm, void* out_i16, simvg_stream_t stream);
 

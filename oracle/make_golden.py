@@ -27,6 +27,9 @@ CASES = {
     "base_nq1":       ("base", 1, 640, 2, False, 13, 23),
     "base_nq10_grec": ("base", 10, 640, 3, True, 14, 24),
     "large_nq1":      ("large", 1, 640, 1, False, 15, 25),
+    # BASELINE config 5: ViT-L + DWBD distillation, GRefCOCO multi-target (nq = 10, 2-target / no-target / 1-target samples)
+    "large_nq10_grec":         ("large", 10, 640, 3, True, 18, 28),
+    "large_nq10_grec_refinit": ("large", 10, 640, 3, True, 19, 29),
     # reference-style initialisation (what training from scratch / the benchmark uses)
     "base_nq1_refinit":       ("base", 1, 640, 2, False, 16, 26),
     "base_nq10_grec_refinit": ("base", 10, 640, 3, True, 17, 27),

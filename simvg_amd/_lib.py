@@ -28,15 +28,15 @@ _SIGS = {
                           c_int, c_int, c_int, c_void_p],
     "simvg_gemm_nt": [c_void_p, c_int, c_void_p, c_long, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
                       c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                      c_void_p],
+                      c_float, c_void_p],
     "simvg_gemm_tn": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_long, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                      c_void_p],
+                      c_float, c_void_p],
     "simvg_colsum": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "simvg_ln_fwd": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
                      c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p],
     "simvg_ln_bwd": [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                      c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
-                     c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+                     c_int, c_int, c_int, c_int, c_int, c_void_p, c_float, c_float, c_void_p],
     "simvg_attn_fwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                        c_float, c_void_p],
     "simvg_attn_bwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
@@ -45,10 +45,10 @@ _SIGS = {
     "simvg_embed_fwd": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                         c_int, c_int, c_int, c_int, c_void_p],
     "simvg_embed_bwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                        c_int, c_int, c_int, c_int, c_void_p],
+                        c_int, c_int, c_int, c_int, c_float, c_void_p],
     "simvg_weight_prep": [c_void_p, c_int, c_int, c_void_p],
-    "simvg_cast_f32_to_bf16": [c_void_p, c_void_p, c_long, c_void_p],
-    "simvg_cast_bf16_to_f32": [c_void_p, c_void_p, c_long, c_void_p],
+    "simvg_cast_f32_to_lp": [c_void_p, c_void_p, c_long, c_float, c_void_p],
+    "simvg_cast_lp_to_f32": [c_void_p, c_void_p, c_long, c_void_p],
     "simvg_resize_u8": [c_void_p, c_int, c_int, c_long, c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "simvg_normalize_pad_u8": [c_void_p, c_long, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
     "simvg_attn_f32_bwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
@@ -101,14 +101,21 @@ def load():
     lib.simvg_last_error.restype = C.c_char_p
     lib.simvg_last_error.argtypes = []
     lib.simvg_version.restype = c_int
+    lib.simvg_lowp_format.restype = c_int
+    lib.simvg_lowp_format.argtypes = []
     lib.simvg_ln_bwd_ws_floats.restype = c_long
     lib.simvg_ln_bwd_ws_floats.argtypes = [c_int, c_int, c_int]
     _lib = lib
     return lib
 
 
+def lowp_format():
+    """"fp16" or "bf16": the 16-bit operand / storage format the loaded library was built for"""
+    return {1: "fp16", 2: "bf16"}[load().simvg_lowp_format()]
+
+
 def exported_symbols():
-    return sorted(_SIGS) + ["simvg_last_error", "simvg_version", "simvg_ln_bwd_ws_floats"]
+    return sorted(_SIGS) + ["simvg_last_error", "simvg_version", "simvg_lowp_format", "simvg_ln_bwd_ws_floats"]
 
 
 def check(rc, what):

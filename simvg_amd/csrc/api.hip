@@ -11,19 +11,19 @@ extern "C" void simvg_set_error(const char* msg) {
   g_err[sizeof(g_err) - 1] = 0;
 }
 extern "C" const char* simvg_last_error(void) { return g_err; }
-extern "C" int simvg_version(void) { return 1; }
+extern "C" int simvg_version(void) { return 2; }
 
 namespace {
 // out[64][4] = D fragment of one v_mfma_f32_16x16x32_bf16 with A[i][k] = a[i*32+k], B[k][j] = b[k*16+j]
-__global__ void probe_mfma_kernel(const bf16_t* a, const bf16_t* b, float* out) {
+__global__ void probe_mfma_kernel(const lp_t* a, const lp_t* b, float* out) {
   const int lane = threadIdx.x, i = lane & 15, g = lane >> 4;
-  bf16x8_t fa, fb;
+  lpx8_t fa, fb;
   for (int e = 0; e < 8; ++e) {
     fa[e] = (short)a[i * 32 + 8 * g + e];
     fb[e] = (short)b[(8 * g + e) * 16 + i];
   }
   f32x4_t c = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, c, 0, 0, 0);
+  c = mfma_lp(fa, fb, c);
   for (int r = 0; r < 4; ++r) out[lane * 4 + r] = c[r];
 }
 // LDS filled with lds[e] = e (16-bit); lane l supplies byte address addr[l]; out[l][0..3] = what it got
@@ -31,7 +31,7 @@ __global__ void probe_tr16_kernel(const int* addr, short* out) {
   __shared__ __attribute__((aligned(16))) short lds[4096];
   for (int e = threadIdx.x; e < 4096; e += 64) lds[e] = (short)e;
   __syncthreads();
-  const bf16x4_t v = lds_read_tr16((const char*)lds + addr[threadIdx.x]);
+  const lpx4_t v = lds_read_tr16((const char*)lds + addr[threadIdx.x]);
   for (int r = 0; r < 4; ++r) out[threadIdx.x * 4 + r] = v[r];
 }
 // one wave: global_load_lds 16 B/lane from src + perm[lane]*8 elements; dump LDS linearly
@@ -45,7 +45,7 @@ __global__ void probe_glds_kernel(const short* src, const int* perm, short* out)
 }  // namespace
 
 extern "C" int simvg_probe_mfma(const void* a, const void* b, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(probe_mfma_kernel, dim3(1), dim3(64), 0, s, (const bf16_t*)a, (const bf16_t*)b, out);
+  hipLaunchKernelGGL(probe_mfma_kernel, dim3(1), dim3(64), 0, s, (const lp_t*)a, (const lp_t*)b, out);
   SIMVG_LAUNCH_CHECK();
   return SIMVG_OK;
 }

@@ -32,10 +32,10 @@ __device__ __forceinline__ int lds_slot(int row, int slot) { return slot ^ (row 
 constexpr int MAX_KT = 28;      // 28 * 16 = 448 >= 421 keys
 
 struct AttnArgs {
-  const bf16_t* qkv; int ld;    // [M, 3*D]
-  bf16_t* out; int ldo;         // [M, D]   forward output / saved O in backward
-  const bf16_t* dout; int lddo; // [M, D]   backward: grad of O
-  bf16_t* dqkv; int lddq;       // [M, 3*D] backward: grads
+  const lp_t* qkv; int ld;    // [M, 3*D]
+  lp_t* out; int ldo;         // [M, D]   forward output / saved O in backward
+  const lp_t* dout; int lddo; // [M, D]   backward: grad of O
+  lp_t* dqkv; int lddq;       // [M, 3*D] backward: grads
   float* lse;                   // [B*H, N]
   float* delta;                 // [B*H, N]
   const unsigned char* pad;     // [B, Nt] 1 = padded text key, or null
@@ -48,7 +48,7 @@ __device__ __forceinline__ long tok_row(const AttnArgs& a, int b, int t) {
 }
 
 // copy rows [0,nrows_pad) x 64 bf16 of one head into LDS (zero beyond N)
-__device__ __forceinline__ void load_head_to_lds(const AttnArgs& a, const bf16_t* base, int ld, int col0, int b, int N,
+__device__ __forceinline__ void load_head_to_lds(const AttnArgs& a, const lp_t* base, int ld, int col0, int b, int N,
                                                  int nrows_pad, char* lds) {
   for (int c = threadIdx.x; c < nrows_pad * 8; c += blockDim.x) {
     const int row = c >> 3, slot = c & 7;
@@ -58,25 +58,25 @@ __device__ __forceinline__ void load_head_to_lds(const AttnArgs& a, const bf16_t
   }
 }
 
-__device__ __forceinline__ bf16x8_t lds_frag(const char* lds, int row, int slot) {
-  return *(const bf16x8_t*)(lds + row * ROWB + lds_slot(row, slot) * 16);
+__device__ __forceinline__ lpx8_t lds_frag(const char* lds, int row, int slot) {
+  return *(const lpx8_t*)(lds + row * ROWB + lds_slot(row, slot) * 16);
 }
 
 // transposed fragment for contraction over LDS rows: lane (i = lane&15 -> column c0 + i,
 // g = lane>>4); rows rowA+4g..+3 (elements 0..3) and rowB+4g..+3 (elements 4..7)
-__device__ __forceinline__ bf16x8_t lds_frag_tr(const char* lds, int rowA, int rowB, int c0, int lane) {
+__device__ __forceinline__ lpx8_t lds_frag_tr(const char* lds, int rowA, int rowB, int c0, int lane) {
   const int i = lane & 15, g = lane >> 4;
   const int col = c0 + 4 * (i & 3), slot = col >> 3, within = (col & 7) * 2;
   const int ra = rowA + 4 * g + (i >> 2), rb = rowB + 4 * g + (i >> 2);
-  const bf16x4_t lo = lds_read_tr16(lds + ra * ROWB + lds_slot(ra, slot) * 16 + within);
-  const bf16x4_t hi = lds_read_tr16(lds + rb * ROWB + lds_slot(rb, slot) * 16 + within);
-  return (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  const lpx4_t lo = lds_read_tr16(lds + ra * ROWB + lds_slot(ra, slot) * 16 + within);
+  const lpx4_t hi = lds_read_tr16(lds + rb * ROWB + lds_slot(rb, slot) * 16 + within);
+  return (lpx8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-__device__ __forceinline__ bf16x8_t pack8(const float* lo, const float* hi) {
-  union { bf16x8_t v; unsigned int u[4]; } r;
-  r.u[0] = pack_bf16x2(lo[0], lo[1]); r.u[1] = pack_bf16x2(lo[2], lo[3]);
-  r.u[2] = pack_bf16x2(hi[0], hi[1]); r.u[3] = pack_bf16x2(hi[2], hi[3]);
+__device__ __forceinline__ lpx8_t pack8(const float* lo, const float* hi) {
+  union { lpx8_t v; unsigned int u[4]; } r;
+  r.u[0] = pack_lp2(lo[0], lo[1]); r.u[1] = pack_lp2(lo[2], lo[3]);
+  r.u[2] = pack_lp2(hi[0], hi[1]); r.u[3] = pack_lp2(hi[2], hi[3]);
   return r.v;
 }
 
@@ -110,16 +110,16 @@ __global__ __launch_bounds__(768) void attn_fwd_kernel(AttnArgs a) {
   const float sc2 = a.scale * 1.44269504088896340736f;
   for (int qb = wave; qb < nkt; qb += nwaves) {
     const int tq = qb * 16 + j;
-    const bf16_t* qp = a.qkv + tok_row(a, b, tq < N ? tq : N - 1) * a.ld + h * HD + 8 * g;
-    const bf16x8_t q0 = *(const bf16x8_t*)qp, q1 = *(const bf16x8_t*)(qp + 32);
+    const lp_t* qp = a.qkv + tok_row(a, b, tq < N ? tq : N - 1) * a.ld + h * HD + 8 * g;
+    const lpx8_t q0 = *(const lpx8_t*)qp, q1 = *(const lpx8_t*)(qp + 32);
     f32x4_t s[MAX_KT];
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < MAX_KT; ++kt) {
       if (kt < nkt) {
         f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(ldsK, kt * 16 + j, g), q0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(ldsK, kt * 16 + j, 4 + g), q1, acc, 0, 0, 0);
+        acc = mfma_lp(lds_frag(ldsK, kt * 16 + j, g), q0, acc);
+        acc = mfma_lp(lds_frag(ldsK, kt * 16 + j, 4 + g), q1, acc);
         const f32x4_t kb = *(const f32x4_t*)(bias + kt * 16 + 4 * g);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -157,21 +157,21 @@ __global__ __launch_bounds__(768) void attn_fwd_kernel(AttnArgs a) {
           lo[r] = s[2 * s2][r];
           hi[r] = (2 * s2 + 1 < nkt) ? s[2 * s2 + 1][r] : 0.f;
         }
-        const bf16x8_t pf = pack8(lo, hi);
+        const lpx8_t pf = pack8(lo, hi);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          const bf16x8_t vf = lds_frag_tr(ldsV, s2 * 32, s2 * 32 + 16, dt * 16, lane);
-          o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
+          const lpx8_t vf = lds_frag_tr(ldsV, s2 * 32, s2 * 32 + 16, dt * 16, lane);
+          o[dt] = mfma_lp(vf, pf, o[dt]);
         }
       }
     }
     if (tq < N) {
       const float inv = 1.f / sum;
-      bf16_t* op = a.out + tok_row(a, b, tq) * a.ldo + h * HD + 4 * g;
+      lp_t* op = a.out + tok_row(a, b, tq) * a.ldo + h * HD + 4 * g;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
-        *(u32x2_t*)(op + dt * 16) = (u32x2_t){pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv),
-                                             pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv)};
+        *(u32x2_t*)(op + dt * 16) = (u32x2_t){pack_lp2(o[dt][0] * inv, o[dt][1] * inv),
+                                             pack_lp2(o[dt][2] * inv, o[dt][3] * inv)};
       if (g == 0 && a.lse) a.lse[(long)blockIdx.x * N + tq] = (mx + __log2f(sum)) * 0.69314718055994530942f;   // natural log
     }
   }
@@ -200,17 +200,17 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnArgs a) {
   for (int qb = wave; qb < nkt; qb += nwaves) {
     const int tq = qb * 16 + j;
     const long row = tok_row(a, b, tq < N ? tq : N - 1);
-    const bf16_t* qp = a.qkv + row * a.ld + h * HD + 8 * g;
-    const bf16x8_t q0 = *(const bf16x8_t*)qp, q1 = *(const bf16x8_t*)(qp + 32);
-    const bf16_t* dop = a.dout + row * a.lddo + h * HD + 8 * g;
-    const bf16x8_t d0 = *(const bf16x8_t*)dop, d1 = *(const bf16x8_t*)(dop + 32);
-    const bf16_t* op = a.out + row * a.ldo + h * HD + 8 * g;
-    const bf16x8_t o0 = *(const bf16x8_t*)op, o1 = *(const bf16x8_t*)(op + 32);
+    const lp_t* qp = a.qkv + row * a.ld + h * HD + 8 * g;
+    const lpx8_t q0 = *(const lpx8_t*)qp, q1 = *(const lpx8_t*)(qp + 32);
+    const lp_t* dop = a.dout + row * a.lddo + h * HD + 8 * g;
+    const lpx8_t d0 = *(const lpx8_t*)dop, d1 = *(const lpx8_t*)(dop + 32);
+    const lp_t* op = a.out + row * a.ldo + h * HD + 8 * g;
+    const lpx8_t o0 = *(const lpx8_t*)op, o1 = *(const lpx8_t*)(op + 32);
     float dl = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      dl += bf16_to_f32((bf16_t)d0[e]) * bf16_to_f32((bf16_t)o0[e]);
-      dl += bf16_to_f32((bf16_t)d1[e]) * bf16_to_f32((bf16_t)o1[e]);
+      dl += lp_to_f32((lp_t)d0[e]) * lp_to_f32((lp_t)o0[e]);
+      dl += lp_to_f32((lp_t)d1[e]) * lp_to_f32((lp_t)o1[e]);
     }
     dl += __shfl_xor(dl, 16, 64);
     dl += __shfl_xor(dl, 32, 64);
@@ -222,10 +222,10 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnArgs a) {
     for (int kt = 0; kt < MAX_KT; ++kt) {
       if (kt < nkt) {
         f32x4_t sa = (f32x4_t){0.f, 0.f, 0.f, 0.f}, dp = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(ldsK, kt * 16 + j, g), q0, sa, 0, 0, 0);
-        sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(ldsK, kt * 16 + j, 4 + g), q1, sa, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(ldsV, kt * 16 + j, g), d0, dp, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(ldsV, kt * 16 + j, 4 + g), d1, dp, 0, 0, 0);
+        sa = mfma_lp(lds_frag(ldsK, kt * 16 + j, g), q0, sa);
+        sa = mfma_lp(lds_frag(ldsK, kt * 16 + j, 4 + g), q1, sa);
+        dp = mfma_lp(lds_frag(ldsV, kt * 16 + j, g), d0, dp);
+        dp = mfma_lp(lds_frag(ldsV, kt * 16 + j, 4 + g), d1, dp);
         const f32x4_t kb = *(const f32x4_t*)(bias + kt * 16 + 4 * g);
         float ds[4];
 #pragma unroll
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnArgs a) {
           const float p = __builtin_amdgcn_exp2f(sa[r] * sc2 + kb[r] - lse2);
           ds[r] = p * (dp[r] - dl);
         }
-        dsb[kt] = (u32x2_t){pack_bf16x2(ds[0], ds[1]), pack_bf16x2(ds[2], ds[3])};
+        dsb[kt] = (u32x2_t){pack_lp2(ds[0], ds[1]), pack_lp2(ds[2], ds[3])};
       }
     }
     f32x4_t dq[4];
@@ -242,23 +242,23 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
     for (int s2 = 0; s2 < MAX_KT / 2; ++s2) {
       if (s2 < ns2) {
-        union { bf16x8_t v; unsigned int u[4]; } pf;
+        union { lpx8_t v; unsigned int u[4]; } pf;
         pf.u[0] = dsb[2 * s2][0]; pf.u[1] = dsb[2 * s2][1];
         if (2 * s2 + 1 < nkt) { pf.u[2] = dsb[2 * s2 + 1][0]; pf.u[3] = dsb[2 * s2 + 1][1]; }
         else { pf.u[2] = 0u; pf.u[3] = 0u; }
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          const bf16x8_t kf = lds_frag_tr(ldsK, s2 * 32, s2 * 32 + 16, dt * 16, lane);
-          dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, pf.v, dq[dt], 0, 0, 0);
+          const lpx8_t kf = lds_frag_tr(ldsK, s2 * 32, s2 * 32 + 16, dt * 16, lane);
+          dq[dt] = mfma_lp(kf, pf.v, dq[dt]);
         }
       }
     }
     if (tq < N) {
-      bf16_t* gp = a.dqkv + tok_row(a, b, tq) * a.lddq + h * HD + 4 * g;
+      lp_t* gp = a.dqkv + tok_row(a, b, tq) * a.lddq + h * HD + 4 * g;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
-        *(u32x2_t*)(gp + dt * 16) = (u32x2_t){pack_bf16x2(dq[dt][0] * a.scale, dq[dt][1] * a.scale),
-                                             pack_bf16x2(dq[dt][2] * a.scale, dq[dt][3] * a.scale)};
+        *(u32x2_t*)(gp + dt * 16) = (u32x2_t){pack_lp2(dq[dt][0] * a.scale, dq[dt][1] * a.scale),
+                                             pack_lp2(dq[dt][2] * a.scale, dq[dt][3] * a.scale)};
     }
   }
 }
@@ -290,10 +290,10 @@ __global__ __launch_bounds__(768) void attn_bwd_dkv_kernel(AttnArgs a) {
   for (int kb = wave; kb < nkt; kb += nwaves) {
     const int tk = kb * 16 + j;
     const long row = tok_row(a, b, tk < N ? tk : N - 1);
-    const bf16_t* kp = a.qkv + row * a.ld + a.D + h * HD + 8 * g;
-    const bf16x8_t k0 = *(const bf16x8_t*)kp, k1 = *(const bf16x8_t*)(kp + 32);
-    const bf16_t* vp = a.qkv + row * a.ld + 2 * a.D + h * HD + 8 * g;
-    const bf16x8_t v0 = *(const bf16x8_t*)vp, v1 = *(const bf16x8_t*)(vp + 32);
+    const lp_t* kp = a.qkv + row * a.ld + a.D + h * HD + 8 * g;
+    const lpx8_t k0 = *(const lpx8_t*)kp, k1 = *(const lpx8_t*)(kp + 32);
+    const lp_t* vp = a.qkv + row * a.ld + 2 * a.D + h * HD + 8 * g;
+    const lpx8_t v0 = *(const lpx8_t*)vp, v1 = *(const lpx8_t*)(vp + 32);
     bool masked = tk >= N;
     if (!masked && a.pad && tk >= a.Nv) masked = a.pad[b * a.Nt + (tk - a.Nv)] != 0;
     const float kbias = masked ? -INFINITY : 0.f;
@@ -308,10 +308,10 @@ __global__ __launch_bounds__(768) void attn_bwd_dkv_kernel(AttnArgs a) {
       for (int hh = 0; hh < 2; ++hh) {
         const int qt = 2 * s2 + hh;   // rows qt*16.. exist in LDS (zero-filled beyond N)
         f32x4_t sa = (f32x4_t){0.f, 0.f, 0.f, 0.f}, dp = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(ldsQ, qt * 16 + j, g), k0, sa, 0, 0, 0);
-        sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(ldsQ, qt * 16 + j, 4 + g), k1, sa, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(ldsDO, qt * 16 + j, g), v0, dp, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(ldsDO, qt * 16 + j, 4 + g), v1, dp, 0, 0, 0);
+        sa = mfma_lp(lds_frag(ldsQ, qt * 16 + j, g), k0, sa);
+        sa = mfma_lp(lds_frag(ldsQ, qt * 16 + j, 4 + g), k1, sa);
+        dp = mfma_lp(lds_frag(ldsDO, qt * 16 + j, g), v0, dp);
+        dp = mfma_lp(lds_frag(ldsDO, qt * 16 + j, 4 + g), v1, dp);
         const f32x4_t l4 = *(const f32x4_t*)(lse_s + qt * 16 + 4 * g);
         const f32x4_t d4 = *(const f32x4_t*)(dl_s + qt * 16 + 4 * g);
 #pragma unroll
@@ -321,24 +321,24 @@ __global__ __launch_bounds__(768) void attn_bwd_dkv_kernel(AttnArgs a) {
           ds[hh][r] = pr * (dp[r] - d4[r]);
         }
       }
-      const bf16x8_t pf = pack8(p[0], p[1]);
-      const bf16x8_t dsf = pack8(ds[0], ds[1]);
+      const lpx8_t pf = pack8(p[0], p[1]);
+      const lpx8_t dsf = pack8(ds[0], ds[1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const bf16x8_t dof = lds_frag_tr(ldsDO, s2 * 32, s2 * 32 + 16, dt * 16, lane);
-        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, pf, dv[dt], 0, 0, 0);
-        const bf16x8_t qf = lds_frag_tr(ldsQ, s2 * 32, s2 * 32 + 16, dt * 16, lane);
-        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, dsf, dk[dt], 0, 0, 0);
+        const lpx8_t dof = lds_frag_tr(ldsDO, s2 * 32, s2 * 32 + 16, dt * 16, lane);
+        dv[dt] = mfma_lp(dof, pf, dv[dt]);
+        const lpx8_t qf = lds_frag_tr(ldsQ, s2 * 32, s2 * 32 + 16, dt * 16, lane);
+        dk[dt] = mfma_lp(qf, dsf, dk[dt]);
       }
     }
     if (tk < N) {
-      bf16_t* gk = a.dqkv + tok_row(a, b, tk) * a.lddq + a.D + h * HD + 4 * g;
-      bf16_t* gv = a.dqkv + tok_row(a, b, tk) * a.lddq + 2 * a.D + h * HD + 4 * g;
+      lp_t* gk = a.dqkv + tok_row(a, b, tk) * a.lddq + a.D + h * HD + 4 * g;
+      lp_t* gv = a.dqkv + tok_row(a, b, tk) * a.lddq + 2 * a.D + h * HD + 4 * g;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        *(u32x2_t*)(gk + dt * 16) = (u32x2_t){pack_bf16x2(dk[dt][0] * a.scale, dk[dt][1] * a.scale),
-                                             pack_bf16x2(dk[dt][2] * a.scale, dk[dt][3] * a.scale)};
-        *(u32x2_t*)(gv + dt * 16) = (u32x2_t){pack_bf16x2(dv[dt][0], dv[dt][1]), pack_bf16x2(dv[dt][2], dv[dt][3])};
+        *(u32x2_t*)(gk + dt * 16) = (u32x2_t){pack_lp2(dk[dt][0] * a.scale, dk[dt][1] * a.scale),
+                                             pack_lp2(dk[dt][2] * a.scale, dk[dt][3] * a.scale)};
+        *(u32x2_t*)(gv + dt * 16) = (u32x2_t){pack_lp2(dv[dt][0], dv[dt][1]), pack_lp2(dv[dt][2], dv[dt][3])};
       }
     }
   }
@@ -363,7 +363,7 @@ extern "C" int simvg_attn_fwd(const void* qkv, int ldqkv, void* out, int ldo, fl
                               int B, int H, int Nv, int Nt, int D, float scale, hipStream_t stream) {
   SIMVG_CHECK_ARG(attn_check(B, H, Nv, Nt, D, ldqkv) && ldo % 8 == 0,
                   "attn_fwd: need head_dim 64, Nv+Nt <= 448, 16-B aligned rows");
-  AttnArgs a{(const bf16_t*)qkv, ldqkv, (bf16_t*)out, ldo, nullptr, 0, nullptr, 0, lse, nullptr, pad, B, H, Nv, Nt, D, scale};
+  AttnArgs a{(const lp_t*)qkv, ldqkv, (lp_t*)out, ldo, nullptr, 0, nullptr, 0, lse, nullptr, pad, B, H, Nv, Nt, D, scale};
   const int N = Nv + Nt, npad = ((cdiv(N, 16) + 1) / 2) * 32;
   const size_t shm = (size_t)2 * npad * ROWB + npad * sizeof(float);
   static bool once = set_lds_limit(attn_fwd_kernel, 160 * 1024);
@@ -381,7 +381,7 @@ extern "C" int simvg_attn_bwd(const void* qkv, int ldqkv, const void* out, int l
   SIMVG_CHECK_ARG(attn_check(B, H, Nv, Nt, D, ldqkv) && ldo % 8 == 0 && lddo % 8 == 0 && lddqkv % 8 == 0,
                   "attn_bwd: need head_dim 64, Nv+Nt <= 448, 16-B aligned rows");
   SIMVG_CHECK_ARG(lse && delta_ws, "attn_bwd: lse and delta workspace required");
-  AttnArgs a{(const bf16_t*)qkv, ldqkv, (bf16_t*)out, ldo, (const bf16_t*)dout, lddo, (bf16_t*)dqkv, lddqkv,
+  AttnArgs a{(const lp_t*)qkv, ldqkv, (lp_t*)out, ldo, (const lp_t*)dout, lddo, (lp_t*)dqkv, lddqkv,
              (float*)lse, delta_ws, pad, B, H, Nv, Nt, D, scale};
   const int N = Nv + Nt, npad = ((cdiv(N, 16) + 1) / 2) * 32;
   const size_t shm1 = (size_t)2 * npad * ROWB + npad * sizeof(float);

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void im2col_f32_kernel(const float* __restrict
   }
 }
 
-__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, bf16_t* __restrict__ cols,
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, lp_t* __restrict__ cols,
                                                      int B, int S, int P, long total4) {
   const int G = S / P, K = 3 * P * P;
   for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total4; t += (long)gridDim.x * 256) {
@@ -41,8 +41,8 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ i
     const int c = (int)(bc % 3), b = (int)(bc / 3);
     const f32x4_t v = *(const f32x4_t*)(img + e);
     const int py = y / P, ky = y - py * P, px = x / P, kx = x - px * P;
-    bf16_t* o = cols + ((long)b * G * G + py * G + px) * K + c * P * P + ky * P + kx;
-    *(u32x2_t*)o = (u32x2_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    lp_t* o = cols + ((long)b * G * G + py * G + px) * K + c * P * P + ky * P + kx;
+    *(u32x2_t*)o = (u32x2_t){pack_lp2(v[0], v[1]), pack_lp2(v[2], v[3])};
   }
 }
 
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(EmbedArgs a) {
 
 struct EmbedBwdArgs {
   const float* dx; int lddx;       // [M, D]
-  bf16_t* dpatch; int lddp;        // [B*np, D] bf16
+  lp_t* dpatch; int lddp;        // [B*np, D] bf16
   float* dcls;                     // [D]
   float* dposA;                    // [np+3, D]
   float* dposB;                    // [1024, D]
@@ -96,6 +96,7 @@ struct EmbedBwdArgs {
   const long long* ids;
   const unsigned char* pad;
   int B, np, T, D;
+  float scale;                     // on the parameter gradients (1 / gradient scale of dx); dpatch keeps dx's scale
 };
 
 // one block per vision token position t (reduction over the batch), then one block per text position j
@@ -112,8 +113,9 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs a) {
         s += v;
         if (t > 0)
           *(u32x2_t*)(a.dpatch + ((long)b * a.np + (t - 1)) * a.lddp + c) =
-              (u32x2_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+              (u32x2_t){pack_lp2(v[0], v[1]), pack_lp2(v[2], v[3])};
       }
+      s *= a.scale;
       float* dp = a.dposA + (long)(t + 2) * a.D + c;
       *(f32x4_t*)dp = *(const f32x4_t*)dp + s;
       if (t == 0) *(f32x4_t*)(a.dcls + c) = *(const f32x4_t*)(a.dcls + c) + s;
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs a) {
       for (int b = 0; b < a.B; ++b) {
         const long r = (long)b * a.T + jn;
         if (a.pad && a.pad[r]) continue;
-        const f32x4_t v = *(const f32x4_t*)(a.dx + (Mv + r) * a.lddx + c);
+        const f32x4_t v = *(const f32x4_t*)(a.dx + (Mv + r) * a.lddx + c) * a.scale;
         s += v;
         float* te = a.dtext + (long)a.ids[r] * a.D + c;
         atomicAdd(te + 0, v[0]); atomicAdd(te + 1, v[1]); atomicAdd(te + 2, v[2]); atomicAdd(te + 3, v[3]);
@@ -138,8 +140,8 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs a) {
 
 struct WeightDesc {      // mirrored by simvg_amd/_lib.py (ctypes)
   const float* src;      // [rows, cols] fp32
-  bf16_t* dst;           // [rows, cols] bf16 or null
-  bf16_t* dst_t;         // [cols, rows] bf16 or null
+  lp_t* dst;           // [rows, cols] bf16 or null
+  lp_t* dst_t;         // [cols, rows] bf16 or null
   int rows, cols;
   int tile_start;        // first 64x64 tile index of this matrix in the launch
   int pad_;
@@ -169,12 +171,12 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const WeightDesc* __re
       if (vec && c + 3 < d.cols) {
         const f32x4_t t = *(const f32x4_t*)(d.src + (long)r * d.cols + c);
         v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
-        if (d.dst) *(u32x2_t*)(d.dst + (long)r * d.cols + c) = (u32x2_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        if (d.dst) *(u32x2_t*)(d.dst + (long)r * d.cols + c) = (u32x2_t){pack_lp2(v[0], v[1]), pack_lp2(v[2], v[3])};
       } else {
         for (int e = 0; e < 4; ++e)
           if (c + e < d.cols) {
             v[e] = d.src[(long)r * d.cols + c + e];
-            if (d.dst) d.dst[(long)r * d.cols + c + e] = f32_to_bf16(v[e]);
+            if (d.dst) d.dst[(long)r * d.cols + c + e] = f32_to_lp(v[e]);
           }
       }
     }
@@ -190,27 +192,29 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const WeightDesc* __re
     const float t0 = tile[4 * tq][ty + 16 * k], t1 = tile[4 * tq + 1][ty + 16 * k], t2 = tile[4 * tq + 2][ty + 16 * k],
                 t3 = tile[4 * tq + 3][ty + 16 * k];
     if (vec && r + 3 < d.rows) {
-      *(u32x2_t*)(d.dst_t + (long)c * d.rows + r) = (u32x2_t){pack_bf16x2(t0, t1), pack_bf16x2(t2, t3)};
+      *(u32x2_t*)(d.dst_t + (long)c * d.rows + r) = (u32x2_t){pack_lp2(t0, t1), pack_lp2(t2, t3)};
     } else {
       const float tt[4] = {t0, t1, t2, t3};
       for (int e = 0; e < 4; ++e)
-        if (r + e < d.rows) d.dst_t[(long)c * d.rows + r + e] = f32_to_bf16(tt[e]);
+        if (r + e < d.rows) d.dst_t[(long)c * d.rows + r + e] = f32_to_lp(tt[e]);
     }
   }
 }
 
-__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n4) {
+__global__ __launch_bounds__(256) void cast_lp_kernel(const float* __restrict__ src, lp_t* __restrict__ dst, long n4, float scale) {
   for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n4; t += (long)gridDim.x * 256) {
-    const f32x4_t v = *(const f32x4_t*)(src + t * 4);
-    *(u32x2_t*)(dst + t * 4) = (u32x2_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    const f32x4_t v = *(const f32x4_t*)(src + t * 4) * scale;
+    *(u32x2_t*)(dst + t * 4) = (u32x2_t){pack_lp2(v[0], v[1]), pack_lp2(v[2], v[3])};
   }
 }
 
-__global__ __launch_bounds__(256) void cast_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, long n4) {
+__global__ __launch_bounds__(256) void cast_f32_kernel(const lp_t* __restrict__ src, float* __restrict__ dst, long n4) {
   for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n4; t += (long)gridDim.x * 256) {
     const u32x2_t v = *(const u32x2_t*)(src + t * 4);
-    *(f32x4_t*)(dst + t * 4) = (f32x4_t){__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xffff0000u),
-                                         __uint_as_float(v[1] << 16), __uint_as_float(v[1] & 0xffff0000u)};
+    float f[4];
+    unpack_lp2(v[0], f[0], f[1]);
+    unpack_lp2(v[1], f[2], f[3]);
+    *(f32x4_t*)(dst + t * 4) = (f32x4_t){f[0], f[1], f[2], f[3]};
   }
 }
 
@@ -220,7 +224,7 @@ extern "C" int simvg_im2col(const float* img, void* cols_bf16, int B, int S, int
   SIMVG_CHECK_ARG(B > 0 && S > 0 && P > 0 && S % P == 0 && P % 4 == 0, "im2col: S must be a multiple of P, P of 4");
   const long total4 = (long)B * 3 * S * S / 4;
   const int grid = (int)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
-  hipLaunchKernelGGL(im2col_kernel, dim3(grid), dim3(256), 0, stream, img, (bf16_t*)cols_bf16, B, S, P, total4);
+  hipLaunchKernelGGL(im2col_kernel, dim3(grid), dim3(256), 0, stream, img, (lp_t*)cols_bf16, B, S, P, total4);
   SIMVG_LAUNCH_CHECK();
   return SIMVG_OK;
 }
@@ -248,9 +252,9 @@ extern "C" int simvg_embed_fwd(const float* patch, int ldp, const float* cls, co
 
 extern "C" int simvg_embed_bwd(const float* dx, int lddx, void* dpatch_bf16, int lddp, float* dcls, float* dposA,
                                float* dposB, float* dtext, const long long* ids, const unsigned char* pad, int B,
-                               int np, int T, int D, hipStream_t stream) {
+                               int np, int T, int D, float param_scale, hipStream_t stream) {
   SIMVG_CHECK_ARG(B > 0 && np > 0 && T >= 0 && D % 4 == 0 && lddx % 4 == 0 && lddp % 4 == 0, "embed_bwd: bad geometry");
-  EmbedBwdArgs a{dx, lddx, (bf16_t*)dpatch_bf16, lddp, dcls, dposA, dposB, dtext, ids, pad, B, np, T, D};
+  EmbedBwdArgs a{dx, lddx, (lp_t*)dpatch_bf16, lddp, dcls, dposA, dposB, dtext, ids, pad, B, np, T, D, param_scale};
   hipLaunchKernelGGL(embed_bwd_kernel, dim3(np + 1 + T), dim3(256), 0, stream, a);
   SIMVG_LAUNCH_CHECK();
   return SIMVG_OK;
@@ -263,20 +267,22 @@ extern "C" int simvg_weight_prep(const void* descs_dev, int n_desc, int total_ti
   return SIMVG_OK;
 }
 
-extern "C" int simvg_cast_f32_to_bf16(const float* src, void* dst, long n, hipStream_t stream) {
+extern "C" int simvg_lowp_format(void) { return SIMVG_LOWP_FORMAT; }   // 1 = IEEE fp16, 2 = bfloat16
+
+extern "C" int simvg_cast_f32_to_lp(const float* src, void* dst, long n, float scale, hipStream_t stream) {
   SIMVG_CHECK_ARG(n > 0 && n % 4 == 0, "cast: n must be a positive multiple of 4");
   const long n4 = n / 4;
   const int grid = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
-  hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid), dim3(256), 0, stream, src, (bf16_t*)dst, n4);
+  hipLaunchKernelGGL(cast_lp_kernel, dim3(grid), dim3(256), 0, stream, src, (lp_t*)dst, n4, scale);
   SIMVG_LAUNCH_CHECK();
   return SIMVG_OK;
 }
 
-extern "C" int simvg_cast_bf16_to_f32(const void* src, float* dst, long n, hipStream_t stream) {
+extern "C" int simvg_cast_lp_to_f32(const void* src, float* dst, long n, hipStream_t stream) {
   SIMVG_CHECK_ARG(n > 0 && n % 4 == 0, "cast: n must be a positive multiple of 4");
   const long n4 = n / 4;
   const int grid = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
-  hipLaunchKernelGGL(cast_f32_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)src, dst, n4);
+  hipLaunchKernelGGL(cast_f32_kernel, dim3(grid), dim3(256), 0, stream, (const lp_t*)src, dst, n4);
   SIMVG_LAUNCH_CHECK();
   return SIMVG_OK;
 }

@@ -20,15 +20,16 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
 
 struct GemmNTArgs {
-  const bf16_t* A; int lda;
-  const bf16_t* W; long w_gstride; int ldw;
+  const lp_t* A; int lda;
+  const lp_t* W; long w_gstride; int ldw;
   const float* bias; int bias_gstride;
   void* C; int ldc; int c_f32;
-  bf16_t* aux; int ldaux;
+  lp_t* aux; int ldaux;
   const float* res; int ldres;
   const float* row_scale; int rps0, rps1;
   int M, N, K, split, act;
   int gn;     // column-group width of the tile walk (0: rows of all column tiles)
+  float alpha; // scalar on the accumulator, before the bias (1/gradient-scale in the head's backward GEMMs)
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -52,7 +53,7 @@ __device__ __forceinline__ void tile_order(int bid, int tiles_m, int tiles_n, in
 }
 
 // stage one [128 rows][64 k] bf16 tile: 16 wave-instructions of 1 KiB, 4 per wave
-__device__ __forceinline__ void stage_tile_k64(const bf16_t* base, int ld, int row0, int row_last, int k0,
+__device__ __forceinline__ void stage_tile_k64(const lp_t* base, int ld, int row0, int row_last, int k0,
                                                char* lds, int wave, int lane) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -61,13 +62,13 @@ __device__ __forceinline__ void stage_tile_k64(const bf16_t* base, int ld, int r
     int row = row0 + r;
     row = row < row_last ? row : row_last;
     const int lslot = (lane & 7) ^ (r & 7);
-    const bf16_t* src = base + (long)row * ld + k0 + lslot * 8;
+    const lp_t* src = base + (long)row * ld + k0 + lslot * 8;
     __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds + inst * 1024), 16, 0, 0);
   }
 }
 
-__device__ __forceinline__ bf16x8_t read_frag_k64(const char* lds, int row, int lslot) {
-  return *(const bf16x8_t*)(lds + row * 128 + ((lslot ^ (row & 7)) << 4));
+__device__ __forceinline__ lpx8_t read_frag_k64(const char* lds, int row, int lslot) {
+  return *(const lpx8_t*)(lds + row * 128 + ((lslot ^ (row & 7)) << 4));
 }
 
 // shared epilogue: bias, optional pre-activation copy, GELU/ReLU, DropPath-scaled residual add, vector stores.
@@ -89,17 +90,17 @@ __device__ __forceinline__ void gemm_nt_epilogue(const GemmNTArgs& a, f32x4_t (&
     for (int j = 0; j < 4; ++j) {
       const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
       if (n >= a.N) continue;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      float v[4] = {acc[i][j][0] * a.alpha, acc[i][j][1] * a.alpha, acc[i][j][2] * a.alpha, acc[i][j][3] * a.alpha};
       const bool full = (n + 3 < a.N);
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (bias && (full || n + r < a.N)) v[r] += bias[n + r];
       if (a.aux) {
-        bf16_t* p = a.aux + (long)m * a.ldaux + n;
+        lp_t* p = a.aux + (long)m * a.ldaux + n;
         if (full) {
-          *(u32x2_t*)p = (u32x2_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          *(u32x2_t*)p = (u32x2_t){pack_lp2(v[0], v[1]), pack_lp2(v[2], v[3])};
         } else {
-          for (int r = 0; r < 4 && n + r < a.N; ++r) p[r] = f32_to_bf16(v[r]);
+          for (int r = 0; r < 4 && n + r < a.N; ++r) p[r] = f32_to_lp(v[r]);
         }
       }
       if (a.act == 1) {
@@ -130,11 +131,11 @@ __device__ __forceinline__ void gemm_nt_epilogue(const GemmNTArgs& a, f32x4_t (&
           for (int r = 0; r < 4 && n + r < a.N; ++r) p[r] = v[r];
         }
       } else {
-        bf16_t* p = (bf16_t*)a.C + (long)m * a.ldc + n;
+        lp_t* p = (lp_t*)a.C + (long)m * a.ldc + n;
         if (full) {
-          *(u32x2_t*)p = (u32x2_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          *(u32x2_t*)p = (u32x2_t){pack_lp2(v[0], v[1]), pack_lp2(v[2], v[3])};
         } else {
-          for (int r = 0; r < 4 && n + r < a.N; ++r) p[r] = f32_to_bf16(v[r]);
+          for (int r = 0; r < 4 && n + r < a.N; ++r) p[r] = f32_to_lp(v[r]);
         }
       }
     }
@@ -179,7 +180,8 @@ __device__ __forceinline__ void gemm_nt_epilogue_lds(const GemmNTArgs& a, f32x4_
       for (int j = 0; j < NJ; ++j) {
         const f32x4_t v = acc[2 * p + ii][j];
         *(f32x4_t*)(st + (ii * 16 + (lane & 15)) * LD + j * 16 + 4 * (lane >> 4)) =
-            (f32x4_t){v[0] + bv[j][0], v[1] + bv[j][1], v[2] + bv[j][2], v[3] + bv[j][3]};
+            (f32x4_t){fmaf(v[0], a.alpha, bv[j][0]), fmaf(v[1], a.alpha, bv[j][1]), fmaf(v[2], a.alpha, bv[j][2]),
+                      fmaf(v[3], a.alpha, bv[j][3])};
       }
     }
     // wave-private slice: only this wave's own LDS writes must have landed (no barrier)
@@ -196,8 +198,8 @@ __device__ __forceinline__ void gemm_nt_epilogue_lds(const GemmNTArgs& a, f32x4_
         const f32x4_t u0 = *(const f32x4_t*)(st + r * LD + c), u1 = *(const f32x4_t*)(st + r * LD + c + 4);
         float v[8] = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3]};
         if (a.aux)
-          *(u32x4_t*)(a.aux + (long)m * a.ldaux + n) = (u32x4_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]),
-                                                                 pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+          *(u32x4_t*)(a.aux + (long)m * a.ldaux + n) = (u32x4_t){pack_lp2(v[0], v[1]), pack_lp2(v[2], v[3]),
+                                                                 pack_lp2(v[4], v[5]), pack_lp2(v[6], v[7])};
         if (a.act == 1) {
 #pragma unroll
           for (int k = 0; k < 8; ++k) v[k] = gelu_erf(v[k]);
@@ -210,8 +212,8 @@ __device__ __forceinline__ void gemm_nt_epilogue_lds(const GemmNTArgs& a, f32x4_
 #pragma unroll
           for (int k = 0; k < 8; ++k) v[k] *= rs;
         }
-        *(u32x4_t*)((bf16_t*)a.C + (long)m * a.ldc + n) = (u32x4_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]),
-                                                                    pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+        *(u32x4_t*)((lp_t*)a.C + (long)m * a.ldc + n) = (u32x4_t){pack_lp2(v[0], v[1]), pack_lp2(v[2], v[3]),
+                                                                    pack_lp2(v[4], v[5]), pack_lp2(v[6], v[7])};
       }
     } else {
       // fp32 output (+ residual): lane -> 4 consecutive columns, 4*NJ lanes per row (NJ = 4: 16 lanes, 4 rows per pass)
@@ -223,7 +225,7 @@ __device__ __forceinline__ void gemm_nt_epilogue_lds(const GemmNTArgs& a, f32x4_
         if (m >= row_end || n >= a.N || 2 * p + (r >> 4) >= MI) continue;
         const f32x4_t u = *(const f32x4_t*)(st + r * LD + c);
         float v[4] = {u[0], u[1], u[2], u[3]};
-        if (a.aux) *(u32x2_t*)(a.aux + (long)m * a.ldaux + n) = (u32x2_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        if (a.aux) *(u32x2_t*)(a.aux + (long)m * a.ldaux + n) = (u32x2_t){pack_lp2(v[0], v[1]), pack_lp2(v[2], v[3])};
         if (a.act == 1) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) v[k] = gelu_erf(v[k]);
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
   const int row0 = group ? a.split + (tile_m - tm0) * BM : tile_m * BM;
   const int row_end = group ? a.M : a.split;
   const int n0 = tile_n * BN;
-  const bf16_t* W = a.W + (long)group * a.w_gstride;
+  const lp_t* W = a.W + (long)group * a.w_gstride;
 
 #define ldsA(c) (smem + (c) * 2 * TILE_BYTES)
 #define ldsB(c) (smem + TILE_BYTES + (c) * 2 * TILE_BYTES)
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf16x8_t fa[4], fb[4];
+      lpx8_t fa[4], fb[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         fa[i] = read_frag_k64(ldsA(cur), wm * 64 + i * 16 + (lane & 15), s * 4 + (lane >> 4));
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           // D[n_local][m_local]: lane holds 4 consecutive n for one m -> vector stores
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma_lp(fb[j], fa[i], acc[i][j]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
 constexpr int BM2 = 256;
 constexpr int STAGE2 = (BM2 + BN) * BK * 2;   // 49152 B
 
-__device__ __forceinline__ void stage_tile_k64_n(const bf16_t* base, int ld, int row0, int row_last, int k0, char* lds,
+__device__ __forceinline__ void stage_tile_k64_n(const lp_t* base, int ld, int row0, int row_last, int k0, char* lds,
                                                  int wave, int lane, int per_wave) {
   for (int i = 0; i < per_wave; ++i) {
     const int inst = wave * per_wave + i;
@@ -324,74 +326,10 @@ __device__ __forceinline__ void stage_tile_k64_n(const bf16_t* base, int ld, int
     int row = row0 + r;
     row = row < row_last ? row : row_last;
     const int lslot = (lane & 7) ^ (r & 7);
-    const bf16_t* src = base + (long)row * ld + k0 + lslot * 8;
+    const lp_t* src = base + (long)row * ld + k0 + lslot * 8;
     __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds + inst * 1024), 16, 0, 0);
   }
 }
-
-__global__ __launch_bounds__(512) void gemm_nt_kernel_256(GemmNTArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int tiles_n = (a.N + BN - 1) / BN;
-  const int tm0 = (a.split + BM2 - 1) / BM2;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
-  const int group = tile_m >= tm0;
-  const int row0 = group ? a.split + (tile_m - tm0) * BM2 : tile_m * BM2;
-  const int row_end = group ? a.M : a.split;
-  const int n0 = tile_n * BN;
-  const bf16_t* W = a.W + (long)group * a.w_gstride;
-
-  f32x4_t acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-  const int nk = a.K / BK;
-#define STA(s_) (smem + (s_) * STAGE2)
-#define STB(s_) (smem + (s_) * STAGE2 + BM2 * BK * 2)
-#define ISSUE(t_)                                                                           \
-  do {                                                                                      \
-    const int st__ = (t_) % 3;                                                              \
-    stage_tile_k64_n(a.A, a.lda, row0, row_end - 1, (t_) * BK, STA(st__), wave, lane, 4);   \
-    stage_tile_k64_n(W, a.ldw, n0, a.N - 1, (t_) * BK, STB(st__), wave, lane, 2);           \
-  } while (0)
-
-  ISSUE(0);
-  if (nk > 1) ISSUE(1);
-  for (int kt = 0; kt < nk; ++kt) {
-    // wait for this wave's 6 loads of tile kt (the 6 of tile kt+1 may stay in flight), then rendezvous
-    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (kt + 2 < nk) ISSUE(kt + 2);      // stage (kt+2)%3 == (kt-1)%3: every wave is past compute(kt-1)
-    const char* sA = STA(kt % 3);
-    const char* sB = STB(kt % 3);
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bf16x8_t fa[4], fb[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        fa[i] = read_frag_k64(sA, wm * 64 + i * 16 + (lane & 15), s * 4 + (lane >> 4));
-        fb[i] = read_frag_k64(sB, wn * 64 + i * 16 + (lane & 15), s * 4 + (lane >> 4));
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-    }
-  }
-#undef STA
-#undef STB
-#undef ISSUE
-  if ((a.N & 7) == 0) { gemm_nt_epilogue_lds<4>(a, acc, group, row0, row_end, n0, wm, wn, wave, lane, smem); return; }
-  gemm_nt_epilogue<4>(a, acc, group, row0, row_end, n0, wm, wn, lane);
-}
-
 
 // ------------------------------------------------------------------------------------------
 // 256x256x64 tile for the wide-N problems (QKV, fc1, dgrad of fc2: N >= 2304): 8 waves as 2 (M) x 4 (N), each
@@ -402,79 +340,16 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel_256(GemmNTArgs a) {
 constexpr int BNQ = 256;
 
 // [n_inst * 8 rows][64 k] tile, wave w stages instructions w, w+8, ... (n_inst need not be a multiple of 8)
-__device__ __forceinline__ void stage_rows_k64(const bf16_t* base, int ld, int row0, int row_last, int k0, char* lds,
+__device__ __forceinline__ void stage_rows_k64(const lp_t* base, int ld, int row0, int row_last, int k0, char* lds,
                                                int wave, int lane, int n_inst, int nwaves = 8) {
   for (int inst = wave; inst < n_inst; inst += nwaves) {
     const int r = inst * 8 + (lane >> 3);
     int row = row0 + r;
     row = row < row_last ? row : row_last;
     const int lslot = (lane & 7) ^ (r & 7);
-    const bf16_t* src = base + (long)row * ld + k0 + lslot * 8;
+    const lp_t* src = base + (long)row * ld + k0 + lslot * 8;
     __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds + inst * 1024), 16, 0, 0);
   }
-}
-
-// MI = 16-row blocks per wave along M: tile = (32*MI) x 256.  MI = 8 (256x256) for N >= 2304; MI = 5 (160x256) for the
-// N = 768 problems, whose 256x128 tiling gave 636 tiles = 2.48 rounds on 256 CUs: 160x256 gives 507 = 1.98 rounds.
-template <int MI>
-__global__ __launch_bounds__(512) void gemm_nt_kernel_256sq(GemmNTArgs a) {
-  constexpr int BMQ = 32 * MI;
-  constexpr int STAGEQ = (BMQ + BNQ) * BK * 2;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  const int tiles_n = (a.N + BNQ - 1) / BNQ;
-  const int tm0 = (a.split + BMQ - 1) / BMQ;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
-  const int group = tile_m >= tm0;
-  const int row0 = group ? a.split + (tile_m - tm0) * BMQ : tile_m * BMQ;
-  const int row_end = group ? a.M : a.split;
-  const int n0 = tile_n * BNQ;
-  const bf16_t* W = a.W + (long)group * a.w_gstride;
-
-  f32x4_t acc[MI][4];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-  const int nk = a.K / BK;
-#define STA(s_) (smem + (s_) * STAGEQ)
-#define STB(s_) (smem + (s_) * STAGEQ + BMQ * BK * 2)
-#define ISSUE(t_)                                                                                  \
-  do {                                                                                             \
-    const int st__ = (t_) & 1;                                                                     \
-    stage_rows_k64(a.A, a.lda, row0, row_end - 1, (t_) * BK, STA(st__), wave, lane, BMQ / 8);      \
-    stage_rows_k64(W, a.ldw, n0, a.N - 1, (t_) * BK, STB(st__), wave, lane, BNQ / 8);              \
-  } while (0)
-
-  ISSUE(0);
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's share of tile kt has landed
-    __builtin_amdgcn_s_barrier();                        // everyone's has, and everyone is past compute(kt-1)
-    if (kt + 1 < nk) ISSUE(kt + 1);
-    const char* sA = STA(kt & 1);
-    const char* sB = STB(kt & 1);
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bf16x8_t fa[MI], fb[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = read_frag_k64(sB, wn * 64 + j * 16 + (lane & 15), s * 4 + (lane >> 4));
-#pragma unroll
-      for (int i = 0; i < MI; ++i) fa[i] = read_frag_k64(sA, wm * (MI * 16) + i * 16 + (lane & 15), s * 4 + (lane >> 4));
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-    }
-  }
-#undef STA
-#undef STB
-#undef ISSUE
-  gemm_nt_epilogue_lds<MI>(a, acc, group, row0, row_end, n0, wm, wn, wave, lane, smem);
 }
 
 // 256x256x64 tile with SIXTEEN waves (4 x 4, each 64x64; 4 waves per SIMD, 112 VGPRs): more waves cover the LDS-read and
@@ -498,7 +373,7 @@ __global__ __launch_bounds__(1024) void gemm_nt_kernel_256sq_w16(GemmNTArgs a) {
   const int row0 = group ? a.split + (tile_m - tm0) * BMQ : tile_m * BMQ;
   const int row_end = group ? a.M : a.split;
   const int n0 = tile_n * BNQ;
-  const bf16_t* W = a.W + (long)group * a.w_gstride;
+  const lp_t* W = a.W + (long)group * a.w_gstride;
 
   f32x4_t acc[MI][4];
 #pragma unroll
@@ -525,7 +400,7 @@ __global__ __launch_bounds__(1024) void gemm_nt_kernel_256sq_w16(GemmNTArgs a) {
     const char* sB = STB(kt & 1);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf16x8_t fa[MI], fb[4];
+      lpx8_t fa[MI], fb[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) fb[j] = read_frag_k64(sB, wn * 64 + j * 16 + (lane & 15), s * 4 + (lane >> 4));
 #pragma unroll
@@ -534,7 +409,7 @@ __global__ __launch_bounds__(1024) void gemm_nt_kernel_256sq_w16(GemmNTArgs a) {
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma_lp(fb[j], fa[i], acc[i][j]);
     }
   }
 #undef STA
@@ -561,7 +436,7 @@ __global__ __launch_bounds__(1024) void gemm_nt_kernel_160x256_w16(GemmNTArgs a)
   const int row0 = group ? a.split + (tile_m - tm0) * BMQ : tile_m * BMQ;
   const int row_end = group ? a.M : a.split;
   const int n0 = tile_n * BNQ;
-  const bf16_t* W = a.W + (long)group * a.w_gstride;
+  const lp_t* W = a.W + (long)group * a.w_gstride;
   f32x4_t acc[5][2];
 #pragma unroll
   for (int i = 0; i < 5; ++i)
@@ -585,7 +460,7 @@ __global__ __launch_bounds__(1024) void gemm_nt_kernel_160x256_w16(GemmNTArgs a)
     const char* sB = STB(kt & 1);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf16x8_t fa[5], fb[2];
+      lpx8_t fa[5], fb[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) fb[j] = read_frag_k64(sB, wn * 32 + j * 16 + (lane & 15), s * 4 + (lane >> 4));
 #pragma unroll
@@ -594,7 +469,7 @@ __global__ __launch_bounds__(1024) void gemm_nt_kernel_160x256_w16(GemmNTArgs a)
       for (int i = 0; i < 5; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma_lp(fb[j], fa[i], acc[i][j]);
     }
   }
 #undef STA
@@ -612,7 +487,7 @@ __global__ __launch_bounds__(1024) void gemm_nt_kernel_160x256_w16(GemmNTArgs a)
 constexpr int BK3 = 32;
 constexpr int STAGE3 = (BM2 + BN) * BK3 * 2;   // 24576 B
 
-__device__ __forceinline__ void stage_tile_k32(const bf16_t* base, int ld, int row0, int row_last, int k0, char* lds,
+__device__ __forceinline__ void stage_tile_k32(const lp_t* base, int ld, int row0, int row_last, int k0, char* lds,
                                                int wave, int lane, int per_wave) {
   for (int i = 0; i < per_wave; ++i) {
     const int inst = wave * per_wave + i;
@@ -620,12 +495,12 @@ __device__ __forceinline__ void stage_tile_k32(const bf16_t* base, int ld, int r
     int row = row0 + r;
     row = row < row_last ? row : row_last;
     const int lslot = (lane & 3) ^ ((r >> 2) & 3);
-    const bf16_t* src = base + (long)row * ld + k0 + lslot * 8;
+    const lp_t* src = base + (long)row * ld + k0 + lslot * 8;
     __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds + inst * 1024), 16, 0, 0);
   }
 }
-__device__ __forceinline__ bf16x8_t read_frag_k32(const char* lds, int row, int lslot) {
-  return *(const bf16x8_t*)(lds + row * 64 + ((lslot ^ ((row >> 2) & 3)) << 4));
+__device__ __forceinline__ lpx8_t read_frag_k32(const char* lds, int row, int lslot) {
+  return *(const lpx8_t*)(lds + row * 64 + ((lslot ^ ((row >> 2) & 3)) << 4));
 }
 
 __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_256k32(GemmNTArgs a) {
@@ -641,7 +516,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_256k32(GemmNTArgs a) {
   const int row0 = group ? a.split + (tile_m - tm0) * BM2 : tile_m * BM2;
   const int row_end = group ? a.M : a.split;
   const int n0 = tile_n * BN;
-  const bf16_t* W = a.W + (long)group * a.w_gstride;
+  const lp_t* W = a.W + (long)group * a.w_gstride;
   f32x4_t acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -665,7 +540,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_256k32(GemmNTArgs a) {
     if (kt + 2 < nk) ISSUE(kt + 2);
     const char* sA = STA(kt % 3);
     const char* sB = STB(kt % 3);
-    bf16x8_t fa[4], fb[4];
+    lpx8_t fa[4], fb[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       fa[i] = read_frag_k32(sA, wm * 64 + i * 16 + (lane & 15), lane >> 4);
@@ -675,7 +550,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_256k32(GemmNTArgs a) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        acc[i][j] = mfma_lp(fb[j], fa[i], acc[i][j]);
   }
 #undef STA
 #undef STB
@@ -689,14 +564,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_256k32(GemmNTArgs a) {
 // wgrad: dW[g][n][k] += sum_m dY[m][n] * X[m][k]
 // ------------------------------------------------------------------------------------------
 struct GemmTNArgs {
-  const bf16_t* dY; int lddy;
-  const bf16_t* X; int ldx;
+  const lp_t* dY; int lddy;
+  const lp_t* X; int ldx;
   float* dW; long dw_gstride; int lddw;
   int M, N, K, split, rows_per_chunk, chunks0;
   float* db; int db_gstride;     // optional bias gradient db[g][n] += column sums of dY over group g (extra blocks)
   int tiles;                     // GEMM tiles along blockIdx.x; blocks beyond them are the column-sum blocks
   int cs_split;                  // row slices per chunk for the column-sum blocks
   int gk;                        // group width of the tile walk along the faster dimension (0: plain)
+  float out_scale;               // scalar on everything this launch adds to dW / db (1 / gradient scale of dY)
 };
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page[64];  // 256 B of zeros
@@ -709,7 +585,7 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero_page[64];  // 256 B 
 __device__ __forceinline__ int tn_swz(int r) { return ((r & 3) << 1) ^ (((r >> 3) & 1) << 3); }
 
 // stage [64 m-rows][128 cols] bf16 (256 B rows): 16 wave-instructions (4 rows each), 4 per wave
-__device__ __forceinline__ void stage_tile_m64(const bf16_t* base, int ld, int m0, int m_end, int c0, int ncols,
+__device__ __forceinline__ void stage_tile_m64(const lp_t* base, int ld, int m0, int m_end, int c0, int ncols,
                                                char* lds, int wave, int lane) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -717,22 +593,22 @@ __device__ __forceinline__ void stage_tile_m64(const bf16_t* base, int ld, int m
     const int r = inst * 4 + (lane >> 4);
     const int lslot = (lane & 15) ^ tn_swz(r);
     const int row = m0 + r, col = c0 + lslot * 8;
-    const bf16_t* src = (row < m_end && col < ncols) ? base + (long)row * ld + col
-                                                      : (const bf16_t*)g_zero_page;
+    const lp_t* src = (row < m_end && col < ncols) ? base + (long)row * ld + col
+                                                      : (const lp_t*)g_zero_page;
     __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds + inst * 1024), 16, 0, 0);
   }
 }
 
 // transposed fragment: lane (i = lane&15 -> column c0+i, g = lane>>4 -> rows ms+8g..+7)
-__device__ __forceinline__ bf16x8_t read_frag_tr(const char* lds, int ms, int c0, int lane) {
+__device__ __forceinline__ lpx8_t read_frag_tr(const char* lds, int ms, int c0, int lane) {
   const int i = lane & 15, g = lane >> 4;
   const int col = c0 + 4 * (i & 3);          // this lane supplies 4 contiguous columns of row (i>>2)
   const int lslot = col >> 3, within = (col & 7) * 2;
-  bf16x8_t out;
+  lpx8_t out;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int row = ms + 8 * g + 4 * h + (i >> 2);
-    const bf16x4_t v = lds_read_tr16(lds + row * 256 + ((lslot ^ tn_swz(row)) << 4) + within);
+    const lpx4_t v = lds_read_tr16(lds + row * 256 + ((lslot ^ tn_swz(row)) << 4) + within);
     out[4 * h + 0] = v[0]; out[4 * h + 1] = v[1]; out[4 * h + 2] = v[2]; out[4 * h + 3] = v[3];
   }
   return out;
@@ -765,16 +641,20 @@ __device__ __forceinline__ void colsum_block(const GemmTNArgs& a, char* smem, in
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          s[2 * e] += __uint_as_float(v[q][e] << 16);
-          s[2 * e + 1] += __uint_as_float(v[q][e] & 0xffff0000u);
+          float lo, hi;
+          unpack_lp2(v[q][e], lo, hi);
+          s[2 * e] += lo;
+          s[2 * e + 1] += hi;
         }
     }
     for (; m < r1; m += RY) {
       const u32x4_t v = *(const u32x4_t*)(a.dY + (long)m * a.lddy + n);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        s[2 * e] += __uint_as_float(v[e] << 16);
-        s[2 * e + 1] += __uint_as_float(v[e] & 0xffff0000u);
+        float lo, hi;
+        unpack_lp2(v[e], lo, hi);
+        s[2 * e] += lo;
+        s[2 * e + 1] += hi;
       }
     }
   }
@@ -787,7 +667,7 @@ __device__ __forceinline__ void colsum_block(const GemmTNArgs& a, char* smem, in
 #pragma unroll
     for (int y = 0; y < RY; ++y) t += red[y][c];
     const int nn = col_block * 256 + c;
-    if (nn < a.N && r0 < r1) atomicAdd(a.db + (long)group * a.db_gstride + nn, t);
+    if (nn < a.N && r0 < r1) atomicAdd(a.db + (long)group * a.db_gstride + nn, t * a.out_scale);
   }
 }
 
@@ -832,7 +712,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs a) {
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf16x8_t fy[4], fx[4];
+      lpx8_t fy[4], fx[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         fy[i] = read_frag_tr(ldsY(cur), s * 32, wn * 64 + i * 16, lane);
@@ -842,7 +722,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs a) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], fx[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma_lp(fy[i], fx[j], acc[i][j]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -857,7 +737,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + wn * 64 + i * 16 + 4 * (lane >> 4) + r;
-        if (n < a.N) atomicAdd(dW + (long)n * a.lddw + k, acc[i][j][r]);
+        if (n < a.N) atomicAdd(dW + (long)n * a.lddw + k, acc[i][j][r] * a.out_scale);
       }
     }
 }
@@ -865,7 +745,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs a) {
 // wgrad, 256 (n) x 128 (k) output tile: 8 waves as 4 (n) x 2 (k), each 64x64; 32-row stages {dY [32][256], X [32][128]}
 // = 24 KiB, 3-stage global_load_lds ring with counted vmcnt + raw barrier, 72 KiB LDS -> two workgroups per CU.
 // 87 FLOP per staged byte instead of 65 (the kernel is load-bound: removing the loads saves 40 %).
-__device__ __forceinline__ void stage_rows32(const bf16_t* base, int ld, int m0, int m_end, int c0, int ncols, int width,
+__device__ __forceinline__ void stage_rows32(const lp_t* base, int ld, int m0, int m_end, int c0, int ncols, int width,
                                              char* lds, int wave, int lane, int per_wave) {
   // width = tile columns (256 or 128); a 1 KiB wave-instruction covers 1024 / (2*width) rows
   const int lanes_per_row = width / 8, rows_per_inst = 64 / lanes_per_row;
@@ -875,20 +755,20 @@ __device__ __forceinline__ void stage_rows32(const bf16_t* base, int ld, int m0,
     const int pslot = lane % lanes_per_row;
     const int lslot = pslot ^ tn_swz(r);
     const int row = m0 + r, col = c0 + lslot * 8;
-    const bf16_t* src = (row < m_end && col < ncols) ? base + (long)row * ld + col : (const bf16_t*)g_zero_page;
+    const lp_t* src = (row < m_end && col < ncols) ? base + (long)row * ld + col : (const lp_t*)g_zero_page;
     __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds + inst * 1024), 16, 0, 0);
   }
 }
 // transposed fragment from a [32 rows][width cols] stage: lane (i = lane&15 -> column c0+i, g = lane>>4 -> rows 8g..8g+7)
-__device__ __forceinline__ bf16x8_t read_frag_tr_w(const char* lds, int row_bytes, int c0, int lane) {
+__device__ __forceinline__ lpx8_t read_frag_tr_w(const char* lds, int row_bytes, int c0, int lane) {
   const int i = lane & 15, g = lane >> 4;
   const int col = c0 + 4 * (i & 3);
   const int lslot = col >> 3, within = (col & 7) * 2;
-  bf16x8_t out;
+  lpx8_t out;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int row = 8 * g + 4 * h + (i >> 2);
-    const bf16x4_t v = lds_read_tr16(lds + row * row_bytes + ((lslot ^ tn_swz(row)) << 4) + within);
+    const lpx4_t v = lds_read_tr16(lds + row * row_bytes + ((lslot ^ tn_swz(row)) << 4) + within);
     out[4 * h + 0] = v[0]; out[4 * h + 1] = v[1]; out[4 * h + 2] = v[2]; out[4 * h + 3] = v[3];
   }
   return out;
@@ -938,7 +818,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel_256(GemmTNArgs a) {
     if (t + 2 < nt) ISSUE(t + 2);
     const char* sy = SY(t % 3);
     const char* sx = SX(t % 3);
-    bf16x8_t fy[4], fx[4];
+    lpx8_t fy[4], fx[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       fy[i] = read_frag_tr_w(sy, 512, wn * 64 + i * 16, lane);
@@ -948,7 +828,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel_256(GemmTNArgs a) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], fx[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = mfma_lp(fy[i], fx[j], acc[i][j]);
   }
 #undef SY
 #undef SX
@@ -963,13 +843,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel_256(GemmTNArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + wn * 64 + i * 16 + 4 * (lane >> 4) + r;
-        if (n < a.N) atomicAdd(dW + (long)n * a.lddw + k, acc[i][j][r]);
+        if (n < a.N) atomicAdd(dW + (long)n * a.lddw + k, acc[i][j][r] * a.out_scale);
       }
     }
 }
 
 // column sums by row group: out[g][n] += sum_{m in group g} Y[m][n]   (bias gradients)
-__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* Y, int ldy, float* out, int out_gstride,
+__global__ __launch_bounds__(256) void colsum_kernel(const lp_t* Y, int ldy, float* out, int out_gstride,
                                                      int M, int N, int split, int rows_per_chunk, int chunks0) {
   __shared__ float red[8][256 + 8];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -984,8 +864,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* Y, int ldy, f
       const u32x4_t v = *(const u32x4_t*)(Y + (long)m * ldy + n);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        s[2 * q] += __uint_as_float(v[q] << 16);
-        s[2 * q + 1] += __uint_as_float(v[q] & 0xffff0000u);
+        float lo, hi;
+        unpack_lp2(v[q], lo, hi);
+        s[2 * q] += lo;
+        s[2 * q + 1] += hi;
       }
     }
   }
@@ -1006,78 +888,45 @@ extern "C" int simvg_gemm_nt(const void* A, int lda, const void* W, long w_gstri
                              const float* bias, int bias_gstride, void* C, int ldc, int c_is_f32,
                              void* aux_preact, int ldaux, const float* residual, int ldres,
                              const float* row_scale, int rows_per_sample0, int rows_per_sample1,
-                             int M, int N, int K, int split, int act, hipStream_t stream) {
+                             int M, int N, int K, int split, int act, float alpha, hipStream_t stream) {
   SIMVG_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm_nt: empty problem");
-  SIMVG_CHECK_ARG(K % BK == 0, "gemm_nt: K must be a multiple of 64");   // also covers the BK=32 variant
+  SIMVG_CHECK_ARG(K % BK == 0, "gemm_nt: K must be a multiple of 64");
   SIMVG_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0, "gemm_nt: leading dims must keep 16-B alignment");
   SIMVG_CHECK_ARG(split >= 0 && split <= M, "gemm_nt: split out of range");
   SIMVG_CHECK_ARG(act >= 0 && act <= 2, "gemm_nt: act must be 0 (none), 1 (gelu) or 2 (relu)");
   if (split == 0) split = M;  // single group uses group 0 weights
-  GemmNTArgs a{(const bf16_t*)A, lda, (const bf16_t*)W, w_gstride, ldw, bias, bias_gstride, C, ldc, c_is_f32,
-               (bf16_t*)aux_preact, ldaux, residual, ldres, row_scale,
+  GemmNTArgs a{(const lp_t*)A, lda, (const lp_t*)W, w_gstride, ldw, bias, bias_gstride, C, ldc, c_is_f32,
+               (lp_t*)aux_preact, ldaux, residual, ldres, row_scale,
                rows_per_sample0 > 0 ? rows_per_sample0 : 1, rows_per_sample1 > 0 ? rows_per_sample1 : 1,
-               M, N, K, split, act, 0};
-  {
-    // column-group width of the tile walk (256sq_w16 kernel): 6 of >= 9 column tiles (fc1-shape fetch 246 -> 190 MB per
-    // launch, qkv 170 -> 160 MB; 4: 206 / 181 MB).  SIMVG_NT_GN = -1 restores the plain row-major walk.
-    static const int gn_env = getenv("SIMVG_NT_GN") ? atoi(getenv("SIMVG_NT_GN")) : 0;
-    a.gn = gn_env < 0 ? 0 : gn_env > 0 ? gn_env : (cdiv(N, BNQ) >= 9 ? 6 : 0);
-  }
-  // auto: short K (<= 1024: QKV, out-proj, fc1, dgrad of fc2) -> BK=32, two workgroups per CU; long K -> BK=64
-  // (measured: profiles/r01_sweeps.md).  SIMVG_GEMM_NT = 128 | 256 | 232 forces one kernel.
-  static const int variant_env = getenv("SIMVG_GEMM_NT") ? atoi(getenv("SIMVG_GEMM_NT")) : 0;
-  const int variant = variant_env ? variant_env : (K <= 1024 ? 232 : 256);
-  // wide-N tiles (N a multiple of 256, big M): 256x256 for N >= 2304; 160x256 for N = 768 (tile-count quantisation,
-  // see the kernel).  SIMVG_GEMM_NT = 2568 / 2565 forces one of them, 256 / 232 / 128 the older kernels.
+               M, N, K, split, act, 0, alpha};
+  // column-group width of the 256x256 tile walk: 6 of >= 9 column tiles (fc1-shape fetch 246 -> 190 MB per launch)
+  a.gn = cdiv(N, BNQ) >= 9 ? 6 : 0;
+  // wide-N tiles (N a multiple of 256, big M): the M extent is picked by tile-count quantisation on the 256 CUs,
+  // cost = rounds x rows per tile (ViT-B: N >= 2304 -> 256 rows, N = 768 -> 160 rows; ViT-L: N = 1024 at B = 32 -> 256 rows)
   const bool wide_ok = (N % 256) == 0 && M >= 2048;
-  // pick the M extent by tile-count quantisation on the 256 CUs: cost = rounds x rows per tile (ViT-B: N >= 2304 -> 256
-  // rows, N = 768 -> 160 rows; ViT-L: N = 1024 at B = 32 -> 256 rows in one round)
   auto tile_cost = [&](int bm) {
     const long tiles = (long)(cdiv(split, bm) + cdiv(M - split, bm)) * cdiv(N, BNQ);
-    // 160-row tiles stage 23 % more bytes per FLOP and measured slower on N = 2304 at equal "rounds x rows": they have
-    // to win the quantisation estimate by 20 % to be chosen
+    // 160-row tiles stage 23 % more bytes per FLOP: they have to win the quantisation estimate by 20 % to be chosen
     return (double)cdiv((int)tiles, 256) * bm * (bm == 160 ? 1.20 : 1.0);
   };
-  const int auto_mi = tile_cost(256) <= tile_cost(160) ? 8 : 5;
-  const int wide_mi = variant_env == 2568 ? 8 : variant_env == 2565 ? 5 : variant_env ? 0 : auto_mi;
-  if (wide_ok && wide_mi == 8) {
-    constexpr int SM = 2 * (256 + BNQ) * BK * 2;
-    static bool onceq = hipFuncSetAttribute((const void*)gemm_nt_kernel_256sq<8>, hipFuncAttributeMaxDynamicSharedMemorySize, SM) == hipSuccess;
-    (void)onceq;
+  if (wide_ok && tile_cost(256) <= tile_cost(160)) {
+    constexpr int SMW = 160 * 1024;      // ring 128 KiB; the 16-wave epilogue staging needs 136 KiB
+    static bool oncew = hipFuncSetAttribute((const void*)gemm_nt_kernel_256sq_w16, hipFuncAttributeMaxDynamicSharedMemorySize, SMW) == hipSuccess;
+    (void)oncew;
     const int tiles = (cdiv(split, 256) + cdiv(M - split, 256)) * cdiv(N, BNQ);
-    static const int w16 = getenv("SIMVG_GEMM_W16") ? atoi(getenv("SIMVG_GEMM_W16")) : 1;
-    if (w16) {
-      constexpr int SMW = 160 * 1024;      // ring 128 KiB; the 16-wave epilogue staging needs 136 KiB
-      static bool oncew = hipFuncSetAttribute((const void*)gemm_nt_kernel_256sq_w16, hipFuncAttributeMaxDynamicSharedMemorySize, SMW) == hipSuccess;
-      (void)oncew;
-      hipLaunchKernelGGL(gemm_nt_kernel_256sq_w16, dim3(tiles), dim3(1024), SMW, stream, a);
-    } else
-    hipLaunchKernelGGL(gemm_nt_kernel_256sq<8>, dim3(tiles), dim3(512), SM, stream, a);
-  } else if (wide_ok && wide_mi == 5) {
-    constexpr int SM = 2 * (160 + BNQ) * BK * 2;
-    static bool onceq5 = hipFuncSetAttribute((const void*)gemm_nt_kernel_256sq<5>, hipFuncAttributeMaxDynamicSharedMemorySize, SM) == hipSuccess;
-    (void)onceq5;
+    hipLaunchKernelGGL(gemm_nt_kernel_256sq_w16, dim3(tiles), dim3(1024), SMW, stream, a);
+  } else if (wide_ok) {
+    constexpr int SMW = 2 * (160 + BNQ) * BK * 2;     // 104 KiB ring; 16 waves x 32 x 36 x 4 B = 72 KiB of epilogue staging fit
+    static bool oncews = hipFuncSetAttribute((const void*)gemm_nt_kernel_160x256_w16, hipFuncAttributeMaxDynamicSharedMemorySize, SMW) == hipSuccess;
+    (void)oncews;
     const int tiles = (cdiv(split, 160) + cdiv(M - split, 160)) * cdiv(N, BNQ);
-    static const int w16s = getenv("SIMVG_GEMM_W16S") ? atoi(getenv("SIMVG_GEMM_W16S")) : 1;
-    if (w16s) {
-      constexpr int SMW = 2 * (160 + BNQ) * BK * 2;     // 104 KiB ring; 16 waves x 32 x 36 x 4 B = 72 KiB of epilogue staging fit
-      static bool oncews = hipFuncSetAttribute((const void*)gemm_nt_kernel_160x256_w16, hipFuncAttributeMaxDynamicSharedMemorySize, SMW) == hipSuccess;
-      (void)oncews;
-      hipLaunchKernelGGL(gemm_nt_kernel_160x256_w16, dim3(tiles), dim3(1024), SMW, stream, a);
-    } else
-    hipLaunchKernelGGL(gemm_nt_kernel_256sq<5>, dim3(tiles), dim3(512), SM, stream, a);
-  } else if (variant == 232 && M >= 512) {
+    hipLaunchKernelGGL(gemm_nt_kernel_160x256_w16, dim3(tiles), dim3(1024), SMW, stream, a);
+  } else if (M >= 512) {
     static bool once3 = hipFuncSetAttribute((const void*)gemm_nt_kernel_256k32, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             3 * STAGE3) == hipSuccess;
     (void)once3;
     const int tiles = (cdiv(split, BM2) + cdiv(M - split, BM2)) * cdiv(N, BN);
     hipLaunchKernelGGL(gemm_nt_kernel_256k32, dim3(tiles), dim3(512), 3 * STAGE3, stream, a);
-  } else if (variant != 128 && M >= 512) {
-    static bool once = hipFuncSetAttribute((const void*)gemm_nt_kernel_256, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           3 * STAGE2) == hipSuccess;
-    (void)once;
-    const int tiles = (cdiv(split, BM2) + cdiv(M - split, BM2)) * cdiv(N, BN);
-    hipLaunchKernelGGL(gemm_nt_kernel_256, dim3(tiles), dim3(512), 3 * STAGE2, stream, a);
   } else {
     const int tiles = (cdiv(split, BM) + cdiv(M - split, BM)) * cdiv(N, BN);
     hipLaunchKernelGGL(gemm_nt_kernel, dim3(tiles), dim3(256), 4 * TILE_BYTES, stream, a);
@@ -1087,29 +936,23 @@ extern "C" int simvg_gemm_nt(const void* A, int lda, const void* W, long w_gstri
 }
 
 extern "C" int simvg_gemm_tn(const void* dY, int lddy, const void* X, int ldx, float* dW, long dw_gstride,
-                             int lddw, float* db, int db_gstride, int M, int N, int K, int split,
+                             int lddw, float* db, int db_gstride, int M, int N, int K, int split, float out_scale,
                              hipStream_t stream) {
   SIMVG_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm_tn: empty problem");
   SIMVG_CHECK_ARG(N % 8 == 0 && K % 8 == 0 && lddy % 8 == 0 && ldx % 8 == 0, "gemm_tn: N, K, ld must be multiples of 8");
   SIMVG_CHECK_ARG(split >= 0 && split <= M, "gemm_tn: split out of range");
   if (split == 0) split = M;
-  static const int tn_variant = getenv("SIMVG_GEMM_TN") ? atoi(getenv("SIMVG_GEMM_TN")) : 256;
   // 256x128 ring kernel for the wide problems (qkv / fc1 / fc2 wgrad); the small out-proj stays on the 128x128 kernel
-  const bool big = tn_variant == 256 && cdiv(N, 256) * cdiv(K, 128) >= 24;
+  const bool big = cdiv(N, 256) * cdiv(K, 128) >= 24;
   const int tiles = big ? cdiv(N, 256) * cdiv(K, 128) : cdiv(N, 128) * cdiv(K, 128);
   // split the contraction so that tiles x chunks ~ 2-3 blocks per CU (measured sweep, profiles/r01_sweeps.md)
-  static const int target_env = getenv("SIMVG_TN_BLOCKS") ? atoi(getenv("SIMVG_TN_BLOCKS")) : 0;
-  const int target_blocks = target_env ? target_env : (big ? 384 : (tiles <= 48 ? 384 : 768));
+  const int target_blocks = big ? 384 : (tiles <= 48 ? 384 : 768);
   int want = cdiv(target_blocks, tiles);
   int rpc = cdiv(cdiv(M, want), 64) * 64;
   if (rpc < 256) rpc = 256;   // multiple of 64 (and of the 32-row stages)
   const int chunks0 = cdiv(split, rpc), chunks1 = cdiv(M - split, rpc);
-  GemmTNArgs a{(const bf16_t*)dY, lddy, (const bf16_t*)X, ldx, dW, dw_gstride, lddw, M, N, K, split, rpc, chunks0,
-               db, db_gstride, tiles, cdiv(rpc, 512), 0};
-  {
-    static const int gk_env = getenv("SIMVG_TN_GK") ? atoi(getenv("SIMVG_TN_GK")) : 0;
-    a.gk = gk_env < 0 ? 0 : gk_env > 0 ? gk_env : 3;
-  }
+  GemmTNArgs a{(const lp_t*)dY, lddy, (const lp_t*)X, ldx, dW, dw_gstride, lddw, M, N, K, split, rpc, chunks0,
+               db, db_gstride, tiles, cdiv(rpc, 512), 3, out_scale};
   const int gx = tiles + (db ? cdiv(N, 256) * a.cs_split : 0);   // + column-sum blocks (bias gradient)
   if (big) {
     static bool once = hipFuncSetAttribute((const void*)gemm_tn_kernel_256, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1130,7 +973,7 @@ extern "C" int simvg_colsum(const void* Y, int ldy, float* out, int out_gstride,
   const int rpc = 512;
   const int chunks0 = cdiv(split, rpc), chunks1 = cdiv(M - split, rpc);
   hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 256), chunks0 + chunks1), dim3(256), 0, stream,
-                     (const bf16_t*)Y, ldy, out, out_gstride, M, N, split, rpc, chunks0);
+                     (const lp_t*)Y, ldy, out, out_gstride, M, N, split, rpc, chunks0);
   SIMVG_LAUNCH_CHECK();
   return SIMVG_OK;
 }

@@ -20,20 +20,20 @@ template <> struct Ld4<float> {
     v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
   }
 };
-template <> struct Ld4<bf16_t> {
-  static __device__ __forceinline__ void ld(const bf16_t* p, float* v) {
+template <> struct Ld4<lp_t> {
+  static __device__ __forceinline__ void ld(const lp_t* p, float* v) {
     const u32x2_t t = *(const u32x2_t*)p;
-    v[0] = __uint_as_float(t[0] << 16); v[1] = __uint_as_float(t[0] & 0xffff0000u);
-    v[2] = __uint_as_float(t[1] << 16); v[3] = __uint_as_float(t[1] & 0xffff0000u);
+    unpack_lp2(t[0], v[0], v[1]);
+    unpack_lp2(t[1], v[2], v[3]);
   }
 };
-__device__ __forceinline__ void st4_bf16(bf16_t* p, const float* v) {
-  *(u32x2_t*)p = (u32x2_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+__device__ __forceinline__ void st4_lp(lp_t* p, const float* v) {
+  *(u32x2_t*)p = (u32x2_t){pack_lp2(v[0], v[1]), pack_lp2(v[2], v[3])};
 }
 
 template <typename TIn, int NIT>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIn* __restrict__ x, int ldx, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, int gstride, bf16_t* __restrict__ y,
+                                                     const float* __restrict__ beta, int gstride, lp_t* __restrict__ y,
                                                      int ldy, float* __restrict__ y32, int ldy32, float* __restrict__ mean,
                                                      float* __restrict__ rstd, int M, int D, int split, float eps,
                                                      int gelu_in) {
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIn* __restrict__ x, 
       float o[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) o[k] = (v[it][k] - mu) * rs * gv[k] + bv[k];
-      if (y) st4_bf16(y + (long)row * ldy + c, o);
+      if (y) st4_lp(y + (long)row * ldy + c, o);
       if (y32) *(f32x4_t*)(y32 + (long)row * ldy32 + c) = (f32x4_t){o[0], o[1], o[2], o[3]};
     }
   }
@@ -101,11 +101,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, int gstride,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                     bf16_t* __restrict__ out_bf16, int ldob, const bf16_t* __restrict__ gelu_u, int ldu,
+                                                     lp_t* __restrict__ out_bf16, int ldob, const lp_t* __restrict__ gelu_u, int ldu,
                                                      const float* __restrict__ dres, float* __restrict__ out_f32, int ldof,
-                                                     bf16_t* __restrict__ out_scaled, int ldos, const float* __restrict__ row_scale,
+                                                     lp_t* __restrict__ out_scaled, int ldos, const float* __restrict__ row_scale,
                                                      int rps0, int rps1, int M, int D, int split, int rows_per_block, int blocks0,
-                                                     float* __restrict__ partial) {
+                                                     float* __restrict__ partial, float dy_scale, float pscale) {
   extern __shared__ float red[];  // [2][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // only a bf16 x can be the GELU pre-activation: for fp32 x this is a compile-time false and the GELU' registers vanish
@@ -139,6 +139,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
         float xv[4];
         Ld4<TIn>::ld(x + (long)row * ldx + c, xv);
         Ld4<TDy>::ld(dy + (long)row * lddy + c, dyv[it]);
+        if (sizeof(TDy) == 4) {      // fp32 dy: the entry of a scaled backward (gradient scale applied here)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) dyv[it][k] *= dy_scale;
+        }
         if (x_is_u) {     // x is the GELU pre-activation: LN input g = u*Phi(u), and keep GELU'(u) for the output
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
@@ -178,11 +182,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
             for (int k = 0; k < 4; ++k) dx[k] *= gp[it][k];
           } else if (gelu_u) {
             float u[4];
-            Ld4<bf16_t>::ld(gelu_u + (long)row * ldu + c, u);
+            Ld4<lp_t>::ld(gelu_u + (long)row * ldu + c, u);
 #pragma unroll
             for (int k = 0; k < 4; ++k) dx[k] *= gelu_erf_grad(u[k]);
           }
-          st4_bf16(out_bf16 + (long)row * ldob + c, dx);
+          st4_lp(out_bf16 + (long)row * ldob + c, dx);
         }
         if (out_f32) {
           if (dres) {
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
           *(f32x4_t*)(out_f32 + (long)row * ldof + c) = (f32x4_t){dx[0], dx[1], dx[2], dx[3]};
           if (out_scaled) {
             float t[4] = {dx[0] * scl, dx[1] * scl, dx[2] * scl, dx[3] * scl};
-            st4_bf16(out_scaled + (long)row * ldos + c, t);
+            st4_lp(out_scaled + (long)row * ldos + c, t);
           }
         }
       }
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
     const int c = (it * 64 + lane) * 4;
     if (c < D) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { atomicAdd(&rg[c + k], ag[it][k]); atomicAdd(&rb[c + k], ab[it][k]); }
+      for (int k = 0; k < 4; ++k) { atomicAdd(&rg[c + k], ag[it][k] * pscale); atomicAdd(&rb[c + k], ab[it][k] * pscale); }
     }
   }
   __syncthreads();
@@ -230,14 +234,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
 // form (two register slots, rows alternate between them) while it works on the current one.  Instances: the residual
 // stream (fp32 x, + dres, fp32 dx and the bf16 copy for the next GEMM) and the attention sub-LayerNorm (bf16 x, bf16 dx).
 template <typename TIn, bool RES, int NIT>
-__global__ __launch_bounds__(256) void ln_bwd_pf_kernel(const bf16_t* __restrict__ dy, int lddy, const TIn* __restrict__ x, int ldx,
+__global__ __launch_bounds__(256) void ln_bwd_pf_kernel(const lp_t* __restrict__ dy, int lddy, const TIn* __restrict__ x, int ldx,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ gamma, int gstride,
                                                         float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                        bf16_t* __restrict__ out_bf16, int ldob,
+                                                        lp_t* __restrict__ out_bf16, int ldob,
                                                         const float* __restrict__ dres, float* __restrict__ out_f32, int ldof,
-                                                        bf16_t* __restrict__ out_scaled, int ldos, const float* __restrict__ row_scale,
-                                                        int rps0, int rps1, int M, int D, int split, int rows_per_block, int blocks0) {
+                                                        lp_t* __restrict__ out_scaled, int ldos, const float* __restrict__ row_scale,
+                                                        int rps0, int rps1, int M, int D, int split, int rows_per_block, int blocks0,
+                                                        float pscale) {
   extern __shared__ float red[];  // [2][D]
   constexpr bool XF = sizeof(TIn) == 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -270,7 +275,7 @@ __global__ __launch_bounds__(256) void ln_bwd_pf_kernel(const bf16_t* __restrict
       const int c = (it * 64 + lane) * 4;
       if (c < D) {
         if constexpr (XF) xf[slot][it] = *(const f32x4_t*)((const float*)x + (long)row * ldx + c);
-        else xb[slot][it] = *(const u32x2_t*)((const bf16_t*)x + (long)row * ldx + c);
+        else xb[slot][it] = *(const u32x2_t*)((const lp_t*)x + (long)row * ldx + c);
         dq[slot][it] = *(const u32x2_t*)(dy + (long)row * lddy + c);
         if constexpr (RES) rq[slot][it] = *(const f32x4_t*)(dres + (long)row * ldof + c);
       }
@@ -288,12 +293,12 @@ __global__ __launch_bounds__(256) void ln_bwd_pf_kernel(const bf16_t* __restrict
         if constexpr (XF) { const f32x4_t t = xf[slot][it]; xv[0] = t[0]; xv[1] = t[1]; xv[2] = t[2]; xv[3] = t[3]; }
         else {
           const u32x2_t t = xb[slot][it];
-          xv[0] = __uint_as_float(t[0] << 16); xv[1] = __uint_as_float(t[0] & 0xffff0000u);
-          xv[2] = __uint_as_float(t[1] << 16); xv[3] = __uint_as_float(t[1] & 0xffff0000u);
+          unpack_lp2(t[0], xv[0], xv[1]);
+          unpack_lp2(t[1], xv[2], xv[3]);
         }
         const u32x2_t d = dq[slot][it];
-        dyv[it][0] = __uint_as_float(d[0] << 16); dyv[it][1] = __uint_as_float(d[0] & 0xffff0000u);
-        dyv[it][2] = __uint_as_float(d[1] << 16); dyv[it][3] = __uint_as_float(d[1] & 0xffff0000u);
+        unpack_lp2(d[0], dyv[it][0], dyv[it][1]);
+        unpack_lp2(d[1], dyv[it][2], dyv[it][3]);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           xh[it][k] = (xv[k] - mu) * rs;
@@ -325,10 +330,10 @@ __global__ __launch_bounds__(256) void ln_bwd_pf_kernel(const bf16_t* __restrict
           *(f32x4_t*)(out_f32 + (long)row * ldof + c) = (f32x4_t){dx[0], dx[1], dx[2], dx[3]};
           if (out_scaled) {
             float t2[4] = {dx[0] * scl, dx[1] * scl, dx[2] * scl, dx[3] * scl};
-            st4_bf16(out_scaled + (long)row * ldos + c, t2);
+            st4_lp(out_scaled + (long)row * ldos + c, t2);
           }
         } else {
-          st4_bf16(out_bf16 + (long)row * ldob + c, dx);
+          st4_lp(out_bf16 + (long)row * ldob + c, dx);
         }
       }
     }
@@ -348,7 +353,7 @@ __global__ __launch_bounds__(256) void ln_bwd_pf_kernel(const bf16_t* __restrict
     const int c = (it * 64 + lane) * 4;
     if (c < D) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { atomicAdd(&rg[c + k], ag[it][k]); atomicAdd(&rb[c + k], ab[it][k]); }
+      for (int k = 0; k < 4; ++k) { atomicAdd(&rg[c + k], ag[it][k] * pscale); atomicAdd(&rb[c + k], ab[it][k] * pscale); }
     }
   }
   __syncthreads();
@@ -365,15 +370,15 @@ __global__ __launch_bounds__(256) void ln_bwd_pf_kernel(const bf16_t* __restrict
 // full occupancy; the two row statistics cross waves through 32 B of LDS (one barrier per row, double-buffered).
 // Each thread owns its columns outright, so dgamma/dbeta need no cross-wave reduction at all.
 template <typename TIn, int NITW>
-__global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const bf16_t* __restrict__ dy, int lddy, const TIn* __restrict__ x, int ldx,
+__global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const lp_t* __restrict__ dy, int lddy, const TIn* __restrict__ x, int ldx,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           const float* __restrict__ gamma, int gstride,
                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                          bf16_t* __restrict__ out_bf16, int ldob, const bf16_t* __restrict__ gelu_u, int ldu,
+                                                          lp_t* __restrict__ out_bf16, int ldob, const lp_t* __restrict__ gelu_u, int ldu,
                                                           const float* __restrict__ dres, float* __restrict__ out_f32, int ldof,
-                                                          bf16_t* __restrict__ out_scaled, int ldos, const float* __restrict__ row_scale,
+                                                          lp_t* __restrict__ out_scaled, int ldos, const float* __restrict__ row_scale,
                                                           int rps0, int rps1, int M, int D, int split, int rows_per_block, int blocks0,
-                                                          float* __restrict__ partial) {
+                                                          float* __restrict__ partial, float pscale) {
   __shared__ float part[2][4][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool x_is_u = gelu_u != nullptr && (const void*)gelu_u == (const void*)x;
@@ -404,8 +409,8 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const bf16_t* __restri
       const int c = (it * 256 + tid) * 4;
       if (c < D) {
         if (!x_is_u) Ld4<TIn>::ld(x + (long)row * ldx + c, xq[it]);
-        Ld4<bf16_t>::ld(dy + (long)row * lddy + c, dq[it]);
-        if (gelu_u) Ld4<bf16_t>::ld(gelu_u + (long)row * ldu + c, uq[it]);
+        Ld4<lp_t>::ld(dy + (long)row * lddy + c, dq[it]);
+        if (gelu_u) Ld4<lp_t>::ld(gelu_u + (long)row * ldu + c, uq[it]);
       }
     }
   };
@@ -456,7 +461,7 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const bf16_t* __restri
 #pragma unroll
             for (int k = 0; k < 4; ++k) dx[k] *= uv[it][k];
           }
-          st4_bf16(out_bf16 + (long)row * ldob + c, dx);
+          st4_lp(out_bf16 + (long)row * ldob + c, dx);
         }
         if (out_f32) {
           if (dres) {
@@ -467,7 +472,7 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const bf16_t* __restri
           *(f32x4_t*)(out_f32 + (long)row * ldof + c) = (f32x4_t){dx[0], dx[1], dx[2], dx[3]};
           if (out_scaled) {
             float t[4] = {dx[0] * scl, dx[1] * scl, dx[2] * scl, dx[3] * scl};
-            st4_bf16(out_scaled + (long)row * ldos + c, t);
+            st4_lp(out_scaled + (long)row * ldos + c, t);
           }
         }
       }
@@ -479,8 +484,8 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const bf16_t* __restri
     for (int it = 0; it < NITW; ++it) {
       const int c = (it * 256 + tid) * 4;
       if (c < D) {
-        *(f32x4_t*)(pp + c) = (f32x4_t){ag[it][0], ag[it][1], ag[it][2], ag[it][3]};
-        *(f32x4_t*)(pp + D + c) = (f32x4_t){ab[it][0], ab[it][1], ab[it][2], ab[it][3]};
+        *(f32x4_t*)(pp + c) = (f32x4_t){ag[it][0], ag[it][1], ag[it][2], ag[it][3]} * pscale;
+        *(f32x4_t*)(pp + D + c) = (f32x4_t){ab[it][0], ab[it][1], ab[it][2], ab[it][3]} * pscale;
       }
     }
   } else if (r_begin < r_end && dgamma) {
@@ -490,8 +495,8 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const bf16_t* __restri
       if (c < D) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          atomicAdd(dgamma + (long)g * gstride + c + k, ag[it][k]);
-          atomicAdd(dbeta + (long)g * gstride + c + k, ab[it][k]);
+          atomicAdd(dgamma + (long)g * gstride + c + k, ag[it][k] * pscale);
+          atomicAdd(dbeta + (long)g * gstride + c + k, ab[it][k] * pscale);
         }
       }
     }
@@ -503,11 +508,12 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const bf16_t* __restri
 // loads in flight per block is ~12 KB; measured 2.5 TB/s), so rows are prefetched TWO ahead and kept as raw bf16 pairs
 // (2 VGPRs per 4 values instead of 4) until they are consumed: twice the bytes in flight for the same registers.
 template <int NITW>
-__global__ __launch_bounds__(256) void ln_bwd_ffn_kernel(const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ u, int ldu,
+__global__ __launch_bounds__(256) void ln_bwd_ffn_kernel(const lp_t* __restrict__ dy, int lddy, const lp_t* __restrict__ u, int ldu,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const float* __restrict__ gamma, int gstride,
-                                                         bf16_t* __restrict__ out, int ldo, int M, int D, int split,
-                                                         int rows_per_block, int blocks0, float* __restrict__ partial) {
+                                                         lp_t* __restrict__ out, int ldo, int M, int D, int split,
+                                                         int rows_per_block, int blocks0, float* __restrict__ partial,
+                                                         float pscale) {
   __shared__ float part[2][4][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int blk = blockIdx.x;
@@ -552,10 +558,11 @@ __global__ __launch_bounds__(256) void ln_bwd_ffn_kernel(const bf16_t* __restric
       const int c = (it * 256 + tid) * 4;
       const bool in = c < D;
       const u32x2_t dr = dq[par][it], ur = uq[par][it];
-      const float dv[4] = {__uint_as_float(dr[0] << 16), __uint_as_float(dr[0] & 0xffff0000u),
-                           __uint_as_float(dr[1] << 16), __uint_as_float(dr[1] & 0xffff0000u)};
-      const float uu[4] = {__uint_as_float(ur[0] << 16), __uint_as_float(ur[0] & 0xffff0000u),
-                           __uint_as_float(ur[1] << 16), __uint_as_float(ur[1] & 0xffff0000u)};
+      float dv[4], uu[4];
+      unpack_lp2(dr[0], dv[0], dv[1]);
+      unpack_lp2(dr[1], dv[2], dv[3]);
+      unpack_lp2(ur[0], uu[0], uu[1]);
+      unpack_lp2(ur[1], uu[2], uu[3]);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         dyv[it][k] = in ? dv[k] : 0.f;
@@ -583,7 +590,7 @@ __global__ __launch_bounds__(256) void ln_bwd_ffn_kernel(const bf16_t* __restric
         float dx[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) dx[k] = rs * (dyv[it][k] * gv[it][k] - c1 - xh[it][k] * c2) * uv[it][k];
-        st4_bf16(out + (long)row * ldo + c, dx);
+        st4_lp(out + (long)row * ldo + c, dx);
       }
     }
   };
@@ -597,8 +604,8 @@ __global__ __launch_bounds__(256) void ln_bwd_ffn_kernel(const bf16_t* __restric
   for (int it = 0; it < NITW; ++it) {
     const int c = (it * 256 + tid) * 4;
     if (c < D) {
-      *(f32x4_t*)(pp + c) = (f32x4_t){ag[it][0], ag[it][1], ag[it][2], ag[it][3]};
-      *(f32x4_t*)(pp + D + c) = (f32x4_t){ab[it][0], ab[it][1], ab[it][2], ab[it][3]};
+      *(f32x4_t*)(pp + c) = (f32x4_t){ag[it][0], ag[it][1], ag[it][2], ag[it][3]} * pscale;
+      *(f32x4_t*)(pp + D + c) = (f32x4_t){ab[it][0], ab[it][1], ab[it][2], ab[it][3]} * pscale;
     }
   }
 }
@@ -662,12 +669,12 @@ extern "C" int simvg_ln_fwd(const void* x, int x_is_bf16, int ldx, const float* 
   const dim3 grid(cdiv(M, 4)), block(256);
 #define CALL(N_)                                                                                                   \
   if (x_is_bf16)                                                                                                   \
-    hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, N_>), grid, block, 0, stream, (const bf16_t*)x, ldx, gamma, beta,    \
-                       group_stride, (bf16_t*)y_bf16, ldy, y_f32, ldy32, mean, rstd, M, D, split, eps,             \
+    hipLaunchKernelGGL((ln_fwd_kernel<lp_t, N_>), grid, block, 0, stream, (const lp_t*)x, ldx, gamma, beta,    \
+                       group_stride, (lp_t*)y_bf16, ldy, y_f32, ldy32, mean, rstd, M, D, split, eps,             \
                        x_is_gelu_preact);                                                                          \
   else                                                                                                             \
     hipLaunchKernelGGL((ln_fwd_kernel<float, N_>), grid, block, 0, stream, (const float*)x, ldx, gamma, beta,      \
-                       group_stride, (bf16_t*)y_bf16, ldy, y_f32, ldy32, mean, rstd, M, D, split, eps,             \
+                       group_stride, (lp_t*)y_bf16, ldy, y_f32, ldy32, mean, rstd, M, D, split, eps,             \
                        x_is_gelu_preact)
   LN_DISPATCH_NIT(D, CALL);
 #undef CALL
@@ -680,8 +687,9 @@ extern "C" int simvg_ln_bwd(const void* dy_bf16, int dy_is_f32, int lddy, const 
                             void* dx_bf16, int lddxb, const void* gelu_u_bf16, int ldu, const float* dres,
                             float* dx_f32, int lddxf, void* dx_scaled_bf16, int lddxs, const float* row_scale,
                             int rows_per_sample0, int rows_per_sample1, int M, int D, int split,
-                            float* partial_ws, hipStream_t stream) {
+                            float* partial_ws, float dy_scale, float param_scale, hipStream_t stream) {
   SIMVG_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 4096, "ln_bwd: D must be a multiple of 4 and <= 4096");
+  SIMVG_CHECK_ARG(dy_is_f32 || dy_scale == 1.0f, "ln_bwd: dy_scale applies to an fp32 dy only (entry of a scaled backward)");
   SIMVG_CHECK_ARG(dx_bf16 || dx_f32, "ln_bwd: no output");
   SIMVG_CHECK_ARG(!dy_is_f32 || !x_is_bf16, "ln_bwd: fp32 dy goes with fp32 x (decoder head, exact-fp32 encoder mode)");
   SIMVG_CHECK_ARG(!(dx_scaled_bf16 && !dx_f32), "ln_bwd: scaled bf16 copy requires the f32 output");
@@ -690,8 +698,7 @@ extern "C" int simvg_ln_bwd(const void* dy_bf16, int dy_is_f32, int lddy, const 
   // global atomics
   // rows per block: the wide two-stage kernel gets its grid into one residency round (2 blocks per CU; >= 16 rows),
   // 32 for the generic wave-per-row kernels (sweeps: profiles/r01_sweeps.md)
-  static const int rpb_env = getenv("SIMVG_LN_RPB") ? atoi(getenv("SIMVG_LN_RPB")) : 0;
-  const int rpb = rpb_env ? rpb_env : ((D >= 2048 && partial_ws) ? ln_wide_rpb(M) : 32);
+  const int rpb = (D >= 2048 && partial_ws) ? ln_wide_rpb(M) : 32;
   const int blocks0 = cdiv(split, rpb), blocks1 = cdiv(M - split, rpb);
   const dim3 grid(blocks0 + blocks1), block(256);
   const size_t shm = (size_t)2 * D * sizeof(float);
@@ -699,9 +706,9 @@ extern "C" int simvg_ln_bwd(const void* dy_bf16, int dy_is_f32, int lddy, const 
   if (dy_is_f32) {      // wave-per-row kernel at every width (the exact mode is a parity mode, not a fast one)
 #define FCALL(N_)                                                                                                       \
     hipLaunchKernelGGL((ln_bwd_kernel<float, float, N_>), grid, block, shm, stream, (const float*)dy_bf16, lddy,        \
-                       (const float*)x, ldx, mean, rstd, gamma, group_stride, dgamma, dbeta, (bf16_t*)dx_bf16, lddxb,   \
-                       (const bf16_t*)gelu_u_bf16, ldu, dres, dx_f32, lddxf, (bf16_t*)dx_scaled_bf16, lddxs, row_scale, \
-                       rps0, rps1, M, D, split, rpb, blocks0, partial_ws)
+                       (const float*)x, ldx, mean, rstd, gamma, group_stride, dgamma, dbeta, (lp_t*)dx_bf16, lddxb,   \
+                       (const lp_t*)gelu_u_bf16, ldu, dres, dx_f32, lddxf, (lp_t*)dx_scaled_bf16, lddxs, row_scale, \
+                       rps0, rps1, M, D, split, rpb, blocks0, partial_ws, dy_scale, param_scale)
     LN_DISPATCH_NIT(D, FCALL);
 #undef FCALL
     if (partial_ws)
@@ -713,18 +720,17 @@ extern "C" int simvg_ln_bwd(const void* dy_bf16, int dy_is_f32, int lddy, const 
   if (D >= 2048) {
     const int nitw = (D + 1023) / 1024;
 #define WCALL(T_, N_)                                                                                                   \
-    hipLaunchKernelGGL((ln_bwd_wide_kernel<T_, N_>), grid, block, 0, stream, (const bf16_t*)dy_bf16, lddy, (const T_*)x, \
-                       ldx, mean, rstd, gamma, group_stride, dgamma, dbeta, (bf16_t*)dx_bf16, lddxb,                    \
-                       (const bf16_t*)gelu_u_bf16, ldu, dres, dx_f32, lddxf, (bf16_t*)dx_scaled_bf16, lddxs, row_scale, \
-                       rps0, rps1, M, D, split, rpb, blocks0, partial_ws)
-    static const int ffn_env = getenv("SIMVG_LN_FFN") ? atoi(getenv("SIMVG_LN_FFN")) : 1;
-    const bool ffn = ffn_env && x_is_bf16 && gelu_u_bf16 && gelu_u_bf16 == x && dx_bf16 && !dx_f32 && !dres && partial_ws &&
+    hipLaunchKernelGGL((ln_bwd_wide_kernel<T_, N_>), grid, block, 0, stream, (const lp_t*)dy_bf16, lddy, (const T_*)x, \
+                       ldx, mean, rstd, gamma, group_stride, dgamma, dbeta, (lp_t*)dx_bf16, lddxb,                    \
+                       (const lp_t*)gelu_u_bf16, ldu, dres, dx_f32, lddxf, (lp_t*)dx_scaled_bf16, lddxs, row_scale, \
+                       rps0, rps1, M, D, split, rpb, blocks0, partial_ws, param_scale)
+    const bool ffn = x_is_bf16 && gelu_u_bf16 && gelu_u_bf16 == x && dx_bf16 && !dx_f32 && !dres && partial_ws &&
                      (nitw == 3 || nitw == 4);
 #define FCALL_FFN(N_)                                                                                                   \
-    hipLaunchKernelGGL((ln_bwd_ffn_kernel<N_>), grid, block, 0, stream, (const bf16_t*)dy_bf16, lddy, (const bf16_t*)x,  \
-                       ldx, mean, rstd, gamma, group_stride, (bf16_t*)dx_bf16, lddxb, M, D, split, rpb, blocks0, partial_ws)
+    hipLaunchKernelGGL((ln_bwd_ffn_kernel<N_>), grid, block, 0, stream, (const lp_t*)dy_bf16, lddy, (const lp_t*)x,  \
+                       ldx, mean, rstd, gamma, group_stride, (lp_t*)dx_bf16, lddxb, M, D, split, rpb, blocks0, partial_ws, param_scale)
     if (ffn) { if (nitw == 3) FCALL_FFN(3); else FCALL_FFN(4); }
-    else if (x_is_bf16) { if (nitw <= 2) WCALL(bf16_t, 2); else if (nitw == 3) WCALL(bf16_t, 3); else WCALL(bf16_t, 4); }
+    else if (x_is_bf16) { if (nitw <= 2) WCALL(lp_t, 2); else if (nitw == 3) WCALL(lp_t, 3); else WCALL(lp_t, 4); }
     else { if (nitw <= 2) WCALL(float, 2); else if (nitw == 3) WCALL(float, 3); else WCALL(float, 4); }
 #undef WCALL
 #undef FCALL_FFN
@@ -735,25 +741,24 @@ extern "C" int simvg_ln_bwd(const void* dy_bf16, int dy_is_f32, int lddy, const 
     return SIMVG_OK;
   }
   {
-    static const int pf_env = getenv("SIMVG_LN_PF") ? atoi(getenv("SIMVG_LN_PF")) : 1;
     const bool res = !x_is_bf16 && dres && dx_f32 && !dx_bf16;
     const bool sub = x_is_bf16 && dx_bf16 && !dx_f32 && !dres;
     const int nit_pf = (D + 255) / 256;
-    if (pf_env && dy_bf16 && !gelu_u_bf16 && !partial_ws && (nit_pf == 3 || nit_pf == 4) && (res || sub)) {
+    if (dy_bf16 && !gelu_u_bf16 && !partial_ws && (nit_pf == 3 || nit_pf == 4) && (res || sub)) {
       // rows per block: the whole grid in ONE residency round (2-3 blocks of 4 waves per CU) -- with 32 rows the 842
       // blocks of a B=64 step took two rounds, the second one a third full (sweep: 32 -> 93.7 / 64.9 us, 53-64 ->
       // 77.4 / 46.6 us for the residual-stream / sub-LN instance)
-      const int rpb_pf = rpb_env ? rpb_env : std::max(32, (cdiv(M, 480) + 3) / 4 * 4);
+      const int rpb_pf = std::max(32, (cdiv(M, 480) + 3) / 4 * 4);
       const int pf_blocks0 = cdiv(split, rpb_pf), pf_blocks1 = cdiv(M - split, rpb_pf);
       const dim3 pf_grid(pf_blocks0 + pf_blocks1);
 #define PFCALL(T_, R_)                                                                                                  \
       if (nit_pf == 3) PFCALL_N(T_, R_, 3); else PFCALL_N(T_, R_, 4)
 #define PFCALL_N(T_, R_, N_)                                                                                            \
-      hipLaunchKernelGGL((ln_bwd_pf_kernel<T_, R_, N_>), pf_grid, block, shm, stream, (const bf16_t*)dy_bf16, lddy,    \
-                         (const T_*)x, ldx, mean, rstd, gamma, group_stride, dgamma, dbeta, (bf16_t*)dx_bf16, lddxb,    \
-                         dres, dx_f32, lddxf, (bf16_t*)dx_scaled_bf16, lddxs, row_scale, rps0, rps1, M, D, split,       \
-                         rpb_pf, pf_blocks0)
-      if (res) { PFCALL(float, true); } else { PFCALL(bf16_t, false); }
+      hipLaunchKernelGGL((ln_bwd_pf_kernel<T_, R_, N_>), pf_grid, block, shm, stream, (const lp_t*)dy_bf16, lddy,    \
+                         (const T_*)x, ldx, mean, rstd, gamma, group_stride, dgamma, dbeta, (lp_t*)dx_bf16, lddxb,    \
+                         dres, dx_f32, lddxf, (lp_t*)dx_scaled_bf16, lddxs, row_scale, rps0, rps1, M, D, split,       \
+                         rpb_pf, pf_blocks0, param_scale)
+      if (res) { PFCALL(float, true); } else { PFCALL(lp_t, false); }
 #undef PFCALL
 #undef PFCALL_N
       SIMVG_LAUNCH_CHECK();
@@ -762,15 +767,15 @@ extern "C" int simvg_ln_bwd(const void* dy_bf16, int dy_is_f32, int lddy, const 
   }
 #define CALL(N_)                                                                                                        \
   if (x_is_bf16)                                                                                                        \
-    hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, bf16_t, N_>), grid, block, shm, stream, (const bf16_t*)dy_bf16, lddy,             \
-                       (const bf16_t*)x, ldx, mean, rstd, gamma, group_stride, dgamma, dbeta, (bf16_t*)dx_bf16, lddxb,  \
-                       (const bf16_t*)gelu_u_bf16, ldu, dres, dx_f32, lddxf, (bf16_t*)dx_scaled_bf16, lddxs, row_scale, \
-                       rps0, rps1, M, D, split, rpb, blocks0, partial_ws);                                                          \
+    hipLaunchKernelGGL((ln_bwd_kernel<lp_t, lp_t, N_>), grid, block, shm, stream, (const lp_t*)dy_bf16, lddy,             \
+                       (const lp_t*)x, ldx, mean, rstd, gamma, group_stride, dgamma, dbeta, (lp_t*)dx_bf16, lddxb,  \
+                       (const lp_t*)gelu_u_bf16, ldu, dres, dx_f32, lddxf, (lp_t*)dx_scaled_bf16, lddxs, row_scale, \
+                       rps0, rps1, M, D, split, rpb, blocks0, partial_ws, 1.0f, param_scale);                                       \
   else                                                                                                                  \
-    hipLaunchKernelGGL((ln_bwd_kernel<float, bf16_t, N_>), grid, block, shm, stream, (const bf16_t*)dy_bf16, lddy,              \
-                       (const float*)x, ldx, mean, rstd, gamma, group_stride, dgamma, dbeta, (bf16_t*)dx_bf16, lddxb,   \
-                       (const bf16_t*)gelu_u_bf16, ldu, dres, dx_f32, lddxf, (bf16_t*)dx_scaled_bf16, lddxs, row_scale, \
-                       rps0, rps1, M, D, split, rpb, blocks0, partial_ws)
+    hipLaunchKernelGGL((ln_bwd_kernel<float, lp_t, N_>), grid, block, shm, stream, (const lp_t*)dy_bf16, lddy,              \
+                       (const float*)x, ldx, mean, rstd, gamma, group_stride, dgamma, dbeta, (lp_t*)dx_bf16, lddxb,   \
+                       (const lp_t*)gelu_u_bf16, ldu, dres, dx_f32, lddxf, (lp_t*)dx_scaled_bf16, lddxs, row_scale, \
+                       rps0, rps1, M, D, split, rpb, blocks0, partial_ws, 1.0f, param_scale)
   LN_DISPATCH_NIT(D, CALL);
 #undef CALL
   if (partial_ws)
@@ -782,6 +787,6 @@ extern "C" int simvg_ln_bwd(const void* dy_bf16, int dy_is_f32, int lddy, const 
 
 extern "C" long simvg_ln_bwd_ws_floats(int M, int D, int split) {
   if (split == 0) split = M;
-  const int rpb = getenv("SIMVG_LN_RPB") ? atoi(getenv("SIMVG_LN_RPB")) : (D >= 2048 ? ln_wide_rpb(M) : 32);
+  const int rpb = D >= 2048 ? ln_wide_rpb(M) : 32;
   return (long)(cdiv(split, rpb) + cdiv(M - split, rpb)) * 2 * D;
 }

@@ -15,7 +15,7 @@ What makes the capture legal:
     happens BEFORE the graphed region (`head.prepare_targets`); the region itself contains no collective, no host copy,
     no synchronisation (the matcher and the criterion run on the device);
   * dropout / attention-dropout masks come from PyTorch's graph-safe Philox generator (fresh masks on every replay);
-  * the bf16 weight refresh of the head's memory projections is part of the captured forward, so replays always see
+  * the 16-bit weight refresh of the head's memory projections is part of the captured forward, so replays always see
     the current master weights.
 A signature = (shapes, dtypes, per-image `img_shape`s, train/eval mode).  Anything else (first steps, a ragged last
 batch, GRefCOCO-style variable metas) runs eagerly; a failed capture disables the feature with a warning.
@@ -60,8 +60,9 @@ class _HeadStep(torch.nn.Module):
         self.img_metas = img_metas
         self.predict_fn = predict_fn
 
-    def forward(self, enc_out, text_mask, tboxes, tlabels, tcount, nums):
+    def forward(self, enc_out, enc_lp, text_mask, tboxes, tlabels, tcount, nums):
         B, Nv, T = self.geo
+        enc_out.lp = enc_lp           # the 16-bit copy of the same rows (operand of the memory projections)
         out = self.head.forward_fused(enc_out, B, Nv, T, self.img_metas, text_mask)
         losses, _ = self.head.loss_from_targets(out, tboxes, tlabels, tcount, nums)
         t, d = out["token_branch_output"], out["decoder_branch_output"]
@@ -120,7 +121,7 @@ class HeadGraphs:
                     time.sleep(0.5)
                 mod = _HeadStep(self.head, B, Nv, T, [dict(m) for m in img_metas], predict_fn)
                 mod.train(self.head.training)
-                sample = (enc_out.detach().clone().requires_grad_(True), text_mask.clone(), tboxes.clone(),
+                sample = (enc_out.detach().clone().requires_grad_(True), enc_out.lp.clone(), text_mask.clone(), tboxes.clone(),
                           tlabels.clone(), tcount.clone(), nums.clone())
                 g = torch.cuda.make_graphed_callables(mod, sample, num_warmup_iters=2, allow_unused_input=True)
             except Exception as e:      # noqa: BLE001 -- any capture problem: stay eager, say so once
@@ -129,7 +130,7 @@ class HeadGraphs:
                 torch.cuda.synchronize()
                 return None
             self.graphs[sig] = g
-        outs = g(enc_out, text_mask, tboxes, tlabels, tcount, nums)
+        outs = g(enc_out, enc_out.lp, text_mask, tboxes, tlabels, tcount, nums)
         losses = dict(zip(LOSS_KEYS, outs[:5]))
         output = dict(token_branch_output={"pred_logits": outs[5], "pred_boxes": outs[6]},
                       decoder_branch_output={"pred_logits": outs[7], "pred_boxes": outs[8]})

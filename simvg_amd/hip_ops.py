@@ -9,7 +9,32 @@ import torch
 
 from . import _lib
 
-BF16 = torch.bfloat16
+_LP = None
+_GRAD_SCALE = None
+
+
+def LP():
+    """torch dtype of the library's 16-bit operand / storage format (float16 unless built with SIMVG_LOWP_BF16)"""
+    global _LP
+    if _LP is None:
+        _LP = torch.float16 if _lib.lowp_format() == "fp16" else torch.bfloat16
+    return _LP
+
+
+def grad_scale():
+    """Power-of-two scale carried by every 16-bit tensor of a backward pass (fp16 has 5 exponent bits: at B = 64 the
+    activation gradients of this model sit at 1e-7 .. 1e-3, i.e. in fp16's subnormal range unscaled).  2^14 puts their
+    median at ~1e-2 and the largest at ~20; stores saturate at 65504.  The scale is removed where parameter gradients
+    are written (`out_scale` / `param_scale` / `alpha` arguments), so `.grad` tensors are true gradients.  bf16: 1."""
+    global _GRAD_SCALE
+    if _GRAD_SCALE is None:
+        _GRAD_SCALE = 16384.0 if LP() == torch.float16 else 1.0
+    return _GRAD_SCALE
+
+
+def set_grad_scale(v):
+    global _GRAD_SCALE
+    _GRAD_SCALE = float(v)
 
 # optional per-launch timing (bench.py): an object with .add(name, ev_start, ev_end, flops, bytes)
 _timer = None
@@ -69,16 +94,16 @@ def _chk(t, dtype=None, name="tensor"):
     return t
 
 
-def gemm_nt(a, w, bias=None, out=None, out_dtype=BF16, split=0, act=0, aux_preact=None, residual=None,
-            row_scale=None, rows_per_sample=(1, 1), w_group_stride=None, bias_group_stride=None):
+def gemm_nt(a, w, bias=None, out=None, out_dtype=None, split=0, act=0, aux_preact=None, residual=None,
+            row_scale=None, rows_per_sample=(1, 1), w_group_stride=None, bias_group_stride=None, alpha=1.0):
     """out[M,N] = a[M,K] @ w[g][N,K]^T (+bias) (+act) (+residual + row_scale*...).  w: [N,K] or [2,N,K]."""
     lib = _lib.load()
-    _chk(a, BF16, "a"); _chk(w, BF16, "w")
+    _chk(a, LP(), "a"); _chk(w, LP(), "w")
     M, K = a.shape
     N = w.shape[-2]
     assert w.shape[-1] == K
     if out is None:
-        out = torch.empty(M, N, device=a.device, dtype=out_dtype)
+        out = torch.empty(M, N, device=a.device, dtype=out_dtype or LP())
     if w_group_stride is None:
         w_group_stride = w.stride(0) if w.dim() == 3 else 0
     if bias is not None:
@@ -93,17 +118,17 @@ def gemm_nt(a, w, bias=None, out=None, out_dtype=BF16, split=0, act=0, aux_preac
                            _p(out), out.stride(0), int(out.dtype == torch.float32),
                            _p(aux_preact), aux_preact.stride(0) if aux_preact is not None else 0,
                            _p(residual), residual.stride(0) if residual is not None else 0,
-                           _p(row_scale), rows_per_sample[0], rows_per_sample[1], M, N, K, split, act, _stream())
+                           _p(row_scale), rows_per_sample[0], rows_per_sample[1], M, N, K, split, act, alpha, _stream())
     if t0 is not None:
         _timer.stop(tname, t0, 2.0 * M * N * K, 2.0 * (M * K + N * K) + out.element_size() * M * N)
     _lib.check(rc, "simvg_gemm_nt")
     return out
 
 
-def gemm_tn(dy, x, dw, split=0, dw_group_stride=None, db=None):
+def gemm_tn(dy, x, dw, split=0, dw_group_stride=None, db=None, out_scale=1.0):
     """dw[g][N,K] += dy[M,N]^T @ x[M,K]   (fp32 accumulate into dw); db[g][N] += column sums of dy (optional)."""
     lib = _lib.load()
-    _chk(dy, BF16, "dy"); _chk(x, BF16, "x"); _chk(dw, torch.float32, "dw")
+    _chk(dy, LP(), "dy"); _chk(x, LP(), "x"); _chk(dw, torch.float32, "dw")
     M, N = dy.shape
     K = x.shape[1]
     if dw_group_stride is None:
@@ -112,7 +137,7 @@ def gemm_tn(dy, x, dw, split=0, dw_group_stride=None, db=None):
     t0 = _timer.start(tname) if _timer is not None else None
     rc = lib.simvg_gemm_tn(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), dw_group_stride, dw.stride(-2),
                            _p(db), (db.stride(0) if db.dim() == 2 else 0) if db is not None else 0,
-                           M, N, K, split, _stream())
+                           M, N, K, split, out_scale, _stream())
     if t0 is not None:
         _timer.stop(tname, t0, 2.0 * M * N * K, 2.0 * M * (N + K) + 4.0 * N * K)
     _lib.check(rc, "simvg_gemm_tn")
@@ -121,7 +146,7 @@ def gemm_tn(dy, x, dw, split=0, dw_group_stride=None, db=None):
 
 def colsum(y, out, split=0, out_group_stride=None):
     lib = _lib.load()
-    _chk(y, BF16, "y"); _chk(out, torch.float32, "out")
+    _chk(y, LP(), "y"); _chk(out, torch.float32, "out")
     M, N = y.shape
     if out_group_stride is None:
         out_group_stride = out.stride(0) if out.dim() == 2 else 0
@@ -133,7 +158,7 @@ def colsum(y, out, split=0, out_group_stride=None):
     return out
 
 
-def ln_fwd(x, gamma, beta, split=0, eps=1e-5, out_bf16=True, out_f32=False, save_stats=True, y=None, y32=None,
+def ln_fwd(x, gamma, beta, split=0, eps=1e-5, out_lp=True, out_f32=False, save_stats=True, y=None, y32=None,
            gelu_in=False):
     """gamma/beta: [D] or [2,D] fp32.  Returns (y_bf16|None, y_f32|None, mean, rstd).  gelu_in: x is the fc1
     pre-activation, LayerNorm(gelu(x)) is computed."""
@@ -141,14 +166,14 @@ def ln_fwd(x, gamma, beta, split=0, eps=1e-5, out_bf16=True, out_f32=False, save
     _chk(x, None, "x")
     M, D = x.shape
     gs = gamma.stride(0) if gamma.dim() == 2 else 0
-    if out_bf16 and y is None:
-        y = torch.empty(M, D, device=x.device, dtype=BF16)
+    if out_lp and y is None:
+        y = torch.empty(M, D, device=x.device, dtype=LP())
     if out_f32 and y32 is None:
         y32 = torch.empty(M, D, device=x.device, dtype=torch.float32)
     mean = torch.empty(M, device=x.device, dtype=torch.float32) if save_stats else None
     rstd = torch.empty(M, device=x.device, dtype=torch.float32) if save_stats else None
     t0 = _timer.start("ln_fwd") if _timer is not None else None
-    rc = lib.simvg_ln_fwd(_p(x), int(x.dtype == BF16), x.stride(0), _p(gamma), _p(beta), gs, _p(y),
+    rc = lib.simvg_ln_fwd(_p(x), int(x.dtype == LP()), x.stride(0), _p(gamma), _p(beta), gs, _p(y),
                           y.stride(0) if y is not None else 0, _p(y32), y32.stride(0) if y32 is not None else 0,
                           _p(mean), _p(rstd), M, D, split, eps, int(gelu_in), _stream())
     if t0 is not None:
@@ -170,8 +195,8 @@ def _ln_workspace(M, D, split, device):
     return t
 
 
-def ln_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, split=0, dx_bf16=None, gelu_u=None, dres=None, dx_f32=None,
-           dx_scaled=None, row_scale=None, rows_per_sample=(1, 1)):
+def ln_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, split=0, dx_lp=None, gelu_u=None, dres=None, dx_f32=None,
+           dx_scaled=None, row_scale=None, rows_per_sample=(1, 1), dy_scale=1.0, param_scale=1.0):
     lib = _lib.load()
     # two-stage dgamma/dbeta reduction pays for wide rows only (measured: profiles/r01_sweeps.md)
     ws = _ln_workspace(dy.shape[0], dy.shape[1], split, dy.device) if (dy.shape[0] >= 1024 and dy.shape[1] >= 2048) else None
@@ -179,29 +204,29 @@ def ln_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, split=0, dx_bf16=None, gelu_
     M, D = dy.shape
     gs = gamma.stride(0) if gamma.dim() == 2 else 0
     t0 = _timer.start("ln_bwd") if _timer is not None else None
-    rc = lib.simvg_ln_bwd(_p(dy), int(dy.dtype == torch.float32), dy.stride(0), _p(x), int(x.dtype == BF16), x.stride(0), _p(mean), _p(rstd),
-                          _p(gamma), gs, _p(dgamma), _p(dbeta), _p(dx_bf16),
-                          dx_bf16.stride(0) if dx_bf16 is not None else 0, _p(gelu_u),
+    rc = lib.simvg_ln_bwd(_p(dy), int(dy.dtype == torch.float32), dy.stride(0), _p(x), int(x.dtype == LP()), x.stride(0), _p(mean), _p(rstd),
+                          _p(gamma), gs, _p(dgamma), _p(dbeta), _p(dx_lp),
+                          dx_lp.stride(0) if dx_lp is not None else 0, _p(gelu_u),
                           gelu_u.stride(0) if gelu_u is not None else 0, _p(dres), _p(dx_f32),
                           dx_f32.stride(0) if dx_f32 is not None else 0, _p(dx_scaled),
                           dx_scaled.stride(0) if dx_scaled is not None else 0, _p(row_scale),
-                          rows_per_sample[0], rows_per_sample[1], M, D, split, _p(ws), _stream())
+                          rows_per_sample[0], rows_per_sample[1], M, D, split, _p(ws), dy_scale, param_scale, _stream())
     if t0 is not None:
-        nb = dy.element_size() + x.element_size() + (2 if dx_bf16 is not None else 0) + (2 if gelu_u is not None else 0) \
+        nb = dy.element_size() + x.element_size() + (2 if dx_lp is not None else 0) + (2 if gelu_u is not None else 0) \
             + (4 if dres is not None else 0) + (4 if dx_f32 is not None else 0) + (2 if dx_scaled is not None else 0)
         _timer.stop("ln_bwd", t0, 0.0, float(M) * D * nb)
     _lib.check(rc, "simvg_ln_bwd")
 
 
 def attn_fwd(qkv, B, H, Nv, Nt, pad=None, out=None, scale=None):
-    """qkv: [M, 3*D] bf16, modality-major rows.  Returns (out [M,D] bf16, lse [B*H, N] fp32)."""
+    """qkv: [M, 3*D] lp, modality-major rows.  Returns (out [M,D] lp, lse [B*H, N] fp32)."""
     lib = _lib.load()
-    _chk(qkv, BF16, "qkv")
+    _chk(qkv, LP(), "qkv")
     M, D3 = qkv.shape
     D = D3 // 3
     N = Nv + Nt
     if out is None:
-        out = torch.empty(M, D, device=qkv.device, dtype=BF16)
+        out = torch.empty(M, D, device=qkv.device, dtype=LP())
     lse = torch.empty(B * H, N, device=qkv.device, dtype=torch.float32)
     if scale is None:
         scale = (D // H) ** -0.5
@@ -239,7 +264,7 @@ def im2col(img, P, out=None):
     B, Cc, S, S2 = img.shape
     assert Cc == 3 and S == S2
     if out is None:
-        out = torch.empty(B * (S // P) ** 2, 3 * P * P, device=img.device, dtype=BF16)
+        out = torch.empty(B * (S // P) ** 2, 3 * P * P, device=img.device, dtype=LP())
     _lib.check(lib.simvg_im2col(_p(img), _p(out), B, S, P, _stream()), "simvg_im2col")
     return out
 
@@ -255,27 +280,28 @@ def embed_fwd(patch, cls, posA, posB, text_embed, ids, pad, B, np_, T, x=None):
     return x
 
 
-def embed_bwd(dx, dpatch, dcls, dposA, dposB, dtext, ids, pad, B, np_, T):
+def embed_bwd(dx, dpatch, dcls, dposA, dposB, dtext, ids, pad, B, np_, T, param_scale=1.0):
     lib = _lib.load()
     D = dx.shape[1]
     rc = lib.simvg_embed_bwd(_p(dx), dx.stride(0), _p(dpatch), dpatch.stride(0), _p(dcls), _p(dposA), _p(dposB),
-                             _p(dtext), _p(ids), _p(pad), B, np_, T, D, _stream())
+                             _p(dtext), _p(ids), _p(pad), B, np_, T, D, param_scale, _stream())
     _lib.check(rc, "simvg_embed_bwd")
 
 
-def cast_bf16(src, dst=None):
+def cast_lp(src, dst=None, scale=1.0):
+    """fp32 -> the 16-bit format (times `scale`, saturating)"""
     lib = _lib.load()
     if dst is None:
-        dst = torch.empty(src.shape, device=src.device, dtype=BF16)
-    _lib.check(lib.simvg_cast_f32_to_bf16(_p(src), _p(dst), src.numel(), _stream()), "simvg_cast_f32_to_bf16")
+        dst = torch.empty(src.shape, device=src.device, dtype=LP())
+    _lib.check(lib.simvg_cast_f32_to_lp(_p(src), _p(dst), src.numel(), scale, _stream()), "simvg_cast_f32_to_lp")
     return dst
 
 
 class WeightPrep:
-    """Batched fp32 -> bf16 (+ transposed bf16) conversion of many weight matrices in ONE launch."""
+    """Batched fp32 -> 16-bit (+ transposed) conversion of many weight matrices in ONE launch."""
 
     def __init__(self, entries, device):
-        # entries: list of (src fp32 2-D tensor, dst bf16 | None, dst_t bf16 | None)
+        # entries: list of (src fp32 2-D tensor, dst lp | None, dst_t lp | None)
         n = len(entries)
         arr = (_lib.WeightDesc * n)()
         tiles = 0

@@ -117,7 +117,7 @@ class MIXDETRMB(OneStageModel):
         enc_out = self.vis_enc.encode(img, ref_expr_inds, text_attention_mask)
         targets = self.head.prepare_targets(gt_bbox, img_metas, enc_out.device)
         graphed = None
-        if self.head_graph and self.training and text_attention_mask is not None and enc_out.dtype == torch.bfloat16:
+        if self.head_graph and self.training and text_attention_mask is not None and getattr(enc_out, "lp", None) is not None:
             if self._head_graphs is None:
                 from ...graphs import HeadGraphs
                 self._head_graphs = HeadGraphs(self.head)

@@ -56,31 +56,35 @@ class LinearF32(torch.autograd.Function):
         return dx, dW, db, None
 
 
-class LinearBF16(torch.autograd.Function):
-    """y = x W^T + b on the bf16 MFMA GEMM for the B*(1+HW) memory rows.  x bf16 [M,K]; W fp32 master
-    [N,K]; the bf16 copies (plain and transposed) are refreshed by the caller's weight-prep."""
+class LinearLP(torch.autograd.Function):
+    """y = x W^T + b on the 16-bit MFMA GEMM for the B*(1+HW) memory rows.  x [M,K] in the library's 16-bit format
+    (hip_ops.LP()); W fp32 master [N,K]; the 16-bit copies (plain and transposed) are refreshed by the caller's
+    weight-prep.  Gradients that cross autograd are true fp32 gradients: the backward rounds dy * S to 16 bits
+    (S = hip_ops.grad_scale(), fp16's exponent range) and the GEMMs remove the scale again."""
 
     @staticmethod
-    def forward(ctx, x, W, b, w_bf16, wT_bf16, out_bf16):
-        y = ops.gemm_nt(x, w_bf16, bias=b, out_dtype=torch.bfloat16 if out_bf16 else torch.float32)
-        ctx.save_for_backward(x, wT_bf16)
+    def forward(ctx, x, W, b, w_lp, wT_lp, out_lp):
+        y = ops.gemm_nt(x, w_lp, bias=b, out_dtype=ops.LP() if out_lp else torch.float32)
+        ctx.save_for_backward(x, wT_lp)
         ctx.shapeW = W.shape
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, wT = ctx.saved_tensors
-        dyb = dy.contiguous() if dy.dtype == torch.bfloat16 else ops.cast_bf16(dy.contiguous())
+        S = ops.grad_scale()
+        dyb = ops.cast_lp(dy.float().contiguous(), scale=S)
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
-            dx = ops.gemm_nt(dyb, wT)                                                    # [M,K] bf16
+            dx = ops.gemm_nt(dyb, wT, out_dtype=torch.float32, alpha=1.0 / S)            # [M,K] fp32
         if ctx.needs_input_grad[1]:
             dW = torch.zeros(ctx.shapeW, device=dy.device, dtype=torch.float32)
             db = torch.zeros(ctx.shapeW[0], device=dy.device, dtype=torch.float32) if ctx.needs_input_grad[2] else None
-            ops.gemm_tn(dyb, x, dW.view(ctx.shapeW[0], -1), db=db)
+            ops.gemm_tn(dyb, x, dW.view(ctx.shapeW[0], -1), db=db, out_scale=1.0 / S)
         elif ctx.needs_input_grad[2]:
             db = torch.zeros(ctx.shapeW[0], device=dy.device, dtype=torch.float32)
             ops.colsum(dyb, db)
+            db.mul_(1.0 / S)
         return dx, dW, db, None, None, None
 
 
@@ -88,7 +92,7 @@ class LayerNormF32(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, g, b, eps):
         x = x.contiguous()
-        _, y, mean, rstd = ops.ln_fwd(x, g, b, eps=eps, out_bf16=False, out_f32=True)
+        _, y, mean, rstd = ops.ln_fwd(x, g, b, eps=eps, out_lp=False, out_f32=True)
         ctx.save_for_backward(x, g, mean, rstd)
         return y
 
@@ -156,7 +160,7 @@ class DecoderLayerFn(torch.autograd.Function):
         cross-attention K|V) gradients that are accumulated with atomics.
     ~20 launches forward and ~25 backward instead of ~26 / ~50 through per-op autograd nodes.
     kind "text": keys / values from fp32 rows xk, xv [B*Lk, E] (the TGQG layer); kind "mem": from the image memory
-    mem [B*Nv, E] (bf16 -> bf16 MFMA GEMMs with cfg.wb / cfg.wbT, fp32 -> exact), key_pos cfg.pos on the patch rows.
+    mem [B*Nv, E] (16-bit -> MFMA GEMMs with cfg.wb / cfg.wbT, fp32 -> exact), key_pos cfg.pos on the patch rows.
     Returns (layer output, post-normed layer output | None)."""
 
     @staticmethod
@@ -173,7 +177,7 @@ class DecoderLayerFn(torch.autograd.Function):
             return cfg.mask_fn((B, H, nq, Lk), dev) if (train and cfg.p_attn > 0) else None
 
         def ln(x, g, b):
-            _, y, mean, rstd = ops.ln_fwd(x, g, b, eps=1e-5, out_bf16=False, out_f32=True)
+            _, y, mean, rstd = ops.ln_fwd(x, g, b, eps=1e-5, out_lp=False, out_f32=True)
             return y, mean, rstd
 
         # ---- self-attention: q = k = tgt + qpos, v = tgt
@@ -206,7 +210,7 @@ class DecoderLayerFn(torch.autograd.Function):
             posk = _f32(pos2.shape[0], E, device=dev)
             probs = [ops.gp(xq, E, 1, Wc, 1, E, q, M, E, E, bias=bc),
                      ops.gp(pos2, E, 1, Wc[E:], 1, E, posk, pos2.shape[0], E, E)]
-            if mem.dtype == torch.bfloat16:
+            if mem.dtype == ops.LP():
                 kv = ops.gemm_nt(mem, cfg.wb, bias=bc[E:], out_dtype=torch.float32)                  # [B*Nv, 2E]
             else:
                 kv = _f32(R, 2 * E, device=dev)
@@ -254,7 +258,7 @@ class DecoderLayerFn(torch.autograd.Function):
         B, H, nq = cfg.B, cfg.H, cfg.nq
         need = ctx.needs_input_grad
         ones = _ones(M, dev)
-        mem_bf = cfg.kind == "mem" and mem.dtype == torch.bfloat16
+        mem_bf = cfg.kind == "mem" and mem.dtype == ops.LP()
         # the one fill of this backward: LayerNorm gradients (atomics) and, with bf16 memory, the cross-attention in_proj
         # gradient that the bf16 wgrad kernel accumulates into
         z = torch.zeros(8 * E + (3 * E * E + 3 * E if mem_bf else 0), device=dev, dtype=torch.float32)
@@ -334,10 +338,11 @@ class DecoderLayerFn(torch.autograd.Function):
                      ops.gp(ones, 0, 1, dq, E, 1, dbc, 1, E, M)]
             if mem_bf:
                 ops.gemm_f32_group(probs)
-                dkvb = ops.cast_bf16(dkv)
+                S = ops.grad_scale()                                                     # 16-bit operand dkv * S
+                dkvb = ops.cast_lp(dkv, scale=S)
                 if need[4]:
-                    dmem = ops.gemm_nt(dkvb, cfg.wbT)                                    # [R, E] bf16
-                ops.gemm_tn(dkvb, mem, dWc[E:], db=dbc[0, E:])
+                    dmem = ops.gemm_nt(dkvb, cfg.wbT, out_dtype=torch.float32, alpha=1.0 / S)   # [R, E] fp32, true gradient
+                ops.gemm_tn(dkvb, mem, dWc[E:], db=dbc[0, E:], out_scale=1.0 / S)
             else:
                 if need[4]:
                     dmem = _f32(R, E, device=dev)
@@ -392,22 +397,24 @@ class Criterion(torch.autograd.Function):
 
 
 class SplitEncoderOutput(torch.autograd.Function):
-    """enc_out [B*Nv + B*T, D] bf16 (modality-major) -> (vision rows bf16 [B*Nv, D] view, text fp32 [B*T, D],
-    cls fp32 [B, D]); backward assembles the single bf16 gradient the encoder engine expects."""
+    """Encoder output (modality-major rows) as fp32 `out32` [B*Nv + B*T, D] and its 16-bit copy `out_lp` -> (vision
+    rows [B*Nv, D] 16-bit view = the A operand of the memory projection, text fp32 [B*T, D], cls fp32 [B, D]); the
+    backward assembles the single fp32 gradient the encoder engine expects."""
 
     @staticmethod
-    def forward(ctx, out, B, Nv, T):
-        D = out.shape[1]
+    def forward(ctx, out32, out_lp, B, Nv, T):
+        D = out32.shape[1]
         ctx.geo = (B, Nv, T, D)
-        vis = out[:B * Nv]
-        text = out[B * Nv:].float()
-        cls = vis.view(B, Nv, D)[:, 0].float()
+        vis = out_lp[:B * Nv]
+        text = out32[B * Nv:].clone()
+        cls = out32[:B * Nv].view(B, Nv, D)[:, 0].clone()
         return vis, text, cls
 
     @staticmethod
     def backward(ctx, dvis, dtext, dcls):
         B, Nv, T, D = ctx.geo
-        d = torch.empty(B * (Nv + T), D, device=dtext.device if dtext is not None else dvis.device, dtype=torch.bfloat16)
+        ref = dvis if dvis is not None else (dtext if dtext is not None else dcls)
+        d = torch.empty(B * (Nv + T), D, device=ref.device, dtype=torch.float32)
         if dvis is not None:
             d[:B * Nv] = dvis
         else:
@@ -417,5 +424,5 @@ class SplitEncoderOutput(torch.autograd.Function):
         else:
             d[B * Nv:].zero_()
         if dcls is not None:
-            d[:B * Nv].view(B, Nv, D)[:, 0] += dcls.to(torch.bfloat16)
-        return d, None, None, None
+            d[:B * Nv].view(B, Nv, D)[:, 0] += dcls
+        return d, None, None, None, None

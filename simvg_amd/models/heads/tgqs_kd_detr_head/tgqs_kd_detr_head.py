@@ -3,7 +3,7 @@
 Host-side mirror of `simvg/models/heads/tgqs_kd_detr_head/tgqs_kd_detr_head.py:22-604` (registered in HEADS,
 same constructor kwargs, `forward_train` / `forward_test` / `inference`), of the DETR decoder in
 `transformer.py:93-235` and of `core/criterion/criterion.py:62-271`, with all arithmetic in hand-written
-gfx950 kernels: bf16 MFMA GEMMs for the B*(1+HW) memory rows, exact-fp32 MFMA GEMMs / LayerNorm / attention
+gfx950 kernels: 16-bit MFMA GEMMs for the B*(1+HW) memory rows, exact-fp32 MFMA GEMMs / LayerNorm / attention
 for the [B*nq, 256] query rows, and an on-device Hungarian matcher + criterion (no host round trips).
 Only the branches the reference configs execute are built ("decoder" + "balanced_distill", `hard_weighted`,
 `score_iou_weighted`, TGQG on; SURVEY.md 8(a) "dead branches").  state_dict keys match Appendix B.
@@ -16,7 +16,7 @@ import torch.nn.functional as F
 
 from ... import builder
 from .... import hip_ops as ops
-from ..functions import (Criterion, DecoderLayerFn, LayerCfg, LayerNormF32, LinearBF16, LinearF32, SplitEncoderOutput)
+from ..functions import (Criterion, DecoderLayerFn, LayerCfg, LayerNormF32, LinearLP, LinearF32, SplitEncoderOutput)
 
 
 def _xavier(*shape):
@@ -184,7 +184,7 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
             state_dict.pop(prefix + k, None)
         return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
-    # ------------------------------------------------------------------ bf16 copies of the memory-row weights
+    # ------------------------------------------------------------------ 16-bit copies of the memory-row weights
     def _P(self, key):
         m = self
         for p in key.split("."):
@@ -200,7 +200,7 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
             return
         if self._prep is None or self._prep_dev != device or self._prep_ptrs != [p.data_ptr() for p in srcs]:
             def bf(*s):
-                return torch.empty(*s, device=device, dtype=torch.bfloat16)
+                return torch.empty(*s, device=device, dtype=ops.LP())
             self.wb = {"ip": bf(E, C), "ipT": bf(C, E)}
             entries = [(srcs[0].data.view(E, C), self.wb["ip"], self.wb["ipT"])]
             for i in range(self.num_decoder_layers):
@@ -284,12 +284,14 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
 
     # ------------------------------------------------------------------ forward_general (:375-454)
     def forward_fused(self, enc_out, B, Nv, T, img_metas, text_mask):
-        """enc_out: encoder output [B*Nv + B*T, D] bf16, modality-major (BEIT3.encode)."""
+        """enc_out: encoder output [B*Nv + B*T, D] fp32, modality-major (BEIT3.encode); with a 16-bit copy of the same
+        rows as `enc_out.lp` the memory projections run on the 16-bit MFMA GEMMs, without it everything is exact fp32."""
         device = enc_out.device
         E, nq, H = self.embed_dim, self.num_queries, self.heads
         HW = Nv - 1
         hw = int(round(HW ** 0.5))
-        exact = enc_out.dtype == torch.float32      # precision="fp32" inference mode: fp32 memory rows as well
+        enc_lp = getattr(enc_out, "lp", None)
+        exact = enc_lp is None                      # precision="fp32" mode: fp32 memory rows as well
         C = self.in_channels
         if exact:
             vis, text32 = enc_out[:B * Nv], enc_out[B * Nv:]
@@ -297,9 +299,9 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
             mem = LinearF32.apply(vis, self._P("input_proj.weight").view(E, C), self._P("input_proj.bias"), False)
         else:
             self._refresh_weights(device)
-            vis, text32, cls32 = SplitEncoderOutput.apply(enc_out, B, Nv, T)
+            vis, text32, cls32 = SplitEncoderOutput.apply(enc_out, enc_lp, B, Nv, T)
             # H1: input_proj on all vision rows (the CLS row is carried along and never used as a key)
-            mem = LinearBF16.apply(vis, self._P("input_proj.weight"), self._P("input_proj.bias"), self.wb["ip"], self.wb["ipT"], True)
+            mem = LinearLP.apply(vis, self._P("input_proj.weight"), self._P("input_proj.bias"), self.wb["ip"], self.wb["ipT"], True)
         text = self._lin(text32, "input_text_proj")                       # [B*T, E]
         cls = self._lin(cls32, "input_cls_proj")                          # [B, E]
         pos2d, img_kpm = self._image_pos(B, hw, img_metas, device)
@@ -436,10 +438,11 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
 
     # ------------------------------------------------------------------ reference entry points
     def _encode_inputs(self, x_mm, cls_feat, text_feat):
-        """Reference-layout inputs ([B,C,h,w] fp32, [B,C], [B,T,C]) -> modality-major bf16 rows."""
+        """Reference-layout inputs ([B,C,h,w] fp32, [B,C], [B,T,C]) -> modality-major fp32 rows (+ their 16-bit copy)."""
         B, C, h, w = x_mm.shape
         vis = torch.cat([cls_feat[:, None, :], x_mm.flatten(2).transpose(1, 2)], 1).reshape(B * (h * w + 1), C)
-        out = torch.cat([vis, text_feat.reshape(-1, C)], 0).to(torch.bfloat16)
+        out = torch.cat([vis, text_feat.reshape(-1, C)], 0).float().contiguous()
+        out.lp = ops.cast_lp(out.detach())
         return out, B, h * w + 1, text_feat.shape[1]
 
     def forward_train(self, x_mm, img_metas, cls_feat=None, text_feat=None, gt_bbox=None, text_mask=None):

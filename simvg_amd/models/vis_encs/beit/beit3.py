@@ -8,10 +8,12 @@ torchscale leaf modules executed by hand-written gfx950 kernels through libsimvg
 MI355X-first design (not a translation of the eager graph):
  * tokens are stored MODALITY-MAJOR ([B*Nv vision rows | B*Nt text rows]) so each multiway Linear /
    LayerNorm is one grouped launch over two contiguous row ranges -- no split/cat copies;
- * fp32 residual stream, bf16 GEMM operands, fp32 accumulate / LayerNorm / softmax / GELU;
+ * fp32 residual stream, 16-bit GEMM operands (fp16 by default -- bf16 cannot meet the 1e-3 box parity bound on trained
+   weights), fp32 accumulate / LayerNorm / softmax / GELU; the backward's 16-bit tensors carry a
+   power-of-two gradient scale (hip_ops.grad_scale) that is removed where parameter gradients are written;
  * DropPath + residual add are fused into the out-proj / fc2 GEMM epilogues; the residual-gradient add
    and the DropPath scaling of the next dgrad operand are fused into the LayerNorm backward;
- * q|k|v (both experts) are one [2,3D,D] grouped GEMM; dgrad uses a transposed bf16 weight copy made by
+ * q|k|v (both experts) are one [2,3D,D] grouped GEMM; dgrad uses a transposed 16-bit weight copy made by
    the batched weight-prep kernel, so forward and dgrad share one NT GEMM kernel;
  * forward and backward are sequenced by hand over pre-allocated HBM workspaces (activations for the
    whole B=64 step are ~14 GB of the 288 GB) -- no autograd graph inside the encoder.
@@ -27,7 +29,6 @@ from ... import builder
 from .... import hip_ops as ops
 from ....arena import ParamArena
 
-BF16 = torch.bfloat16
 
 _VIT = {"base": dict(embed_dim=768, heads=12, ffn_dim=3072, layers=12),
         "large": dict(embed_dim=1024, heads=16, ffn_dim=4096, layers=24)}
@@ -57,7 +58,7 @@ def _trunc_normal(shape, std=0.02):
 class BEIT3(nn.Module):
     def __init__(self, img_size=384, patch_size=32, vit_type="base", drop_path_rate=0.1, vocab_size=64010,
                  norm_layer=None, freeze_layer=-1, vision_embed_proj_interpolate=False, pretrain=None,
-                 encoder_cfg=None, precision="bf16"):
+                 encoder_cfg=None, precision="lowp"):
         super().__init__()
         if encoder_cfg is not None:           # explicit geometry (tests); not a reference config
             geo = dict(encoder_cfg)
@@ -77,8 +78,7 @@ class BEIT3(nn.Module):
         self.ln_eps = 1e-5
         self.drop_path_probs = [float(v) for v in np.linspace(0, dpr, self.L)] if dpr > 0 else [0.0] * self.L
         self.vision_embed_proj_interpolate = vision_embed_proj_interpolate
-        assert precision in ("bf16", "fp32")
-        self.precision = precision  # "bf16": MFMA bf16 operands (training + inference); "fp32": exact forward-only mode
+        self.precision = self._norm_precision(precision)   # "lowp": 16-bit MFMA operands; "fp32": exact parity mode
         self._build_parameters()
         self._arena = None
         self._ws = {}
@@ -92,6 +92,14 @@ class BEIT3(nn.Module):
         if freeze_layer >= 0:
             self.frozen_stages = min(freeze_layer, self.L)
             self._freeze_stages()
+
+    @staticmethod
+    def _norm_precision(precision):
+        if precision in ("lowp", "fp16", "bf16"):      # the 16-bit format itself is a property of the built library
+            return "lowp"
+        if precision == "fp32":
+            return "fp32"
+        raise ValueError('precision must be "lowp" (16-bit MFMA operands; aliases "fp16" / "bf16") or "fp32"')
 
     # ------------------------------------------------------------------ parameters (reference schema)
     def _build_parameters(self):
@@ -175,7 +183,7 @@ class BEIT3(nn.Module):
         D, F_, L, P = self.D, self.F, self.L, self.patch_size
 
         def bf(*shape):
-            return torch.empty(*shape, device=device, dtype=BF16)
+            return torch.empty(*shape, device=device, dtype=ops.LP())
 
         self.wb = {"patch": bf(D, 3 * P * P)}
         entries = [(A.params["beit3.vision_embed.proj.weight"].data.view(D, 3 * P * P), self.wb["patch"], None)]
@@ -222,12 +230,12 @@ class BEIT3(nn.Module):
         M = B * (Nv + T)
 
         def bf(*s):
-            return torch.empty(*s, device=device, dtype=BF16)
+            return torch.empty(*s, device=device, dtype=ops.LP())
 
         def f32(*s):
             return torch.empty(*s, device=device, dtype=torch.float32)
 
-        ws = dict(cols=bf(B * self.np, 3 * P * P), patch=f32(B * self.np, D), out=bf(M, D), out32=None)
+        ws = dict(cols=bf(B * self.np, 3 * P * P), patch=f32(B * self.np, D), out=bf(M, D), out32=f32(M, D))
         nx = 2 * L + 1 if save else 3
         ws["xs"] = [f32(M, D) for _ in range(nx)]
         nl = L if save else 1
@@ -280,19 +288,19 @@ class BEIT3(nn.Module):
             ops.gemm_nt(st["g2"], self.wb[f"w2{i}"], bias=V[f"b2{i}"], out=x_out, split=Mv, residual=x_mid,
                         row_scale=None if dp is None else dp[i][1], rows_per_sample=rps)
         x_last = xs[2 * L] if save else xs[(2 * L) % 3]
-        _, _, mF, rF = ops.ln_fwd(x_last, V["lnog"], V["lnob"], split=Mv, eps=eps, y=ws["out"], save_stats=save)
+        # the head reads the CLS / text rows in fp32 (token branch) and the patch rows as 16-bit MFMA operands
+        _, _, mF, rF = ops.ln_fwd(x_last, V["lnog"], V["lnob"], split=Mv, eps=eps, y=ws["out"], y32=ws["out32"], save_stats=save)
         ws["final_stats"] = (mF, rF)
         ws["ctx"] = (B, T, ids, pad_u8, dp)
         self._last_ids = ids          # which text-table rows this step touches (GradReducer exchanges only those)
-        return ws["out"], ws
+        return ws["out32"], ws
 
     # ------------------------------------------------------------------ engine: exact fp32 forward (inference)
     def set_precision(self, precision):
-        """"bf16" (default) or "fp32": the reference's own arithmetic (use_fp16=False in every config) end to end in
-        fp32 on v_mfma_f32_16x16x4_f32 / VALU -- ~1/16 of the bf16 MFMA rate, forward only; used to show that the
-        kernels' logic is exact and that the bf16 deviation is operand rounding."""
-        assert precision in ("bf16", "fp32")
-        self.precision = precision
+        """"lowp" (default: 16-bit MFMA operands) or "fp32": the reference's own arithmetic (use_fp16=False in every
+        config) end to end in fp32 on v_mfma_f32_16x16x4_f32 / VALU -- 1/16 of the 16-bit MFMA rate; used to show that the
+        kernels' logic is exact and that the fast mode's deviation is operand rounding."""
+        self.precision = self._norm_precision(precision)
         return self
 
     def _engine_forward_fp32(self, img, ids, pad_u8, save=False):
@@ -309,7 +317,7 @@ class BEIT3(nn.Module):
         saved = dict(ctx=(B, T, ids, pad_u8), layers=[]) if save else None
 
         def ln(x, gk, bk):
-            _, y, m, r = ops.ln_fwd(x, V[gk], V[bk], split=Mv, eps=eps, out_bf16=False, out_f32=True, save_stats=save)
+            _, y, m, r = ops.ln_fwd(x, V[gk], V[bk], split=Mv, eps=eps, out_lp=False, out_f32=True, save_stats=save)
             return y, (m, r)
 
         def mw(x, wk, bk, out=None, act=0, accumulate=False):
@@ -399,7 +407,7 @@ class BEIT3(nn.Module):
             dqkv = ops.attn_f32_bwd(st["qkv"], do, B, H, Nv, T, pad=pad_u8)
             dh = lin_bwd(dqkv, st["h"], f"wqkv{i}", f"bqkv{i}")
             dx = lnb(dh, st["x"], st["s1"], f"ln1g{i}", f"ln1b{i}", dres=dx)
-        scratch = torch.empty(B * self.np, D, device=dx.device, dtype=BF16)
+        scratch = torch.empty(B * self.np, D, device=dx.device, dtype=ops.LP())
         ops.embed_bwd(dx, scratch, A.grad("beit3.vision_embed.cls_token").view(-1),
                       A.grad("beit3.encoder.embed_positions.A.weight"), A.grad("beit3.encoder.embed_positions.B.weight"),
                       A.grad("beit3.text_embed.weight"), ids, pad_u8, B, self.np, T)
@@ -422,38 +430,44 @@ class BEIT3(nn.Module):
         xs = ws["xs"]
         dx, dyb, dF, dF2, dD, dO, dQKV = ws["dx"], ws["dyb"], ws["dF"], ws["dF2"], ws["dD"], ws["dO"], ws["dQKV"]
         mF, rF = ws["final_stats"]
+        # dout is the true fp32 gradient; from here on every tensor of the backward is gradient * S (hip_ops.grad_scale) and
+        # the kernels that write parameter gradients multiply by 1/S
+        S = ops.grad_scale()
+        inv = 1.0 / S
         ops.ln_bwd(dout, xs[2 * L], mF, rF, V["lnog"], G["lnog"], G["lnob"], split=Mv, dx_f32=dx, dx_scaled=dyb,
-                   row_scale=None if dp is None else dp[L - 1][1], rows_per_sample=rps)
+                   row_scale=None if dp is None else dp[L - 1][1], rows_per_sample=rps, dy_scale=S, param_scale=inv)
         for i in reversed(range(L)):
             st = ws["layer"][i]
             s = st["stats"]
             # ---- FFN branch: x_out = x_mid + dp1 * fc2(LN(gelu(fc1(LN(x_mid)))))
             ops.gemm_nt(dyb, self.wb[f"w2T{i}"], out=dF, split=Mv)
-            ops.gemm_tn(dyb, st["g2"], G[f"w2{i}"], split=Mv, db=G[f"b2{i}"])
+            ops.gemm_tn(dyb, st["g2"], G[f"w2{i}"], split=Mv, db=G[f"b2{i}"], out_scale=inv)
             ops.ln_bwd(dF, st["u"], s["m4"], s["r4"], V[f"lnfg{i}"], G[f"lnfg{i}"], G[f"lnfb{i}"], split=Mv,
-                       dx_bf16=dF2, gelu_u=st["u"])      # x == gelu_u: LN input gelu(u) and GELU'(u) recomputed from u
+                       dx_lp=dF2, gelu_u=st["u"], param_scale=inv)      # x == gelu_u: LN input gelu(u) and GELU'(u) recomputed from u
             ops.gemm_nt(dF2, self.wb[f"w1T{i}"], out=dD, split=Mv)
-            ops.gemm_tn(dF2, st["h2"], G[f"w1{i}"], split=Mv, db=G[f"b1{i}"])
+            ops.gemm_tn(dF2, st["h2"], G[f"w1{i}"], split=Mv, db=G[f"b1{i}"], out_scale=inv)
             ops.ln_bwd(dD, xs[2 * i + 1], s["m3"], s["r3"], V[f"ln2g{i}"], G[f"ln2g{i}"], G[f"ln2b{i}"], split=Mv,
-                       dres=dx, dx_f32=dx, dx_scaled=dyb, row_scale=None if dp is None else dp[i][0], rows_per_sample=rps)
+                       dres=dx, dx_f32=dx, dx_scaled=dyb, row_scale=None if dp is None else dp[i][0], rows_per_sample=rps,
+                       param_scale=inv)
             # ---- attention branch: x_mid = x_in + dp0 * out_proj(LN(attn(qkv(LN(x_in)))))
             ops.gemm_nt(dyb, self.wb[f"woutT{i}"], out=dD, split=Mv)
-            ops.gemm_tn(dyb, st["o2"], G[f"wout{i}"], split=Mv, db=G[f"bout{i}"])
-            ops.ln_bwd(dD, st["o"], s["m2"], s["r2"], V[f"lnig{i}"], G[f"lnig{i}"], G[f"lnib{i}"], split=Mv, dx_bf16=dO)
+            ops.gemm_tn(dyb, st["o2"], G[f"wout{i}"], split=Mv, db=G[f"bout{i}"], out_scale=inv)
+            ops.ln_bwd(dD, st["o"], s["m2"], s["r2"], V[f"lnig{i}"], G[f"lnig{i}"], G[f"lnib{i}"], split=Mv, dx_lp=dO,
+                       param_scale=inv)
             ops.attn_bwd(st["qkv"], st["o"], dO, st["lse"], B, H, Nv, T, pad=pad_u8, dqkv=dQKV)
             ops.gemm_nt(dQKV, self.wb[f"wqkvT{i}"], out=dD, split=Mv)
-            ops.gemm_tn(dQKV, st["h"], G[f"wqkv{i}"], split=Mv, db=G[f"bqkv{i}"])
+            ops.gemm_tn(dQKV, st["h"], G[f"wqkv{i}"], split=Mv, db=G[f"bqkv{i}"], out_scale=inv)
             ops.ln_bwd(dD, xs[2 * i], s["m1"], s["r1"], V[f"ln1g{i}"], G[f"ln1g{i}"], G[f"ln1b{i}"], split=Mv,
                        dres=dx, dx_f32=dx, dx_scaled=dyb,
-                       row_scale=None if (dp is None or i == 0) else dp[i - 1][1], rows_per_sample=rps)
+                       row_scale=None if (dp is None or i == 0) else dp[i - 1][1], rows_per_sample=rps, param_scale=inv)
             if layer_done_cb is not None:
                 layer_done_cb(i)
         ops.embed_bwd(dx, ws["dpatch"], A.grad("beit3.vision_embed.cls_token").view(-1),
                       A.grad("beit3.encoder.embed_positions.A.weight"), A.grad("beit3.encoder.embed_positions.B.weight"),
-                      A.grad("beit3.text_embed.weight"), ids, pad_u8, B, self.np, T)
+                      A.grad("beit3.text_embed.weight"), ids, pad_u8, B, self.np, T, param_scale=inv)
         P = self.patch_size
         ops.gemm_tn(ws["dpatch"], ws["cols"], A.grad("beit3.vision_embed.proj.weight").view(D, 3 * P * P),
-                    db=A.grad("beit3.vision_embed.proj.bias"))
+                    db=A.grad("beit3.vision_embed.proj.bias"), out_scale=inv)
         if layer_done_cb is not None:
             layer_done_cb(-1)
 
@@ -471,7 +485,9 @@ class BEIT3(nn.Module):
         return [(None, None) if p == 0.0 else (m[i, 0], m[i, 1]) for i, p in enumerate(self.drop_path_probs)]
 
     def encode(self, image, question, padding_mask=None, dp_scales=None):
-        """-> encoder output [B*Nv + B*Nt, D] bf16, modality-major rows (the fused model path)."""
+        """-> encoder output [B*Nv + B*Nt, D] fp32, modality-major rows (the fused model path).  In the 16-bit mode the
+        returned tensor carries the same rows in the MFMA operand format as attribute `.lp` (not differentiable: the
+        head's memory projections read it, gradients come back through the fp32 tensor)."""
         if not image.is_cuda:
             raise ops._lib.SimvgHipError("BEIT3 (simvg_amd) runs on an MI355X only: inputs must be HIP tensors")
         device = image.device
@@ -491,7 +507,9 @@ class BEIT3(nn.Module):
                 raise NotImplementedError('precision="fp32" is the exact parity mode and has no DropPath: call .eval() or '
                                           'build with drop_path_rate=0 (stochastic masks cannot be compared anyway)')
             return _EncoderFnF32.apply(self, img, ids, pad_u8, self._anchor)
-        return _EncoderFn.apply(self, img, ids, pad_u8, dp_scales, need_grad, self._anchor)
+        out = _EncoderFn.apply(self, img, ids, pad_u8, dp_scales, need_grad, self._anchor)
+        out.lp = self._ws[(B, T, need_grad)]["out"]
+        return out
 
     def split_output(self, out, B, T):
         Nv = self.np + 1
@@ -502,7 +520,7 @@ class BEIT3(nn.Module):
     def forward(self, image, question, padding_mask, **kwargs):
         """Reference API (beit3.py:176-185): -> img_feat [B,np,D], text_feat [B,T,D], cls_feat [B,D] (fp32)."""
         out = self.encode(image, question, padding_mask)
-        img_feat, text_feat, cls_feat = self.split_output(out.float(), question.shape[0], question.shape[1])
+        img_feat, text_feat, cls_feat = self.split_output(out, question.shape[0], question.shape[1])
         return img_feat, text_feat, cls_feat
 
 

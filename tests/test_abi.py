@@ -24,14 +24,15 @@ def test_library_exports_every_declared_symbol():
     # and the ctypes binding covers the same set
     assert set(_lib.exported_symbols()) == set(names), set(_lib.exported_symbols()) ^ set(names)
     lib2 = _lib.load()
-    assert lib2.simvg_version() >= 1
+    assert lib2.simvg_version() >= 2
+    assert _lib.lowp_format() in ("fp16", "bf16")
 
 
 def test_argument_errors_are_reported_not_thrown():
     from simvg_amd import _lib
     lib = _lib.load()
     # K not a multiple of 64 -> argument error before any launch (safe without a GPU)
-    rc = lib.simvg_gemm_nt(None, 8, None, 0, 8, None, 0, None, 8, 0, None, 0, None, 0, None, 1, 1, 4, 4, 30, 0, 0, None)
+    rc = lib.simvg_gemm_nt(None, 8, None, 0, 8, None, 0, None, 8, 0, None, 0, None, 0, None, 1, 1, 4, 4, 30, 0, 0, 1.0, None)
     assert rc < 0
     assert b"multiple of 64" in lib.simvg_last_error()
 
@@ -52,4 +53,4 @@ def test_product_refuses_cpu_tensors():
     import torch
     from simvg_amd import hip_ops, _lib
     with pytest.raises(_lib.SimvgHipError):
-        hip_ops.gemm_nt(torch.zeros(4, 64, dtype=torch.bfloat16), torch.zeros(4, 64, dtype=torch.bfloat16))
+        hip_ops.gemm_nt(torch.zeros(4, 64, dtype=hip_ops.LP()), torch.zeros(4, 64, dtype=hip_ops.LP()))

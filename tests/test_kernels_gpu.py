@@ -1,7 +1,8 @@
 """GPU (MI355X) op-level parity: every HIP kernel against fp32/fp64 torch math on the CPU, on the same
-bf16-representable inputs.  Tolerances: kernels accumulate in fp32 and store bf16 (8 mantissa bits,
-half-ulp 2^-9 ~ 2e-3 relative), so bf16 outputs are compared at 1e-2 of the reference scale and fp32
-outputs at 1e-3 (inputs to the MFMA are bf16-exact, products are exact in fp32)."""
+inputs, which are exactly representable in both 16-bit formats the library can be built for (bf16's 8 significand
+bits are a subset of fp16's 11).  Tolerances: kernels accumulate in fp32 and store 16-bit values (fp16 half-ulp 2^-12,
+bf16 2^-9 relative), so 16-bit outputs are compared at 2e-3 (fp16 build) / 1e-2 (bf16 build) of the reference scale
+and fp32 outputs at 1e-3 (inputs to the MFMA are exact, products are exact in fp32)."""
 import math
 
 import pytest
@@ -18,8 +19,18 @@ def _ops():
     return hip_ops
 
 
+def LPD():
+    """torch dtype of the library's 16-bit format"""
+    return _ops().LP()
+
+
+def LPTOL(extra=1.0):
+    """relative tolerance of a value stored in the 16-bit format (x `extra` for outputs of longer rounding chains)"""
+    return (2e-3 if LPD() == torch.float16 else 1e-2) * extra
+
+
 def bf(t):
-    return t.to(torch.bfloat16)
+    return t.to(LPD())
 
 
 def rnd_bf16(*shape, scale=1.0, gen=None):
@@ -129,13 +140,13 @@ def test_gemm_nt(M, N, K, split, mode):
     ad, wd, bd = bf(a).to(DEV), bf(w).to(DEV), bias.to(DEV)
     if mode == "plain":
         out = ops.gemm_nt(ad, wd, split=split)
-        assert_close(out, ref_lin(False), 1e-2, "gemm plain")
+        assert_close(out, ref_lin(False), LPTOL(), "gemm plain")
     elif mode == "bias_gelu_aux":
-        aux = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        aux = torch.empty(M, N, device=DEV, dtype=LPD())
         out = ops.gemm_nt(ad, wd, bias=bd, split=split, act=1, aux_preact=aux)
         u = ref_lin(True)
-        assert_close(aux, u, 1e-2, "gemm aux preact")
-        assert_close(out, F.gelu(u), 1e-2, "gemm gelu")
+        assert_close(aux, u, LPTOL(), "gemm aux preact")
+        assert_close(out, F.gelu(u), LPTOL(), "gemm gelu")
     elif mode == "residual_scale_f32":
         rps = (50, 21) if split else (M, 1)
         nsamp = max(math.ceil(sp / rps[0]), math.ceil((M - sp) / rps[1]) if split else 1)
@@ -196,9 +207,9 @@ def test_layernorm_fwd_bwd(M, D, split, xdtype):
     gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
     y_ref = torch.cat([F.layer_norm(xr[:sp], (D,), gr[0], br[0], 1e-5), F.layer_norm(xr[sp:], (D,), gr[-1], br[-1], 1e-5)], 0)
     xd = x.to(DEV) if xdtype == "f32" else bf(x).to(DEV)
-    y, y32, mean, rstd = ops.ln_fwd(xd, gamma.to(DEV), beta.to(DEV), split=split, out_bf16=True, out_f32=True)
+    y, y32, mean, rstd = ops.ln_fwd(xd, gamma.to(DEV), beta.to(DEV), split=split, out_lp=True, out_f32=True)
     assert_close(y32, y_ref, 1e-5 if xdtype == "f32" else 1e-5, "ln fwd f32")
-    assert_close(y, y_ref, 1e-2, "ln fwd bf16")
+    assert_close(y, y_ref, LPTOL(), "ln fwd bf16")
     # backward
     dy = rnd_bf16(M, D, gen=g)
     y_ref.backward(dy)
@@ -208,23 +219,23 @@ def test_layernorm_fwd_bwd(M, D, split, xdtype):
     nsamp = max(math.ceil(sp / rps[0]), math.ceil((M - sp) / rps[1]) if split else 1)
     scale = torch.rand(nsamp, generator=g) + 0.5
     dx_f32 = torch.empty(M, D, device=DEV)
-    dx_scaled = torch.empty(M, D, device=DEV, dtype=torch.bfloat16)
+    dx_scaled = torch.empty(M, D, device=DEV, dtype=LPD())
     ops.ln_bwd(bf(dy).to(DEV), xd, mean, rstd, gamma.to(DEV), dgamma, dbeta, split=split, dres=dres.to(DEV),
                dx_f32=dx_f32, dx_scaled=dx_scaled, row_scale=scale.to(DEV), rows_per_sample=rps)
     assert_close(dx_f32, dres + xr.grad, 1e-4, "ln bwd dx (+residual)")
     rows = torch.arange(M)
     samp = torch.where(rows < sp, rows // rps[0], (rows - sp) // rps[1])
-    assert_close(dx_scaled, (dres + xr.grad) * scale[samp][:, None], 1e-2, "ln bwd scaled bf16 copy")
+    assert_close(dx_scaled, (dres + xr.grad) * scale[samp][:, None], LPTOL(), "ln bwd scaled bf16 copy")
     assert_close(dgamma, gr.grad, 1e-4, "ln bwd dgamma")
     assert_close(dbeta, br.grad, 1e-4, "ln bwd dbeta")
     # bf16 output with fused GELU'
     u = rnd_bf16(M, D, gen=g)
-    dxb = torch.empty(M, D, device=DEV, dtype=torch.bfloat16)
+    dxb = torch.empty(M, D, device=DEV, dtype=LPD())
     dgamma.zero_(); dbeta.zero_()
-    ops.ln_bwd(bf(dy).to(DEV), xd, mean, rstd, gamma.to(DEV), dgamma, dbeta, split=split, dx_bf16=dxb, gelu_u=bf(u).to(DEV))
+    ops.ln_bwd(bf(dy).to(DEV), xd, mean, rstd, gamma.to(DEV), dgamma, dbeta, split=split, dx_lp=dxb, gelu_u=bf(u).to(DEV))
     ur = u.clone().requires_grad_(True)
     F.gelu(ur).backward(xr.grad)
-    assert_close(dxb, ur.grad, 1e-2, "ln bwd * gelu'")
+    assert_close(dxb, ur.grad, LPTOL(), "ln bwd * gelu'")
 
 
 @pytest.mark.parametrize("M,D,split", [(90, 3072, 61), (37, 256, 0), (33, 4096, 9)])
@@ -242,14 +253,14 @@ def test_layernorm_of_recomputed_gelu(M, D, split):
     a = F.gelu(ur)
     y_ref = torch.cat([F.layer_norm(a[:sp], (D,), gr[0], br[0], 1e-5), F.layer_norm(a[sp:], (D,), gr[-1], br[-1], 1e-5)], 0)
     ud = bf(u).to(DEV)
-    y, y32, mean, rstd = ops.ln_fwd(ud, gamma.to(DEV), beta.to(DEV), split=split, out_bf16=True, out_f32=True, gelu_in=True)
+    y, y32, mean, rstd = ops.ln_fwd(ud, gamma.to(DEV), beta.to(DEV), split=split, out_lp=True, out_f32=True, gelu_in=True)
     assert_close(y32, y_ref, 2e-5, "ln(gelu(u)) fwd")
     dy = rnd_bf16(M, D, gen=g)
     y_ref.backward(dy)
     dgamma, dbeta = torch.zeros(ng, D, device=DEV), torch.zeros(ng, D, device=DEV)
-    dxb = torch.empty(M, D, device=DEV, dtype=torch.bfloat16)
-    ops.ln_bwd(bf(dy).to(DEV), ud, mean, rstd, gamma.to(DEV), dgamma, dbeta, split=split, dx_bf16=dxb, gelu_u=ud)
-    assert_close(dxb, ur.grad, 1e-2, "d/du of ln(gelu(u))")
+    dxb = torch.empty(M, D, device=DEV, dtype=LPD())
+    ops.ln_bwd(bf(dy).to(DEV), ud, mean, rstd, gamma.to(DEV), dgamma, dbeta, split=split, dx_lp=dxb, gelu_u=ud)
+    assert_close(dxb, ur.grad, LPTOL(), "d/du of ln(gelu(u))")
     assert_close(dgamma, gr.grad, 1e-4, "dgamma")
     assert_close(dbeta, br.grad, 1e-4, "dbeta")
 
@@ -270,18 +281,18 @@ def test_ffn_layernorm_hot_kernels(M, D, split):
     a = F.gelu(ur)
     y_ref = torch.cat([F.layer_norm(a[:sp], (D,), gr[0], br[0], 1e-5), F.layer_norm(a[sp:], (D,), gr[-1], br[-1], 1e-5)], 0)
     ud = bf(u).to(DEV)
-    y, y32, mean, rstd = ops.ln_fwd(ud, gamma.to(DEV), beta.to(DEV), split=split, out_bf16=True, out_f32=False, gelu_in=True)
+    y, y32, mean, rstd = ops.ln_fwd(ud, gamma.to(DEV), beta.to(DEV), split=split, out_lp=True, out_f32=False, gelu_in=True)
     assert y32 is None
-    assert_close(y, y_ref, 1e-2, "ln(gelu(u)) fwd, bf16")
+    assert_close(y, y_ref, LPTOL(), "ln(gelu(u)) fwd, bf16")
     ad = a.detach().double()
     assert_close(mean, ad.mean(1).float(), 1e-5, "row mean")
     assert_close(rstd, (ad.var(1, unbiased=False) + 1e-5).rsqrt().float(), 1e-5, "row rstd")
     dy = rnd_bf16(M, D, gen=g)
     y_ref.backward(dy)
     dgamma, dbeta = torch.zeros(ng, D, device=DEV), torch.zeros(ng, D, device=DEV)
-    dxb = torch.empty(M, D, device=DEV, dtype=torch.bfloat16)
-    ops.ln_bwd(bf(dy).to(DEV), ud, mean, rstd, gamma.to(DEV), dgamma, dbeta, split=split, dx_bf16=dxb, gelu_u=ud)
-    assert_close(dxb, ur.grad, 1e-2, "d/du of ln(gelu(u))")
+    dxb = torch.empty(M, D, device=DEV, dtype=LPD())
+    ops.ln_bwd(bf(dy).to(DEV), ud, mean, rstd, gamma.to(DEV), dgamma, dbeta, split=split, dx_lp=dxb, gelu_u=ud)
+    assert_close(dxb, ur.grad, LPTOL(), "d/du of ln(gelu(u))")
     assert_close(dgamma, gr.grad, 2e-4, "dgamma")
     assert_close(dbeta, br.grad, 2e-4, "dbeta")
 
@@ -298,13 +309,13 @@ def test_sub_layernorm_backward_prefetch_kernel(M, D, split):
     xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
     y_ref = torch.cat([F.layer_norm(xr[:sp], (D,), gr[0], br[0], 1e-5), F.layer_norm(xr[sp:], (D,), gr[-1], br[-1], 1e-5)], 0)
     xd = bf(x).to(DEV)
-    _, _, mean, rstd = ops.ln_fwd(xd, gamma.to(DEV), beta.to(DEV), split=split, out_bf16=True, out_f32=False)
+    _, _, mean, rstd = ops.ln_fwd(xd, gamma.to(DEV), beta.to(DEV), split=split, out_lp=True, out_f32=False)
     dy = rnd_bf16(M, D, gen=g)
     y_ref.backward(dy)
     dgamma, dbeta = torch.zeros(ng, D, device=DEV), torch.zeros(ng, D, device=DEV)
-    dxb = torch.empty(M, D, device=DEV, dtype=torch.bfloat16)
-    ops.ln_bwd(bf(dy).to(DEV), xd, mean, rstd, gamma.to(DEV), dgamma, dbeta, split=split, dx_bf16=dxb)
-    assert_close(dxb, xr.grad, 1e-2, "dx")
+    dxb = torch.empty(M, D, device=DEV, dtype=LPD())
+    ops.ln_bwd(bf(dy).to(DEV), xd, mean, rstd, gamma.to(DEV), dgamma, dbeta, split=split, dx_lp=dxb)
+    assert_close(dxb, xr.grad, LPTOL(), "dx")
     assert_close(dgamma, gr.grad, 2e-4, "dgamma")
     assert_close(dbeta, br.grad, 2e-4, "dbeta")
 
@@ -350,7 +361,7 @@ def test_attention_fwd_bwd(B, H, Nv, Nt):
     padd = pad[:, :Nt].contiguous().to(DEV) if Nt else None
     out, lse = ops.attn_fwd(qd, B, H, Nv, Nt, pad=padd)
     out_tok = out.float().cpu()[idx.reshape(-1)].view(B, N, D)
-    assert_close(out_tok, o_ref, 1.5e-2, "attention fwd")
+    assert_close(out_tok, o_ref, LPTOL(1.5), "attention fwd")
     lse_ref = torch.logsumexp(w, -1).reshape(B * H, N)
     assert_close(lse, lse_ref, 1e-3, "attention lse")
     # backward
@@ -361,7 +372,7 @@ def test_attention_fwd_bwd(B, H, Nv, Nt):
     dqkv = ops.attn_bwd(qd, out, bf(do_mm).to(DEV), lse, B, H, Nv, Nt, pad=padd)
     dq_tok = dqkv.float().cpu()[idx.reshape(-1)].view(B, N, 3 * D)
     for name, sl in [("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))]:
-        assert_close(dq_tok[..., sl], t.grad[..., sl], 2e-2, "attention bwd " + name)
+        assert_close(dq_tok[..., sl], t.grad[..., sl], LPTOL(2.0), "attention bwd " + name)
 
 
 # ------------------------------------------------------------------------------------------
@@ -403,10 +414,10 @@ def test_embed_fwd_bwd():
     assert_close(x, x_ref, 1e-6, "embed fwd")
     dx = torch.randn(B * (np_ + 1 + T), D, generator=g)
     x_ref.backward(dx)
-    dpatch = torch.empty(B * np_, D, device=DEV, dtype=torch.bfloat16)
+    dpatch = torch.empty(B * np_, D, device=DEV, dtype=LPD())
     dcls, dposA, dposB, dtext = (torch.zeros(s, device=DEV) for s in [(D,), (np_ + 3, D), (1024, D), (V, D)])
     ops.embed_bwd(dx.to(DEV), dpatch, dcls, dposA, dposB, dtext, ids.to(DEV), pad.to(DEV), B, np_, T)
-    assert_close(dpatch, pr.grad, 1e-2, "embed bwd dpatch")
+    assert_close(dpatch, pr.grad, LPTOL(), "embed bwd dpatch")
     assert_close(dcls, cr.grad, 1e-5, "embed bwd dcls")
     assert_close(dposA, ar.grad, 1e-5, "embed bwd dposA")
     assert_close(dposB, br_.grad, 1e-5, "embed bwd dposB")
@@ -419,14 +430,14 @@ def test_weight_prep():
     mats = [torch.randn(r, c, generator=g).to(DEV) for r, c in [(70, 33), (128, 256), (5, 300), (132, 200), (768, 3072)]]
     entries = []
     for i, m in enumerate(mats):
-        dst = torch.empty_like(m, dtype=torch.bfloat16) if i != 2 else None
-        dst_t = torch.empty(m.shape[1], m.shape[0], device=DEV, dtype=torch.bfloat16) if i != 0 else None
+        dst = torch.empty_like(m, dtype=LPD()) if i != 2 else None
+        dst_t = torch.empty(m.shape[1], m.shape[0], device=DEV, dtype=LPD()) if i != 0 else None
         entries.append((m, dst, dst_t))
     wp = ops.WeightPrep(entries, DEV)
     wp.run()
     torch.cuda.synchronize()
     for m, dst, dst_t in entries:
         if dst is not None:
-            assert torch.equal(dst, m.to(torch.bfloat16))
+            assert torch.equal(dst, m.to(LPD()))
         if dst_t is not None:
-            assert torch.equal(dst_t, m.t().contiguous().to(torch.bfloat16))
+            assert torch.equal(dst_t, m.t().contiguous().to(LPD()))

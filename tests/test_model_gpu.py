@@ -1,13 +1,15 @@
 """GPU: the whole HIP model (simvg_amd MIXDETRMB: encoder engine + head + on-device matcher/criterion)
 against the fixtures recorded from the REAL reference (tests/golden/*.pt), same seeded weights and inputs.
 
-Stated tolerances.  north_star bound: normalised boxes (cx,cy,w,h in [0,1]) within 1e-3 L1 of the reference,
-pixel boxes within 640*1e-3 px -- asserted on the `*_refinit` fixtures (the reference's own initialisation, i.e.
-what training from scratch and bench.py run).  The other fixtures use deliberately harsh weights (O(1) attention
-logits and pre-sigmoid box values, fan_in^-1/2 everywhere) where bf16 operand rounding (2^-9 per GEMM input,
-fp32 accumulate) is visible: there the bound is 1.5e-2 L1 (measured: decoder <= 4e-3, token <= 1.1e-2; see
-DESIGN.md "Numerics").  Logits / losses within 3e-2 relative; matcher assignments identical; sampled parameter
-gradients: see the comment at the check."""
+Stated tolerances (default build: fp16 MFMA operands, fp32 accumulate).  north_star bound: normalised boxes
+(cx,cy,w,h in [0,1]) within 1e-3 L1 of the reference, pixel boxes within 640*1e-3 px -- asserted on EVERY fixture of a
+reference geometry (ViT-B / ViT-L, nq 1 / 10): the `*_refinit` ones (the reference's own initialisation; measured
+<= 7e-5) and the deliberately harsh ones (O(1) attention logits and pre-sigmoid box values, fan_in^-1/2 everywhere, i.e.
+trained-scale weights; measured decoder <= 3.8e-4, token <= 6.4e-4).  The 2-layer, 128-wide `tiny_*` fixtures are a
+test-only geometry whose narrow rows average less rounding noise: bound 2.5e-3 (measured <= 1.7e-3).  A bf16 build of the
+same kernels (SIMVG_LOWP=bf16) sits at 4e-3 / 1.1e-2 on the harsh fixtures -- rounding the weights alone costs more than
+the bound (tests/test_precision_cpu.py, DESIGN.md "Numerics") -- and is given 1.5e-2.  Logits within 5e-3 of their scale,
+losses within 2e-3 relative; matcher assignments identical; sampled parameter gradients: see the comment at the check."""
 import pytest
 import torch
 
@@ -41,11 +43,21 @@ def _rel(a, b):
     return float((a.float().cpu() - b).abs().max() / max(float(b.abs().max()), 1e-6))
 
 
-ALL = ["base_nq1_refinit", "base_nq10_grec_refinit", "tiny_nq1", "tiny_nq10_grec", "base_nq1", "base_nq10_grec", "large_nq1"]
+ALL = ["base_nq1_refinit", "base_nq10_grec_refinit", "large_nq10_grec_refinit", "tiny_nq1", "tiny_nq10_grec", "base_nq1",
+       "base_nq10_grec", "large_nq1", "large_nq10_grec"]
+
+
+def _fp16():
+    from simvg_amd import _lib
+    return _lib.lowp_format() == "fp16"
 
 
 def _box_tol(fx):
-    return 1e-3 if fx.get("refinit") else 1.5e-2
+    if fx.get("refinit"):
+        return 1e-3
+    if not _fp16():
+        return 1.5e-2
+    return 2.5e-3 if fx["vit"] == "tiny" else 1e-3
 
 
 @pytest.mark.parametrize("name", ALL)
@@ -61,9 +73,9 @@ def test_forward_train_matches_reference(golden, name):
         l1 = float((out[key].detach().float().cpu() - fx[fkey]).abs().sum(-1).max())
         assert l1 <= _box_tol(fx), (key, l1)
     for key, fkey in [("outputs_class_decoder_branch", "dec_logits"), ("outputs_class_token_branch", "tok_logits")]:
-        assert _rel(out[key].detach(), fx[fkey]) <= 3e-2, key
+        assert _rel(out[key].detach(), fx[fkey]) <= (5e-3 if _fp16() else 3e-2), key
     for k, v in fx["losses"].items():
-        assert abs(float(losses[k]) - v) <= 2e-2 * max(1.0, abs(v)), (k, float(losses[k]), v)
+        assert abs(float(losses[k]) - v) <= (2e-3 if _fp16() else 2e-2) * max(1.0, abs(v)), (k, float(losses[k]), v)
     # matcher on the decoder's final layer vs the reference's own HungarianMatcher call
     m = model._last_detail["match_dec"][-1].cpu()
     for b, (ri, ci) in enumerate(fx["matcher_gt"]):
@@ -100,7 +112,8 @@ def test_forward_train_matches_reference(golden, name):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("name", ["base_nq1_refinit", "base_nq10_grec_refinit", "tiny_nq1", "base_nq1", "base_nq10_grec"])
+@pytest.mark.parametrize("name", ["base_nq1_refinit", "base_nq10_grec_refinit", "tiny_nq1", "base_nq1", "base_nq10_grec",
+                                  "large_nq10_grec"])
 def test_forward_test_boxes(golden, name):
     fx = golden(name)
     model, batch, cfg = _build(fx)
@@ -118,7 +131,7 @@ def test_forward_test_boxes(golden, name):
             for a, b in zip(pred[i]["pred_bboxes"], fx[key]):
                 assert a["boxes"].shape == b["boxes"].shape
                 assert float((a["boxes"].float().cpu() - b["boxes"]).abs().max()) <= tol_px
-                assert float((a["scores"].float().cpu() - b["scores"]).abs().max()) <= 3e-2
+                assert float((a["scores"].float().cpu() - b["scores"]).abs().max()) <= (5e-3 if _fp16() else 3e-2)
 
 
 def test_train_mode_runs_with_dropout_and_droppath():
@@ -164,7 +177,8 @@ def test_exact_fp32_mode_meets_1e3_on_harsh_weights(golden, name):
             assert float((pred[i]["pred_bboxes"].float().cpu() - fx[key]).abs().max()) <= fx["img_size"] * 1e-3
 
 
-@pytest.mark.parametrize("name", ["tiny_nq1", "tiny_nq10_grec", "base_nq1", "base_nq10_grec", "base_nq1_refinit", "large_nq1"])
+@pytest.mark.parametrize("name", ["tiny_nq1", "tiny_nq10_grec", "base_nq1", "base_nq10_grec", "base_nq1_refinit", "large_nq1",
+                                  "large_nq10_grec"])
 def test_exact_fp32_training_step_matches_reference_gradients(golden, name):
     """precision="fp32" with gradients: forward AND backward in the reference's own arithmetic (exact fp32 MFMA GEMMs,
     fp32 attention / LayerNorm / GELU backward kernels).  On every fixture -- the harsh ones included, where the bf16

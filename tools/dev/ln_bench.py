@@ -16,11 +16,11 @@ for D, xdt in [(3072, torch.bfloat16), (768, torch.float32), (768, torch.bfloat1
     dres = torch.randn(M, D, device=dev)
     def run():
         if D == 3072:
-            ops.ln_bwd(dy, u, mean, rstd, g, dg, db, split=SPLIT, dx_bf16=dxb, gelu_u=None if os.environ.get('NOGELU') else u)   # x == u: GELU recompute path
+            ops.ln_bwd(dy, u, mean, rstd, g, dg, db, split=SPLIT, dx_lp=dxb, gelu_u=None if os.environ.get('NOGELU') else u)   # x == u: GELU recompute path
         elif xdt == torch.float32:
             ops.ln_bwd(dy, x, mean, rstd, g, dg, db, split=SPLIT, dres=dres, dx_f32=dxf, dx_scaled=dxb)
         else:
-            ops.ln_bwd(dy, x, mean, rstd, g, dg, db, split=SPLIT, dx_bf16=dxb)
+            ops.ln_bwd(dy, x, mean, rstd, g, dg, db, split=SPLIT, dx_lp=dxb)
     for _ in range(30): run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -32,10 +32,10 @@ for D, xdt in [(3072, torch.bfloat16), (768, torch.float32), (768, torch.bfloat1
 # forward of ffn_layernorm: LayerNorm(gelu(u)), bf16 in / bf16 out
 u = torch.randn(M, 3072, device=dev).to(torch.bfloat16)
 g, b = torch.ones(2, 3072, device=dev), torch.zeros(2, 3072, device=dev)
-for _ in range(30): ops.ln_fwd(u, g, b, split=SPLIT, out_bf16=True, out_f32=False, gelu_in=True)
+for _ in range(30): ops.ln_fwd(u, g, b, split=SPLIT, out_lp=True, out_f32=False, gelu_in=True)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-for _ in range(20): ops.ln_fwd(u, g, b, split=SPLIT, out_bf16=True, out_f32=False, gelu_in=True)
+for _ in range(20): ops.ln_fwd(u, g, b, split=SPLIT, out_lp=True, out_f32=False, gelu_in=True)
 e1.record(); torch.cuda.synchronize()
 print(f"ln_fwd(gelu) D=3072 bf16: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us", flush=True)
