@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsimvg_hip.so")
+LIB_PATH = os.environ.get("SIMVG_HIP_LIB") or os.path.join(_HERE, "lib", "libsimvg_hip.so")   # override: dev builds
 
 c_void_p, c_int, c_long, c_float = C.c_void_p, C.c_int, C.c_long, C.c_float
 

@@ -124,4 +124,35 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ lpx4_t lds_read_tr16(const void* lds_addr) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) lpx4_t*)(lds_addr));
 }
+// ---- LDS reads that must stay invisible to hipcc's wait-count insertion -----------------------------------------------
+// hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of an LDS read that follows an LDS-DMA (global_load_lds / buffer_load
+// ... lds) in program order whenever it cannot prove that the two do not alias -- always for the ds_read_tr builtin (no
+// memory operand), and for plain reads next to the buffer form.  In a ring pipeline that drains every in-flight stage
+// right after it was issued.  Inline-asm reads are not modelled by that pass; the caller counts them (lds_wait_all) and
+// must not touch their outputs before that (cdna_hip_programming.md 5.7).
+template <int OFF>
+__device__ __forceinline__ u32x2_t lds_tr16_asm(unsigned addr) {
+  u32x2_t v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int OFF>
+__device__ __forceinline__ u32x4_t lds_b128_asm(unsigned addr) {
+  u32x4_t v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+__device__ __forceinline__ void lds_wait_all() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);      // register-only instructions (MFMA) must not be hoisted above the wait
+}
+__device__ __forceinline__ void lds_pin(u32x2_t& a, u32x2_t& b) { asm volatile("" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ lpx8_t frag8(u32x2_t lo, u32x2_t hi) {
+  return __builtin_bit_cast(lpx8_t, (u32x4_t){lo[0], lo[1], hi[0], hi[1]});
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)LDS_PTR(p); }
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+// wgrad.hip: XCD-partitioned weight gradient for the ViT-B encoder shapes; false = not handled (generic kernels run)
+bool simvg_wgrad_x(const void* dY, int lddy, const void* X, int ldx, float* dW, long dw_gstride, int lddw, float* db,
+                   int db_gstride, int M, int N, int K, int split, float out_scale, hipStream_t stream);

@@ -599,19 +599,18 @@ __device__ __forceinline__ void stage_tile_m64(const lp_t* base, int ld, int m0,
   }
 }
 
-// transposed fragment: lane (i = lane&15 -> column c0+i, g = lane>>4 -> rows ms+8g..+7)
-__device__ __forceinline__ lpx8_t read_frag_tr(const char* lds, int ms, int c0, int lane) {
+// transposed fragment: lane (i = lane&15 -> column c0+i, g = lane>>4 -> rows ms+8g..+7); raw halves by inline-asm reads
+// (common.h: a builtin read behind the LDS-DMA of the next stage would make hipcc drain the ring) -- the caller waits
+// (lds_wait_all), pins (lds_pin) and packs (frag8)
+__device__ __forceinline__ void read_frag_tr(const char* lds, int ms, int c0, int lane, u32x2_t (&out)[2]) {
   const int i = lane & 15, g = lane >> 4;
   const int col = c0 + 4 * (i & 3);          // this lane supplies 4 contiguous columns of row (i>>2)
   const int lslot = col >> 3, within = (col & 7) * 2;
-  lpx8_t out;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int row = ms + 8 * g + 4 * h + (i >> 2);
-    const lpx4_t v = lds_read_tr16(lds + row * 256 + ((lslot ^ tn_swz(row)) << 4) + within);
-    out[4 * h + 0] = v[0]; out[4 * h + 1] = v[1]; out[4 * h + 2] = v[2]; out[4 * h + 3] = v[3];
+    out[h] = lds_tr16_asm<0>(lds_addr(lds + row * 256 + ((lslot ^ tn_swz(row)) << 4) + within));
   }
-  return out;
 }
 
 // Bias gradient as a horizontal fusion: blocks with blockIdx.x >= a.tiles of the SAME launch each sum 256 columns of dY
@@ -712,11 +711,20 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs a) {
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
+      u32x2_t ry[4][2], rx[4][2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        read_frag_tr(ldsY(cur), s * 32, wn * 64 + i * 16, lane, ry[i]);
+        read_frag_tr(ldsX(cur), s * 32, wk * 64 + i * 16, lane, rx[i]);
+      }
+      lds_wait_all();
       lpx8_t fy[4], fx[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        fy[i] = read_frag_tr(ldsY(cur), s * 32, wn * 64 + i * 16, lane);
-        fx[i] = read_frag_tr(ldsX(cur), s * 32, wk * 64 + i * 16, lane);
+        lds_pin(ry[i][0], ry[i][1]);
+        lds_pin(rx[i][0], rx[i][1]);
+        fy[i] = frag8(ry[i][0], ry[i][1]);
+        fx[i] = frag8(rx[i][0], rx[i][1]);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -760,18 +768,15 @@ __device__ __forceinline__ void stage_rows32(const lp_t* base, int ld, int m0, i
   }
 }
 // transposed fragment from a [32 rows][width cols] stage: lane (i = lane&15 -> column c0+i, g = lane>>4 -> rows 8g..8g+7)
-__device__ __forceinline__ lpx8_t read_frag_tr_w(const char* lds, int row_bytes, int c0, int lane) {
+__device__ __forceinline__ void read_frag_tr_w(const char* lds, int row_bytes, int c0, int lane, u32x2_t (&out)[2]) {
   const int i = lane & 15, g = lane >> 4;
   const int col = c0 + 4 * (i & 3);
   const int lslot = col >> 3, within = (col & 7) * 2;
-  lpx8_t out;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int row = 8 * g + 4 * h + (i >> 2);
-    const lpx4_t v = lds_read_tr16(lds + row * row_bytes + ((lslot ^ tn_swz(row)) << 4) + within);
-    out[4 * h + 0] = v[0]; out[4 * h + 1] = v[1]; out[4 * h + 2] = v[2]; out[4 * h + 3] = v[3];
+    out[h] = lds_tr16_asm<0>(lds_addr(lds + row * row_bytes + ((lslot ^ tn_swz(row)) << 4) + within));
   }
-  return out;
 }
 
 __global__ __launch_bounds__(512, 2) void gemm_tn_kernel_256(GemmTNArgs a) {
@@ -818,11 +823,20 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel_256(GemmTNArgs a) {
     if (t + 2 < nt) ISSUE(t + 2);
     const char* sy = SY(t % 3);
     const char* sx = SX(t % 3);
+    u32x2_t ry[4][2], rx[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      read_frag_tr_w(sy, 512, wn * 64 + i * 16, lane, ry[i]);
+      read_frag_tr_w(sx, 256, wk * 64 + i * 16, lane, rx[i]);
+    }
+    lds_wait_all();
     lpx8_t fy[4], fx[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      fy[i] = read_frag_tr_w(sy, 512, wn * 64 + i * 16, lane);
-      fx[i] = read_frag_tr_w(sx, 256, wk * 64 + i * 16, lane);
+      lds_pin(ry[i][0], ry[i][1]);
+      lds_pin(rx[i][0], rx[i][1]);
+      fy[i] = frag8(ry[i][0], ry[i][1]);
+      fx[i] = frag8(rx[i][0], rx[i][1]);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -942,6 +956,10 @@ extern "C" int simvg_gemm_tn(const void* dY, int lddy, const void* X, int ldx, f
   SIMVG_CHECK_ARG(N % 8 == 0 && K % 8 == 0 && lddy % 8 == 0 && ldx % 8 == 0, "gemm_tn: N, K, ld must be multiples of 8");
   SIMVG_CHECK_ARG(split >= 0 && split <= M, "gemm_tn: split out of range");
   if (split == 0) split = M;
+  if (simvg_wgrad_x(dY, lddy, X, ldx, dW, dw_gstride, lddw, db, db_gstride, M, N, K, split, out_scale, stream)) {
+    SIMVG_LAUNCH_CHECK();
+    return SIMVG_OK;
+  }
   // 256x128 ring kernel for the wide problems (qkv / fc1 / fc2 wgrad); the small out-proj stays on the 128x128 kernel
   const bool big = cdiv(N, 256) * cdiv(K, 128) >= 24;
   const int tiles = big ? cdiv(N, 256) * cdiv(K, 128) : cdiv(N, 128) * cdiv(K, 128);

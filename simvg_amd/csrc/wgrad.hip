@@ -1,0 +1,267 @@
+// Weight gradient of the encoder's Linears, XCD-partitioned (gfx950):  dW[g][N,K] += s * dY[M,N]^T . X[M,K],
+// db[g][N] += s * column sums of dY   (wgrad + bias gradient of torchscale's multiway nn.Linear: autograd of the calls at
+// beit3_base.py:137-145,159; s = 1 / gradient scale of dY).
+//
+// The contraction runs over M = 26 944 token rows while the output is only N x K (2.4 M elements for fc1), so the
+// operand panels dominate the traffic.  The first kernel (gemm.hip: 256x128 output tiles, rows cut into ~5 chunks, tiles
+// spread over all XCDs) moved 2.4-2.8x its algorithmic bytes across the fabric: every XCD streamed the dY / X panels of
+// its tile block over ALL rows, and a separate set of blocks re-read dY for the bias gradient.  Here
+//   * each of the 8 XCDs (blockIdx % 8; a speed assumption only) owns a contiguous RANGE OF ROWS and computes the whole
+//     N x K output for it: its 32 workgroups (one per CU, all resident, ONE round, no tail) walk those rows in lockstep,
+//     so every dY / X row is fetched from HBM once per launch and the re-use happens in the XCD's L2;
+//   * 384 x 192 (or 288 x 192 / 192 x 384) output tiles: 128 FLOP per staged byte instead of 85; 12 waves per workgroup
+//     (3 per SIMD), each a 96 x 64 block (96 accumulator VGPRs): 20 transposed fragment reads feed 24 MFMAs per stage;
+//   * the three waves of a SIMD rotate through LOAD / LOAD / MFMA roles a third of a stage apart (see the kernel);
+//   * the bias gradient is taken from the dY stage that is in LDS anyway (each block sums 1/tiles_k of its columns);
+//   * the 8 partial results meet in dW / db through fp32 atomics (8 x N x K x 4 B = 75 MB per fc1 launch; measured 37 us of
+//     the 165: the device-scope atomics are memory-side read-modify-writes, their cost follows the byte count -- private
+//     slabs per XCD are no faster -- so it is the price of streaming every row from HBM once).
+// LDS image: a stage is 32 contraction rows, row-major, each row padded by 32 B so that the row stride is an ODD multiple
+// of 32 B.  A transposed fragment read (ds_read_b64_tr_b16) is served 32 lanes per LDS cycle = 8 rows x 32 B; with lane
+// group g reading rows 16h + 4g + (0..3) those are 8 CONSECUTIVE rows, which the odd stride spreads over all 64 banks:
+// conflict-free without any address swizzle (the MFMA contraction index <-> stage row assignment is free as long as both
+// operands use the same one), so fragment addresses are one per-lane base plus compile-time immediates and the global
+// reads stay whole, unpermuted rows.
+#include "common.h"
+
+namespace {
+
+struct WgradXArgs {
+  const lp_t* dY; int lddy;
+  const lp_t* X; int ldx;
+  float* dW; long dw_gstride; int lddw;
+  float* db; int db_gstride;
+  int M, N, K, split;
+  float out_scale;
+};
+
+// The LDS reads of the main loop are inline asm (common.h: lds_tr16_asm / lds_wait_all): the compiler would otherwise
+// drain the ring with `s_waitcnt vmcnt(0)` right after every stage is issued, which is what the first wgrad kernel did.
+
+// A x B = 12 waves (along n x along k), each a (16 WI) x (16 WJ) block of the output tile; 4-deep LDS ring.
+//
+// Schedule.  Measured with s_memtime on the 8-wave predecessor of this kernel (one wave per SIMD issuing): a
+// ds_read_b64_tr_b16 costs its wave ~19 cycles of issue, an LDS-DMA piece ~90 (descriptor SALU included), an MFMA ~21 --
+// per stage and SIMD 912 + 900 + 1512 cycles, and with the waves of a SIMD in lockstep (or ping-ponging behind two
+// barriers per stage with a LOAD segment twice as long as the MFMA segment) those simply added up (MFMA pipe 38 % busy).
+// Here the THREE waves of a SIMD (w, w + 4, w + 8: waves are dealt to the SIMDs round-robin) rotate through three
+// roles, one barrier-delimited interval each, a third of a stage apart:
+//     LOADa(t): issue the fragment reads of stage t          (~20 x 19 cycles)
+//     LOADb(t): wait for them, bias-gradient partial sums, issue the LDS-DMA of stage t + 3
+//     MFMA(t) : 24 MFMAs at priority 1
+// so in every interval exactly one wave per SIMD owns the MFMA pipe while its two partners prepare.
+//   group g runs LOADa(t) / LOADb(t) / MFMA(t) in intervals 3t + g, 3t + g + 1, 3t + g + 2.
+//   RAW: stage t + 1 is first read in interval 3t + 3, so every wave waits for ITS pieces of stage t + 1 (counted vmcnt)
+//        before the barrier that closes interval 3t + 2 -- the end of MFMA(t) / LOADb(t) / LOADa(t) for g = 0 / 1 / 2;
+//   WAR: stage t + 3 lands in the buffer of stage t - 1, last read (group 2, LOADb(t - 1)) in interval 3t; the earliest
+//        DMA into it is issued in interval 3t + 1 (group 0's LOADb(t)).
+template <int A, int B, int WI, int WJ>
+__global__ __launch_bounds__(A * B * 64) void wgrad_x_kernel(WgradXArgs a) {
+  constexpr int NW = A * B, NST = 4;
+  constexpr int TN = 16 * WI * A, TK = 16 * WJ * B;
+  constexpr int SN = TN * 2 + 32, SK = TK * 2 + 32;      // padded row strides (bytes), odd multiples of 32
+  constexpr int PN = SN / 32, PK = SK / 32, P = PN + PK;  // 1 KiB pieces per stage (32 rows)
+  constexpr int STAGE = 32 * (SN + SK);
+  constexpr int MAXP = (P + NW - 1) / NW;                  // waves [0, P - (MAXP-1) NW) issue MAXP pieces, the others MAXP - 1
+  static_assert((SN / 32) % 2 == 1 && (SK / 32) % 2 == 1, "row strides must be odd multiples of 32 B");
+  static_assert(NW == 12, "three waves per SIMD");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave / B, wk = wave % B;
+  const int grp3 = wave >> 2;                              // role phase of this wave: 0, 1, 2
+  const int tiles_k = a.K / TK;
+  const int ntile = (a.N / TN) * tiles_k;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int tile = local % ntile, sub = local / ntile, nsub = (int)(gridDim.x >> 3) / ntile;
+  const int tn = tile / tiles_k, tk = tile - tn * tiles_k;
+  const int n0 = tn * TN, k0 = tk * TK;
+  // the launch's rows as a list of 32-row stages, group 0 (rows [0, split)) first; this block takes a contiguous share
+  const int st0 = (a.split + 31) >> 5, st1 = (a.M - a.split + 31) >> 5, ST = st0 + st1;
+  const int q = xcd * nsub + sub, Q = 8 * nsub;
+  const int s_begin = q * ST / Q, s_end = (q + 1) * ST / Q;
+
+  // ---- this wave's pieces of a stage: LDS piece p holds bytes [p * 1024, +1024) of the stage image.  The loads are
+  // buffer loads (`buffer_load_dwordx4 ... offen lds`): the descriptor is rebuilt per stage with its base at the stage's
+  // first row and its size at the end of the row group, so rows beyond the group and the 32 padding bytes of every LDS row
+  // (voffset = ~0) read as zero by the hardware's range check -- no per-lane pointer selects, one constant VGPR per piece
+  unsigned poff[MAXP];
+#pragma unroll
+  for (int ii = 0; ii < MAXP; ++ii) {
+    const int p = wave + ii * NW;
+    poff[ii] = 0xffffffffu;
+    const bool x = p >= PN;
+    const int o = (x ? p - PN : p) * 1024 + lane * 16;
+    const int S = x ? SK : SN;
+    const int row = o / S, byte = o - row * S;
+    if (p < P && byte < S - 32) poff[ii] = (unsigned)(row * (x ? a.ldx : a.lddy) * 2 + (x ? k0 : n0) * 2 + byte);
+  }
+  const bool full = wave + (MAXP - 1) * NW < P;           // wave-uniform: this wave issues MAXP pieces per stage
+
+  // ---- per-lane fragment bases (stage-relative): lane (i = lane & 15, g = lane >> 4) reads rows 16h + 4g + (i >> 2)
+  const int i16 = lane & 15, g4 = lane >> 4;
+  const int fb_n = (4 * g4 + (i16 >> 2)) * SN + (wn * (16 * WI) + 4 * (i16 & 3)) * 2;
+  const int fb_k = 32 * SN + (4 * g4 + (i16 >> 2)) * SK + (wk * (16 * WJ) + 4 * (i16 & 3)) * 2;
+  // ---- bias gradient: this block sums columns [n0 + tk * CS, +CS) of its dY stage, CS = TN / tiles_k
+  const int CS = TN / tiles_k, cpr = CS >> 3;               // 16-B chunks per row
+  const bool cs_lane = a.db != nullptr && tid < 32 * cpr;
+  const int cs_row = cs_lane ? tid / cpr : 0, cs_cc = cs_lane ? tid - cs_row * cpr : 0;
+  const int cs_off = cs_row * SN + (tk * CS + cs_cc * 8) * 2;
+
+  const unsigned lds0 = lds_addr(smem);
+  for (int grp = 0; grp < 2; ++grp) {
+    const int sb = grp ? max(s_begin, st0) : s_begin, se = grp ? s_end : min(s_end, st0);
+    if (sb >= se) continue;
+    const int r_first = grp ? a.split + (sb - st0) * 32 : sb * 32;      // first row of this segment
+    const int m_end = grp ? a.M : a.split;
+    const int nt = se - sb;
+    f32x4_t acc[WI][WJ];
+#pragma unroll
+    for (int i = 0; i < WI; ++i)
+#pragma unroll
+      for (int j = 0; j < WJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    auto issue = [&](int t) {
+      const int row0 = r_first + t * 32;
+      char* st = smem + (t % NST) * STAGE;
+      const long left = (long)(m_end - row0);             // rows of this group from the stage's first row on
+      const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dY + (long)row0 * a.lddy), 0,
+                                                                         (int)(left * a.lddy * 2), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.X + (long)row0 * a.ldx), 0,
+                                                                         (int)(left * a.ldx * 2), 0x00020000);
+#pragma unroll
+      for (int ii = 0; ii < MAXP; ++ii) {
+        const int p = wave + ii * NW;
+        if (p < P) {
+          if (p >= PN) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(st + p * 1024), 16, (int)poff[ii], 0, 0, 0);
+          else __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, LDS_PTR(st + p * 1024), 16, (int)poff[ii], 0, 0, 0);
+        }
+      }
+    };
+    // own pieces of the oldest `stages` + 1 outstanding stages: wait for the oldest one
+    auto wait_oldest = [&](int later) {                   // later = stages issued after the awaited one (wave-uniform)
+      if (later >= 2) {
+        if (full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * MAXP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (MAXP - 1)) : "memory");
+      } else if (later == 1) {
+        if (full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MAXP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MAXP - 1) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    };
+    issue(0);
+    if (nt > 1) issue(1);
+    if (nt > 2) issue(2);
+    wait_oldest(min(nt - 1, 2));
+    __builtin_amdgcn_s_barrier();
+    for (int k = 0; k < grp3; ++k) __builtin_amdgcn_s_barrier();        // phase shift of this wave's group
+    for (int t = 0; t < nt; ++t) {
+      // ---------------- LOADa(t): fragment reads
+      const unsigned sb_ = lds0 + (unsigned)(t % NST) * STAGE;
+      const unsigned an = sb_ + fb_n, ak = sb_ + fb_k;
+      u32x2_t ry[WI][2], rx[WJ][2];
+#define RD_Y(i_) if constexpr ((i_) < WI) { ry[i_][0] = lds_tr16_asm<(i_) * 32>(an); ry[i_][1] = lds_tr16_asm<16 * SN + (i_) * 32>(an); }
+#define RD_X(j_) if constexpr ((j_) < WJ) { rx[j_][0] = lds_tr16_asm<(j_) * 32>(ak); rx[j_][1] = lds_tr16_asm<16 * SK + (j_) * 32>(ak); }
+      RD_Y(0) RD_Y(1) RD_Y(2) RD_Y(3) RD_Y(4) RD_Y(5) RD_Y(6) RD_Y(7) RD_Y(8)
+      RD_X(0) RD_X(1) RD_X(2) RD_X(3) RD_X(4) RD_X(5)
+#undef RD_Y
+#undef RD_X
+      u32x4_t csv;
+      if (cs_lane) csv = lds_b128_asm<0>(sb_ + cs_off);
+      if (grp3 == 2 && t + 1 < nt) wait_oldest(min(nt - 2 - t, 1));     // stage t + 1 (t + 3 not issued yet)
+      __builtin_amdgcn_s_barrier();
+      // ---------------- LOADb(t): reads complete, bias partial sums, DMA of stage t + 3
+      if (t + 3 < nt) issue(t + 3);
+      lds_wait_all();
+#pragma unroll
+      for (int i = 0; i < WI; ++i) lds_pin(ry[i][0], ry[i][1]);
+#pragma unroll
+      for (int j = 0; j < WJ; ++j) lds_pin(rx[j][0], rx[j][1]);
+      lpx8_t fy[WI], fx[WJ];
+#pragma unroll
+      for (int i = 0; i < WI; ++i) fy[i] = frag8(ry[i][0], ry[i][1]);
+#pragma unroll
+      for (int j = 0; j < WJ; ++j) fx[j] = frag8(rx[j][0], rx[j][1]);
+      if (cs_lane) {
+        asm volatile("" : "+v"(csv));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float lo, hi;
+          unpack_lp2(csv[e], lo, hi);
+          cs[2 * e] += lo;
+          cs[2 * e + 1] += hi;
+        }
+      }
+      if (grp3 == 1 && t + 1 < nt) wait_oldest(min(nt - 2 - t, 2));
+      __builtin_amdgcn_s_barrier();
+      // ---------------- MFMA(t)
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < WI; ++i)
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) acc[i][j] = mfma_lp(fy[i], fx[j], acc[i][j]);
+      __builtin_amdgcn_s_setprio(0);
+      if (grp3 == 0 && t + 1 < nt) wait_oldest(min(nt - 2 - t, 2));
+      __builtin_amdgcn_s_barrier();
+    }
+    for (int k = grp3; k < 2; ++k) __builtin_amdgcn_s_barrier();
+    // ---- flush: fp32 atomics into dW[grp] (lanes 0-15 of a 16-lane group cover 64 contiguous bytes of one row)
+    float* dW = a.dW + (long)grp * a.dw_gstride;
+#pragma unroll
+    for (int i = 0; i < WI; ++i)
+#pragma unroll
+      for (int j = 0; j < WJ; ++j) {
+        const int k = k0 + wk * (16 * WJ) + j * 16 + i16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = n0 + wn * (16 * WI) + i * 16 + 4 * g4 + r;
+          atomicAdd(dW + (long)n * a.lddw + k, acc[i][j][r] * a.out_scale);
+        }
+      }
+    if (a.db) {
+      __syncthreads();                                    // the ring is free: reduce the 32 rows' partial sums in LDS
+      float* red = (float*)smem;
+      for (int c = tid; c < CS; c += NW * 64) red[c] = 0.f;
+      __syncthreads();
+      if (cs_lane) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(&red[cs_cc * 8 + e], cs[e]);
+      }
+      __syncthreads();
+      for (int c = tid; c < CS; c += NW * 64)
+        atomicAdd(a.db + (long)grp * a.db_gstride + n0 + tk * CS + c, red[c] * a.out_scale);
+      __syncthreads();                                    // before the next segment's loads land in the ring
+    }
+  }
+}
+
+template <int A, int B, int WI, int WJ>
+bool launch(const WgradXArgs& a, hipStream_t stream) {
+  constexpr int TN = 16 * WI * A, TK = 16 * WJ * B;
+  constexpr int LDS = 4 * 32 * (TN * 2 + 32 + TK * 2 + 32);
+  static bool once = hipFuncSetAttribute((const void*)wgrad_x_kernel<A, B, WI, WJ>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
+  (void)once;
+  const int ntile = (a.N / TN) * (a.K / TK);
+  hipLaunchKernelGGL((wgrad_x_kernel<A, B, WI, WJ>), dim3(8 * ntile), dim3(A * B * 64), LDS, stream, a);
+  return true;
+}
+
+}  // namespace
+
+// -> true when the problem was launched here (ViT-B encoder shapes at training sizes); false: the caller falls back to the
+// generic kernels of gemm.hip
+bool simvg_wgrad_x(const void* dY, int lddy, const void* X, int ldx, float* dW, long dw_gstride, int lddw, float* db,
+                   int db_gstride, int M, int N, int K, int split, float out_scale, hipStream_t stream) {
+  if (M < 4096 || (lddy & 7) || (ldx & 7)) return false;
+  WgradXArgs a{(const lp_t*)dY, lddy, (const lp_t*)X, ldx, dW, dw_gstride, lddw, db, db_gstride, M, N, K, split, out_scale};
+  auto fits = [&](int tn, int tk) {
+    return N % tn == 0 && K % tk == 0 && (N / tn) * (K / tk) == 32 && ((tn / (K / tk)) % 8) == 0;
+  };
+  if (fits(384, 192)) return launch<4, 3, 6, 4>(a, stream);      // fc1: 3072 x 768, waves 4 x 3 of 96 x 64
+  if (fits(288, 192)) return launch<3, 4, 6, 3>(a, stream);      // qkv: 2304 x 768, waves 3 x 4 of 96 x 48
+  if (fits(192, 384)) return launch<3, 4, 4, 6>(a, stream);      // fc2 / patch embed: 768 x 3072, waves 3 x 4 of 64 x 96
+  return false;
+}

@@ -163,7 +163,11 @@ def test_gemm_nt(M, N, K, split, mode):
 
 
 @pytest.mark.parametrize("M,N,K,split", [(300, 192, 128, 200), (1684, 768, 768, 1604), (5000, 128, 256, 0),
-                                         (1684, 3072, 768, 1604), (1684, 768, 3072, 1604), (3000, 2304, 768, 2500)])
+                                         (1684, 3072, 768, 1604), (1684, 768, 3072, 1604), (3000, 2304, 768, 2500),
+                                         # M >= 4096 and an encoder shape: the XCD-partitioned kernel (csrc/wgrad.hip) --
+                                         # ragged row counts, a row-group boundary inside a block's share, no text rows
+                                         (4133, 3072, 768, 3850), (6011, 2304, 768, 5614), (4500, 768, 3072, 0),
+                                         (8421, 768, 3072, 8020), (4096, 3072, 768, 4090)])
 def test_gemm_tn_and_colsum(M, N, K, split):
     ops = _ops()
     g = torch.Generator().manual_seed(7 * M + N)

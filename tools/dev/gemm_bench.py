@@ -10,11 +10,11 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 which = sys.argv[2] if len(sys.argv) > 2 else "nt"
 dev = "cuda"
 for name, N, K in shapes:
-    a = (torch.randn(M, K, device=dev) * 1.0).to(torch.bfloat16)
-    w = (torch.randn(2, N, K, device=dev) * K ** -0.5).to(torch.bfloat16)
+    a = (torch.randn(M, K, device=dev) * 1.0).to(ops.LP())
+    w = (torch.randn(2, N, K, device=dev) * K ** -0.5).to(ops.LP())
     bias = torch.randn(2, N, device=dev)
-    out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-    dy = (torch.randn(M, N, device=dev)).to(torch.bfloat16)
+    out = torch.empty(M, N, device=dev, dtype=ops.LP())
+    dy = (torch.randn(M, N, device=dev)).to(ops.LP())
     dw = torch.zeros(2, N, K, device=dev)
     for _ in range(30):
         if which == "nt":
