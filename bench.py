@@ -157,8 +157,8 @@ def main():
 
     # the step runs on a non-default HIP stream (what `train_model` does as well; required by the optional hipGraph
     # replay of the head, SIMVG_HEAD_GRAPH=1, see simvg_amd/graphs.py).  The roofline events are recorded on that stream.
-    from simvg_amd.graphs import train_stream
-    with torch.cuda.stream(train_stream(device)):
+    from simvg_amd.graphs import training_stream
+    with training_stream(device):
         # set-up, not warm-up: lazily created workspaces / constants (and, with SIMVG_HEAD_GRAPH=1, the capture of the head's
         # hipGraphs after four steps with the same input signature) happen here so that they can never land in the timed
         # steps whatever --warmup is.  No optimizer step: the weights the warm-up starts from are untouched.

@@ -198,7 +198,8 @@ int simvg_normalize_pad_u8(const void* src_hwc, long src_row_bytes, int h, int w
  *   g' = g * min(1, max_norm / (*total_norm + 1e-6));  Adam (L2 weight decay, amsgrad when max_exp_avg_sq != NULL):
  *   p -= step_size * m / (sqrt(vmax) / bias_correction2_sqrt + eps),  step_size = lr / (1 - beta1^t).
  * total_norm is a DEVICE scalar (no host sync); NULL = no clipping. */
-int simvg_sumsq(const float* x, long n, float* out_accum, simvg_stream_t stream);
+int simvg_sumsq(const float* x, long n, float* out_accum, float* partial_ws /* >= 2048 floats: per-block partial sums, added
+                in a fixed order (no atomics: the norm is bit-reproducible) */, simvg_stream_t stream);
 int simvg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, long n,
                     float step_size, float bias_correction2_sqrt, float beta1, float beta2, float eps, float weight_decay,
                     const float* total_norm, float max_norm, simvg_stream_t stream);

@@ -54,7 +54,7 @@ _SIGS = {
     "simvg_attn_f32_bwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                            c_float, c_void_p],
     "simvg_gelu_f32": [c_void_p, c_void_p, c_void_p, c_long, c_void_p],
-    "simvg_sumsq": [c_void_p, c_long, c_void_p, c_void_p],
+    "simvg_sumsq": [c_void_p, c_long, c_void_p, c_void_p, c_void_p],
     "simvg_adam_step": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float, c_float, c_float,
                         c_float, c_void_p, c_float, c_void_p],
     "simvg_gemm_f32": [c_void_p, c_long, c_long, c_void_p, c_long, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long,

@@ -4,7 +4,7 @@ tools/test.py:117-127): `_base_` inheritance, dict-into-dict merging with `_dele
 
 mmcv is a third-party dependency of the reference that is not in this image (and not in /root/reference): this file
 restates its published behaviour (mmcv 1.x `mmcv/utils/config.py`); the parity tests anchor on how the reference's
-own config files and tools use it (`tests/test_config_cpu.py`) -- parity UNPINNED against mmcv itself.
+own config files and tools use it (`tests/test_apis_cpu.py`) -- parity UNPINNED against mmcv itself.
 
 What is reproduced, because the reference's configs or tools rely on it:
   * a config is a Python file; every top-level name that is not dunder / module / function / class becomes a key

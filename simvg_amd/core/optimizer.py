@@ -50,6 +50,10 @@ class FlatAdam(torch.optim.Adam):
     `clip_grad_norm(max_norm)` is the global-norm clip of apis/train.py:81-82 over the same set of gradients."""
 
     def __init__(self, params, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
+        if weight_decay != 0:      # the fused kernel updates the WHOLE arena: parameters that never receive a gradient
+            raise NotImplementedError(       # (vision_embed.mask_token) would decay, which per-tensor Adam does not do
+                "FlatAdam implements the reference's setting weight_decay=0 (every config); use optimizer_config.flat=False "
+                "for L2 weight decay")
         enc = getattr(model, "vis_enc", None)
         arena = getattr(enc, "_arena", None)
         if arena is None:
@@ -127,6 +131,8 @@ class FlatAdam(torch.optim.Adam):
             st["exp_avg_sq"] = torch.zeros_like(self.arena.flat)
             if group["amsgrad"]:
                 st["max_exp_avg_sq"] = torch.zeros_like(self.arena.flat)
+        if st["step"].is_cuda:      # a fused optimizer's load_state_dict moves `step` to the parameter's device: bring the
+            st["step"] = st["step"].cpu()     # arena's counter home once, or every step would synchronise on int(...)
         st["step"] += 1
         t = int(st["step"])
         b1, b2 = group["betas"]

@@ -2,7 +2,7 @@
 per EPOCH (tools/train.py:177).  `MultiStepLRWarmUp` is a LambdaLR whose factor for epoch e (0-based) is
 (e+1)/(warmup_epochs+1) while e <= warmup_epochs-1, afterwards decay_ratio^(#decay_steps s with e+1 >= s), or -- when
 both decay_steps and decay_ratio are None -- a linear ramp down to 0 at max_epoch.  Pinned against the imported
-reference class by `tests/golden/apis_golden.json` (`oracle/make_golden_apis.py`)."""
+reference class by `tests/golden/apis_golden.pt` (`oracle/make_golden_apis.py`)."""
 from collections.abc import Sequence
 
 import torch.optim.lr_scheduler as lr_scheduler

@@ -143,61 +143,64 @@ class LargeScaleJitter:
         wh = rb - lt
         return wh[0] * wh[1] / ((gt_bbox[2] - gt_bbox[0]) * (gt_bbox[3] - gt_bbox[1]))
 
+    def _search_window(self, span_w, span_h, w_out, h_out, gt_bbox):
+        """Random w_out x h_out windows inside the rescaled image, judged by the share of the target box they contain:
+        thresholds from strict to lenient, `jitter_times` draws each, the first window that reaches the current threshold
+        wins.  -> (window xyxy | None, coverage of the best window seen, that window, last offset drawn).  Consumes two
+        `random.random()` per draw, like the reference's loop (transforms.py:262-286)."""
+        windows, coverage, hit = [], [], None
+        for thr in reversed(self.crop_iou_thr):
+            for _ in range(self.jitter_times):
+                ox, oy = random.random() * span_w, random.random() * span_h
+                win = numpy.array([ox, oy, ox + w_out, oy + h_out])
+                cov = self._bbox_overlaps(win, gt_bbox) if gt_bbox is not None else 0.0
+                windows.append(win)
+                coverage.append(cov)
+                if cov >= thr:
+                    hit = win
+                    break
+            if hit is not None:
+                break
+        top = max(coverage)
+        # the reference remembers the FIRST draw that improved on everything before it (strict >, starting from 0), and
+        # falls back to index -1 when no window touched the box at all
+        runner_up = windows[coverage.index(top)] if top > 0 else windows[-1]
+        return hit, top, runner_up, (ox, oy)
+
     def __call__(self, results):
-        img = results["img"]
-        h, w = results["ori_shape"][:2]
         if results.get("with_mask"):
             raise NotImplementedError("mask transforms are outside this hot path")
-        with_bbox = results["with_bbox"]
-        rand_scale = self.jitter_min + random.random() * (self.jitter_max - self.jitter_min)
-        scale = rand_scale * (self.out_max_size / max(h, w))
-        new_w, new_h = rescale_size((int(img.shape[1]), int(img.shape[0])), scale)
-        window = None                                     # (y0, x0, h, w) inside the rescaled image
-        if with_bbox:
-            gt_bbox = results["gt_bbox"]
-            factor = numpy.array([new_w / w, new_h / h, new_w / w, new_h / h])
-            gt_bbox = [box * factor for box in gt_bbox] if isinstance(gt_bbox, list) else gt_bbox * factor
-        cur_h, cur_w = new_h, new_w
-        if rand_scale > 1.0:
+        img = results["img"]
+        h, w = results["ori_shape"][:2]
+        channels = int(img.shape[2])
+        jitter = self.jitter_min + random.random() * (self.jitter_max - self.jitter_min)
+        new_w, new_h = rescale_size((int(img.shape[1]), int(img.shape[0])), jitter * (self.out_max_size / max(h, w)))
+        boxes = None
+        if results["with_bbox"]:
+            grow = numpy.array([new_w / w, new_h / h, new_w / w, new_h / h])
+            raw = results["gt_bbox"]
+            boxes = [b * grow for b in raw] if isinstance(raw, list) else raw * grow
+        out_w, out_h, window = new_w, new_h, None              # window = (y0, x0, h, w) inside the rescaled image
+        if jitter > 1.0:                                       # larger than the canvas: cut an out_max_size window out of it
             w_out, h_out = rescale_size((w, h), (self.out_max_size, self.out_max_size))
-            flag, best_idx, best_iou, history = False, -1, 0, []
-            for i, iou_thr in enumerate(self.crop_iou_thr[::-1]):
-                if not flag:
-                    for it in range(self.jitter_times):
-                        offset = (random.random() * (new_w - w_out), random.random() * (new_h - h_out))
-                        crop_bbox = numpy.array([offset[0], offset[1], offset[0] + w_out, offset[1] + h_out])
-                        iou = self._bbox_overlaps(crop_bbox, gt_bbox) if with_bbox else 0.0
-                        history.append(crop_bbox)
-                        if iou > best_iou:
-                            best_iou, best_idx = iou, i * self.jitter_times + it
-                        if iou >= iou_thr:
-                            flag = True
-                            break
-            if not flag:
-                if best_iou < self.min_iou_thr:           # "escape, do nothing": image and boxes stay as they were
-                    results["img_shape"] = (new_h, new_w, int(img.shape[2]))
-                    results["pad_shape"] = (new_h, new_w, int(img.shape[2]))
-                    results["scale_factor"] = numpy.array([1.0, 1.0, 1.0, 1.0])
-                    results["keep_ratio"] = True
-                    return results
-                crop_bbox = history[best_idx]
-            crop_bbox = crop_bbox.astype(numpy.uint32)
-            window = (int(crop_bbox[1]), int(crop_bbox[0]), int(crop_bbox[3] - crop_bbox[1]), int(crop_bbox[2] - crop_bbox[0]))
-            cur_h, cur_w = window[2], window[3]
-            assert cur_h == h_out and cur_w == w_out
-            if with_bbox:
-                gt_bbox = gt_bbox - numpy.array([offset[0], offset[1], offset[0], offset[1]])
-        if with_bbox:
-            gt_bbox[0::2] = numpy.clip(gt_bbox[0::2], 0, cur_w - 1)
-            gt_bbox[1::2] = numpy.clip(gt_bbox[1::2], 0, cur_h - 1)
-            assert gt_bbox[0] >= 0 and gt_bbox[1] >= 0 and gt_bbox[2] <= cur_w and gt_bbox[3] <= cur_h
-            results["gt_bbox"] = gt_bbox
-        img = ops.resize_u8(img, (new_h, new_w), window)   # rescale (+ crop) in one pass
-        results["img"] = img
-        results["img_shape"] = _shape(img)
-        results["pad_shape"] = _shape(img)
-        results["scale_factor"] = numpy.array([cur_w / w, cur_h / h, cur_w / w, cur_h / h])
-        results["keep_ratio"] = True
+            hit, top, runner_up, last_offset = self._search_window(new_w - w_out, new_h - h_out, w_out, h_out, boxes)
+            if hit is None and top < self.min_iou_thr:         # no acceptable window: the sample passes through untouched
+                results.update(img_shape=(new_h, new_w, channels), pad_shape=(new_h, new_w, channels),
+                               scale_factor=numpy.array([1.0, 1.0, 1.0, 1.0]), keep_ratio=True)
+                return results
+            x0, y0, x1, y1 = [int(v) for v in (hit if hit is not None else runner_up).astype(numpy.uint32)]
+            window, out_w, out_h = (y0, x0, y1 - y0, x1 - x0), x1 - x0, y1 - y0
+            assert (out_h, out_w) == (h_out, w_out)
+            if boxes is not None:      # shifted by the LAST offset drawn, also when an earlier window is used (reference quirk)
+                boxes = boxes - numpy.array([last_offset[0], last_offset[1], last_offset[0], last_offset[1]])
+        if boxes is not None:
+            boxes[0::2] = numpy.clip(boxes[0::2], 0, out_w - 1)
+            boxes[1::2] = numpy.clip(boxes[1::2], 0, out_h - 1)
+            assert boxes[0] >= 0 and boxes[1] >= 0 and boxes[2] <= out_w and boxes[3] <= out_h
+            results["gt_bbox"] = boxes
+        img = ops.resize_u8(img, (new_h, new_w), window)       # rescale (+ crop) in one pass over the source image
+        results.update(img=img, img_shape=_shape(img), pad_shape=_shape(img), keep_ratio=True,
+                       scale_factor=numpy.array([out_w / w, out_h / h, out_w / w, out_h / h]))
         return results
 
 

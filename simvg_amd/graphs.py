@@ -20,8 +20,8 @@ What makes the capture legal:
 A signature = (shapes, dtypes, per-image `img_shape`s, train/eval mode).  Anything else (first steps, a ragged last
 batch, GRefCOCO-style variable metas) runs eagerly; a failed capture disables the feature with a warning.
 
-Stream rule: the training step must run on a NON-default HIP stream (`with torch.cuda.stream(simvg_amd.graphs.
-train_stream()):` -- bench.py, `train_model` and the tests do).  The autograd engine waits, at the end of every backward,
+Stream rule: the training step must run on a NON-default HIP stream (`with simvg_amd.graphs.training_stream():`
+-- bench.py, `train_model` and the tests do).  The autograd engine waits, at the end of every backward,
 on the stream each parameter's gradient accumulator was created on; accumulators created by an eager step on the legacy
 default stream make the captured backward touch that stream, which is illegal during a global capture (this HIP runtime
 dies in hipStreamEndCapture instead of reporting it).  A model that has ever run a training forward on the default
@@ -46,6 +46,27 @@ def train_stream(device=None):
         s = torch.cuda.Stream(device=device)
         _train_streams[device.index] = s
     return s
+
+
+class training_stream:
+    """`with training_stream(device):` -- make the training stream current, ORDERED against the caller's stream on both
+    sides: the side stream first waits for whatever the caller already queued (model.to(device), checkpoint loads, input
+    copies), and on exit the caller's stream waits for the steps (so a following evaluation or save sees them)."""
+
+    def __init__(self, device=None):
+        self.side = train_stream(device)
+        self.outer = torch.cuda.current_stream(self.side.device)
+        self._ctx = torch.cuda.stream(self.side)
+
+    def __enter__(self):
+        self.side.wait_stream(self.outer)
+        self._ctx.__enter__()
+        return self.side
+
+    def __exit__(self, *exc):
+        self._ctx.__exit__(*exc)
+        self.outer.wait_stream(self.side)
+        return False
 
 
 class _HeadStep(torch.nn.Module):

@@ -485,11 +485,17 @@ def linear_f32(x, W, b=None, out=None, act=0, accumulate=False):
     return out
 
 
+_sumsq_ws = {}
+
+
 def sumsq_accum(x, out):
-    """out[0] += sum(x^2) over a contiguous fp32 tensor (numel % 4 == 0)."""
+    """out[0] += sum(x^2) over a contiguous fp32 tensor (numel % 4 == 0); deterministic (fixed-order partial sums)."""
     lib = _lib.load()
     _chk(x, torch.float32, "x")
-    _lib.check(lib.simvg_sumsq(_p(x), x.numel(), _p(out), _stream()), "simvg_sumsq")
+    ws = _sumsq_ws.get(x.device)
+    if ws is None:
+        ws = _sumsq_ws[x.device] = torch.empty(2048, device=x.device, dtype=torch.float32)
+    _lib.check(lib.simvg_sumsq(_p(x), x.numel(), _p(out), _p(ws), _stream()), "simvg_sumsq")
     return out
 
 

@@ -43,6 +43,13 @@ class KeptInstances(Sequence):
     def __getitem__(self, i):
         return self._materialise()[i]
 
+    def host_arrays(self):
+        """per image (scores float64 [k_b], boxes float32 [k_b, 4]) as numpy -- the kept counts differ between images, so
+        the padded rows and the counts cross to the host in ONE copy each and are cut there (the GRefCOCO metric's input)"""
+        counts = self._kept.tolist()
+        scores, boxes = self._scores.detach().double().cpu().numpy(), self._xyxy.detach().float().cpu().numpy()
+        return [(scores[b, :c], boxes[b, :c]) for b, c in enumerate(counts)]
+
 
 class KeptLabels:
     """`predict_classes` for num_queries > 1: the classes of ALL kept queries of the batch, concatenated

@@ -51,12 +51,12 @@ def _worker(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     from simvg_amd.dist import GradReducer
-    from simvg_amd.graphs import train_stream
+    from simvg_amd.graphs import training_stream
     cfg, model, _batch = _setup()
     red = GradReducer(model)
     full = _batch(cfg, B=4, seed=31)
     half = {k: (v[2 * rank: 2 * rank + 2] if torch.is_tensor(v) or isinstance(v, list) else v) for k, v in full.items()}
-    with torch.cuda.stream(train_stream()):
+    with training_stream():
         losses = _run(model, half)
         red.begin()
         losses["loss_total"].backward()
@@ -78,10 +78,10 @@ def test_two_ranks_average_to_the_single_process_gradient_on_the_global_batch():
     for n in g0:                                   # both replicas hold the same averaged gradient
         assert torch.equal(g0[n], g1[n]), n
     # single process, global batch
-    from simvg_amd.graphs import train_stream
+    from simvg_amd.graphs import training_stream
     cfg, model, _batch = _setup()
     full = _batch(cfg, B=4, seed=31)
-    with torch.cuda.stream(train_stream()):
+    with training_stream():
         losses = _run(model, full)
         losses["loss_total"].backward()
         torch.cuda.synchronize()

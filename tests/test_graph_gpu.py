@@ -28,6 +28,7 @@ def test_graphed_head_equals_eager_over_several_steps():
     _no_dropout(model)
     model.train()
     used_graph = []
+    train_stream().wait_stream(torch.cuda.current_stream())     # model.to(device) was queued on the caller's stream
     torch.cuda.set_stream(train_stream())          # the stream rule of simvg_amd/graphs.py
     try:
         for step in range(7):
@@ -72,6 +73,7 @@ def test_graphed_head_draws_fresh_dropout_masks_and_falls_back_on_new_shapes():
     batch = _batch(cfg, B=4, seed=1)
     vals = []
     from simvg_amd.graphs import train_stream
+    train_stream().wait_stream(torch.cuda.current_stream())
     torch.cuda.set_stream(train_stream())
     for _ in range(7):
         model.zero_grad(set_to_none=True)

@@ -142,7 +142,7 @@ def test_training_overfits_a_fixed_batch(head_graph):
     Det@0.5 0 % -> >= 87.5 %."""
     from simvg_amd.core import build_optimizer
     from simvg_amd.apis import accuracy
-    from simvg_amd.graphs import train_stream
+    from simvg_amd.graphs import training_stream
     cfg, model = _tiny_model(0)
     model.vis_enc.drop_path_probs = [0.0] * model.vis_enc.L
     model.head_graph = head_graph
@@ -153,7 +153,7 @@ def test_training_overfits_a_fixed_batch(head_graph):
               {"params": [p for n, p in named if "vis_enc" not in n], "lr": 5e-4}]
     opt = build_optimizer(dict(type="Adam", lr=5e-4, betas=(0.9, 0.98), eps=1e-9, weight_decay=0, amsgrad=True), groups, model=model)
     first = last = None
-    with torch.cuda.stream(train_stream()):
+    with training_stream():
         for step in range(220):
             losses, preds = model(**batch, rescale=False)
             opt.zero_grad()
