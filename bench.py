@@ -10,12 +10,25 @@ resident in HBM: forward_train (encoder + head + on-device matcher/criterion) ->
 all-reduce of the gradient arenas when N > 1) -> global-norm clip 0.15 -> Adam(amsgrad) -> bf16 weight refresh.
 Nothing is skipped inside the timed region.  Prints ONE JSON line on rank 0.
 
+The timed steps rotate through `--batches` (default 8) distinct synthetic batches (different images, expressions,
+token ids and boxes), so the embedding rows touched -- and with them the Adam kernel's untouched-row skip -- and the
+cache contents change from step to step as they do in training.
+
 Extra objects in the line:
-  roofline     : the dominant kernel (bf16 MFMA GEMM `gemm_nt_kernel`): algorithmic FLOPs of its launches divided by
-                 their HIP-event-measured durations (events recorded on the launch stream during the timed steps; every
-                 launch of every `--roofline-every`-th step, default 4: an event pair costs the stream ~6 us).
-  cpu_baseline : the CPU oracle (oracle/simvg_cpu.py, a restatement pinned to the reference) timed on the host
-                 cores of the same box on a bounded sample (rank 0, N == 1 only).
+  roofline      : the dominant kernel (16-bit MFMA GEMM `gemm_nt_kernel_*`): algorithmic FLOPs of its launches divided by
+                  their HIP-event-measured durations (events recorded on the launch stream during the timed steps; every
+                  launch of every `--roofline-every`-th step, default 4: an event pair costs the stream ~6 us).
+                  `traffic` is the PMC figure of profiles/gemm_nt_hbm_traffic.json, reported only while the kernel source
+                  it was measured on (sha256 of csrc/gemm.hip) is the one this library was built from; otherwise null.
+  roofline_attn : SURVEY section 8(d) metric (ii): the encoder self-attention kernels (QK^T + softmax + PV) in isolation --
+                  back-to-back launches on the bench geometry (B x heads x 421 tokens x 64) between two HIP events -- and the
+                  same kernels in situ (HIP-event brackets inside the timed steps).  Algorithmic FLOPs (N = 421) beside the
+                  tile-padded FLOPs the MFMA pipe actually executes (N rounded up to the 64-row tile).
+  ms_per_step_p50: median of the per-step times (one HIP event per step boundary on the training stream).
+  cpu_baseline  : the CPU oracle (oracle/simvg_cpu.py, a restatement pinned to the reference) timed on the host
+                  cores of the same box on a bounded sample (rank 0, N == 1 only): one training step at B = 8 and
+                  `forward_test` at B = 1 and B = 8 (the protocol of the reference's tools/misc/inference_time.py:68-75:
+                  warm-up, then the mean over repeated calls).
 """
 import argparse
 import json
@@ -68,11 +81,13 @@ def synthetic_batch(B, seed, device):
 
 
 def cpu_baseline(batch_size=8, max_threads=32):
-    """The oracle's training step (forward_train + backward + clip + Adam amsgrad) on the host cores.
+    """The oracle's training step (forward_train + backward + clip + Adam amsgrad) and its forward_test on the host cores.
     Bounded sample: the thread count is capped (eager PyTorch on hundreds of threads is slower, not faster, for the
-    ~1400 small ops of this model -- measured 678 s/step with 256 threads) and one B=8 step is timed (a few seconds)."""
+    ~1400 small ops of this model -- measured 678 s/step with 256 threads); one B=8 training step and a few forward_test
+    calls at B=1 / B=8 are timed (a few seconds each)."""
     from oracle import simvg_cpu as O, weights as W
-    torch.set_num_threads(max(1, min(os.cpu_count() or 1, max_threads)))
+    host_cores = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(host_cores, max_threads)))
     cfg = O.make_cfg("base", 1, 640)
     sd = W.reference_init_state_dict(cfg, 1)
     params = {k: v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "empty_weight" not in k}
@@ -91,8 +106,78 @@ def cpu_baseline(batch_size=8, max_threads=32):
     t0 = time.perf_counter()
     step(batch_size, 1)
     dt = time.perf_counter() - t0
-    return dict(value=round(batch_size / dt, 4), unit="pairs/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"1 training step (fwd+bwd+clip+Adam amsgrad), ViT-B/32 @640, B={batch_size}, fp32, {dt:.1f} s")
+
+    def infer(B, reps):           # tools/misc/inference_time.py:68-75: eval mode, warm-up, mean over repeated forward_test
+        b = W.synthetic_batch(cfg, B, 7)
+        with torch.no_grad():
+            O.forward_test(sd, cfg, b["img"], b["ref_expr_inds"], b["img_metas"], b["text_attention_mask"])
+            t = time.perf_counter()
+            for _ in range(reps):
+                O.forward_test(sd, cfg, b["img"], b["ref_expr_inds"], b["img_metas"], b["text_attention_mask"])
+            return (time.perf_counter() - t) / reps
+
+    t1, t8 = infer(1, 5), infer(8, 2)
+    return dict(value=round(batch_size / dt, 4), unit="pairs/s", cores=torch.get_num_threads(), host_cores=host_cores,
+                kind="port",
+                sample=f"1 training step (fwd+bwd+clip+Adam amsgrad), ViT-B/32 @640, B={batch_size}, fp32, {dt:.1f} s",
+                forward_test_b1=dict(value=round(1 / t1, 3), unit="pairs/s", ms_per_call=round(t1 * 1e3, 1),
+                                     sample="mean of 5 forward_test calls after 1 warm-up, B=1, fp32"),
+                forward_test_b8=dict(value=round(8 / t8, 3), unit="pairs/s", ms_per_call=round(t8 * 1e3, 1),
+                                     sample="mean of 2 forward_test calls after 1 warm-up, B=8, fp32"))
+
+
+def attention_roofline(B, H, Nv, T, hd, device, reps=50):
+    """Encoder self-attention kernels alone: `reps` back-to-back launches between two HIP events (after 5 warm-up
+    launches) on random q/k/v of the bench geometry, key padding as in the synthetic batches."""
+    from simvg_amd import hip_ops as ops
+    N, D = Nv + T, H * hd
+    g = torch.Generator(device="cpu").manual_seed(5)
+    qkv = (torch.randn(B * N, 3 * D, generator=g) * 0.5).to(device).to(ops.LP())
+    dout = (torch.randn(B * N, D, generator=g) * 0.1).to(device).to(ops.LP())
+    pad = torch.zeros(B, T, dtype=torch.uint8)
+    for b in range(B):
+        pad[b, 3 + int(torch.randint(2, 11, (1,), generator=g)):] = 1
+    pad = pad.to(device)
+    out, lse = ops.attn_fwd(qkv, B, H, Nv, T, pad=pad)
+    dqkv = torch.empty_like(qkv)
+
+    def timed(fn):
+        for _ in range(5):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+
+    tf = timed(lambda: ops.attn_fwd(qkv, B, H, Nv, T, pad=pad, out=out))
+    tb = timed(lambda: ops.attn_bwd(qkv, out, dout, lse, B, H, Nv, T, pad=pad, dqkv=dqkv))
+    Np = (N + 63) // 64 * 64
+    fl = lambda n, gemms: 2.0 * gemms * B * H * n * n * hd       # fwd: QK^T, PV; bwd: S, dP, dV, dQ, dK
+    return dict(fwd_us=tf * 1e6, bwd_us=tb * 1e6, fwd_tf=fl(N, 2) / tf / 1e12, bwd_tf=fl(N, 5) / tb / 1e12,
+                fwd_tf_padded=fl(Np, 2) / tf / 1e12, bwd_tf_padded=fl(Np, 5) / tb / 1e12, N=N, Np=Np)
+
+
+def traffic_stamp():
+    """profiles/gemm_nt_hbm_traffic.json -> (bytes per launch | None, provenance).  The PMC pass cannot run inside this
+    process (rocprofv3 wraps it), so the committed figure is reported only while it describes the kernels that are
+    running: the JSON records the sha256 of csrc/gemm.hip it was measured on."""
+    import hashlib
+    tfile = os.path.join(ROOT, "profiles", "gemm_nt_hbm_traffic.json")
+    src = os.path.join(ROOT, "simvg_amd", "csrc", "gemm.hip")
+    try:
+        j = json.load(open(tfile))
+        sha = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
+    except Exception as e:
+        return None, {"stale": True, "why": repr(e)}
+    prov = {"file": "profiles/gemm_nt_hbm_traffic.json", "measured": j.get("measured"), "commit": j.get("commit"),
+            "gemm_hip_sha256": j.get("gemm_hip_sha256")}
+    if j.get("gemm_hip_sha256") != sha:
+        prov.update(stale=True, why=f"csrc/gemm.hip is now {sha}: re-run tools/dev/pmc_bench.sh")
+        return None, prov
+    return j.get("hbm_bytes_per_launch"), prov
 
 
 def main():
@@ -103,6 +188,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE: 64)")
     ap.add_argument("--vit", choices=["base", "large"], default="base", help="encoder size (BASELINE metric: base)")
     ap.add_argument("--queries", type=int, default=1, help="num_queries (GRefCOCO configs: 10)")
+    ap.add_argument("--batches", type=int, default=8, help="distinct synthetic batches the steps rotate through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="per-op HIP-event breakdown on stderr")
     ap.add_argument("--roofline-every", type=int, default=4,
@@ -132,7 +218,9 @@ def main():
         for p in model.parameters():
             dist.broadcast(p.data, 0)
     B = a.batch
-    batch = synthetic_batch(B, 1000 + rank, device)
+    batches = [synthetic_batch(B, 1000 + 64 * rank + i, device) for i in range(max(1, a.batches))]
+    batch = batches[0]
+    counter = [0]
     model.vis_enc._ensure_engine(device)
     # the reference's optimizer construction (tools/train.py:78-96 + configs: Adam amsgrad, lr 5e-4, vis_enc lr/10)
     named = list(model.named_parameters())
@@ -145,6 +233,8 @@ def main():
     reducer = GradReducer(model)
 
     def step():
+        batch = batches[counter[0] % len(batches)]
+        counter[0] += 1
         losses, _ = model(batch["img"], batch["ref_expr_inds"], batch["img_metas"], return_loss=True,
                           text_attention_mask=batch["text_attention_mask"], gt_bbox=batch["gt_bbox"], rescale=False)
         opt.zero_grad()
@@ -172,16 +262,19 @@ def main():
         opt.zero_grad()
         for _ in range(a.warmup):
             step()
-        timer = hip_ops.KernelTimer(only=None if a.breakdown else {"gemm_nt"}) if rank == 0 else None
+        timer = hip_ops.KernelTimer(only=None if a.breakdown else {"gemm_nt", "attn_fwd", "attn_bwd"}) if rank == 0 else None
         every = 1 if a.breakdown else max(1, a.roofline_every)
         sampled_steps = len(range(0, a.steps, every))
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(a.steps):
+            marks[i].record()
             hip_ops.set_timer(timer if i % every == 0 else None)
             losses = step()
+        marks[a.steps].record()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -192,6 +285,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     loss_val = float(losses["loss_total"].detach())
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
+    p50 = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
     if rank != 0:
         if use_dist:
             dist.destroy_process_group()
@@ -207,33 +302,44 @@ def main():
             for f in g:
                 g[f] += d[f]
     ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "gemm_nt_hbm_traffic.json")
-    if os.path.exists(tfile):
-        try:
-            traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    traffic, traffic_src = traffic_stamp()
+    H, hd = (12, 64) if a.vit == "base" else (16, 64)
+    Nv_tok, T_tok = (640 // 32) ** 2 + 1, 20
+    with training_stream(device):
+        iso = attention_roofline(B, H, Nv_tok, T_tok, hd, device)
+    situ = {k: summ[k] for k in ("attn_fwd", "attn_bwd") if k in summ}
     out = {
         "metric": "image-text pairs/sec (whole node), RefCOCO 640x640 bs=64/GPU, 1/2/4/8 MI355X",
         "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(dt / a.steps * 1e3, 3), "ms_per_step_p50": round(p50, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": _lowp, "data": "synthetic",
         "config": {"workload": f"ViT-{'B' if a.vit == 'base' else 'L'}/32 SimVG (MIXDETRMB), synthetic RefCOCO 640x640 + 20-token expr, num_queries={a.queries}, "
                                f"full training step: forward+backward {_lowp} MFMA operands (fp32 accumulate, fp32 residual/master), "
                                "DropPath+dropout on, clip 0.15, Adam(amsgrad)",
-                   "global_batch": world * B, "per_gpu_batch": B, "tokens_per_pair": 421,
+                   "global_batch": world * B, "per_gpu_batch": B, "tokens_per_pair": 421, "distinct_batches": len(batches),
                    "parallelism": f"dp{world}", "loss_total": round(loss_val, 4)},
         "model_tflops_per_gpu": round(value / world * FLOP_PER_PAIR_FWD_BWD[a.vit] / 1e12, 2),
         "model_mfma_frac": round(value / world * FLOP_PER_PAIR_FWD_BWD[a.vit] / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
-        "roofline": {"kernel": "gemm_nt (bf16 MFMA 16x16x32; every launch: 16-wave 256x256x64 tiles for N >= 2304, 16-wave "
-                               "160x256x64 for N = 768, global_load_lds double buffer, LDS-staged coalesced epilogue)", "bound": "mfma",
+        "roofline": {"kernel": f"gemm_nt ({_lowp} MFMA 16x16x32, fp32 accumulate; every launch: 16-wave 256x256x64 tiles for N >= 2304, "
+                               "16-wave 160x256x64 for N = 768, global_load_lds double buffer, LDS-staged coalesced epilogue)", "bound": "mfma",
                      "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
+                     "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": round(g["bytes"] / g["calls"]),
                      "launches": g["calls"], "avg_launch_us": round(g["ms"] / g["calls"] * 1e3, 2),
                      "timed_steps": sampled_steps,
                      "share_of_step": round(g["ms"] / (dt * 1e3 * sampled_steps / a.steps), 4)},
+    }
+    out["roofline_attn"] = {
+        "kernel": f"encoder self-attention (QK^T + key-padding softmax + PV; {_lowp} MFMA 16x16x32), B={B} x {H} heads x {iso['N']} tokens x {hd}",
+        "bound": "mfma", "achieved": round(iso["fwd_tf"], 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(iso["fwd_tf"] / MFMA_BF16_PEAK_TFLOPS, 4),
+        "isolated": {"fwd_us": round(iso["fwd_us"], 2), "bwd_us": round(iso["bwd_us"], 2),
+                     "fwd_tflops": round(iso["fwd_tf"], 2), "bwd_tflops": round(iso["bwd_tf"], 2),
+                     "fwd_tflops_tile_padded": round(iso["fwd_tf_padded"], 2), "bwd_tflops_tile_padded": round(iso["bwd_tf_padded"], 2),
+                     "bwd_frac": round(iso["bwd_tf"] / MFMA_BF16_PEAK_TFLOPS, 4), "padded_tokens": iso["Np"],
+                     "method": "50 back-to-back launches between two HIP events after 5 warm-up launches"},
+        "in_situ": {k: {"avg_launch_us": round(d["ms"] / d["calls"] * 1e3, 2), "launches": d["calls"],
+                        "tflops": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 2)} for k, d in situ.items()},
     }
     if a.breakdown:
         tot = dt * 1e3

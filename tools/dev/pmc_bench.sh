@@ -14,7 +14,9 @@ for cname in ["FETCH_SIZE", "WRITE_SIZE"]:
     agg = collections.defaultdict(lambda: [0.0, set()])
     for r in csv.DictReader(open(f[0])):
         k = r["Kernel_Name"]
-        key = "gemm_nt" if "gemm_nt_kernel" in k else ("gemm_tn" if "gemm_tn_kernel" in k else None)   # all variants of each
+        key = ("gemm_nt" if "gemm_nt_kernel" in k else "wgrad_x" if "wgrad_x_kernel" in k else
+               "gemm_tn" if "gemm_tn_kernel" in k else "attn_fwd" if "attn_fwd_kernel" in k else
+               "attn_bwd" if "attn_bwd" in k else None)   # all variants of each
         if key is None or r["Counter_Name"] != cname: continue
         agg[key][0] += float(r["Counter_Value"]); agg[key][1].add(r["Dispatch_Id"])
     res[cname] = {k: (v[0], len(v[1])) for k, v in agg.items()}
@@ -25,6 +27,9 @@ for k in res["FETCH_SIZE"]:
     # counters are in KiB; gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM)
     out[k] = dict(launches=n, fetch_KiB_raw_per_launch=fs / n, write_KiB_per_launch=ws / max(n2, 1),
                   hbm_bytes_per_launch=(2.0 * fs / n + ws / max(n2, 1)) * 1024.0)
+import hashlib, time
+out["gemm_hip_sha256"] = hashlib.sha256(open("simvg_amd/csrc/gemm.hip", "rb").read()).hexdigest()[:16]
+out["measured"] = time.strftime("%Y-%m-%dT%H:%MZ", time.gmtime())
 json.dump(out, open("gpurun_out/pmc/hbm_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY
