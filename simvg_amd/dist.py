@@ -6,6 +6,12 @@ SURVEY.md 2.4).  MI355X-first: gradients already live in flat fp32 arenas, so th
 contiguous all-reduces -- one per encoder layer, issued asynchronously from inside the hand-sequenced backward the
 moment that layer's wgrads are written (overlapping the remaining backward), then one for the embeddings and one
 for the head.  No per-tensor buckets, no unused-parameter search.
+
+Message format: fp32 by default (the reference's DDP arithmetic).  `GradReducer(model, message_dtype="bf16")` (or
+SIMVG_GRAD_MESSAGE=bf16) halves the bytes on xGMI: every message is rounded to bf16 (fp32's exponent range: no scaling
+needed), averaged in bf16 by RCCL and written back into the fp32 gradient arena, which stays the master copy (the clip
+norm and Adam run on fp32 as before).  Off by default: it changes the arithmetic (8 significand bits per addend) and the
+fp32 exchange already hides under the backward on one node.
 """
 import os
 
@@ -14,12 +20,17 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, model, bucket_bytes=None):
+    def __init__(self, model, message_dtype=None):
         self.model = model
+        message_dtype = message_dtype or os.environ.get("SIMVG_GRAD_MESSAGE") or None
+        if message_dtype not in (None, "fp32", "bf16"):
+            raise ValueError(f"message_dtype must be None / 'fp32' / 'bf16', got {message_dtype!r}")
+        self.message_dtype = torch.bfloat16 if message_dtype == "bf16" else None
+        self._lowp = []             # (fp32 destination, 16-bit message) pairs of the step in flight
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         # SIMVG_FORCE_REDUCE=1 exercises the exchange even with a single rank (all-reduce over 1 rank == identity)
         self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("SIMVG_FORCE_REDUCE") == "1")
-        self.pending, self._scale, self._head = [], [], None
+        self.pending, self._scale, self._head, self._lowp = [], [], None, []
         self._all_ids, self._ids_done, self._text_rows = None, False, None
         self.last_sparse_rows = 0
         self.last_late = 0          # head gradients that missed the early message in the last step (diagnostic)
@@ -94,6 +105,10 @@ class GradReducer:
     def _launch(self, t):
         if t.numel():
             op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+            if self.message_dtype is not None:
+                msg = t.to(self.message_dtype)
+                self._lowp.append((t, msg))
+                t = msg
             self.pending.append(dist.all_reduce(t, op=op, async_op=True))
             if not self._avg:
                 self._scale.append(t)
@@ -110,7 +125,7 @@ class GradReducer:
         self._launch(flat)
 
     def begin(self):
-        self.pending, self._scale, self._head = [], [], None
+        self.pending, self._scale, self._head, self._lowp = [], [], None, []
         self._all_ids, self._ids_done, self._text_rows = None, False, None
 
     def finish(self):
@@ -133,6 +148,8 @@ class GradReducer:
             w.wait()
         for t in self._scale:
             t.div_(self.world)
+        for dst, msg in self._lowp:          # 16-bit messages: back into the fp32 master gradients
+            dst.copy_(msg)
         grads, flat = self._head
         if grads:
             torch._foreach_copy_(grads, [v.view_as(g) for g, v in zip(grads, flat.split([g.numel() for g in grads]))])
@@ -141,5 +158,5 @@ class GradReducer:
         if self._text_rows is not None:
             table, ids, rows = self._text_rows
             table.index_copy_(0, ids, rows)
-        self.pending, self._scale, self._head = [], [], None
+        self.pending, self._scale, self._head, self._lowp = [], [], None, []
         self._all_ids, self._ids_done, self._text_rows = None, False, None

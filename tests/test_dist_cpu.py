@@ -45,20 +45,30 @@ class _FakeModel(torch.nn.Module):
         self.head = torch.nn.Linear(8, 2)
 
 
-def _worker(rank, world, port, out):
+def _rank_ids(rank, g, uneven):
+    """token ids of one rank's 2 x 4 batch.  `uneven`: ranks touch very different SETS of rows -- rank 0 one row only
+    (all positions the same token), rank 1 two rows shared with rank 2, rank 3 eight distinct rows -- so duplicates inside
+    a rank, overlaps between ranks and rows nobody touches all occur."""
+    if not uneven:
+        return torch.randint(0, 50, (2, 4), generator=g)
+    return [torch.full((2, 4), 7), torch.tensor([[3, 9, 3, 9], [9, 9, 3, 3]]), torch.tensor([[9, 3, 11, 12], [13, 3, 9, 7]]),
+            torch.arange(20, 28).reshape(2, 4)][rank % 4]
+
+
+def _worker(rank, world, port, out, uneven=False, message=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from simvg_amd.dist import GradReducer
     torch.manual_seed(0)
     model = _FakeModel()
-    red = GradReducer(model)
+    red = GradReducer(model, message_dtype=message)
     A = model.vis_enc._arena
     g = torch.Generator().manual_seed(100 + rank)
     red.begin()
     A.begin_backward()
     A.flat_grad.copy_(torch.randn(A.total, generator=g))          # this rank's local gradients
     # text table: rows of THIS rank's tokens carry gradient, every other row is exactly zero (as embed_bwd leaves it)
-    ids = torch.randint(0, 50, (2, 4), generator=g)
+    ids = _rank_ids(rank, g, uneven)
     model.vis_enc._last_ids = ids
     tg = A.grad("beit3.text_embed.weight")
     keep = torch.zeros(50, dtype=torch.bool)
@@ -78,10 +88,22 @@ def _worker(rank, world, port, out):
     exp_flat = sum(x[0] for x in gathered) / world
     exp_w = sum(x[1] for x in gathered) / world
     exp_b = sum(x[2] for x in gathered) / world
-    ok = (torch.allclose(A.flat_grad, exp_flat, atol=1e-6) and torch.allclose(model.head.weight.grad, exp_w, atol=1e-6)
-          and torch.allclose(model.head.bias.grad, exp_b, atol=1e-6)
+    # fp32 messages: the mean up to summation order; bf16 messages: every addend and the result rounded to 8 bits
+    tol = dict(atol=1e-6) if message is None else dict(atol=4e-2, rtol=2e-2)
+    ok = (torch.allclose(A.flat_grad, exp_flat, **tol) and torch.allclose(model.head.weight.grad, exp_w, **tol)
+          and torch.allclose(model.head.bias.grad, exp_b, **tol)
           and all(torch.equal(p.grad, A.grad(n)) for n, p in A.params.items()))
-    out[rank] = bool(ok) and red.last_sparse_rows == 2 * 8       # the text table went as 2 ranks x 8 token rows
+    # rows of the text table no rank touched stay exactly zero (they are never exchanged)
+    touched = torch.zeros(50, dtype=torch.bool)
+    all_ids = [None] * world
+    dist.all_gather_object(all_ids, ids)
+    for t in all_ids:
+        touched[t.reshape(-1)] = True
+    ok = ok and bool((A.grad("beit3.text_embed.weight")[~touched] == 0).all())
+    flats = [None] * world
+    dist.all_gather_object(flats, A.flat_grad.clone())
+    ok = ok and all(torch.equal(flats[0], f) for f in flats)       # replicas end bit-identical
+    out[rank] = bool(ok) and red.last_sparse_rows == world * 8     # the text table went as `world` x 8 token rows
     dist.destroy_process_group()
 
 
@@ -90,6 +112,20 @@ def test_grad_reducer_world2_gloo():
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}
+
+
+def test_grad_reducer_world4_uneven_token_sets():
+    world = 4
+    out = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, _free_port(), out, True), nprocs=world, join=True)
+    assert dict(out) == {r: True for r in range(world)}
+
+
+def test_grad_reducer_bf16_message_keeps_fp32_master():
+    world = 2
+    out = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, _free_port(), out, True, "bf16"), nprocs=world, join=True)
     assert dict(out) == {0: True, 1: True}
 
 
