@@ -177,6 +177,136 @@ __global__ __launch_bounds__(768) void attn_fwd_kernel(AttnArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// forward, compile-time geometry.  NKT key tiles of 16 (N in (16 NKT - 16, 16 NKT]); the first KFULL tiles hold vision
+// keys only (never masked), so the -inf key bias is applied to the last NKT - KFULL tiles alone.  Differences to the
+// generic kernel above, all aimed at the VALU / scalar work that bounded it (per 16-query strip: 128 v_med3 saturation
+// clamps, 96 v_cndmask + ~70 scalar branches of the run-time tile guards, 125 SGPR spill moves, 112 row-sum adds):
+//   * no run-time tile guards (every loop bound is a constant);
+//   * exp2(s * c - max * c) is ONE fma + v_exp per score (the scale is folded into the subtraction, the running maximum is
+//     taken over the raw accumulators);
+//   * the row sum comes out of the MFMA pipe: one extra MFMA per 32 keys with an all-ones A operand (the sum of the SAME
+//     16-bit-rounded probabilities the PV product uses), no VALU adds, no shuffles;
+//   * probabilities are packed without the +-65504 clamp (they are in [0, 1]);
+//   * PV MFMAs of key pair s2 are issued right after its 8 exponentials, so the matrix pipe works under the next pair's
+//     transcendental VALU instead of after all of it.
+// ------------------------------------------------------------------------------------------
+template <int NKT, int KFULL, int NTHREADS, int G = 2>
+__global__ __launch_bounds__(NTHREADS) void attn_fwd_t_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NS2 = (NKT + 1) / 2, NPAD = NS2 * 32;
+  const int N = a.Nv + a.Nt;
+  char* ldsK = smem;
+  char* ldsV = smem + NPAD * ROWB;
+  float* bias = (float*)(smem + 2 * NPAD * ROWB);
+  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+
+  load_head_to_lds(a, a.qkv, a.ld, a.D + h * HD, b, N, NPAD, ldsK);
+  load_head_to_lds(a, a.qkv, a.ld, 2 * a.D + h * HD, b, N, NPAD, ldsV);
+  fill_key_bias(a, b, N, NPAD, bias);
+  __syncthreads();
+
+  const float sc2 = a.scale * 1.44269504088896340736f;
+  const unsigned int one2 = pack_lp2_raw(1.f, 1.f);
+  union { lpx8_t v; unsigned int u[4]; } ones;
+  ones.u[0] = ones.u[1] = ones.u[2] = ones.u[3] = one2;
+
+  for (int qb = wave; qb < NKT; qb += nwaves) {
+    const int tq = qb * 16 + j;
+    const lp_t* qp = a.qkv + tok_row(a, b, tq < N ? tq : N - 1) * a.ld + h * HD + 8 * g;
+    const lpx8_t q0 = *(const lpx8_t*)qp, q1 = *(const lpx8_t*)(qp + 32);
+    f32x4_t s[2 * NS2];
+    float mx = -INFINITY;
+    // K fragments one GROUP of G tiles ahead of their MFMAs (an LDS read takes ~100+ cycles to land, two MFMAs only ~35:
+    // one tile ahead left every iteration waiting); within a group the first halves of all tiles are issued before the
+    // second halves, so no MFMA follows the one that produces its accumulator.  The scheduling fences keep hipcc from
+    // hoisting every LDS read of the unrolled loop to the top (it did: 200 spilled dwords).
+    constexpr int NG = (NKT + G - 1) / G;
+    lpx8_t kn[G][2];
+#pragma unroll
+    for (int t = 0; t < G; ++t) { kn[t][0] = lds_frag(ldsK, t * 16 + j, g); kn[t][1] = lds_frag(ldsK, t * 16 + j, 4 + g); }
+#pragma unroll
+    for (int grp = 0; grp < NG; ++grp) {
+      lpx8_t kc[G][2];
+#pragma unroll
+      for (int t = 0; t < G; ++t) {
+        kc[t][0] = kn[t][0]; kc[t][1] = kn[t][1];
+        const int kt = (grp + 1) * G + t;
+        if (kt < NKT) { kn[t][0] = lds_frag(ldsK, kt * 16 + j, g); kn[t][1] = lds_frag(ldsK, kt * 16 + j, 4 + g); }
+      }
+      f32x4_t acc[G];
+#pragma unroll
+      for (int t = 0; t < G; ++t)
+        if (grp * G + t < NKT) acc[t] = mfma_lp(kc[t][0], q0, (f32x4_t){0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+      for (int t = 0; t < G; ++t)
+        if (grp * G + t < NKT) acc[t] = mfma_lp(kc[t][1], q1, acc[t]);
+#pragma unroll
+      for (int t = 0; t < G; ++t) {
+        const int kt = grp * G + t;
+        if (kt < NKT) {
+          if (kt >= KFULL) {
+            const f32x4_t kb = *(const f32x4_t*)(bias + kt * 16 + 4 * g);     // 0 or -inf
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[t][r] += kb[r];
+          }
+          mx = fmaxf(fmaxf(mx, acc[t][0]), fmaxf(acc[t][1], fmaxf(acc[t][2], acc[t][3])));
+          s[kt] = acc[t];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mxs = mx * sc2;          // sc2 > 0: max(s) * c == max(s * c)
+    f32x4_t o[4], rs = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    lpx8_t vn[4];                                 // V^T fragments one key pair ahead of their MFMAs
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) vn[dt] = lds_frag_tr(ldsV, 0, 16, dt * 16, lane);
+#pragma unroll
+    for (int s2 = 0; s2 < NS2; ++s2) {
+      lpx8_t vc[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        vc[dt] = vn[dt];
+        if (s2 + 1 < NS2) vn[dt] = lds_frag_tr(ldsV, (s2 + 1) * 32, (s2 + 1) * 32 + 16, dt * 16, lane);
+      }
+      union { lpx8_t v; unsigned int u[4]; } pf;
+      {
+        const f32x4_t t = s[2 * s2];
+        pf.u[0] = pack_lp2_raw(__builtin_amdgcn_exp2f(fmaf(t[0], sc2, -mxs)), __builtin_amdgcn_exp2f(fmaf(t[1], sc2, -mxs)));
+        pf.u[1] = pack_lp2_raw(__builtin_amdgcn_exp2f(fmaf(t[2], sc2, -mxs)), __builtin_amdgcn_exp2f(fmaf(t[3], sc2, -mxs)));
+      }
+      if (2 * s2 + 1 < NKT) {
+        const f32x4_t t = s[2 * s2 + 1];
+        pf.u[2] = pack_lp2_raw(__builtin_amdgcn_exp2f(fmaf(t[0], sc2, -mxs)), __builtin_amdgcn_exp2f(fmaf(t[1], sc2, -mxs)));
+        pf.u[3] = pack_lp2_raw(__builtin_amdgcn_exp2f(fmaf(t[2], sc2, -mxs)), __builtin_amdgcn_exp2f(fmaf(t[3], sc2, -mxs)));
+      } else {
+        pf.u[2] = 0u; pf.u[3] = 0u;
+      }
+      rs = mfma_lp(ones.v, pf.v, rs);            // every row of the result = sum over these 32 keys, per query column
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o[dt] = mfma_lp(vc[dt], pf.v, o[dt]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (tq < N) {
+      const float sum = rs[0];
+      const float inv = 1.f / sum;
+      lp_t* op = a.out + tok_row(a, b, tq) * a.ldo + h * HD + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        *(u32x2_t*)(op + dt * 16) = (u32x2_t){pack_lp2(o[dt][0] * inv, o[dt][1] * inv),
+                                             pack_lp2(o[dt][2] * inv, o[dt][3] * inv)};
+      if (g == 0 && a.lse) a.lse[(long)blockIdx.x * N + tq] = (mxs + __log2f(sum)) * 0.69314718055994530942f;   // natural log
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // backward, part 1: dQ (+ delta = rowsum(dO*O)).  K and V resident in LDS.
 // ------------------------------------------------------------------------------------------
@@ -252,6 +382,107 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnArgs a) {
           dq[dt] = mfma_lp(kf, pf.v, dq[dt]);
         }
       }
+    }
+    if (tq < N) {
+      lp_t* gp = a.dqkv + tok_row(a, b, tq) * a.lddq + h * HD + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        *(u32x2_t*)(gp + dt * 16) = (u32x2_t){pack_lp2(dq[dt][0] * a.scale, dq[dt][1] * a.scale),
+                                             pack_lp2(dq[dt][2] * a.scale, dq[dt][3] * a.scale)};
+    }
+  }
+}
+
+
+// backward part 1 with compile-time geometry (same idea as attn_fwd_t_kernel: constant loop bounds, K / V fragments one
+// tile ahead of their MFMAs, the key bias only on the tiles that can hold a masked key, exp2 argument as one fma)
+template <int NKT, int KFULL, int NTHREADS>
+__global__ __launch_bounds__(NTHREADS) void attn_bwd_dq_t_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NS2 = (NKT + 1) / 2, NPAD = NS2 * 32;
+  const int N = a.Nv + a.Nt;
+  char* ldsK = smem;
+  char* ldsV = smem + NPAD * ROWB;
+  float* bias = (float*)(smem + 2 * NPAD * ROWB);
+  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+
+  load_head_to_lds(a, a.qkv, a.ld, a.D + h * HD, b, N, NPAD, ldsK);
+  load_head_to_lds(a, a.qkv, a.ld, 2 * a.D + h * HD, b, N, NPAD, ldsV);
+  fill_key_bias(a, b, N, NPAD, bias);
+  __syncthreads();
+
+  const float sc2 = a.scale * 1.44269504088896340736f;
+  for (int qb = wave; qb < NKT; qb += nwaves) {
+    const int tq = qb * 16 + j;
+    const long row = tok_row(a, b, tq < N ? tq : N - 1);
+    const lp_t* qp = a.qkv + row * a.ld + h * HD + 8 * g;
+    const lpx8_t q0 = *(const lpx8_t*)qp, q1 = *(const lpx8_t*)(qp + 32);
+    const lp_t* dop = a.dout + row * a.lddo + h * HD + 8 * g;
+    const lpx8_t d0 = *(const lpx8_t*)dop, d1 = *(const lpx8_t*)(dop + 32);
+    const lp_t* op = a.out + row * a.ldo + h * HD + 8 * g;
+    const lpx8_t o0 = *(const lpx8_t*)op, o1 = *(const lpx8_t*)(op + 32);
+    float dl = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      dl += lp_to_f32((lp_t)d0[e]) * lp_to_f32((lp_t)o0[e]);
+      dl += lp_to_f32((lp_t)d1[e]) * lp_to_f32((lp_t)o1[e]);
+    }
+    dl += __shfl_xor(dl, 16, 64);
+    dl += __shfl_xor(dl, 32, 64);
+    const float nlse2 = -a.lse[(long)blockIdx.x * N + (tq < N ? tq : N - 1)] * 1.44269504088896340736f;
+    if (tq < N && g == 0) a.delta[(long)blockIdx.x * N + tq] = dl;
+
+    u32x2_t dsb[2 * NS2];
+    lpx8_t ka = lds_frag(ldsK, j, g), kb2 = lds_frag(ldsK, j, 4 + g), va = lds_frag(ldsV, j, g), vb = lds_frag(ldsV, j, 4 + g);
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      const lpx8_t cka = ka, ckb = kb2, cva = va, cvb = vb;
+      if (kt + 1 < NKT) {
+        ka = lds_frag(ldsK, (kt + 1) * 16 + j, g);
+        kb2 = lds_frag(ldsK, (kt + 1) * 16 + j, 4 + g);
+        va = lds_frag(ldsV, (kt + 1) * 16 + j, g);
+        vb = lds_frag(ldsV, (kt + 1) * 16 + j, 4 + g);
+      }
+      f32x4_t sa = (f32x4_t){0.f, 0.f, 0.f, 0.f}, dp = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      sa = mfma_lp(cka, q0, sa);
+      dp = mfma_lp(cva, d0, dp);
+      sa = mfma_lp(ckb, q1, sa);
+      dp = mfma_lp(cvb, d1, dp);
+      float ds[4];
+      if (kt >= KFULL) {
+        const f32x4_t kb = *(const f32x4_t*)(bias + kt * 16 + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ds[r] = __builtin_amdgcn_exp2f(fmaf(sa[r], sc2, kb[r] + nlse2)) * (dp[r] - dl);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ds[r] = __builtin_amdgcn_exp2f(fmaf(sa[r], sc2, nlse2)) * (dp[r] - dl);
+      }
+      dsb[kt] = (u32x2_t){pack_lp2(ds[0], ds[1]), pack_lp2(ds[2], ds[3])};
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (NKT & 1) dsb[NKT] = (u32x2_t){0u, 0u};
+    f32x4_t dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    lpx8_t kn[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) kn[dt] = lds_frag_tr(ldsK, 0, 16, dt * 16, lane);
+#pragma unroll
+    for (int s2 = 0; s2 < NS2; ++s2) {
+      lpx8_t kc[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        kc[dt] = kn[dt];
+        if (s2 + 1 < NS2) kn[dt] = lds_frag_tr(ldsK, (s2 + 1) * 32, (s2 + 1) * 32 + 16, dt * 16, lane);
+      }
+      union { lpx8_t v; unsigned int u[4]; } pf;
+      pf.u[0] = dsb[2 * s2][0]; pf.u[1] = dsb[2 * s2][1];
+      pf.u[2] = dsb[2 * s2 + 1][0]; pf.u[3] = dsb[2 * s2 + 1][1];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma_lp(kc[dt], pf.v, dq[dt]);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (tq < N) {
       lp_t* gp = a.dqkv + tok_row(a, b, tq) * a.lddq + h * HD + 4 * g;
@@ -344,6 +575,133 @@ __global__ __launch_bounds__(768) void attn_bwd_dkv_kernel(AttnArgs a) {
   }
 }
 
+
+// backward part 2 with compile-time geometry.  NQT query tiles (== key tiles); key strips kb < KFULL hold vision keys only.
+template <int NQT, bool MASKED, bool AHEAD>
+__device__ __forceinline__ void dkv_strip(const char* ldsQ, const char* ldsDO, const float* nlse_s, const float* dl_s,
+                                          const lpx8_t k0, const lpx8_t k1, const lpx8_t v0, const lpx8_t v1, float kbias,
+                                          float sc2, int lane, f32x4_t (&dk)[4], f32x4_t (&dv)[4]) {
+  constexpr int NS2 = (NQT + 1) / 2;
+  const int j = lane & 15, g = lane >> 4;
+  lpx8_t qn[2][2], dn[2][2];                    // AHEAD: K-major Q / dO fragments of the NEXT query pair (32 registers)
+  if (AHEAD) {
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      qn[hh][0] = lds_frag(ldsQ, hh * 16 + j, g);  qn[hh][1] = lds_frag(ldsQ, hh * 16 + j, 4 + g);
+      dn[hh][0] = lds_frag(ldsDO, hh * 16 + j, g); dn[hh][1] = lds_frag(ldsDO, hh * 16 + j, 4 + g);
+    }
+  }
+#pragma unroll
+  for (int s2 = 0; s2 < NS2; ++s2) {
+    lpx8_t qc[2][2], dc[2][2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      if (AHEAD) {
+        qc[hh][0] = qn[hh][0]; qc[hh][1] = qn[hh][1]; dc[hh][0] = dn[hh][0]; dc[hh][1] = dn[hh][1];
+      } else {
+        const int r0 = (2 * s2 + hh) * 16 + j;
+        qc[hh][0] = lds_frag(ldsQ, r0, g);  qc[hh][1] = lds_frag(ldsQ, r0, 4 + g);
+        dc[hh][0] = lds_frag(ldsDO, r0, g); dc[hh][1] = lds_frag(ldsDO, r0, 4 + g);
+      }
+    }
+    // transposed fragments of THIS pair (needed after the exponentials) and the K-major ones of the next pair
+    lpx8_t dof[4], qf[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      dof[dt] = lds_frag_tr(ldsDO, s2 * 32, s2 * 32 + 16, dt * 16, lane);
+      qf[dt] = lds_frag_tr(ldsQ, s2 * 32, s2 * 32 + 16, dt * 16, lane);
+    }
+    if (AHEAD && s2 + 1 < NS2) {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int r0 = (2 * s2 + 2 + hh) * 16 + j;
+        qn[hh][0] = lds_frag(ldsQ, r0, g);  qn[hh][1] = lds_frag(ldsQ, r0, 4 + g);
+        dn[hh][0] = lds_frag(ldsDO, r0, g); dn[hh][1] = lds_frag(ldsDO, r0, 4 + g);
+      }
+    }
+    float p[2][4], ds[2][4];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int qt = 2 * s2 + hh;   // rows qt*16.. exist in LDS (zero-filled beyond N)
+      f32x4_t sa = (f32x4_t){0.f, 0.f, 0.f, 0.f}, dp = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      sa = mfma_lp(qc[hh][0], k0, sa);
+      dp = mfma_lp(dc[hh][0], v0, dp);
+      sa = mfma_lp(qc[hh][1], k1, sa);
+      dp = mfma_lp(dc[hh][1], v1, dp);
+      const f32x4_t l4 = *(const f32x4_t*)(nlse_s + qt * 16 + 4 * g);
+      const f32x4_t d4 = *(const f32x4_t*)(dl_s + qt * 16 + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pr = __builtin_amdgcn_exp2f(fmaf(sa[r], sc2, MASKED ? l4[r] + kbias : l4[r]));
+        p[hh][r] = pr;
+        ds[hh][r] = pr * (dp[r] - d4[r]);
+      }
+    }
+    union { lpx8_t v; unsigned int u[4]; } pf;
+    pf.u[0] = pack_lp2_raw(p[0][0], p[0][1]); pf.u[1] = pack_lp2_raw(p[0][2], p[0][3]);
+    pf.u[2] = pack_lp2_raw(p[1][0], p[1][1]); pf.u[3] = pack_lp2_raw(p[1][2], p[1][3]);
+    const lpx8_t dsf = pack8(ds[0], ds[1]);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      dv[dt] = mfma_lp(dof[dt], pf.v, dv[dt]);
+      dk[dt] = mfma_lp(qf[dt], dsf, dk[dt]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int NQT, int KFULL, int NTHREADS>
+__global__ __launch_bounds__(NTHREADS) void attn_bwd_dkv_t_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NS2 = (NQT + 1) / 2, NPAD = NS2 * 32;
+  const int N = a.Nv + a.Nt;
+  char* ldsQ = smem;
+  char* ldsDO = smem + NPAD * ROWB;
+  float* nlse_s = (float*)(smem + 2 * NPAD * ROWB);
+  float* dl_s = nlse_s + NPAD;
+  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+
+  load_head_to_lds(a, a.qkv, a.ld, h * HD, b, N, NPAD, ldsQ);
+  load_head_to_lds(a, a.dout, a.lddo, h * HD, b, N, NPAD, ldsDO);
+  for (int q = threadIdx.x; q < NPAD; q += blockDim.x) {
+    nlse_s[q] = q < N ? -a.lse[(long)blockIdx.x * N + q] * 1.44269504088896340736f : -INFINITY;   // log2 domain, negated; exp2(.. - inf) = 0 for pad rows
+    dl_s[q] = q < N ? a.delta[(long)blockIdx.x * N + q] : 0.f;
+  }
+  __syncthreads();
+
+  const float sc2 = a.scale * 1.44269504088896340736f;
+  for (int kb = wave; kb < NQT; kb += nwaves) {
+    const int tk = kb * 16 + j;
+    const long row = tok_row(a, b, tk < N ? tk : N - 1);
+    const lp_t* kp = a.qkv + row * a.ld + a.D + h * HD + 8 * g;
+    const lpx8_t k0 = *(const lpx8_t*)kp, k1 = *(const lpx8_t*)(kp + 32);
+    const lp_t* vp = a.qkv + row * a.ld + 2 * a.D + h * HD + 8 * g;
+    const lpx8_t v0 = *(const lpx8_t*)vp, v1 = *(const lpx8_t*)(vp + 32);
+    f32x4_t dk[4], dv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dk[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+    if (kb >= KFULL) {
+      bool masked = tk >= N;
+      if (!masked && a.pad && tk >= a.Nv) masked = a.pad[b * a.Nt + (tk - a.Nv)] != 0;
+      dkv_strip<NQT, true, (NTHREADS <= 512)>(ldsQ, ldsDO, nlse_s, dl_s, k0, k1, v0, v1, masked ? -INFINITY : 0.f, sc2, lane, dk, dv);
+    } else {
+      dkv_strip<NQT, false, (NTHREADS <= 512)>(ldsQ, ldsDO, nlse_s, dl_s, k0, k1, v0, v1, 0.f, sc2, lane, dk, dv);
+    }
+    if (tk < N) {
+      lp_t* gk = a.dqkv + tok_row(a, b, tk) * a.lddq + a.D + h * HD + 4 * g;
+      lp_t* gv = a.dqkv + tok_row(a, b, tk) * a.lddq + 2 * a.D + h * HD + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        *(u32x2_t*)(gk + dt * 16) = (u32x2_t){pack_lp2(dk[dt][0] * a.scale, dk[dt][1] * a.scale),
+                                             pack_lp2(dk[dt][2] * a.scale, dk[dt][3] * a.scale)};
+        *(u32x2_t*)(gv + dt * 16) = (u32x2_t){pack_lp2(dv[dt][0], dv[dt][1]), pack_lp2(dv[dt][2], dv[dt][3])};
+      }
+    }
+  }
+}
+
 template <typename K>
 int set_lds_limit(K kernel, size_t bytes) {
   return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
@@ -366,8 +724,13 @@ extern "C" int simvg_attn_fwd(const void* qkv, int ldqkv, void* out, int ldo, fl
   AttnArgs a{(const lp_t*)qkv, ldqkv, (lp_t*)out, ldo, nullptr, 0, nullptr, 0, lse, nullptr, pad, B, H, Nv, Nt, D, scale};
   const int N = Nv + Nt, npad = ((cdiv(N, 16) + 1) / 2) * 32;
   const size_t shm = (size_t)2 * npad * ROWB + npad * sizeof(float);
-  static bool once = set_lds_limit(attn_fwd_kernel, 160 * 1024);
+  static bool once = set_lds_limit(attn_fwd_kernel, 160 * 1024) && set_lds_limit(attn_fwd_t_kernel<27, 25, 768>, 160 * 1024);
   (void)once;
+  if (cdiv(N, 16) == 27 && Nv / 16 >= 25) {        // the path's geometry: 1 + (640/32)^2 vision + 20 text tokens
+    hipLaunchKernelGGL((attn_fwd_t_kernel<27, 25, 768>), dim3(B * H), dim3(768), shm, stream, a);
+    SIMVG_LAUNCH_CHECK();
+    return SIMVG_OK;
+  }
   // 12 waves per workgroup (3 per SIMD): the 27 query strips of a 421-token head take 3 rounds instead of 4 and the
   // MFMA / softmax-VALU / LDS phases of three waves overlap on every SIMD (512 threads: 112 us, 768: 95 us)
   hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H), dim3(768), shm, stream, a);
@@ -389,8 +752,17 @@ extern "C" int simvg_attn_bwd(const void* qkv, int ldqkv, const void* out, int l
   static bool once1 = set_lds_limit(attn_bwd_dq_kernel, 160 * 1024);
   static bool once2 = set_lds_limit(attn_bwd_dkv_kernel, 160 * 1024);
   (void)once1; (void)once2;
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(B * H), dim3(768), shm1, stream, a);
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(B * H), dim3(768), shm2, stream, a);
+  static bool once3 = set_lds_limit(attn_bwd_dq_t_kernel<27, 25, 768>, 160 * 1024) && set_lds_limit(attn_bwd_dkv_t_kernel<27, 25, 512>, 160 * 1024);
+  (void)once3;
+  if (cdiv(N, 16) == 27 && Nv / 16 >= 25) {
+    // dQ: 12 waves (88 us; 8 waves 94); dK/dV: 8 waves with the next query pair's fragments in flight (115 us; the 12-wave
+    // build of the same code spills in its loop: 190 us) -- profiles/r02_sweeps.md
+    hipLaunchKernelGGL((attn_bwd_dq_t_kernel<27, 25, 768>), dim3(B * H), dim3(768), shm1, stream, a);
+    hipLaunchKernelGGL((attn_bwd_dkv_t_kernel<27, 25, 512>), dim3(B * H), dim3(512), shm2, stream, a);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(B * H), dim3(768), shm1, stream, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(B * H), dim3(768), shm2, stream, a);
+  }
   SIMVG_LAUNCH_CHECK();
   return SIMVG_OK;
 }

@@ -84,6 +84,11 @@ __device__ __forceinline__ unsigned int pack_lp2(float lo, float hi) {
   const hw_lpx2_t v = __builtin_convertvector((hw_f32x2_t){lp_sat(lo), lp_sat(hi)}, hw_lpx2_t);
   return __builtin_bit_cast(unsigned int, v);
 }
+// the same without the saturation clamp: for values known to be in range (softmax probabilities)
+__device__ __forceinline__ unsigned int pack_lp2_raw(float lo, float hi) {
+  const hw_lpx2_t v = __builtin_convertvector((hw_f32x2_t){lo, hi}, hw_lpx2_t);
+  return __builtin_bit_cast(unsigned int, v);
+}
 // exact-erf GELU (torch F.gelu default) with erf from Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. ~orders
 // below the 16-bit rounding of the stored result) -- one v_exp + one v_rcp instead of the ~50-instruction libm erff;
 // the same exp(-x^2/2) also gives the Gaussian density that GELU' needs.
