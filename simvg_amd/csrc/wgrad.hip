@@ -238,14 +238,14 @@ __global__ __launch_bounds__(A * B * 64) void wgrad_x_kernel(WgradXArgs a) {
 }
 
 template <int A, int B, int WI, int WJ>
-bool launch(const WgradXArgs& a, hipStream_t stream) {
+bool launch(const WgradXArgs& a, hipStream_t stream, int nsub = 1) {
   constexpr int TN = 16 * WI * A, TK = 16 * WJ * B;
   constexpr int LDS = 4 * 32 * (TN * 2 + 32 + TK * 2 + 32);
   static bool once = hipFuncSetAttribute((const void*)wgrad_x_kernel<A, B, WI, WJ>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
   (void)once;
   const int ntile = (a.N / TN) * (a.K / TK);
-  hipLaunchKernelGGL((wgrad_x_kernel<A, B, WI, WJ>), dim3(8 * ntile), dim3(A * B * 64), LDS, stream, a);
+  hipLaunchKernelGGL((wgrad_x_kernel<A, B, WI, WJ>), dim3(8 * ntile * nsub), dim3(A * B * 64), LDS, stream, a);
   return true;
 }
 
@@ -263,5 +263,9 @@ bool simvg_wgrad_x(const void* dY, int lddy, const void* X, int ldx, float* dW, 
   if (fits(384, 192)) return launch<4, 3, 6, 4>(a, stream);      // fc1: 3072 x 768, waves 4 x 3 of 96 x 64
   if (fits(288, 192)) return launch<3, 4, 6, 3>(a, stream);      // qkv: 2304 x 768, waves 3 x 4 of 96 x 48
   if (fits(192, 384)) return launch<3, 4, 4, 6>(a, stream);      // fc2 / patch embed: 768 x 3072, waves 3 x 4 of 64 x 96
+  // out-proj: 768 x 768 = 16 tiles of 192 x 192 (waves 3 x 4 of 64 x 48); every XCD's row range is halved once more so that
+  // 32 workgroups per XCD exist (16 row partitions, 38 MB of fp32 atomics)
+  if (N % 192 == 0 && K % 192 == 0 && (N / 192) * (K / 192) == 16 && ((192 / (K / 192)) % 8) == 0)
+    return launch<3, 4, 4, 3>(a, stream, 2);
   return false;
 }
