@@ -25,16 +25,24 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, lowp=None):
+    """lowp="bf16" (or env SIMVG_LOWP=bf16): the bf16 variant of the same kernels, for A/B measurements -- objects and library
+    get a `_bf16` suffix (load it with SIMVG_HIP_LIB=simvg_amd/lib/libsimvg_hip_bf16.so); the default build is fp16."""
+    lowp = lowp or os.environ.get("SIMVG_LOWP", "fp16")
+    if lowp not in ("fp16", "bf16"):
+        raise ValueError("SIMVG_LOWP must be fp16 or bf16")
+    suffix = "_bf16" if lowp == "bf16" else ""
+    flags = FLAGS + (["-DSIMVG_LOWP_BF16"] if lowp == "bf16" else [])
+    lib = os.path.join(LIBDIR, f"libsimvg_hip{suffix}.so")
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     hdrs = sorted(glob.glob(os.path.join(CSRC, "*.h")))
     objs, jobs = [], []
     for s in srcs:
-        o = os.path.join(LIBDIR, os.path.basename(s)[:-4] + ".o")
+        o = os.path.join(LIBDIR, os.path.basename(s)[:-4] + suffix + ".o")
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([_hipcc(), *FLAGS, "-c", s, "-o", o])
+            jobs.append([_hipcc(), *flags, "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -47,9 +55,9 @@ def build(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
-    if jobs or not os.path.exists(LIB):
-        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
-    return LIB
+    if jobs or not os.path.exists(lib):
+        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs])
+    return lib
 
 
 if __name__ == "__main__":
