@@ -84,7 +84,9 @@ int simvg_ln_bwd(const void* dy, int dy_is_f32, int lddy, const void* x, int x_i
 long simvg_ln_bwd_ws_floats(int M, int D, int split);
 
 /* ---- fused encoder self-attention ----------------------------------------------------------------
- * softmax(scale * Q K^T + key_padding(-inf)) V per (sample, head), head_dim 64, N = Nv+Nt <= 448.
+ * softmax(scale * Q K^T + key_padding(-inf)) V per (sample, head), head_dim 64.  N = Nv+Nt <= 448: K and V of a
+ * head resident in LDS (the path's 421 tokens have compile-time-geometry kernels); larger N (patch 16, images above 640):
+ * K / V streamed through LDS in 256-row blocks with an online softmax.
  * torchscale MultiheadAttention.forward as called at beit3_base.py:137-145 (bmm, masked_fill, fp32
  * softmax, bmm, head merge).  qkv: [M, 3D] = q | k | v columns.  pad: [B,Nt] bytes, 1 = padded key. */
 int simvg_attn_fwd(const void* qkv_lp, int ldqkv, void* out_lp, int ldo, float* lse, const unsigned char* pad,

@@ -5,7 +5,7 @@
 // §2.3 E7-E12).  The score matrix never goes to HBM.
 //
 // Geometry of the path: N = 1 + (640/32)^2 + 20 = 421 tokens, head_dim 64.  One workgroup owns one
-// (sample, head): the whole K and V (448 x 64 bf16 each, 144-B padded rows) sit in LDS; each wave
+// (sample, head): the whole K and V (448 x 64 16-bit values each, 128-B swizzled rows) sit in LDS; each wave
 // takes 16 query rows at a time, holds the complete S^T = K·Q^T strip (28 tiles of 16x16) in
 // registers, does an exact (non-online) fp32 softmax with wavefront shuffles for the row reduce,
 // and feeds P straight back as the MFMA B operand of O^T = V^T·P^T (V^T fragments come from
@@ -702,6 +702,256 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_dkv_t_kernel(AttnArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Any token count (N > 448: patch 16, images above 640): K / V (forward, dQ) or Q / dO (dK, dV) are streamed through the
+// LDS in blocks of TB rows, the forward with an online softmax over the key blocks (running maximum and sum per query,
+// accumulator rescaled when the maximum moves), the backward from the saved LSE.  One workgroup of TW waves per
+// (sample, head, 16 TW queries or keys).  Same LDS row layout, fragment reads and masking as the resident kernels above;
+// these are the general path, not the tuned one.
+// ------------------------------------------------------------------------------------------
+constexpr int TB = 256;        // rows per LDS block (2 operands x 256 x 128 B = 64 KiB: two workgroups per CU)
+constexpr int TW = 8;          // waves per workgroup: 128 queries (or keys) per workgroup
+
+// rows [r0, r0 + TB) of one head -> LDS block rows [0, TB) (zero beyond N)
+__device__ __forceinline__ void load_block_to_lds(const AttnArgs& a, const lp_t* base, int ld, int col0, int b, int N, int r0,
+                                                  char* lds) {
+  for (int c = threadIdx.x; c < TB * 8; c += blockDim.x) {
+    const int row = c >> 3, slot = c & 7;
+    u32x4_t v = (u32x4_t){0u, 0u, 0u, 0u};
+    if (r0 + row < N) v = *(const u32x4_t*)(base + tok_row(a, b, r0 + row) * ld + col0 + slot * 8);
+    *(u32x4_t*)(lds + row * ROWB + lds_slot(row, slot) * 16) = v;
+  }
+}
+
+__device__ __forceinline__ void fill_key_bias_block(const AttnArgs& a, int b, int N, int r0, float* bias) {
+  for (int k = threadIdx.x; k < TB; k += blockDim.x) {
+    const int t = r0 + k;
+    bool masked = t >= N;
+    if (!masked && a.pad && t >= a.Nv) masked = a.pad[b * a.Nt + (t - a.Nv)] != 0;
+    bias[k] = masked ? -INFINITY : 0.f;
+  }
+}
+
+constexpr int TILED_LDS = 2 * TB * ROWB + 2 * TB * (int)sizeof(float);
+
+__global__ __launch_bounds__(TW * 64) void attn_fwd_tiled_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ldsK = smem;
+  char* ldsV = smem + TB * ROWB;
+  float* bias = (float*)(smem + 2 * TB * ROWB);
+  const int N = a.Nv + a.Nt;
+  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int tq = (blockIdx.y * TW + wave) * 16 + j;
+  const lp_t* qp = a.qkv + tok_row(a, b, tq < N ? tq : N - 1) * a.ld + h * HD + 8 * g;
+  const lpx8_t q0 = *(const lpx8_t*)qp, q1 = *(const lpx8_t*)(qp + 32);
+  const float sc2 = a.scale * 1.44269504088896340736f;
+  float m = -INFINITY, l = 0.f;          // running maximum (raw score units) and sum of this lane's query
+  f32x4_t o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  for (int r0 = 0; r0 < N; r0 += TB) {
+    __syncthreads();                     // everyone is done with the previous block
+    load_block_to_lds(a, a.qkv, a.ld, a.D + h * HD, b, N, r0, ldsK);
+    load_block_to_lds(a, a.qkv, a.ld, 2 * a.D + h * HD, b, N, r0, ldsV);
+    fill_key_bias_block(a, b, N, r0, bias);
+    __syncthreads();
+    f32x4_t s[TB / 16];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < TB / 16; ++kt) {
+      f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      acc = mfma_lp(lds_frag(ldsK, kt * 16 + j, g), q0, acc);
+      acc = mfma_lp(lds_frag(ldsK, kt * 16 + j, 4 + g), q1, acc);
+      const f32x4_t kb = *(const f32x4_t*)(bias + kt * 16 + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { acc[r] += kb[r]; mx = fmaxf(mx, acc[r]); }
+      s[kt] = acc;
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m, mx);
+    const float m_use = m_new == -INFINITY ? 0.f : m_new;          // a fully masked prefix: nothing to rescale, p = 0
+    const float alpha = __builtin_amdgcn_exp2f((m - m_use) * sc2);  // exp2(-inf) = 0 on the first block
+    m = m_new;
+    l *= alpha;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+    const float mxs = m_use * sc2;
+    float sum = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < TB / 32; ++s2) {
+      float lo[4], hi[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        lo[r] = __builtin_amdgcn_exp2f(fmaf(s[2 * s2][r], sc2, -mxs));
+        hi[r] = __builtin_amdgcn_exp2f(fmaf(s[2 * s2 + 1][r], sc2, -mxs));
+        sum += lo[r] + hi[r];
+      }
+      const lpx8_t pf = pack8(lo, hi);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o[dt] = mfma_lp(lds_frag_tr(ldsV, s2 * 32, s2 * 32 + 16, dt * 16, lane), pf, o[dt]);
+    }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    l += sum;
+  }
+  if (tq < N) {
+    const float inv = 1.f / l;
+    lp_t* op = a.out + tok_row(a, b, tq) * a.ldo + h * HD + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+      *(u32x2_t*)(op + dt * 16) = (u32x2_t){pack_lp2(o[dt][0] * inv, o[dt][1] * inv), pack_lp2(o[dt][2] * inv, o[dt][3] * inv)};
+    if (g == 0 && a.lse) a.lse[(long)blockIdx.x * N + tq] = (m * sc2 + __log2f(l)) * 0.69314718055994530942f;
+  }
+}
+
+__global__ __launch_bounds__(TW * 64) void attn_bwd_dq_tiled_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ldsK = smem;
+  char* ldsV = smem + TB * ROWB;
+  float* bias = (float*)(smem + 2 * TB * ROWB);
+  const int N = a.Nv + a.Nt;
+  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int tq = (blockIdx.y * TW + wave) * 16 + j;
+  const long row = tok_row(a, b, tq < N ? tq : N - 1);
+  const lp_t* qp = a.qkv + row * a.ld + h * HD + 8 * g;
+  const lpx8_t q0 = *(const lpx8_t*)qp, q1 = *(const lpx8_t*)(qp + 32);
+  const lp_t* dop = a.dout + row * a.lddo + h * HD + 8 * g;
+  const lpx8_t d0 = *(const lpx8_t*)dop, d1 = *(const lpx8_t*)(dop + 32);
+  const lp_t* op = a.out + row * a.ldo + h * HD + 8 * g;
+  const lpx8_t o0 = *(const lpx8_t*)op, o1 = *(const lpx8_t*)(op + 32);
+  float dl = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    dl += lp_to_f32((lp_t)d0[e]) * lp_to_f32((lp_t)o0[e]);
+    dl += lp_to_f32((lp_t)d1[e]) * lp_to_f32((lp_t)o1[e]);
+  }
+  dl += __shfl_xor(dl, 16, 64);
+  dl += __shfl_xor(dl, 32, 64);
+  const float nlse2 = -a.lse[(long)blockIdx.x * N + (tq < N ? tq : N - 1)] * 1.44269504088896340736f;
+  if (tq < N && g == 0) a.delta[(long)blockIdx.x * N + tq] = dl;
+  const float sc2 = a.scale * 1.44269504088896340736f;
+  f32x4_t dq[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  for (int r0 = 0; r0 < N; r0 += TB) {
+    __syncthreads();
+    load_block_to_lds(a, a.qkv, a.ld, a.D + h * HD, b, N, r0, ldsK);
+    load_block_to_lds(a, a.qkv, a.ld, 2 * a.D + h * HD, b, N, r0, ldsV);
+    fill_key_bias_block(a, b, N, r0, bias);
+    __syncthreads();
+#pragma unroll
+    for (int s2 = 0; s2 < TB / 32; ++s2) {
+      float ds[2][4];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int kt = 2 * s2 + hh;
+        f32x4_t sa = (f32x4_t){0.f, 0.f, 0.f, 0.f}, dp = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        sa = mfma_lp(lds_frag(ldsK, kt * 16 + j, g), q0, sa);
+        dp = mfma_lp(lds_frag(ldsV, kt * 16 + j, g), d0, dp);
+        sa = mfma_lp(lds_frag(ldsK, kt * 16 + j, 4 + g), q1, sa);
+        dp = mfma_lp(lds_frag(ldsV, kt * 16 + j, 4 + g), d1, dp);
+        const f32x4_t kb = *(const f32x4_t*)(bias + kt * 16 + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ds[hh][r] = __builtin_amdgcn_exp2f(fmaf(sa[r], sc2, kb[r] + nlse2)) * (dp[r] - dl);
+      }
+      const lpx8_t dsf = pack8(ds[0], ds[1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma_lp(lds_frag_tr(ldsK, s2 * 32, s2 * 32 + 16, dt * 16, lane), dsf, dq[dt]);
+    }
+  }
+  if (tq < N) {
+    lp_t* gp = a.dqkv + tok_row(a, b, tq) * a.lddq + h * HD + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+      *(u32x2_t*)(gp + dt * 16) = (u32x2_t){pack_lp2(dq[dt][0] * a.scale, dq[dt][1] * a.scale),
+                                           pack_lp2(dq[dt][2] * a.scale, dq[dt][3] * a.scale)};
+  }
+}
+
+__global__ __launch_bounds__(TW * 64) void attn_bwd_dkv_tiled_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ldsQ = smem;
+  char* ldsDO = smem + TB * ROWB;
+  float* nlse_s = (float*)(smem + 2 * TB * ROWB);
+  float* dl_s = nlse_s + TB;
+  const int N = a.Nv + a.Nt;
+  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int tk = (blockIdx.y * TW + wave) * 16 + j;
+  const long row = tok_row(a, b, tk < N ? tk : N - 1);
+  const lp_t* kp = a.qkv + row * a.ld + a.D + h * HD + 8 * g;
+  const lpx8_t k0 = *(const lpx8_t*)kp, k1 = *(const lpx8_t*)(kp + 32);
+  const lp_t* vp = a.qkv + row * a.ld + 2 * a.D + h * HD + 8 * g;
+  const lpx8_t v0 = *(const lpx8_t*)vp, v1 = *(const lpx8_t*)(vp + 32);
+  bool masked = tk >= N;
+  if (!masked && a.pad && tk >= a.Nv) masked = a.pad[b * a.Nt + (tk - a.Nv)] != 0;
+  const float kbias = masked ? -INFINITY : 0.f;
+  const float sc2 = a.scale * 1.44269504088896340736f;
+  f32x4_t dk[4], dv[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) { dk[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+
+  for (int r0 = 0; r0 < N; r0 += TB) {
+    __syncthreads();
+    load_block_to_lds(a, a.qkv, a.ld, h * HD, b, N, r0, ldsQ);
+    load_block_to_lds(a, a.dout, a.lddo, h * HD, b, N, r0, ldsDO);
+    for (int q = threadIdx.x; q < TB; q += blockDim.x) {
+      const int t = r0 + q;
+      nlse_s[q] = t < N ? -a.lse[(long)blockIdx.x * N + t] * 1.44269504088896340736f : -INFINITY;   // pad rows: p = 0
+      dl_s[q] = t < N ? a.delta[(long)blockIdx.x * N + t] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s2 = 0; s2 < TB / 32; ++s2) {
+      float p[2][4], ds[2][4];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int qt = 2 * s2 + hh;
+        f32x4_t sa = (f32x4_t){0.f, 0.f, 0.f, 0.f}, dp = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        sa = mfma_lp(lds_frag(ldsQ, qt * 16 + j, g), k0, sa);
+        dp = mfma_lp(lds_frag(ldsDO, qt * 16 + j, g), v0, dp);
+        sa = mfma_lp(lds_frag(ldsQ, qt * 16 + j, 4 + g), k1, sa);
+        dp = mfma_lp(lds_frag(ldsDO, qt * 16 + j, 4 + g), v1, dp);
+        const f32x4_t l4 = *(const f32x4_t*)(nlse_s + qt * 16 + 4 * g);
+        const f32x4_t d4 = *(const f32x4_t*)(dl_s + qt * 16 + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pr = __builtin_amdgcn_exp2f(fmaf(sa[r], sc2, l4[r] + kbias));
+          p[hh][r] = pr;
+          ds[hh][r] = pr * (dp[r] - d4[r]);
+        }
+      }
+      const lpx8_t pf = pack8(p[0], p[1]);
+      const lpx8_t dsf = pack8(ds[0], ds[1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        dv[dt] = mfma_lp(lds_frag_tr(ldsDO, s2 * 32, s2 * 32 + 16, dt * 16, lane), pf, dv[dt]);
+        dk[dt] = mfma_lp(lds_frag_tr(ldsQ, s2 * 32, s2 * 32 + 16, dt * 16, lane), dsf, dk[dt]);
+      }
+    }
+  }
+  if (tk < N) {
+    lp_t* gk = a.dqkv + tok_row(a, b, tk) * a.lddq + a.D + h * HD + 4 * g;
+    lp_t* gv = a.dqkv + tok_row(a, b, tk) * a.lddq + 2 * a.D + h * HD + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      *(u32x2_t*)(gk + dt * 16) = (u32x2_t){pack_lp2(dk[dt][0] * a.scale, dk[dt][1] * a.scale),
+                                           pack_lp2(dk[dt][2] * a.scale, dk[dt][3] * a.scale)};
+      *(u32x2_t*)(gv + dt * 16) = (u32x2_t){pack_lp2(dv[dt][0], dv[dt][1]), pack_lp2(dv[dt][2], dv[dt][3])};
+    }
+  }
+}
+
 template <typename K>
 int set_lds_limit(K kernel, size_t bytes) {
   return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
@@ -712,7 +962,6 @@ int set_lds_limit(K kernel, size_t bytes) {
 static int attn_check(int B, int H, int Nv, int Nt, int D, int ld) {
   if (B <= 0 || H <= 0 || Nv < 0 || Nt < 0 || Nv + Nt <= 0) return 0;
   if (D != H * HD) return 0;
-  if (Nv + Nt > MAX_KT * 16) return 0;
   if (ld % 8 != 0) return 0;
   return 1;
 }
@@ -720,9 +969,16 @@ static int attn_check(int B, int H, int Nv, int Nt, int D, int ld) {
 extern "C" int simvg_attn_fwd(const void* qkv, int ldqkv, void* out, int ldo, float* lse, const unsigned char* pad,
                               int B, int H, int Nv, int Nt, int D, float scale, hipStream_t stream) {
   SIMVG_CHECK_ARG(attn_check(B, H, Nv, Nt, D, ldqkv) && ldo % 8 == 0,
-                  "attn_fwd: need head_dim 64, Nv+Nt <= 448, 16-B aligned rows");
+                  "attn_fwd: need head_dim 64, 16-B aligned rows");
   AttnArgs a{(const lp_t*)qkv, ldqkv, (lp_t*)out, ldo, nullptr, 0, nullptr, 0, lse, nullptr, pad, B, H, Nv, Nt, D, scale};
   const int N = Nv + Nt, npad = ((cdiv(N, 16) + 1) / 2) * 32;
+  if (N > MAX_KT * 16) {      // K / V do not fit the LDS: stream them in blocks (online softmax)
+    static bool oncet = set_lds_limit(attn_fwd_tiled_kernel, TILED_LDS);
+    (void)oncet;
+    hipLaunchKernelGGL(attn_fwd_tiled_kernel, dim3(B * H, cdiv(N, 16 * TW)), dim3(TW * 64), TILED_LDS, stream, a);
+    SIMVG_LAUNCH_CHECK();
+    return SIMVG_OK;
+  }
   const size_t shm = (size_t)2 * npad * ROWB + npad * sizeof(float);
   static bool once = set_lds_limit(attn_fwd_kernel, 160 * 1024) && set_lds_limit(attn_fwd_t_kernel<27, 25, 768>, 160 * 1024);
   (void)once;
@@ -742,11 +998,19 @@ extern "C" int simvg_attn_bwd(const void* qkv, int ldqkv, const void* out, int l
                               void* dqkv, int lddqkv, const float* lse, float* delta_ws, const unsigned char* pad,
                               int B, int H, int Nv, int Nt, int D, float scale, hipStream_t stream) {
   SIMVG_CHECK_ARG(attn_check(B, H, Nv, Nt, D, ldqkv) && ldo % 8 == 0 && lddo % 8 == 0 && lddqkv % 8 == 0,
-                  "attn_bwd: need head_dim 64, Nv+Nt <= 448, 16-B aligned rows");
+                  "attn_bwd: need head_dim 64, 16-B aligned rows");
   SIMVG_CHECK_ARG(lse && delta_ws, "attn_bwd: lse and delta workspace required");
   AttnArgs a{(const lp_t*)qkv, ldqkv, (lp_t*)out, ldo, (const lp_t*)dout, lddo, (lp_t*)dqkv, lddqkv,
              (float*)lse, delta_ws, pad, B, H, Nv, Nt, D, scale};
   const int N = Nv + Nt, npad = ((cdiv(N, 16) + 1) / 2) * 32;
+  if (N > MAX_KT * 16) {
+    static bool oncet = set_lds_limit(attn_bwd_dq_tiled_kernel, TILED_LDS) && set_lds_limit(attn_bwd_dkv_tiled_kernel, TILED_LDS);
+    (void)oncet;
+    hipLaunchKernelGGL(attn_bwd_dq_tiled_kernel, dim3(B * H, cdiv(N, 16 * TW)), dim3(TW * 64), TILED_LDS, stream, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_tiled_kernel, dim3(B * H, cdiv(N, 16 * TW)), dim3(TW * 64), TILED_LDS, stream, a);
+    SIMVG_LAUNCH_CHECK();
+    return SIMVG_OK;
+  }
   const size_t shm1 = (size_t)2 * npad * ROWB + npad * sizeof(float);
   const size_t shm2 = (size_t)2 * npad * ROWB + 2 * npad * sizeof(float);
   static bool once1 = set_lds_limit(attn_bwd_dq_kernel, 160 * 1024);

@@ -401,7 +401,8 @@ extern "C" int simvg_attn_small_fwd(const float* q, int ldq, const float* k, int
                                     float* out, int ldo, float* P, const unsigned char* key_padding_mask,
                                     const float* drop_mult, int B, int H, int Lq, int Lk, int kv_rows_per_batch,
                                     float scale, hipStream_t stream) {
-  SIMVG_CHECK_ARG(B > 0 && H > 0 && Lq > 0 && Lq <= 16 && Lk > 0 && Lk <= 1024, "attn_small: Lq <= 16, Lk <= 1024");
+  SIMVG_CHECK_ARG(B > 0 && H > 0 && Lq > 0 && Lq <= 16 && Lk > 0 && (size_t)(Lq * SHD + Lq * Lk) * sizeof(float) <= 160 * 1024,
+                  "attn_small: Lq <= 16 and the [Lq, Lk] score strip must fit the 160 KiB LDS");
   SIMVG_CHECK_ARG(ldk % 4 == 0 && ldv % 4 == 0, "attn_small: K/V rows must be 16-B aligned");
   SAArgs a{q, ldq, k, ldk, v, ldv, out, ldo, P, key_padding_mask, drop_mult, nullptr, 0, nullptr, 0, nullptr, 0,
            nullptr, 0, B, H, Lq, Lk, kv_rows_per_batch > 0 ? kv_rows_per_batch : Lk, scale};
@@ -419,7 +420,9 @@ extern "C" int simvg_attn_small_bwd(const float* q, int ldq, const float* k, int
                                     const float* dout, int lddo, float* dq, int lddq, float* dk, int lddk, float* dv,
                                     int lddv, int B, int H, int Lq, int Lk, int kv_rows_per_batch, float scale,
                                     hipStream_t stream) {
-  SIMVG_CHECK_ARG(B > 0 && H > 0 && Lq > 0 && Lq <= 16 && Lk > 0 && Lk <= 1024, "attn_small: Lq <= 16, Lk <= 1024");
+  SIMVG_CHECK_ARG(B > 0 && H > 0 && Lq > 0 && Lq <= 16 && Lk > 0 &&
+                  (size_t)(2 * Lq * SHD + 2 * Lq * Lk + Lq) * sizeof(float) <= 160 * 1024,
+                  "attn_small: Lq <= 16 and two [Lq, Lk] strips must fit the 160 KiB LDS");
   SIMVG_CHECK_ARG(ldk % 4 == 0 && ldv % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0, "attn_small: rows must be 16-B aligned");
   SAArgs a{q, ldq, k, ldk, v, ldv, nullptr, 0, (float*)P, key_padding_mask, drop_mult, dout, lddo, dq, lddq, dk, lddk,
            dv, lddv, B, H, Lq, Lk, kv_rows_per_batch > 0 ? kv_rows_per_batch : Lk, scale};

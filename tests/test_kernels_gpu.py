@@ -336,7 +336,9 @@ def _mm_rows(B, Nv, Nt):
     return idx
 
 
-@pytest.mark.parametrize("B,H,Nv,Nt", [(2, 2, 17, 20), (2, 12, 401, 20), (1, 3, 50, 0), (3, 2, 100, 7)])
+# N <= 448: K / V resident in LDS (421 = the path's compile-time geometry); N > 448: streamed blocks + online softmax
+@pytest.mark.parametrize("B,H,Nv,Nt", [(2, 2, 17, 20), (2, 12, 401, 20), (1, 3, 50, 0), (3, 2, 100, 7), (2, 2, 500, 13),
+                                       (1, 2, 1601, 20), (2, 1, 512, 0)])
 def test_attention_fwd_bwd(B, H, Nv, Nt):
     ops = _ops()
     d, N = 64, Nv + Nt

@@ -118,3 +118,60 @@ def test_other_geometry_512px_15_tokens_batch_independence_and_training_step():
     losses["loss_total"].backward()
     grads = [p.grad for p in model.parameters() if p.grad is not None]
     assert torch.isfinite(losses["loss_total"]) and len(grads) > 300 and all(torch.isfinite(x).all() for x in grads)
+
+
+@pytest.mark.parametrize("img_size,tokens", [(640, 1621), (480, 921)])
+def test_other_geometry_patch16_against_the_exact_engine(img_size, tokens):
+    """patch_size 16 (the BEiT-3 base checkpoint's native patch size): 1 + (S/16)^2 + 20 tokens per pair -- 1621 at 640x640 --
+    beyond what one head's K / V can keep in LDS: the streamed-block attention kernels (online softmax over 256-key blocks).
+    Checked against the exact-fp32 engine (its own fp32 attention kernels share no tiling with the 16-bit path): boxes within
+    1e-3 L1, batch independence bit-exact, a finite training step; at 921 tokens (480x480 -- the exact backward keeps two
+    [16, N] strips in LDS, N <= 1024) also the loss and the encoder gradient's direction and norm."""
+    import bench
+    from simvg_amd.models import build_model
+    torch.manual_seed(13)
+    cfg = bench.model_cfg()
+    cfg["vis_enc"]["patch_size"] = 16
+    cfg["vis_enc"]["img_size"] = img_size
+    cfg["vis_enc"]["drop_path_rate"] = 0.0
+    model = build_model(cfg).to("cuda")
+    B, S = 3, img_size
+    b = bench.synthetic_batch(B, 21, torch.device("cuda"))
+    b["img"] = b["img"][:, :, :S, :S].contiguous()
+    for m in b["img_metas"]:
+        m.update(img_shape=(S, S, 3), pad_shape=(S, S, 3), ori_shape=(S, S, 3))
+    b["gt_bbox"] = [g.clamp(max=float(S)) for g in b["gt_bbox"]]
+    assert model.vis_enc.np + 1 + 20 == tokens
+    model.eval()
+    kw = dict(return_loss=False, rescale=False)
+
+    def boxes(sl=slice(None)):
+        with torch.no_grad():
+            model(img=b["img"][sl], ref_expr_inds=b["ref_expr_inds"][sl], img_metas=b["img_metas"][sl],
+                  text_attention_mask=b["text_attention_mask"][sl], **kw)
+        out = model._last_output
+        return torch.cat([out["outputs_coord_decoder_branch"][-1], out["outputs_coord_token_branch"][-1]], 1).float().clone()
+
+    full = boxes()
+    assert torch.equal(full[:2], boxes(slice(0, 2)))
+    model.vis_enc.set_precision("fp32")
+    exact = boxes()
+    model.vis_enc.set_precision("lowp")
+    l1 = float((full - exact).abs().sum(-1).max())
+    res = {}
+    for prec in (("lowp", "fp32") if tokens <= 1024 else ("lowp",)):
+        model.vis_enc.set_precision(prec)
+        model.zero_grad(set_to_none=True)
+        losses, _ = model(img=b["img"], ref_expr_inds=b["ref_expr_inds"], img_metas=b["img_metas"],
+                          text_attention_mask=b["text_attention_mask"], gt_bbox=b["gt_bbox"], rescale=False)
+        losses["loss_total"].backward()
+        res[prec] = (float(losses["loss_total"]), model.vis_enc._arena.flat_grad.detach().clone())
+    l16, g16 = res["lowp"]
+    print(f"[patch16, {tokens} tokens] boxes vs exact fp32 {l1:.2e}; loss {l16:.5f}")
+    assert torch.isfinite(g16).all() and l16 == l16 and l1 <= 1e-3
+    if "fp32" in res:
+        l32, g32 = res["fp32"]
+        cos = float(torch.dot(g16.double(), g32.double()) / (g16.double().norm() * g32.double().norm()))
+        ratio = float(g16.norm() / g32.norm())
+        print(f"[patch16, {tokens} tokens] loss fp32 {l32:.5f}; encoder gradient cosine {cos:.5f}, norm ratio {ratio:.4f}")
+        assert abs(l16 - l32) <= 2e-3 * max(1.0, abs(l32)) and cos >= 0.99 and abs(ratio - 1) <= 0.03
