@@ -321,7 +321,7 @@ def main():
         "model_tflops_per_gpu": round(value / world * FLOP_PER_PAIR_FWD_BWD[a.vit] / 1e12, 2),
         "model_mfma_frac": round(value / world * FLOP_PER_PAIR_FWD_BWD[a.vit] / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
         "roofline": {"kernel": f"gemm_nt ({_lowp} MFMA 16x16x32, fp32 accumulate; every launch: 16-wave 256x256x64 tiles for N >= 2304, "
-                               "16-wave 160x256x64 for N = 768, global_load_lds double buffer, LDS-staged coalesced epilogue)", "bound": "mfma",
+                               "16-wave 160x256x64 with a 3-stage ring for N = 768, global_load_lds, LDS-staged coalesced epilogue)", "bound": "mfma",
                      "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": round(g["bytes"] / g["calls"]),

@@ -421,7 +421,13 @@ __global__ __launch_bounds__(1024) void gemm_nt_kernel_256sq_w16(GemmNTArgs a) {
 
 // 160x256x64 tile with sixteen waves: 2 (M) x 8 (N), each 80x32 = acc[5][2] -- the 16-wave layout for the N = 768 problems
 // (160 rows do not split over 4 M-waves).  7 fragment reads per 10 MFMAs (8-wave layout: 9 per 20).
-__global__ __launch_bounds__(1024) void gemm_nt_kernel_160x256_w16(GemmNTArgs a) {
+// THREE-stage LDS ring (3 x 52 KiB = 156 KiB, the double buffer left 54 KiB of the CU's LDS unused): the
+// LDS-DMA of k-tile t+2 is issued at the top of iteration t and has two compute intervals to land.  With one stage of
+// look-ahead the ring holds 52 KiB in flight per CU; a CU that consumes a 52 KiB stage every ~0.8 us (75 GB/s) across a
+// ~1.5 us L2 / HBM latency needs ~110 KiB in flight (Little) -- the double-buffered kernel waited on `vmcnt(0)` at every
+// rendezvous (PMC: 54 % of the wave cycles in waitcnt / barrier).  A wave waits for its OWN pieces of the oldest stage only
+// (counted vmcnt: 3 or 4 pieces per wave and stage).
+__global__ __launch_bounds__(1024) void gemm_nt_kernel_160x256_r3(GemmNTArgs a) {
   constexpr int BMQ = 160;
   constexpr int STAGEQ = (BMQ + BNQ) * BK * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -443,21 +449,29 @@ __global__ __launch_bounds__(1024) void gemm_nt_kernel_160x256_w16(GemmNTArgs a)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   const int nk = a.K / BK;
+  const bool four = wave < 4;            // A: 20 pieces over 16 waves (waves 0-3 take two), B: 32 pieces (two each)
 #define STA(s_) (smem + (s_) * STAGEQ)
 #define STB(s_) (smem + (s_) * STAGEQ + BMQ * BK * 2)
 #define ISSUE(t_)                                                                                      \
   do {                                                                                                 \
-    const int st__ = (t_) & 1;                                                                         \
+    const int st__ = (t_) % 3;                                                                         \
     stage_rows_k64(a.A, a.lda, row0, row_end - 1, (t_) * BK, STA(st__), wave, lane, BMQ / 8, 16);      \
     stage_rows_k64(W, a.ldw, n0, a.N - 1, (t_) * BK, STB(st__), wave, lane, BNQ / 8, 16);              \
   } while (0)
   ISSUE(0);
+  if (nk > 1) ISSUE(1);
   for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (kt + 1 < nk) ISSUE(kt + 1);
-    const char* sA = STA(kt & 1);
-    const char* sB = STB(kt & 1);
+    // this wave's share of tile kt has landed; the pieces of tile kt+1 may still be in flight
+    if (kt + 1 < nk) {
+      if (four) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                        // everyone's has, and everyone is past compute(kt-1): slot (kt+2)%3 is free
+    if (kt + 2 < nk) ISSUE(kt + 2);
+    const char* sA = STA(kt % 3);
+    const char* sB = STB(kt % 3);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       lpx8_t fa[5], fb[2];
@@ -930,11 +944,11 @@ extern "C" int simvg_gemm_nt(const void* A, int lda, const void* W, long w_gstri
     const int tiles = (cdiv(split, 256) + cdiv(M - split, 256)) * cdiv(N, BNQ);
     hipLaunchKernelGGL(gemm_nt_kernel_256sq_w16, dim3(tiles), dim3(1024), SMW, stream, a);
   } else if (wide_ok) {
-    constexpr int SMW = 2 * (160 + BNQ) * BK * 2;     // 104 KiB ring; 16 waves x 32 x 36 x 4 B = 72 KiB of epilogue staging fit
-    static bool oncews = hipFuncSetAttribute((const void*)gemm_nt_kernel_160x256_w16, hipFuncAttributeMaxDynamicSharedMemorySize, SMW) == hipSuccess;
-    (void)oncews;
+    constexpr int SM3 = 3 * (160 + BNQ) * BK * 2;     // 156 KiB ring; 16 waves x 32 x 36 x 4 B = 72 KiB of epilogue staging fit
+    static bool once3r = hipFuncSetAttribute((const void*)gemm_nt_kernel_160x256_r3, hipFuncAttributeMaxDynamicSharedMemorySize, SM3) == hipSuccess;
+    (void)once3r;
     const int tiles = (cdiv(split, 160) + cdiv(M - split, 160)) * cdiv(N, BNQ);
-    hipLaunchKernelGGL(gemm_nt_kernel_160x256_w16, dim3(tiles), dim3(1024), SMW, stream, a);
+    hipLaunchKernelGGL(gemm_nt_kernel_160x256_r3, dim3(tiles), dim3(1024), SM3, stream, a);
   } else if (M >= 512) {
     static bool once3 = hipFuncSetAttribute((const void*)gemm_nt_kernel_256k32, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             3 * STAGE3) == hipSuccess;
