@@ -355,7 +355,7 @@ __device__ __forceinline__ void stage_rows_k64(const lp_t* base, int ld, int row
 // 256x256x64 tile with SIXTEEN waves (4 x 4, each 64x64; 4 waves per SIMD, 112 VGPRs): more waves cover the LDS-read and
 // rendezvous latencies of the one-workgroup-per-CU tile and issue the store-heavy epilogues 2x wider, at the price of 33 %
 // more LDS reads per MFMA (still ~50 % of the LDS bandwidth).  fc1 shape 124 vs 134 us, with fp32 residual epilogue
-// 212 vs 275 us (same box, warm).  SIMVG_GEMM_W16=0 selects the 8-wave kernel above.
+// 212 vs 275 us (same box, warm).
 __global__ __launch_bounds__(1024) void gemm_nt_kernel_256sq_w16(GemmNTArgs a) {
   constexpr int MI = 4;
   constexpr int BMQ = 256;

@@ -362,7 +362,7 @@ extern "C" int simvg_gemm_f32(const float* A, long sam, long sak, const float* B
   SIMVG_CHECK_ARG(act >= 0 && act <= 2, "gemm_f32: act must be 0 (none), 1 (gelu) or 2 (relu)");
   SGArgs a{A, sam, sak, B, sbk, sbn, C, ldc, bias, addend, ld_addend, addend_rows > 0 ? addend_rows : 1, M, N, K,
            accumulate, act};
-  static const int small_env = getenv("SIMVG_GEMM_F32_SMALL") ? atoi(getenv("SIMVG_GEMM_F32_SMALL")) : 32;
+  constexpr int small_env = 32;      // <= 32 tiles of 64x64: the small-M kernel (sweep in profiles/r01_sweeps.md)
   if (cdiv(N, 64) * cdiv(M, 64) <= small_env)   // too few 64x64 tiles to fill the chip: one workgroup per 16x16 tile
     hipLaunchKernelGGL(gemm_f32_small_kernel, dim3(cdiv(N, 16), cdiv(M, 16)), dim3(256), 0, stream, a);
   else
@@ -373,7 +373,7 @@ extern "C" int simvg_gemm_f32(const float* A, long sam, long sak, const float* B
 
 extern "C" int simvg_gemm_f32_grouped(const simvg_gemm_f32_problem* problems, int count, hipStream_t stream) {
   SIMVG_CHECK_ARG(problems != nullptr && count > 0 && count <= SG_MAX, "gemm_f32_grouped: 1..12 problems");
-  static const int small_env = getenv("SIMVG_GEMM_F32_SMALL") ? atoi(getenv("SIMVG_GEMM_F32_SMALL")) : 32;
+  constexpr int small_env = 32;      // <= 32 tiles of 64x64: the small-M kernel (sweep in profiles/r01_sweeps.md)
   SGGroup g;
   g.count = count;
   int total = 0;
