@@ -86,15 +86,15 @@ def test_forward_train_matches_reference(golden, name):
     model.zero_grad(set_to_none=True)
     losses["loss_total"].backward()
     params = dict(model.named_parameters())
-    # reference-init fixtures: strict -- per-tensor norm within 6e-2, direction cosine >= 0.99 and <= 1.5e-1 relative L2 on
-    # the 64 sampled entries (for equal norms the two are the same statement: e = sqrt(2 (1 - cos)), cos 0.99 <-> e 0.141).
-    # The worst tensor is the nq=10 `head.query_embed.weight` (e 0.118, cos 0.9933, norm 3e-4): its gradient is the sum
-    # over 10 queries of signals that pass the bf16 encoder memory; every encoder tensor sits at 4e-2..8e-2.
-    # harsh fixtures: the box losses are only piecewise smooth (L1 sign, GIoU max/min, assignment near-ties), and a
-    # 1e-2 box perturbation legitimately flips a few of those in the token/KD terms, so there the gradient is
-    # checked for direction (cosine >= 0.85) and magnitude (norm within 20 %) only.
+    # fp16 build, EVERY fixture (harsh weights included): per-tensor direction cosine >= 0.99, relative L2 on the 64 sampled
+    # entries <= 1.2e-1, norm within 3e-2.  Measured worst over all parameters: cosine 0.9964 / L2 8.6e-2 (large_nq1), norm 1.9e-2
+    # (tiny_nq10_grec; <= 6.2e-3 on the reference geometries); reference-init fixtures cosine >= 0.9994, norm <= 2.4e-3.
+    # bf16 build: reference-init fixtures as above with L2 1.5e-1 / norm 6e-2; on the harsh fixtures its 1e-2 box deviations flip
+    # pieces of the piecewise-smooth box losses (L1 sign, GIoU max/min, assignment near-ties), so only direction (cosine >= 0.85)
+    # and magnitude (20 %) are checked there.
     strict = bool(fx.get("refinit"))
     bad = []
+    worst = [0.0, 1.0, 0.0]
     for k, gp in fx["grads"].items():
         g = params[k].grad
         assert g is not None, k
@@ -106,9 +106,14 @@ def test_forward_train_matches_reference(golden, name):
         else:
             e = float((got - ref["vals"]).norm()) / float(ref["vals"].norm())
             cos = float((got * ref["vals"]).sum() / (got.norm() * ref["vals"].norm() + 1e-20))
-        ok = (e <= 1.5e-1 and cos >= 0.99 and en <= 6e-2) if strict else (cos >= 0.85 and en <= 0.20)
+        worst = [max(worst[0], e), min(worst[1], cos), max(worst[2], en)]
+        if _fp16():
+            ok = e <= 1.2e-1 and cos >= 0.99 and en <= 3e-2
+        else:
+            ok = (e <= 1.5e-1 and cos >= 0.99 and en <= 6e-2) if strict else (cos >= 0.85 and en <= 0.20)
         if not ok:
             bad.append((k, round(e, 4), round(cos, 4), round(en, 4)))
+    print(f"[gradients {name}] worst relative L2 on probes {worst[0]:.3e}, worst cosine {worst[1]:.5f}, worst norm error {worst[2]:.3e}")
     assert not bad, bad
 
 
