@@ -22,19 +22,73 @@ def LP():
 
 
 def grad_scale():
-    """Power-of-two scale carried by every 16-bit tensor of a backward pass (fp16 has 5 exponent bits: at B = 64 the
-    activation gradients of this model sit at 1e-7 .. 1e-3, i.e. in fp16's subnormal range unscaled).  2^14 puts their
-    median at ~1e-2 and the largest at ~20; stores saturate at 65504.  The scale is removed where parameter gradients
-    are written (`out_scale` / `param_scale` / `alpha` arguments), so `.grad` tensors are true gradients.  bf16: 1."""
+    """Power-of-two scale S carried by every 16-bit tensor of a backward pass (fp16 has 5 exponent bits: at B = 64 the
+    activation gradients of this model sit at 1e-7 .. 1e-3, i.e. in fp16's subnormal range unscaled).  The scale is
+    removed where parameter gradients are written (`out_scale` / `param_scale` / `alpha` arguments), so `.grad` tensors
+    are true gradients, and because S is a power of two the results do not depend on it as long as nothing leaves fp16's
+    normal range.  S follows the gradient the encoder receives (`GradScaleTracker`: the largest |d loss / d encoder
+    output| of the previous step is brought to ~2^6, three orders of magnitude below the saturation value 65504), starting
+    from 2^10; `set_grad_scale(v)` pins it.  bf16 builds: always 1."""
     global _GRAD_SCALE
     if _GRAD_SCALE is None:
-        _GRAD_SCALE = 16384.0 if LP() == torch.float16 else 1.0
+        _GRAD_SCALE = 1024.0 if LP() == torch.float16 else 1.0
     return _GRAD_SCALE
 
 
+_GRAD_SCALE_PINNED = False
+
+
 def set_grad_scale(v):
-    global _GRAD_SCALE
-    _GRAD_SCALE = float(v)
+    """pin the backward's 16-bit gradient scale (a power of two); None returns to the tracked scale"""
+    global _GRAD_SCALE, _GRAD_SCALE_PINNED
+    _GRAD_SCALE_PINNED = v is not None
+    _GRAD_SCALE = None if v is None else float(v)
+
+
+class GradScaleTracker:
+    """Keeps S where the incoming gradient needs it WITHOUT a host synchronisation: `observe(dout)` (called at the entry of
+    the encoder backward) queues max|dout| -> pinned host memory behind an event; `update()` (called at the next training
+    forward, a whole step later) reads it if the copy has completed and sets S = 2^floor(log2(64 / max|dout|)), clamped to
+    [1, 2^24].  A step whose gradient jumps by > 2^9 before the scale follows saturates (stores clamp at +-65504, no inf)."""
+
+    TARGET = 64.0
+
+    def __init__(self):
+        self._host = None
+        self._event = None
+
+    def __deepcopy__(self, memo):          # events / pinned buffers are per-instance runtime state, never copied
+        return GradScaleTracker()
+
+    def __getstate__(self):
+        return {}
+
+    def __setstate__(self, state):
+        self._host, self._event = None, None
+
+    def observe(self, dout):
+        if LP() != torch.float16 or _GRAD_SCALE_PINNED or torch.cuda.is_current_stream_capturing():
+            return
+        if self._host is None:
+            self._host = torch.zeros(1, dtype=torch.float32).pin_memory()
+            self._event = torch.cuda.Event()
+        elif not self._event.query():
+            return                         # the previous observation has not been read back yet: keep it
+        self._host.copy_(torch.linalg.vector_norm(dout.reshape(-1), float("inf")).reshape(1), non_blocking=True)
+        self._event.record()
+        self._fresh = True
+
+    def update(self):
+        global _GRAD_SCALE
+        if self._host is None or _GRAD_SCALE_PINNED or not getattr(self, "_fresh", False) or not self._event.query():
+            return
+        self._fresh = False
+        amax = float(self._host[0])
+        if amax > 0.0 and amax == amax and amax != float("inf"):
+            import math
+            k = min(24, max(0, math.floor(math.log2(self.TARGET / amax))))
+            _GRAD_SCALE = float(2 ** k)
+
 
 # optional per-launch timing (bench.py): an object with .add(name, ev_start, ev_end, flops, bytes)
 _timer = None

@@ -85,6 +85,7 @@ class BEIT3(nn.Module):
         self._prep_version = -1
         self._anchor = None
         self._last_ids = None
+        self._scale_tracker = ops.GradScaleTracker()
         if isinstance(pretrain, str):
             from ....checkpoint import load_beit3_pretrain
             load_beit3_pretrain(self, pretrain)
@@ -434,6 +435,7 @@ class BEIT3(nn.Module):
         # the kernels that write parameter gradients multiply by 1/S
         S = ops.grad_scale()
         inv = 1.0 / S
+        self._scale_tracker.observe(dout)
         ops.ln_bwd(dout, xs[2 * L], mF, rF, V["lnog"], G["lnog"], G["lnob"], split=Mv, dx_f32=dx, dx_scaled=dyb,
                    row_scale=None if dp is None else dp[L - 1][1], rows_per_sample=rps, dy_scale=S, param_scale=inv)
         for i in reversed(range(L)):
@@ -507,6 +509,8 @@ class BEIT3(nn.Module):
                 raise NotImplementedError('precision="fp32" is the exact parity mode and has no DropPath: call .eval() or '
                                           'build with drop_path_rate=0 (stochastic masks cannot be compared anyway)')
             return _EncoderFnF32.apply(self, img, ids, pad_u8, self._anchor)
+        if need_grad:
+            self._scale_tracker.update()          # 16-bit gradient scale of this step's backward (head and encoder)
         out = _EncoderFn.apply(self, img, ids, pad_u8, dp_scales, need_grad, self._anchor)
         out.lp = self._ws[(B, T, need_grad)]["out"]
         return out

@@ -3,13 +3,20 @@
 Tolerances (stated, bf16 pipeline vs fp32 oracle): GEMM operands are rounded to bf16 (rel 2^-9) at ~6
 points per layer, accumulation / LayerNorm / softmax / GELU are fp32 and the residual stream is fp32.
 Forward features are checked at 3e-2 of max|ref| (tiny, 2 layers) and 6e-2 (ViT-B, 12 layers); parameter
-gradients per tensor at 5e-2 relative L2 error.  The end-to-end north_star tolerance (boxes within 1e-3 L1)
+gradients per tensor at 5e-2 relative L2 error.  The default fp16 build is held to a QUARTER of each (measured: features
+<= 1.2e-3 of max, gradients <= 1.7e-3).  The end-to-end north_star tolerance (boxes within 1e-3 L1)
 is checked in tests/test_model_gpu.py."""
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
+
+
+def FEAT_TOL(bf16_tol):
+    """the stated bf16 tolerance; an fp16 build (3 more significand bits) is held to a quarter of it"""
+    from simvg_amd import _lib
+    return bf16_tol * (0.25 if _lib.lowp_format() == "fp16" else 1.0)
 
 
 def _rel_l2(a, b):
@@ -54,7 +61,8 @@ def test_encoder_tiny_fwd_bwd_vs_oracle(with_dp):
     ri, rt, rc = O.beit3_forward(sdg, cfg, batch["img"], batch["ref_expr_inds"], batch["text_attention_mask"], dp_cpu)
     for got, ref, name in [(img_feat, ri, "img_feat"), (text_feat, rt, "text_feat"), (cls_feat, rc, "cls_feat")]:
         err = float((got.float().cpu() - ref.detach()).abs().max())
-        assert err <= 3e-2 * float(ref.abs().max()), (name, err)
+        print(f"[encoder tiny dp={with_dp}] {name}: {err / float(ref.abs().max()):.2e} of max")
+        assert err <= FEAT_TOL(3e-2) * float(ref.abs().max()), (name, err)
     # backward with a bf16-representable upstream gradient
     di = (torch.randn(ri.shape, generator=g) * 0.1).to(torch.bfloat16).float()
     dt = (torch.randn(rt.shape, generator=g) * 0.1).to(torch.bfloat16).float()
@@ -62,7 +70,7 @@ def test_encoder_tiny_fwd_bwd_vs_oracle(with_dp):
     torch.autograd.backward([ri, rt, rc], [di, dt, dc])
     torch.autograd.backward([img_feat, text_feat, cls_feat],
                             [di.to(DEV).to(out.dtype), dt.to(DEV).to(out.dtype), dc.to(DEV).to(out.dtype)])
-    bad = []
+    bad, worst = [], 0.0
     for n, p in enc.named_parameters():
         ref = sdg["vis_enc." + n].grad
         if ref is None or float(ref.abs().max()) == 0.0:
@@ -70,8 +78,10 @@ def test_encoder_tiny_fwd_bwd_vs_oracle(with_dp):
             continue
         assert p.grad is not None, n
         e = _rel_l2(p.grad, ref)
-        if e > 5e-2:
+        worst = max(worst, e)
+        if e > FEAT_TOL(5e-2):
             bad.append((n, e))
+    print(f"[encoder tiny dp={with_dp}] worst per-tensor gradient relative L2 {worst:.2e}")
     assert not bad, bad[:10]
 
 
@@ -90,9 +100,11 @@ def test_encoder_base_forward_vs_reference_fixture(golden):
     for got, s, name in [(img_feat, fx["img_feat"], "img_feat"), (text_feat, fx["text_feat"], "text_feat")]:
         t = got.float().cpu().reshape(-1)[s["idx"]]
         err = float((t - s["vals"]).abs().max())
-        assert err <= 6e-2 * s["max"], (name, err, s["max"])
+        print(f"[encoder base] {name}: {err / s['max']:.2e} of max")
+        assert err <= FEAT_TOL(6e-2) * s["max"], (name, err, s["max"])
     err = float((cls_feat.float().cpu() - fx["cls_feat"]).abs().max())
-    assert err <= 6e-2 * float(fx["cls_feat"].abs().max()), ("cls_feat", err)
+    print(f"[encoder base] cls_feat: {err / float(fx['cls_feat'].abs().max()):.2e} of max")
+    assert err <= FEAT_TOL(6e-2) * float(fx["cls_feat"].abs().max()), ("cls_feat", err)
 
 
 def test_drop_path_masks_are_per_sample_bernoulli_draws():
@@ -115,3 +127,41 @@ def test_drop_path_masks_are_per_sample_bernoulli_draws():
     assert 0.3 < float(((a > 0) == (b > 0)).float().mean()) < 0.75      # independent: P(agree) = 0.7^2 + 0.3^2 = 0.58
     enc.eval()
     assert enc._drop_path_scales(B, torch.device("cuda", 0)) is None
+
+
+def test_gradient_scale_follows_the_incoming_gradient():
+    """fp16 backward: S (power of two) tracks max|d loss / d encoder output| of the previous step towards 2^6 without a host
+    synchronisation; parameter gradients do not depend on S (exact power-of-two scaling) while every tensor stays in fp16's
+    range (a pinned 2^14 saturated the 0.1-per-element upstream gradient of the DropPath test above: 3.7e-2 error)."""
+    from oracle import simvg_cpu as O, weights as W
+    from simvg_amd import hip_ops as ops, _lib
+    if _lib.lowp_format() != "fp16":
+        pytest.skip("bf16 build: no gradient scale")
+    cfg = O.make_cfg("tiny", 1, 128)
+    sd = W.golden_state_dict(cfg, 11)
+    batch = W.synthetic_batch(cfg, 3, 21)
+    enc = _build(cfg)
+    enc.load_state_dict(_enc_sd(sd), strict=True)
+    enc.to(DEV).train()
+    enc.drop_path_probs = [0.0] * enc.L
+    args = (batch["img"].to(DEV), batch["ref_expr_inds"].to(DEV), batch["text_attention_mask"].to(DEV))
+
+    def grads(up):
+        enc.zero_grad(set_to_none=True)
+        out = enc.encode(*args)
+        out.backward(torch.full_like(out, up))
+        torch.cuda.synchronize()
+        return enc._arena.flat_grad.clone(), ops.grad_scale()
+
+    try:
+        ops.set_grad_scale(None)
+        g1, s1 = grads(0.5)               # observed: max|dout| = 0.5
+        g2, s2 = grads(0.5)               # this step runs at 2^floor(log2(64 / 0.5)) = 128
+        assert s2 == 128.0, (s1, s2)
+        g3, s3 = grads(2.0 ** -10)
+        g4, s4 = grads(2.0 ** -10)
+        assert s4 == 65536.0, s4
+    finally:
+        ops.set_grad_scale(None)
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    assert rel(g1, g2) <= 1e-6 and rel(g3 * 512.0, g2) <= 2e-3, (rel(g1, g2), rel(g3 * 512.0, g2))
