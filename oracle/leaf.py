@@ -753,3 +753,45 @@ def mmdet_bbox_overlaps(bboxes1, bboxes2, mode="iou", is_aligned=False, eps=1e-6
         union = area1[..., None] + area2[..., None, :] - overlap
     union = torch.max(union, union.new_tensor([eps]))
     return overlap / union
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# transformers 4.x `XLMRobertaTokenizer` (sentencepiece-backed "slow" tokenizer; transformers 5.x in this image only has
+# the `tokenizers`-backed class with another constructor).  Restated from its published algorithm
+# (tokenization_xlm_roberta.py): fairseq alignment of the first four ids, spm ids shifted by one, <mask> last.
+# Used only to execute the reference's `LoadImageAnnotationsFromFile` (loading.py:74-77,157-182).  Parity unpinned at
+# this boundary.
+# ---------------------------------------------------------------------------------------------------------------------
+class XLMRobertaTokenizer:
+    def __init__(self, vocab_file, bos_token="<s>", eos_token="</s>", sep_token="</s>", cls_token="<s>", unk_token="<unk>",
+                 pad_token="<pad>", mask_token="<mask>", **kwargs):
+        import sentencepiece as spm
+        self.sp_model = spm.SentencePieceProcessor()
+        self.sp_model.Load(str(vocab_file))
+        self.fairseq_tokens_to_ids = {"<s>": 0, "<pad>": 1, "</s>": 2, "<unk>": 3}
+        self.fairseq_offset = 1
+        self.fairseq_tokens_to_ids["<mask>"] = len(self.sp_model) + self.fairseq_offset
+        self.fairseq_ids_to_tokens = {v: k for k, v in self.fairseq_tokens_to_ids.items()}
+        self.bos_token, self.eos_token, self.pad_token, self.unk_token = bos_token, eos_token, pad_token, unk_token
+        self.bos_token_id = self.fairseq_tokens_to_ids[bos_token]
+        self.eos_token_id = self.fairseq_tokens_to_ids[eos_token]
+        self.pad_token_id = self.fairseq_tokens_to_ids[pad_token]
+        self.unk_token_id = self.fairseq_tokens_to_ids[unk_token]
+
+    @property
+    def vocab_size(self):
+        return len(self.sp_model) + self.fairseq_offset + 1
+
+    def tokenize(self, text):
+        return self.sp_model.encode(text, out_type=str)
+
+    def _convert_token_to_id(self, token):
+        if token in self.fairseq_tokens_to_ids:
+            return self.fairseq_tokens_to_ids[token]
+        spm_id = self.sp_model.PieceToId(token)
+        return spm_id + self.fairseq_offset if spm_id else self.unk_token_id
+
+    def convert_tokens_to_ids(self, tokens):
+        if isinstance(tokens, str):
+            return self._convert_token_to_id(tokens)
+        return [self._convert_token_to_id(t) for t in tokens]

@@ -91,7 +91,7 @@ def _train_epoch(epoch, cfg, model, model_ema, optimizer, loader):
     from ..datasets import extract_data
     model.train()
     sampler = getattr(loader, "sampler", None)
-    if cfg.distributed and hasattr(sampler, "set_epoch"):
+    if hasattr(sampler, "set_epoch") and (cfg.distributed or getattr(sampler, "reshuffles_single_process", False)):
         sampler.set_epoch(epoch)
     device = next(model.parameters()).device
     reducer = _grad_reducer(model) if cfg.distributed else None

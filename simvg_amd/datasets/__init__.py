@@ -1,14 +1,15 @@
-"""Data side of the drop-in tools: registry + loader construction with the reference's call shape
+"""Data side of the drop-in tools: registries + loader construction with the reference's call shape
 (`simvg/datasets/builder.py:16-58`: `build_dataset(cfg.data.train)`, `build_dataloader(cfg, dataset)`,
-`extract_data(inputs)`), and the one dataset this round ships: `SyntheticRefDataset`, RefCOCO-shaped random pairs
-generated ON THE DEVICE (there are no images / annotation files in this image and no network).
+`extract_data(inputs)`).
 
-The image transforms of the reference's pipeline (LargeScaleJitter / Resize / Normalize / Pad / DefaultFormatBundle /
-CollectData) exist as device-side classes in `simvg_amd.datasets.pipelines`.  The
-file-backed part -- annotation json, JPEG decode, the XLM-R sentencepiece model -- needs artefacts that are not in this
-image: naming one of the reference's dataset types raises NotImplementedError that says so.  A config selects the synthetic source either with
-`type="SyntheticRefDataset"` or globally with `--cfg-options data.synthetic=True`, which keeps every other key of a
-reference config (pipelines, annsfile, ...) untouched and simply ignores them."""
+Two sources:
+  * the reference's annotation-file datasets under their own names (`refsets.py`: RefCOCOUNC ... GRefCOCO, Mixed), whose
+    pipeline starts with `LoadImageAnnotationsFromFile` (`loading.py`: file naming, decode, expression choice, XLM-R
+    sentencepiece ids, boxes) and continues with the DEVICE-side transforms of `pipelines.py` (LargeScaleJitter / Resize
+    / Normalize / Pad / DefaultFormatBundle / CollectData as HIP kernels on a uint8 frame in HBM);
+  * `SyntheticRefDataset`, RefCOCO-shaped random pairs (this image holds no dataset and has no network): selected with
+    `type="SyntheticRefDataset"` or globally with `--cfg-options data.synthetic=True`, which keeps every other key of a
+    reference config (pipelines, annsfile, ...) untouched and ignores them."""
 import torch
 from torch.utils.data import DataLoader, Dataset
 from torch.utils.data.distributed import DistributedSampler
@@ -69,37 +70,58 @@ class SyntheticRefDataset(Dataset):
 
 
 from . import pipelines as _pipelines   # noqa: E402,F401  (registers the device-side transforms in PIPELINES)
+from . import loading as _loading       # noqa: E402,F401  (LoadImageAnnotationsFromFile)
+from . import refsets as _refsets       # noqa: E402,F401  (the file-backed datasets under the reference's names)
+from .refsets import AspectGroupSampler  # noqa: E402
+
+
+def _stack_images(imgs):
+    """[C, h, w] tensors -> [B, C, H, W], zero-padded at the bottom / right to the largest frame of the batch (the
+    reference's collate pads the last two dims, `datasets/utils.py:76-100`)"""
+    H, W = max(int(i.shape[-2]) for i in imgs), max(int(i.shape[-1]) for i in imgs)
+    if all(tuple(i.shape[-2:]) == (H, W) for i in imgs):
+        return torch.stack(imgs)
+    out = imgs[0].new_zeros((len(imgs), imgs[0].shape[0], H, W))
+    for k, i in enumerate(imgs):
+        out[k, :, :i.shape[-2], :i.shape[-1]] = i
+    return out
 
 
 def _collate(batch):
-    out = dict(img=torch.stack([b["img"] for b in batch]),
-               ref_expr_inds=torch.stack([b["ref_expr_inds"] for b in batch]),
-               text_attention_mask=torch.stack([b["text_attention_mask"] for b in batch]),
-               img_metas=[b["img_metas"] for b in batch])
-    gts = [b["gt_bbox"] for b in batch]
-    out["gt_bbox"] = torch.stack(gts) if all(g.dim() == 1 for g in gts) else gts
+    out = dict(img=_stack_images([b["img"] for b in batch]), img_metas=[b["img_metas"] for b in batch])
+    for key in ("ref_expr_inds", "text_attention_mask"):          # the mask exists for tokenizer ids only
+        if key in batch[0]:
+            out[key] = torch.stack([torch.as_tensor(b[key]) for b in batch])
+    if "gt_bbox" in batch[0]:
+        gts = [b["gt_bbox"] for b in batch]
+        out["gt_bbox"] = torch.stack(gts) if all(g.dim() == 1 for g in gts) else gts
     return out
 
 
 def build_dataset(cfg, default_args=None):
     cfg = dict(cfg)
     typ = cfg.get("type")
-    if typ in _REFERENCE_DATASETS and not cfg.pop("synthetic", False):
-        raise NotImplementedError(
-            f"dataset type {typ!r} reads annotation json + jpg files through the reference's CPU pipeline; the file-bound "
-            "part of the input pipeline (json / JPEG / sentencepiece artefacts) is not available in this build.  Use type='SyntheticRefDataset' or pass "
-            "--cfg-options data.synthetic=True to run the reference config on synthetic pairs of the same shape.")
-    if typ in _REFERENCE_DATASETS:
+    synthetic = cfg.pop("synthetic", False)
+    if typ in _REFERENCE_DATASETS and synthetic:
         keep = {k: cfg[k] for k in ("which_set", "length", "img_size", "max_token", "seed", "max_targets") if k in cfg}
         cfg = dict(type="SyntheticRefDataset", dataset=typ, **keep)
-    cfg.pop("synthetic", None)
+    elif typ in ("MixedSeg", "RefClef"):
+        raise NotImplementedError(f"dataset type {typ!r} (segmentation targets) is not built; see datasets/refsets.py for the "
+                                  "file-backed detection datasets or pass --cfg-options data.synthetic=True")
+    elif typ in _REFERENCE_DATASETS:
+        for k in ("length", "img_size", "max_token", "seed", "max_targets"):      # keys of the synthetic source only
+            cfg.pop(k, None)
     return DATASETS.build(cfg, default_args=default_args)
 
 
 def build_dataloader(cfg, dataset):
     sampler, shuffle = None, False
     train = dataset.which_set == "train"
-    if cfg.distributed:
+    grouped = train and isinstance(dataset, _refsets.RefFileDataset)      # aspect-ratio batches for real frames
+    if grouped:
+        sampler = AspectGroupSampler(dataset.flag, cfg.data.samples_per_gpu, cfg.world_size if cfg.distributed else 1,
+                                     cfg.rank if cfg.distributed else 0, seed=cfg.seed or 0)
+    elif cfg.distributed:
         sampler = DistributedSampler(dataset, cfg.world_size, cfg.rank, shuffle=train, seed=cfg.seed or 0)
     elif train:
         shuffle = True

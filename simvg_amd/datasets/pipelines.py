@@ -9,8 +9,8 @@ LargeScaleJitter including its crop search, its "escape" branch (image and boxes
 and its clipping of boxes to the crop.  LargeScaleJitter never materialises the rescaled image: rescale + crop is one
 windowed resize.  `DeviceFormat` = Normalize + Pad + DefaultFormatBundle's HWC->CHW transpose in one kernel.
 
-Not here (host-side, file-bound, or dependent on artefacts that are not in this image): `LoadImageAnnotationsFromFile`
-(JPEG decode, the XLM-R sentencepiece model `beit3.spm`), mask transforms."""
+The pipeline's first step, `LoadImageAnnotationsFromFile` (file naming, decode, expression choice, token ids, boxes), is
+`loading.py`; mask transforms are not built."""
 import math
 import random
 

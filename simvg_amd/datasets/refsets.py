@@ -1,0 +1,146 @@
+"""Annotation-file datasets with the reference's registry names and constructor arguments (`simvg/datasets/base.py:13-175`:
+RefCOCOUNC, RefCOCOGoogle, RefCOCOgUMD, RefCOCOgGoogle, RefCOCOPlusUNC, ReferItGameBerkeley, Flickr30k, Mixed, GRefCOCO).
+
+One annotation json holds every split: {"train": [record...], "val": [...], ...}; a record carries image_id, width, height,
+expressions, bbox (xywh; GRefCOCO: one list of boxes and one list of `annotations` per expression) and, for `Mixed`,
+data_source.  A dataset item = the split's record pushed through the config's pipeline (first step
+`LoadImageAnnotationsFromFile`, then the device transforms).  The word vocabulary (`token2idx`, handed to `build_model` as
+num_token / word_emb by tools/train.py) is built by scanning all expressions in file order, or read from the
+token_to_ix.pkl / ix_to_token.pkl / word_emb.npz cache the reference leaves beside the json (`datasets/utils.py:136-190`)."""
+import json
+import os.path as osp
+import pickle
+
+import numpy
+import torch
+from torch.utils.data import Dataset, Sampler
+
+from . import DATASETS
+from .loading import clean_string
+
+SPLITS = ("train", "val", "testA", "testB", "test", "val_refcoco_unc", "val_refcocoplus_unc", "val_refcocog_umd",
+          "val_flickr30k", "val_referitgame_berkeley")
+IMAGE_SOURCES = ("coco", "visual-genome", "flickr", "saiaprtc12")
+
+
+def build_vocabulary(annsfile, anns_all, word_emb_cfg=None, write_cache=False):
+    """-> (token2idx, idx2token, word_emb).  Ids follow first occurrence over the splits in json order after PAD 0 / UNK 1 /
+    CLS 2.  GloVe vectors need spacy's en_vectors_web_lg; the BEiT-3 models take no word embedding (lan_enc=None), so a
+    missing package yields an empty `word_emb` instead of the reference's ImportError."""
+    base = osp.dirname(annsfile)
+    paths = [osp.join(base, n) for n in ("token_to_ix.pkl", "ix_to_token.pkl", "word_emb.npz")]
+    if all(osp.exists(p) for p in paths):
+        with open(paths[0], "rb") as f:
+            token2idx = pickle.load(f)
+        with open(paths[1], "rb") as f:
+            idx2token = pickle.load(f)
+        return token2idx, idx2token, numpy.load(paths[2], allow_pickle=True)["word_emb"]
+    vectors = None
+    if word_emb_cfg is not None and dict(word_emb_cfg).get("type") == "GloVe":
+        try:
+            import en_vectors_web_lg
+            vectors = en_vectors_web_lg.load()
+        except ImportError:
+            vectors = None
+    token2idx = {"PAD": 0, "UNK": 1, "CLS": 2}
+    for records in anns_all.values():
+        for record in records:
+            for expression in record["expressions"]:
+                for word in clean_string(expression).split():
+                    token2idx.setdefault(word, len(token2idx))
+    idx2token = {i: t for t, i in token2idx.items()}
+    word_emb = numpy.array([vectors(t).vector for t in token2idx]) if vectors is not None else numpy.array([])
+    if write_cache:
+        with open(paths[0], "wb") as f:
+            pickle.dump(token2idx, f, protocol=pickle.HIGHEST_PROTOCOL)
+        with open(paths[1], "wb") as f:
+            pickle.dump(idx2token, f, protocol=pickle.HIGHEST_PROTOCOL)
+        numpy.savez_compressed(paths[2], word_emb=word_emb)
+    return token2idx, idx2token, word_emb
+
+
+class RefFileDataset(Dataset):
+    """imgsfile: image directory (one source) or {source: directory} (several, `Mixed`)"""
+
+    def __init__(self, imgsfile, annsfile, pipeline, which_set="train", img_source=("coco",), word_emb_cfg=None,
+                 write_vocab_cache=False):
+        from .pipelines import Compose
+        if which_set not in SPLITS:
+            raise ValueError(f"which_set must be one of {SPLITS}")
+        img_source = list(img_source)
+        if not img_source:
+            raise TypeError("img_source should be a list of str")
+        if len(img_source) == 1:
+            if img_source[0] not in IMAGE_SOURCES:
+                raise ValueError(f"unknown image source {img_source[0]!r}")
+        elif not (isinstance(imgsfile, dict) and len(imgsfile) == len(img_source)):
+            raise ValueError("several image sources need imgsfile = {source: directory}")
+        self.which_set, self.imgsfile = which_set, imgsfile
+        with open(annsfile, "r") as f:
+            self.anns_all = json.load(f)
+        self.token2idx, self.idx2token, self.word_emb = build_vocabulary(annsfile, self.anns_all, word_emb_cfg, write_vocab_cache)
+        train = self.anns_all.get("train", [])
+        if train and train[0].get("data_source") is not None:
+            self.anns_all["train"] = [r for r in train if r["data_source"] in img_source]
+        self.records = self.anns_all[which_set]
+        if which_set == "train":       # aspect-ratio groups of the group sampler: 1 = landscape
+            self.flag = numpy.array([1 if r["width"] / r["height"] > 1 else 0 for r in self.records], dtype=numpy.uint8)
+        self.pipeline = Compose(pipeline)
+        head = self.pipeline.transforms[0]
+        if getattr(head, "use_token_type", "default") == "beit3":
+            self.num_token = -1        # the encoder owns its 64 010-row table: build_model ignores num_token
+        else:
+            self.num_token = len(self.token2idx)
+
+    def __len__(self):
+        return len(self.records)
+
+    def __getitem__(self, index):
+        return self.pipeline(dict(ann=self.records[index], which_set=self.which_set, token2idx=self.token2idx,
+                                  imgsfile=self.imgsfile))
+
+
+def _register(name):
+    cls = type(name, (RefFileDataset,), {"__doc__": f"`{name}` of the reference's DATASETS registry (file-backed)"})
+    DATASETS.register_module()(cls)
+    return cls
+
+
+FILE_DATASETS = {n: _register(n) for n in ("GRefCOCO", "RefCOCOUNC", "RefCOCOGoogle", "RefCOCOgUMD", "RefCOCOgGoogle",
+                                           "RefCOCOPlusUNC", "ReferItGameBerkeley", "Flickr30k", "Mixed")}
+
+
+class AspectGroupSampler(Sampler):
+    """Batches of `samples_per_gpu` indices that share an aspect-ratio group (the role of mmdet's GroupSampler /
+    DistributedGroupSampler in `datasets/builder.py:31-40`): each group is shuffled and padded (by re-drawing its own
+    members) to a multiple of the batch -- of batch x world for the distributed form --, the batches of all groups are
+    shuffled, and rank r takes every world-th batch.  Reshuffles per epoch through `set_epoch`."""
+
+    reshuffles_single_process = True       # train_model calls set_epoch for it also without torch.distributed
+
+    def __init__(self, flags, samples_per_gpu, world_size=1, rank=0, seed=0):
+        self.flags = numpy.asarray(flags)
+        self.batch, self.world, self.rank, self.seed, self.epoch = int(samples_per_gpu), int(world_size), int(rank), int(seed or 0), 0
+        chunk = self.batch * self.world
+        self._len = sum(-(-int(n) // chunk) * chunk for n in numpy.bincount(self.flags) if n) // self.world
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
+    def __len__(self):
+        return self._len
+
+    def __iter__(self):
+        g = torch.Generator().manual_seed(self.seed + self.epoch)
+        chunk = self.batch * self.world
+        batches = []
+        for flag in numpy.unique(self.flags):
+            members = torch.from_numpy(numpy.where(self.flags == flag)[0])
+            order = members[torch.randperm(len(members), generator=g)]
+            short = -len(order) % chunk
+            if short:
+                order = torch.cat([order, order[torch.randint(len(order), (short,), generator=g)]])
+            batches += list(order.view(-1, self.batch))
+        pick = torch.randperm(len(batches) // self.world, generator=g)
+        mine = [batches[int(i) * self.world + self.rank] for i in pick]
+        return iter(torch.cat(mine).tolist()) if mine else iter(())

@@ -6,8 +6,8 @@ The command lines, the config semantics, the split names, the log lines and the 
   * one process per GPU, no DistributedDataParallel wrapper -- replicas are made identical by a broadcast of the flat
     arenas' tensors and kept identical by `simvg_amd.dist.GradReducer` inside `train_model`;
   * the encoder is laid out in its flat arenas BEFORE the optimizer, the EMA or a checkpoint take views of it;
-  * file-backed datasets are SURVEY section 8 f-3: `data.synthetic=True` swaps every split for RefCOCO-shaped synthetic
-    pairs with the split's own name and geometry."""
+  * the annotation-file datasets of a reference config are read as they are (`simvg_amd/datasets/refsets.py`);
+    `data.synthetic=True` swaps every split for RefCOCO-shaped synthetic pairs with the split's own name and geometry."""
 import os.path as osp
 import time
 

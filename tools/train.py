@@ -14,8 +14,8 @@ Deliberate differences, all consequences of the MI355X mapping:
    state_dict keys never carry a `module.` prefix;
  * `type="Adam"` resolves to the fused flat-arena Adam (same arithmetic); `optimizer_config.flat=False` opts out;
  * `use_fp16` (apex O1) is refused; `--cfg-options model.vis_enc.precision=fp32` selects the exact-fp32 parity mode;
- * `--cfg-options data.synthetic=True` runs any reference config on synthetic RefCOCO-shaped pairs (datasets on disk are
-   SURVEY section 8 f-3)."""
+ * `--cfg-options data.synthetic=True` runs any reference config on synthetic RefCOCO-shaped pairs when its `data/` tree
+   is absent."""
 import argparse
 import os
 import os.path as osp
