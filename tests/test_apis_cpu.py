@@ -202,8 +202,8 @@ def test_train_and_evaluate_loops_match_reference(dataset):
 def test_synthetic_dataset_and_loader_shapes():
     from simvg_amd.datasets import build_dataset, build_dataloader, extract_data
     from oracle.mock_loop import Cfg
-    with pytest.raises(NotImplementedError):
-        build_dataset(dict(type="RefCOCOUNC", which_set="train", annsfile="x", pipeline=[]))
+    with pytest.raises(FileNotFoundError):          # without synthetic=True the annotation json is opened (tests/test_datasets_cpu.py)
+        build_dataset(dict(type="RefCOCOUNC", which_set="train", imgsfile="x", annsfile="/nonexistent/instances.json", pipeline=[]))
     ds = build_dataset(dict(type="RefCOCOUNC", which_set="train", annsfile="x", pipeline=[], synthetic=True, length=10, img_size=64))
     assert len(ds) == 10 and ds.word_emb is None and ds.num_token == -1
     a, b = ds[3], ds[3]
