@@ -10,6 +10,8 @@ Two sources:
   * `SyntheticRefDataset`, RefCOCO-shaped random pairs (this image holds no dataset and has no network): selected with
     `type="SyntheticRefDataset"` or globally with `--cfg-options data.synthetic=True`, which keeps every other key of a
     reference config (pipelines, annsfile, ...) untouched and ignores them."""
+import functools
+
 import torch
 from torch.utils.data import DataLoader, Dataset
 from torch.utils.data.distributed import DistributedSampler
@@ -127,8 +129,26 @@ def build_dataloader(cfg, dataset):
         shuffle = True
     g = torch.Generator()
     g.manual_seed(cfg.seed or 0)
+    if isinstance(dataset, _refsets.RefFileDataset) and dataset.host_steps() > 0:
+        # file read + JPEG decode + tokenisation in `workers_per_gpu` worker processes (seeded like the reference's:
+        # num_workers * rank + worker_id + seed), every pixel transform on the GPU in this process
+        workers = int(cfg.data.get("workers_per_gpu", 0) or 0)
+        rank, seed = (cfg.rank if cfg.distributed else 0), cfg.seed
+        init = None if seed is None else functools.partial(_seed_worker, num_workers=workers, rank=rank, seed=seed)
+        host = DataLoader(_refsets.HostStageView(dataset), batch_size=cfg.data.samples_per_gpu, sampler=sampler, shuffle=shuffle,
+                          generator=g, num_workers=workers, pin_memory=workers > 0 and torch.cuda.is_available(),
+                          collate_fn=list, worker_init_fn=init, drop_last=False, persistent_workers=workers > 0)
+        return _refsets.TwoStageLoader(dataset, host, _collate)
     return DataLoader(dataset, batch_size=cfg.data.samples_per_gpu, sampler=sampler, shuffle=shuffle, generator=g,
                       num_workers=0, pin_memory=False, collate_fn=_collate, drop_last=False)
+
+
+def _seed_worker(worker_id, num_workers, rank, seed):
+    import random
+    import numpy
+    s = num_workers * rank + worker_id + seed
+    numpy.random.seed(s)
+    random.seed(s)
 
 
 def extract_data(inputs, device=None):

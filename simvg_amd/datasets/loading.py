@@ -63,6 +63,8 @@ def _xyxy_clipped(box_xywh, h, w):
 
 @PIPELINES.register_module()
 class LoadImageAnnotationsFromFile:
+    host_side = True          # runs in DataLoader workers when the loader is two-stage (refsets.TwoStageLoader)
+
     def __init__(self, dataset="RefCOCOUNC", color_type="color", backend=None, file_client_cfg=dict(backend="disk"),
                  max_token=15, with_bbox=False, with_mask=False, use_token_type="default",
                  spm_path="pretrain_weights/beit3.spm", device=None):
@@ -94,12 +96,14 @@ class LoadImageAnnotationsFromFile:
             return torch.device(self.device)
         return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
 
-    def __call__(self, results):
+    def __call__(self, results, host_only=False):
+        """host_only: leave the decoded frame in (CPU) memory -- the consumer moves it to the GPU"""
         ann = results["ann"]
         path = image_path(self.dataset, results["imgsfile"], ann)
         frame = decode_image(path, self.color_type)
         shape = tuple(int(s) for s in frame.shape)
-        results.update(filename=path, img=torch.from_numpy(frame).to(self._device(), non_blocking=True), img_shape=shape,
+        img = torch.from_numpy(frame)
+        results.update(filename=path, img=img if host_only else img.to(self._device(), non_blocking=True), img_shape=shape,
                        ori_shape=shape)
         # ---- expression: one of the record's expressions, drawn like the reference draws it
         expressions = ann["expressions"]

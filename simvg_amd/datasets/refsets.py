@@ -95,9 +95,69 @@ class RefFileDataset(Dataset):
     def __len__(self):
         return len(self.records)
 
+    def _record(self, index):
+        return dict(ann=self.records[index], which_set=self.which_set, token2idx=self.token2idx, imgsfile=self.imgsfile)
+
     def __getitem__(self, index):
-        return self.pipeline(dict(ann=self.records[index], which_set=self.which_set, token2idx=self.token2idx,
-                                  imgsfile=self.imgsfile))
+        return self.pipeline(self._record(index))
+
+    # ---- two-stage form used by build_dataloader: the host stage (file read, JPEG decode, tokenisation) can run in
+    # DataLoader worker processes, the device stage (every pixel transform) runs in the training process on the GPU
+    def host_steps(self):
+        n = 0
+        for t in self.pipeline.transforms:
+            if not getattr(t, "host_side", False):
+                break
+            n += 1
+        return n
+
+    def host_item(self, index):
+        results = self._record(index)
+        for t in self.pipeline.transforms[:self.host_steps()]:
+            results = t(results, host_only=True)
+        return results
+
+    def device_item(self, results, device):
+        if torch.is_tensor(results.get("img")):
+            results["img"] = results["img"].to(device, non_blocking=True)
+        for t in self.pipeline.transforms[self.host_steps():]:
+            results = t(results)
+        return results
+
+
+class HostStageView(Dataset):
+    """what the DataLoader's workers see of a RefFileDataset: records -> decoded uint8 frame (CPU) + ids + boxes"""
+
+    def __init__(self, dataset):
+        self.dataset = dataset
+
+    def __len__(self):
+        return len(self.dataset)
+
+    def __getitem__(self, index):
+        out = self.dataset.host_item(index)
+        out.pop("token2idx", None)           # the vocabulary table does not need to travel back from the worker
+        return out
+
+
+class TwoStageLoader:
+    """DataLoader over the host stage (optionally in worker processes) + the device stage and the collate in the consumer.
+    Presents what `train_model` / `evaluate_model` use of a DataLoader: iteration, len(), .dataset, .sampler."""
+
+    def __init__(self, dataset, host_loader, collate, device=None):
+        self.dataset, self.host_loader, self.collate, self.device = dataset, host_loader, collate, device
+        self.sampler = host_loader.sampler
+        self.batch_size = host_loader.batch_size
+
+    def __len__(self):
+        return len(self.host_loader)
+
+    def __iter__(self):
+        device = self.device
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        for host_batch in self.host_loader:
+            yield self.collate([self.dataset.device_item(r, device) for r in host_batch])
 
 
 def _register(name):

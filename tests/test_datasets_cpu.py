@@ -143,3 +143,40 @@ def test_aspect_group_sampler_batches_share_a_group_and_ranks_partition_the_epoc
     for part in (a, b):
         for i in range(0, len(part), 4):
             assert len({int(flags[j]) for j in part[i:i + 4]}) == 1
+
+
+def test_two_stage_loader_runs_the_host_stage_in_seeded_workers(mini):
+    """decode + tokenisation in DataLoader worker processes (host stage), the remaining transforms in the consumer; the
+    expression draw of a worker follows the reference's worker seed (num_workers * rank + worker_id + seed)"""
+    from simvg_amd.datasets import build_dataset, build_dataloader
+    from simvg_amd.datasets.refsets import TwoStageLoader
+    from oracle.mock_loop import Cfg
+    fx, root = mini
+    pipe = [dict(type="LoadImageAnnotationsFromFile", dataset="RefCOCOUNC", max_token=12, with_bbox=True, use_token_type="beit3",
+                 spm_path=os.path.join(root, "beit3.spm"), device="cpu"),
+            dict(type="CollectData", keys=["img", "ref_expr_inds", "text_attention_mask", "gt_bbox"])]
+    ds = build_dataset(dict(type="RefCOCOUNC", which_set="train", img_source=["coco"], imgsfile=os.path.join(root, "coco"),
+                            annsfile=os.path.join(root, "anns", "RefCOCOUNC", "instances.json"), pipeline=pipe))
+    assert ds.host_steps() == 1
+    cfg = Cfg(distributed=False, seed=5, rank=0, world_size=1, data=Cfg(samples_per_gpu=2, workers_per_gpu=2))
+    loader = build_dataloader(cfg, ds)
+    assert isinstance(loader, TwoStageLoader) and loader.dataset is ds and len(loader) == 2 and hasattr(loader.sampler, "set_epoch")
+    loader.collate = lambda items: items                       # frames of different sizes: no stacking in this test
+    seen = []
+    for epoch in range(2):
+        loader.sampler.set_epoch(epoch)
+        for batch in loader:
+            assert len(batch) == 2
+            for item in batch:
+                assert item["img"].dtype == torch.uint8 and item["img"].dim() == 3 and not item["img"].is_cuda
+                assert len(item["ref_expr_inds"]) == 12 and item["img_metas"]["expression"]
+                seen.append((os.path.basename(item["img_metas"]["filename"]), item["img_metas"]["expression"]))
+    assert {n for n, _ in seen} == {"COCO_train2014_%012d.jpg" % i for i in (1, 2, 3)}
+    again = []
+    loader2 = build_dataloader(cfg, ds)
+    loader2.collate = lambda items: items
+    for epoch in range(2):
+        loader2.sampler.set_epoch(epoch)
+        for batch in loader2:
+            again += [(os.path.basename(i["img_metas"]["filename"]), i["img_metas"]["expression"]) for i in batch]
+    assert again == seen                                       # same seed -> same order and the same expression draws

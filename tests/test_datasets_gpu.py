@@ -83,7 +83,7 @@ def test_grefcoco_items_carry_box_lists_and_targets_through_the_loader(mini):
     ds = build_dataset(dict(type="GRefCOCO", which_set="train", img_source=["coco"], imgsfile=os.path.join(root, "coco"),
                             annsfile=os.path.join(root, "anns", "GRefCOCO", "instances.json"),
                             pipeline=_pipeline(root, "GRefCOCO", False, meta=meta)))
-    cfg = Config(dict(distributed=False, seed=1, data=dict(samples_per_gpu=2)))
+    cfg = Config(dict(distributed=False, seed=1, data=dict(samples_per_gpu=2, workers_per_gpu=2)))      # decode in 2 worker processes
     np.random.seed(0)
     batches = [extract_data(b, torch.device("cuda")) for b in build_dataloader(cfg, ds)]
     assert len(batches) == 1 and all(b["img"].shape == (2, 3, S, S) and b["img"].is_cuda for b in batches)
@@ -104,7 +104,7 @@ def test_train_and_test_tools_on_the_annotation_file_dataset(mini, tmp_path):
     tail = tail.split("model = dict(", 1)[1]
     common = (f'img_source=["coco"], imgsfile={os.path.join(root, "coco")!r}, '
               f'annsfile={os.path.join(root, "anns", "RefCOCOUNC", "instances.json")!r}')
-    data = ("data = dict(samples_per_gpu=2, workers_per_gpu=0,\n"
+    data = ("data = dict(samples_per_gpu=2, workers_per_gpu=2,\n"
             f"    train=dict(type='RefCOCOUNC', which_set='train', {common}, pipeline={_pipeline(root, 'RefCOCOUNC', True)!r}),\n"
             + "".join(f"    {s}=dict(type='RefCOCOUNC', which_set='{s}', {common}, pipeline={_pipeline(root, 'RefCOCOUNC', False)!r}),\n"
                       for s in ("val", "testA", "testB")) + ")\n")
