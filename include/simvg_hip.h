@@ -193,6 +193,22 @@ int simvg_resize_u8(const void* src_hwc, int src_h, int src_w, long src_row_byte
                     int out_h, int out_w, int full_h, int full_w, int win_y0, int win_x0, simvg_stream_t stream);
 int simvg_normalize_pad_u8(const void* src_hwc, long src_row_bytes, int h, int w, float* dst_chw, int pad_h, int pad_w,
                            const float* mean3_host, const float* std3_host, int to_rgb, simvg_stream_t stream);
+/* Batched forms: ONE launch for up to SIMVG_PREPROCESS_MAX_JOBS frames of different geometry (a loader issues two resizes
+ * and one format pass per frame: 3 launches per 32 frames instead of 96).  `jobs` is a HOST array consumed before the call
+ * returns; same arithmetic per job as the single-frame entry points. */
+#define SIMVG_PREPROCESS_MAX_JOBS 32
+typedef struct simvg_resize_job {
+  const void* src; int src_h, src_w; long src_row_bytes;
+  void* dst; long dst_row_bytes;
+  int out_h, out_w, full_h, full_w, win_y0, win_x0;
+} simvg_resize_job;
+typedef struct simvg_format_job {
+  const void* src; long src_row_bytes; int h, w;
+  float* dst_chw; int pad_h, pad_w;
+} simvg_format_job;
+int simvg_resize_u8_batched(const simvg_resize_job* jobs, int count, simvg_stream_t stream);
+int simvg_normalize_pad_u8_batched(const simvg_format_job* jobs, int count, const float* mean3_host, const float* std3_host,
+                                   int to_rgb, simvg_stream_t stream);
 
 /* ---- optimizer step over a flat fp32 arena (csrc/optim.hip) ------------------------------------------------------
  * Replaces torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step of apis/train.py:81-83 (core/optimizer.py:52-68)

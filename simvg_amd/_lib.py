@@ -51,6 +51,8 @@ _SIGS = {
     "simvg_cast_lp_to_f32": [c_void_p, c_void_p, c_long, c_void_p],
     "simvg_resize_u8": [c_void_p, c_int, c_int, c_long, c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "simvg_normalize_pad_u8": [c_void_p, c_long, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
+    "simvg_resize_u8_batched": [c_void_p, c_int, c_void_p],
+    "simvg_normalize_pad_u8_batched": [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p],
     "simvg_attn_f32_bwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                            c_float, c_void_p],
     "simvg_gelu_f32": [c_void_p, c_void_p, c_void_p, c_long, c_void_p],

@@ -89,8 +89,10 @@ def _stack_images(imgs):
     return out
 
 
-def _collate(batch):
-    out = dict(img=_stack_images([b["img"] for b in batch]), img_metas=[b["img_metas"] for b in batch])
+def _collate(batch, stacked_img=None):
+    """stacked_img: the frames already as one [B, C, H, W] tensor (the batched device stage writes them in place)"""
+    img = stacked_img if stacked_img is not None else _stack_images([b["img"] for b in batch])
+    out = dict(img=img, img_metas=[b["img_metas"] for b in batch])
     for key in ("ref_expr_inds", "text_attention_mask"):          # the mask exists for tokenizer ids only
         if key in batch[0]:
             out[key] = torch.stack([torch.as_tensor(b[key]) for b in batch])
@@ -134,10 +136,10 @@ def build_dataloader(cfg, dataset):
         # num_workers * rank + worker_id + seed), every pixel transform on the GPU in this process
         workers = int(cfg.data.get("workers_per_gpu", 0) or 0)
         rank, seed = (cfg.rank if cfg.distributed else 0), cfg.seed
-        init = None if seed is None else functools.partial(_seed_worker, num_workers=workers, rank=rank, seed=seed)
+        init = functools.partial(_seed_worker, num_workers=workers, rank=rank, seed=seed)
         host = DataLoader(_refsets.HostStageView(dataset), batch_size=cfg.data.samples_per_gpu, sampler=sampler, shuffle=shuffle,
-                          generator=g, num_workers=workers, pin_memory=workers > 0 and torch.cuda.is_available(),
-                          collate_fn=list, worker_init_fn=init, drop_last=False, persistent_workers=workers > 0)
+                          generator=g, num_workers=workers, pin_memory=bool(cfg.data.get("pin_memory", False)),
+                          collate_fn=_refsets.pack_host_batch, worker_init_fn=init, drop_last=False, persistent_workers=workers > 0)
         return _refsets.TwoStageLoader(dataset, host, _collate)
     return DataLoader(dataset, batch_size=cfg.data.samples_per_gpu, sampler=sampler, shuffle=shuffle, generator=g,
                       num_workers=0, pin_memory=False, collate_fn=_collate, drop_last=False)
@@ -146,9 +148,11 @@ def build_dataloader(cfg, dataset):
 def _seed_worker(worker_id, num_workers, rank, seed):
     import random
     import numpy
-    s = num_workers * rank + worker_id + seed
-    numpy.random.seed(s)
-    random.seed(s)
+    torch.set_num_threads(1)           # a worker decodes and copies one frame at a time: no intra-op thread pool per worker
+    if seed is not None:
+        s = num_workers * rank + worker_id + seed
+        numpy.random.seed(s)
+        random.seed(s)
 
 
 def extract_data(inputs, device=None):

@@ -118,7 +118,7 @@ class LoadImageAnnotationsFromFile:
             ids = torch.zeros(self.max_token, dtype=torch.long)
             for i, word in enumerate(expression.split()[:self.max_token]):
                 ids[i] = table.get(word, table["UNK"])
-            results["ref_expr_inds"] = ids
+            results["ref_expr_inds"] = ids.numpy() if host_only else ids        # numpy pickles inline across the worker boundary
         results.update(expression=expression, max_token=self.max_token)
         # ---- boxes
         h, w = shape[:2]

@@ -101,25 +101,40 @@ class RefFileDataset(Dataset):
     def __getitem__(self, index):
         return self.pipeline(self._record(index))
 
-    # ---- two-stage form used by build_dataloader: the host stage (file read, JPEG decode, tokenisation) can run in
-    # DataLoader worker processes, the device stage (every pixel transform) runs in the training process on the GPU
+    # ---- two-stage form used by build_dataloader: the host stage runs in DataLoader worker processes -- file read, JPEG
+    # decode, tokenisation and, when every later transform can record its pixel work on a DeferredFrame, the WHOLE pipeline's
+    # host logic (random draws, crop search, box arithmetic) --, the device stage in the training process on the GPU
     def host_steps(self):
+        ts = self.pipeline.transforms
         n = 0
-        for t in self.pipeline.transforms:
-            if not getattr(t, "host_side", False):
-                break
+        while n < len(ts) and getattr(ts[n], "host_side", False):
             n += 1
+        if n and all(getattr(t, "deferrable", False) for t in ts[n:]):
+            return len(ts)
         return n
 
     def host_item(self, index):
+        from .pipelines import DeferredFrame
         results = self._record(index)
-        for t in self.pipeline.transforms[:self.host_steps()]:
-            results = t(results, host_only=True)
+        ts = self.pipeline.transforms
+        n = self.host_steps()
+        for k, t in enumerate(ts[:n]):
+            if getattr(t, "host_side", False):
+                results = t(results, host_only=True)
+                if n == len(ts) and torch.is_tensor(results.get("img")):
+                    results["img"] = DeferredFrame(results["img"])
+            else:
+                results = t(results)
         return results
 
-    def device_item(self, results, device):
-        if torch.is_tensor(results.get("img")):
-            results["img"] = results["img"].to(device, non_blocking=True)
+    def device_item(self, results, device, packed=None):
+        img = results.get("img")
+        if hasattr(img, "materialize"):
+            from .pipelines import tensorize
+            results["img"] = img.materialize(device, packed if img.offset is not None else None)
+            tensorize(results)
+        elif torch.is_tensor(img):
+            results["img"] = img.to(device, non_blocking=True)
         for t in self.pipeline.transforms[self.host_steps():]:
             results = t(results)
         return results
@@ -140,24 +155,109 @@ class HostStageView(Dataset):
         return out
 
 
+def pack_host_batch(items):
+    """collate of the HOST stage (runs in the worker): the batch's decoded frames become ONE flat uint8 tensor -- one
+    shared-memory hand-over, one pinned copy and one host-to-device transfer per batch instead of one per frame (64
+    separate tensors kept the DataLoader's single pin-memory thread at ~40 ms per batch) -- and every DeferredFrame keeps
+    its offset into it."""
+    frames = [it["img"] for it in items if hasattr(it.get("img"), "materialize") and it["img"].pixels is not None]
+    if not frames:
+        return dict(items=items, frames=None)
+    blob = torch.empty(sum(f.pixels.numel() for f in frames), dtype=torch.uint8)
+    at = 0
+    for f in frames:
+        n = f.pixels.numel()
+        blob[at:at + n] = f.pixels.reshape(-1)
+        f.offset, f.pixels = at, None
+        at += n
+    return dict(items=items, frames=blob)
+
+
 class TwoStageLoader:
     """DataLoader over the host stage (optionally in worker processes) + the device stage and the collate in the consumer.
-    Presents what `train_model` / `evaluate_model` use of a DataLoader: iteration, len(), .dataset, .sampler."""
+    Presents what `train_model` / `evaluate_model` use of a DataLoader: iteration, len(), .dataset, .sampler.
+    With worker processes and a GPU the device stage of batch k+1 (one host-to-device copy, 2-3 kernel launches per frame,
+    the stack) runs in a background thread on its own HIP stream while the training step of batch k is being enqueued;
+    the consumer's stream waits on the batch's event."""
 
-    def __init__(self, dataset, host_loader, collate, device=None):
+    def __init__(self, dataset, host_loader, collate, device=None, background=None):
         self.dataset, self.host_loader, self.collate, self.device = dataset, host_loader, collate, device
         self.sampler = host_loader.sampler
         self.batch_size = host_loader.batch_size
+        self.background = background
 
     def __len__(self):
         return len(self.host_loader)
+
+    def _batches(self, device):
+        from .pipelines import materialize_batch, tensorize
+        for host_batch in self.host_loader:
+            packed, items = host_batch["frames"], host_batch["items"]
+            if packed is not None and device.type == "cuda" and all(getattr(it.get("img"), "offset", None) is not None for it in items):
+                # the whole batch's pixel work in a handful of launches (pipelines.materialize_batch)
+                packed = packed.to(device, non_blocking=True)
+                imgs, stacked = materialize_batch([it["img"] for it in items], packed, device)
+                for it, img in zip(items, imgs):
+                    it["img"] = img
+                    tensorize(it)
+                yield self.collate(items, stacked) if stacked is not None else self.collate(items)
+                continue
+            if packed is not None:
+                packed = packed.to(device, non_blocking=True)
+            yield self.collate([self.dataset.device_item(r, device, packed) for r in items])
 
     def __iter__(self):
         device = self.device
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
-        for host_batch in self.host_loader:
-            yield self.collate([self.dataset.device_item(r, device) for r in host_batch])
+        background = self.background
+        if background is None:
+            background = device.type == "cuda" and self.host_loader.num_workers > 0
+        if not background:
+            yield from self._batches(device)
+            return
+        import queue
+        import threading
+        ready, stop = queue.Queue(maxsize=2), threading.Event()
+        side = torch.cuda.Stream(device)
+
+        def produce():
+            try:
+                with torch.cuda.stream(side):
+                    for batch in self._batches(device):
+                        done = torch.cuda.Event()
+                        done.record(side)
+                        while not stop.is_set():
+                            try:
+                                ready.put((batch, done), timeout=0.1)
+                                break
+                            except queue.Full:
+                                continue
+                        if stop.is_set():
+                            return
+                ready.put(None)
+            except BaseException as err:          # surfaces in the consumer
+                ready.put(err)
+
+        worker = threading.Thread(target=produce, name="simvg-device-stage", daemon=True)
+        worker.start()
+        try:
+            while True:
+                got = ready.get()
+                if got is None:
+                    break
+                if isinstance(got, BaseException):
+                    raise got
+                batch, done = got
+                current = torch.cuda.current_stream(device)
+                current.wait_event(done)
+                for v in batch.values():           # allocated on the side stream, consumed on this one
+                    for t in (v if isinstance(v, (list, tuple)) else [v]):
+                        if torch.is_tensor(t) and t.is_cuda:
+                            t.record_stream(current)
+                yield batch
+        finally:
+            stop.set()
 
 
 def _register(name):

@@ -597,6 +597,52 @@ def normalize_pad_u8(src, mean, std, to_rgb, pad_hw, out=None):
     return out
 
 
+class _ResizeJob(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("src_h", C.c_int), ("src_w", C.c_int), ("src_row_bytes", C.c_long), ("dst", C.c_void_p),
+                ("dst_row_bytes", C.c_long), ("out_h", C.c_int), ("out_w", C.c_int), ("full_h", C.c_int), ("full_w", C.c_int),
+                ("win_y0", C.c_int), ("win_x0", C.c_int)]
+
+
+class _FormatJob(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("src_row_bytes", C.c_long), ("h", C.c_int), ("w", C.c_int), ("dst_chw", C.c_void_p),
+                ("pad_h", C.c_int), ("pad_w", C.c_int)]
+
+
+PREPROCESS_MAX_JOBS = 32
+
+
+def resize_u8_batched(jobs):
+    """jobs: list of (src [H,W,3] uint8 view, dst [oh,ow,3] uint8 view, full_hw, window | None) -- one launch per 32 jobs,
+    frames of different geometry; same arithmetic as resize_u8."""
+    lib = _lib.load()
+    stream = _stream()
+    for at in range(0, len(jobs), PREPROCESS_MAX_JOBS):
+        chunk = jobs[at:at + PREPROCESS_MAX_JOBS]
+        arr = (_ResizeJob * len(chunk))()
+        for k, (src, dst, full_hw, window) in enumerate(chunk):
+            fh, fw = int(full_hw[0]), int(full_hw[1])
+            y0, x0, oh, ow = (0, 0, fh, fw) if window is None else window
+            assert (int(dst.shape[0]), int(dst.shape[1])) == (oh, ow)
+            arr[k] = _ResizeJob(src.data_ptr(), src.shape[0], src.shape[1], src.stride(0), dst.data_ptr(), dst.stride(0), oh, ow,
+                                fh, fw, y0, x0)
+        _lib.check(lib.simvg_resize_u8_batched(arr, len(chunk), stream), "simvg_resize_u8_batched")
+
+
+def normalize_pad_u8_batched(jobs, mean, std, to_rgb):
+    """jobs: list of (src [h,w,3] uint8 view, dst fp32 [3,ph,pw] view) sharing one normalisation"""
+    lib = _lib.load()
+    stream = _stream()
+    m = (C.c_float * 3)(*[float(v) for v in mean])
+    sd = (C.c_float * 3)(*[float(v) for v in std])
+    for at in range(0, len(jobs), PREPROCESS_MAX_JOBS):
+        chunk = jobs[at:at + PREPROCESS_MAX_JOBS]
+        arr = (_FormatJob * len(chunk))()
+        for k, (src, dst) in enumerate(chunk):
+            arr[k] = _FormatJob(src.data_ptr(), src.stride(0), src.shape[0], src.shape[1], dst.data_ptr(), dst.shape[1], dst.shape[2])
+        _lib.check(lib.simvg_normalize_pad_u8_batched(arr, len(chunk), m, sd, int(bool(to_rgb)), stream),
+                   "simvg_normalize_pad_u8_batched")
+
+
 def attn_f32_bwd(qkv, dout, B, H, Nv, Nt, pad=None):
     """exact-fp32 attention backward -> dqkv [M, 3D] fp32."""
     lib = _lib.load()

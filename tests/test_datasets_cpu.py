@@ -157,7 +157,7 @@ def test_two_stage_loader_runs_the_host_stage_in_seeded_workers(mini):
             dict(type="CollectData", keys=["img", "ref_expr_inds", "text_attention_mask", "gt_bbox"])]
     ds = build_dataset(dict(type="RefCOCOUNC", which_set="train", img_source=["coco"], imgsfile=os.path.join(root, "coco"),
                             annsfile=os.path.join(root, "anns", "RefCOCOUNC", "instances.json"), pipeline=pipe))
-    assert ds.host_steps() == 1
+    assert ds.host_steps() == 2                                # the loader and every (deferrable) transform after it
     cfg = Cfg(distributed=False, seed=5, rank=0, world_size=1, data=Cfg(samples_per_gpu=2, workers_per_gpu=2))
     loader = build_dataloader(cfg, ds)
     assert isinstance(loader, TwoStageLoader) and loader.dataset is ds and len(loader) == 2 and hasattr(loader.sampler, "set_epoch")

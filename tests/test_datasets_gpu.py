@@ -119,3 +119,31 @@ def test_train_and_test_tools_on_the_annotation_file_dataset(mini, tmp_path):
     assert "nan" not in log.lower()
     res = test_tool.main([cfg_path, "--load-from", os.path.join(run, "latest.pth")])
     assert set(res) == {"val", "val_ema", "testA", "testA_ema", "testB", "testB_ema"}
+
+
+def test_batched_device_stage_equals_the_per_frame_pipeline(mini):
+    """the two-stage loader's device stage (pixel operations recorded in the worker, replayed as batched launches on frames
+    packed into one buffer) against the same transforms run frame by frame on the device -- bit-exact, train pipeline
+    (LargeScaleJitter incl. its crop / escape branches) and eval pipeline"""
+    import random
+    from simvg_amd.datasets import build_dataset
+    from simvg_amd.datasets.pipelines import materialize_batch
+    from simvg_amd.datasets.refsets import pack_host_batch
+    fx, root = mini
+    for train in (True, False):
+        ds = build_dataset(dict(type="RefCOCOUNC", which_set="train", img_source=["coco"], imgsfile=os.path.join(root, "coco"),
+                                annsfile=os.path.join(root, "anns", "RefCOCOUNC", "instances.json"),
+                                pipeline=_pipeline(root, "RefCOCOUNC", train)))
+        assert ds.host_steps() == len(ds.pipeline.transforms)
+        order = [0, 1, 2, 1, 0, 2, 2, 0] * 5                    # 40 frames: more than one 32-job launch
+        random.seed(4); np.random.seed(4)
+        direct = [ds[i] for i in order]
+        random.seed(4); np.random.seed(4)
+        host = pack_host_batch([ds.host_item(i) for i in order])
+        frames = [it["img"] for it in host["items"]]
+        imgs, stacked = materialize_batch(frames, host["frames"].cuda(), torch.device("cuda"))
+        assert stacked is not None and tuple(stacked.shape) == (len(order), 3, S, S)
+        for a, b, it in zip(direct, imgs, host["items"]):
+            assert torch.equal(a["img"], b)
+            assert np.array_equal(a["gt_bbox"].numpy(), np.asarray(it["gt_bbox"]))
+            assert a["img_metas"]["img_shape"] == it["img_metas"]["img_shape"]
