@@ -341,6 +341,25 @@ def main():
         "in_situ": {k: {"avg_launch_us": round(d["ms"] / d["calls"] * 1e3, 2), "launches": d["calls"],
                         "tflops": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 2)} for k, d in situ.items()},
     }
+    # forward_test latency / throughput on the GPU (same protocol as the CPU figures of cpu_baseline: warm-up, mean of repeated
+    # calls with a synchronisation after each call -- tools/misc/inference_time.py:68-75 of the reference)
+    model.eval()
+    infer = {}
+    with torch.no_grad(), training_stream(device):
+        for nb, reps in ((1, 20), (8, 20), (B, 5)):
+            bb = synthetic_batch(nb, 4242, device)
+            kw = dict(return_loss=False, text_attention_mask=bb["text_attention_mask"], with_bbox=True, with_mask=False, rescale=False)
+            for _ in range(3):
+                model(bb["img"], bb["ref_expr_inds"], bb["img_metas"], **kw)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                model(bb["img"], bb["ref_expr_inds"], bb["img_metas"], **kw)
+                torch.cuda.synchronize()
+            ms = (time.perf_counter() - t1) / reps * 1e3
+            infer[f"b{nb}"] = {"ms_per_call": round(ms, 3), "pairs_per_s": round(nb / ms * 1e3, 1)}
+    model.train()
+    out["forward_test"] = dict(infer, note="MIXDETRMB.forward_test incl. post-processing, one synchronisation per call")
     if a.breakdown:
         tot = dt * 1e3
         for k, d in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
