@@ -61,11 +61,18 @@ class ParamArena:
             self.grad_views[vname] = self.flat_grad[s:s + n].view(shape)
         self._grad_of = {n: self.flat_grad[self.offsets[n]: self.offsets[n] + p.numel()].view(p.shape)
                          for n, p in self.params.items()}
+        self._param_list = list(self.params.values())
 
-    def intact(self):
-        """False if someone re-allocated the parameters (e.g. model.to(other_device))."""
+    def intact(self, thorough=False):
+        """False if someone re-allocated the parameters (e.g. model.to(other_device)).  Called several times per step
+        (engine, optimizer, EMA): a move re-allocates EVERY parameter, so the first, the middle and the last one are the
+        per-step probe (walking all ~500 cost 0.5 ms per call); every 256th call and `thorough=True` check them all."""
         base = self.flat.untyped_storage().data_ptr()
-        return all(p.data.untyped_storage().data_ptr() == base for p in self.params.values())
+        ps = self._param_list
+        self._intact_calls = getattr(self, "_intact_calls", 0) + 1
+        if not thorough and self._intact_calls % 256:
+            ps = (ps[0], ps[len(ps) // 2], ps[-1])
+        return all(p.data.untyped_storage().data_ptr() == base for p in ps)
 
     def grad(self, name):
         return self._grad_of[name]

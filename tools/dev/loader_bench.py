@@ -81,6 +81,11 @@ if os.environ.get("TRAIN"):
                 loader.sampler.set_epoch(epoch)
                 torch.cuda.synchronize()
                 t0, n = time.perf_counter(), 0
+                prof = None
+                if os.environ.get("PROFILE_TRAIN") and epoch == 1 and background:
+                    import cProfile
+                    prof = cProfile.Profile()
+                    prof.enable()
                 for batch in loader:
                     b = extract_data(batch, dev)
                     losses, _ = model(b["img"], b["ref_expr_inds"], b["img_metas"], return_loss=True,
@@ -92,5 +97,12 @@ if os.environ.get("TRAIN"):
                     n += b["img"].shape[0]
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t0
+                if prof is not None:
+                    import pstats
+                    prof.disable()
+                    pstats.Stats(prof).sort_stats("tottime").print_stats(14)
+        hg = getattr(model, "_head_graphs", None)
+        if hg is not None:
+            print("head graphs captured:", len(hg.graphs), "disabled:", hg.disabled, "default stream seen:", hg.default_stream_seen)
         print(f"training from JPEG files, workers {workers}, background device stage {background}: {n / dt:7.1f} pairs/s "
               f"({dt / (n / 64) * 1e3:5.1f} ms per step)", flush=True)
