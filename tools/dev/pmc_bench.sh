@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/pmc
 for set in "FETCH_SIZE" "WRITE_SIZE"; do
   rm -rf /tmp/pmcb_$set
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pmcb_$set -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > /tmp/pmcb_$set.log 2>&1
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pmcb_$set -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-forward-test > /tmp/pmcb_$set.log 2>&1
 done
 python - <<'PY'
 import csv, glob, json, collections
