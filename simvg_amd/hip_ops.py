@@ -134,7 +134,16 @@ def _p(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
+
+
 def _stream():
+    """the calling thread's current HIP stream as a raw handle.  `torch.cuda.current_stream().cuda_stream` builds a Stream
+    object through five Python frames (8.5 us; ~465 kernel launches per training step = 4 ms of host time per step); the C
+    accessor behind it costs 0.3 us."""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(_raw_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

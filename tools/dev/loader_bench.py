@@ -61,6 +61,8 @@ if os.environ.get("PROFILE"):
     pr.disable()
     pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
 if os.environ.get("TRAIN"):
+    if os.environ.get("SWITCH"):
+        sys.setswitchinterval(float(os.environ["SWITCH"]))
     import bench
     from simvg_amd.models import build_model
     from simvg_amd.core import build_optimizer
