@@ -110,7 +110,7 @@ class LoadImageAnnotationsFromFile:
         self.random_ind = int(numpy.random.choice(list(range(len(expressions)))))
         expression = clean_string(expressions[self.random_ind])
         if self.use_token_type == "beit3":
-            ids, mask = self.tokenizer.encode_pair_free(expression, self.max_token)
+            ids, mask = self.tokenizer.encode_expression(expression, self.max_token)
             results["ref_expr_inds"] = numpy.array(ids, dtype=int)
             results["text_attention_mask"] = numpy.array(mask, dtype=int)
         else:

@@ -44,7 +44,7 @@ class XLMRTokenizer:
         p = self.sp_model.PieceToId(token)
         return p + self.fairseq_offset if p else self.unk_token_id
 
-    def encode_pair_free(self, text, max_token):
+    def encode_expression(self, text, max_token):
         """<s> pieces </s> padded to max_token -> (ids, padding_mask) with mask 1 = pad (loading.py:157-182)"""
         ids = self.convert_tokens_to_ids(self.tokenize(text))
         if not ids:

@@ -115,12 +115,12 @@ def test_xlmr_alignment_rules(mini):
     pieces = tok.tokenize("the man in the red shirt")
     assert tok.convert_tokens_to_ids(pieces) == [tok.sp_model.PieceToId(p) + 1 for p in pieces]
     assert tok.convert_tokens_to_ids(["<s>", "<pad>", "</s>", "<unk>", "<mask>", "▁qqqqzzzz"]) == [0, 1, 2, 3, n + 1, 3]
-    ids, mask = tok.encode_pair_free("kid with a kite", 12)
+    ids, mask = tok.encode_expression("kid with a kite", 12)
     assert ids[0] == 0 and ids[mask.index(1) - 1] == 2 and set(ids[mask.index(1):]) == {1} and len(ids) == len(mask) == 12
-    ids, mask = tok.encode_pair_free("very " * 40, 6)
+    ids, mask = tok.encode_expression("very " * 40, 6)
     assert len(ids) == 6 and ids[0] == 0 and ids[-1] == 2 and mask == [0] * 6
     with pytest.raises(RuntimeError):
-        tok.encode_pair_free("", 6)
+        tok.encode_expression("", 6)
     with pytest.raises(FileNotFoundError):
         XLMRTokenizer(os.path.join(root, "missing.spm"))
 
