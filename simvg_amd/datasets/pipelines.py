@@ -133,6 +133,80 @@ def materialize_batch(frames, packed, device):
     return cur, stacked
 
 
+# ---- the batch's pixel work compiled in the WORKER into launch descriptors -------------------------------------------
+# numpy mirrors of simvg_resize_job / simvg_format_job (include/simvg_hip.h); pointers hold byte OFFSETS until the consumer
+# adds the base addresses of the buffers it allocated
+RESIZE_JOB = numpy.dtype([("src", "<u8"), ("src_h", "<i4"), ("src_w", "<i4"), ("src_row_bytes", "<i8"), ("dst", "<u8"),
+                          ("dst_row_bytes", "<i8"), ("out_h", "<i4"), ("out_w", "<i4"), ("full_h", "<i4"), ("full_w", "<i4"),
+                          ("win_y0", "<i4"), ("win_x0", "<i4")], align=True)
+FORMAT_JOB = numpy.dtype([("src", "<u8"), ("src_row_bytes", "<i8"), ("h", "<i4"), ("w", "<i4"), ("dst_chw", "<u8"),
+                          ("pad_h", "<i4"), ("pad_w", "<i4")], align=True)
+assert RESIZE_JOB.itemsize == 64 and FORMAT_JOB.itemsize == 40
+
+
+def compile_batch_program(frames):
+    """frames: DeferredFrames whose `offset` points into the batch's packed source buffer.  -> dict(rounds=[...],
+    out_shape=(B, 3, ph, pw)) or None when the batch does not end in one common format pass (then the consumer replays the
+    frames with `materialize_batch`).  Buffer ids: 0 = the packed source frames, k = the pool written by round k - 1."""
+    if not frames or any(not f.ops or f.ops[-1][0] != "format" for f in frames):
+        return None
+    last = [f.ops[-1] for f in frames]
+    if any(o[4] != last[0][4] or o[3] != last[0][3] or not numpy.array_equal(o[1], last[0][1]) or not numpy.array_equal(o[2], last[0][2])
+           for o in last) or any(op[0] != "resize" for f in frames for op in f.ops[:-1]):
+        return None
+    B = len(frames)
+    ph, pw = last[0][4]
+    buf = [0] * B                                            # buffer holding each frame's current pixels
+    off = [int(f.offset) for f in frames]
+    shape = [f.source_shape[:2] for f in frames]
+    rounds = []
+    depth = max(len(f.ops) for f in frames) - 1              # resize rounds
+    for r in range(depth):
+        idx = [i for i, f in enumerate(frames) if r < len(f.ops) - 1]
+        jobs = numpy.zeros(len(idx), dtype=RESIZE_JOB)
+        src_buf = numpy.zeros(len(idx), dtype=numpy.int64)
+        at = 0
+        for k, i in enumerate(idx):
+            _, (fh, fw), window = frames[i].ops[r]
+            y0, x0, oh, ow = (0, 0, fh, fw) if window is None else window
+            h, w = shape[i]
+            jobs[k] = (off[i], h, w, 3 * w, at, 3 * ow, oh, ow, fh, fw, y0, x0)
+            src_buf[k] = buf[i]
+            buf[i], off[i], shape[i] = r + 1, at, (oh, ow)
+            at += 3 * oh * ow
+        rounds.append(dict(kind="resize", jobs=jobs, src_buf=src_buf, pool_bytes=at))
+    jobs = numpy.zeros(B, dtype=FORMAT_JOB)
+    src_buf = numpy.zeros(B, dtype=numpy.int64)
+    for i in range(B):
+        h, w = shape[i]
+        jobs[i] = (off[i], 3 * w, h, w, i * 3 * ph * pw * 4, ph, pw)
+        src_buf[i] = buf[i]
+    rounds.append(dict(kind="format", jobs=jobs, src_buf=src_buf, mean=numpy.asarray(last[0][1], dtype=numpy.float32),
+                       std=numpy.asarray(last[0][2], dtype=numpy.float32), to_rgb=bool(last[0][3])))
+    return dict(rounds=rounds, out_shape=(B, 3, int(ph), int(pw)))
+
+
+def run_batch_program(program, packed, device):
+    """consumer side: allocate the pools, turn offsets into addresses (vectorised), launch -- no per-frame Python"""
+    bases = [packed.data_ptr()]
+    keep = [packed]
+    out = torch.empty(program["out_shape"], device=device, dtype=torch.float32)
+    for rd in program["rounds"]:
+        jobs = rd["jobs"].copy()
+        base = numpy.asarray(bases, dtype=numpy.uint64)
+        jobs["src"] += base[rd["src_buf"]]
+        if rd["kind"] == "resize":
+            pool = torch.empty(max(int(rd["pool_bytes"]), 1), device=device, dtype=torch.uint8)
+            keep.append(pool)
+            bases.append(pool.data_ptr())
+            jobs["dst"] += numpy.uint64(pool.data_ptr())
+            ops.launch_resize_jobs(jobs)
+        else:
+            jobs["dst_chw"] += numpy.uint64(out.data_ptr())
+            ops.launch_format_jobs(jobs, rd["mean"], rd["std"], rd["to_rgb"])
+    return out
+
+
 def tensorize(results):
     """ids / padding mask / boxes -> torch tensors (the tail of DefaultFormatBundle; the two-stage loader calls it in the
     training process)"""

@@ -156,13 +156,15 @@ class HostStageView(Dataset):
 
 
 def pack_host_batch(items):
-    """collate of the HOST stage (runs in the worker): the batch's decoded frames become ONE flat uint8 tensor -- one
-    shared-memory hand-over, one pinned copy and one host-to-device transfer per batch instead of one per frame (64
-    separate tensors kept the DataLoader's single pin-memory thread at ~40 ms per batch) -- and every DeferredFrame keeps
-    its offset into it."""
+    """collate of the HOST stage (runs in the worker).  The batch's decoded frames become ONE flat uint8 tensor -- one
+    shared-memory hand-over and one host-to-device transfer per batch instead of one per frame --, their recorded pixel
+    operations are compiled into launch descriptors (pipelines.compile_batch_program), ids / masks / single boxes are stacked:
+    what reaches the training process is a handful of arrays, and its share of the work is a copy, three to five launches
+    and no per-frame Python."""
+    from .pipelines import compile_batch_program
     frames = [it["img"] for it in items if hasattr(it.get("img"), "materialize") and it["img"].pixels is not None]
-    if not frames:
-        return dict(items=items, frames=None)
+    if not frames or len(frames) != len(items):
+        return dict(items=items, frames=None, program=None)
     blob = torch.empty(sum(f.pixels.numel() for f in frames), dtype=torch.uint8)
     at = 0
     for f in frames:
@@ -170,7 +172,16 @@ def pack_host_batch(items):
         blob[at:at + n] = f.pixels.reshape(-1)
         f.offset, f.pixels = at, None
         at += n
-    return dict(items=items, frames=blob)
+    program = compile_batch_program(frames)
+    if program is None:
+        return dict(items=items, frames=blob, program=None)
+    fields = {}
+    for key in items[0]:
+        if key in ("img", "img_metas"):
+            continue
+        vals = [numpy.asarray(it[key]) for it in items]
+        fields[key] = numpy.stack(vals) if (key != "gt_bbox" or all(v.ndim == 1 for v in vals)) else vals
+    return dict(items=None, frames=blob, program=program, fields=fields, metas=[it["img_metas"] for it in items])
 
 
 class TwoStageLoader:
@@ -209,8 +220,19 @@ class TwoStageLoader:
 
     def _host_batches(self, device):
         from .pipelines import materialize_batch, tensorize
+        from .pipelines import run_batch_program
         for host_batch in self.host_loader:
             packed, items = host_batch["frames"], host_batch["items"]
+            if host_batch.get("program") is not None and device.type == "cuda":
+                # the worker compiled the batch: one copy, a few batched launches, ready-made arrays
+                batch = dict(img=run_batch_program(host_batch["program"], packed.to(device, non_blocking=True), device),
+                             img_metas=host_batch["metas"])
+                for key, v in host_batch["fields"].items():
+                    batch[key] = [torch.from_numpy(x) for x in v] if isinstance(v, list) else torch.from_numpy(v)
+                yield batch
+                continue
+            if host_batch.get("program") is not None:        # no GPU (CPU tests): back to per-frame form
+                raise RuntimeError("a compiled batch program needs the GPU; build the loader with device transforms on a GPU box")
             if packed is not None and device.type == "cuda" and all(getattr(it.get("img"), "offset", None) is not None for it in items):
                 # the whole batch's pixel work in a handful of launches (pipelines.materialize_batch)
                 packed = packed.to(device, non_blocking=True)

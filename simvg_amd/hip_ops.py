@@ -5,6 +5,8 @@ current HIP stream and never synchronises.  PyTorch here is device memory + stre
 """
 import ctypes as C
 
+import numpy
+
 import torch
 
 from . import _lib
@@ -649,6 +651,28 @@ def normalize_pad_u8_batched(jobs, mean, std, to_rgb):
         for k, (src, dst) in enumerate(chunk):
             arr[k] = _FormatJob(src.data_ptr(), src.stride(0), src.shape[0], src.shape[1], dst.data_ptr(), dst.shape[1], dst.shape[2])
         _lib.check(lib.simvg_normalize_pad_u8_batched(arr, len(chunk), m, sd, int(bool(to_rgb)), stream),
+                   "simvg_normalize_pad_u8_batched")
+
+
+def launch_resize_jobs(jobs):
+    """jobs: numpy structured array laid out like simvg_resize_job[] (datasets.pipelines.RESIZE_JOB), addresses filled in"""
+    lib = _lib.load()
+    stream = _stream()
+    jobs = numpy.ascontiguousarray(jobs)
+    for at in range(0, len(jobs), PREPROCESS_MAX_JOBS):
+        n = min(PREPROCESS_MAX_JOBS, len(jobs) - at)
+        _lib.check(lib.simvg_resize_u8_batched(C.c_void_p(jobs.ctypes.data + at * jobs.itemsize), n, stream), "simvg_resize_u8_batched")
+
+
+def launch_format_jobs(jobs, mean, std, to_rgb):
+    lib = _lib.load()
+    stream = _stream()
+    jobs = numpy.ascontiguousarray(jobs)
+    m = (C.c_float * 3)(*[float(v) for v in mean])
+    sd = (C.c_float * 3)(*[float(v) for v in std])
+    for at in range(0, len(jobs), PREPROCESS_MAX_JOBS):
+        n = min(PREPROCESS_MAX_JOBS, len(jobs) - at)
+        _lib.check(lib.simvg_normalize_pad_u8_batched(C.c_void_p(jobs.ctypes.data + at * jobs.itemsize), n, m, sd, int(bool(to_rgb)), stream),
                    "simvg_normalize_pad_u8_batched")
 
 

@@ -121,15 +121,17 @@ def test_train_and_test_tools_on_the_annotation_file_dataset(mini, tmp_path):
     assert set(res) == {"val", "val_ema", "testA", "testA_ema", "testB", "testB_ema"}
 
 
-def test_batched_device_stage_equals_the_per_frame_pipeline(mini):
-    """the two-stage loader's device stage (pixel operations recorded in the worker, replayed as batched launches on frames
-    packed into one buffer) against the same transforms run frame by frame on the device -- bit-exact, train pipeline
-    (LargeScaleJitter incl. its crop / escape branches) and eval pipeline"""
+def test_batched_device_stage_equals_the_per_frame_pipeline(mini, monkeypatch):
+    """the two-stage loader's device stage against the same transforms run frame by frame on the device -- bit-exact, train
+    pipeline (LargeScaleJitter incl. its crop / escape branches) and eval pipeline.  Two forms: the batch program compiled
+    in the worker (launch descriptors with offsets, `run_batch_program`) and the fallback that replays the recorded
+    operations of the DeferredFrames (`materialize_batch`)."""
     import random
-    from simvg_amd.datasets import build_dataset
-    from simvg_amd.datasets.pipelines import materialize_batch
+    from simvg_amd.datasets import build_dataset, pipelines
+    from simvg_amd.datasets.pipelines import materialize_batch, run_batch_program
     from simvg_amd.datasets.refsets import pack_host_batch
     fx, root = mini
+    dev = torch.device("cuda")
     for train in (True, False):
         ds = build_dataset(dict(type="RefCOCOUNC", which_set="train", img_source=["coco"], imgsfile=os.path.join(root, "coco"),
                                 annsfile=os.path.join(root, "anns", "RefCOCOUNC", "instances.json"),
@@ -138,12 +140,24 @@ def test_batched_device_stage_equals_the_per_frame_pipeline(mini):
         order = [0, 1, 2, 1, 0, 2, 2, 0] * 5                    # 40 frames: more than one 32-job launch
         random.seed(4); np.random.seed(4)
         direct = [ds[i] for i in order]
+        # (1) compiled program
         random.seed(4); np.random.seed(4)
         host = pack_host_batch([ds.host_item(i) for i in order])
-        frames = [it["img"] for it in host["items"]]
-        imgs, stacked = materialize_batch(frames, host["frames"].cuda(), torch.device("cuda"))
-        assert stacked is not None and tuple(stacked.shape) == (len(order), 3, S, S)
-        for a, b, it in zip(direct, imgs, host["items"]):
+        assert host["program"] is not None and host["items"] is None
+        out = run_batch_program(host["program"], host["frames"].to(dev), dev)
+        assert tuple(out.shape) == (len(order), 3, S, S)
+        for k, a in enumerate(direct):
+            assert torch.equal(a["img"], out[k])
+            assert np.array_equal(a["gt_bbox"].numpy(), host["fields"]["gt_bbox"][k])
+            assert np.array_equal(a["ref_expr_inds"].numpy(), host["fields"]["ref_expr_inds"][k])
+            assert a["img_metas"]["img_shape"] == host["metas"][k]["img_shape"]
+        # (2) fallback: recorded operations replayed
+        monkeypatch.setattr(pipelines, "compile_batch_program", lambda frames: None)
+        random.seed(4); np.random.seed(4)
+        host = pack_host_batch([ds.host_item(i) for i in order])
+        assert host["program"] is None
+        imgs, stacked = materialize_batch([it["img"] for it in host["items"]], host["frames"].to(dev), dev)
+        assert stacked is not None
+        for a, b in zip(direct, imgs):
             assert torch.equal(a["img"], b)
-            assert np.array_equal(a["gt_bbox"].numpy(), np.asarray(it["gt_bbox"]))
-            assert a["img_metas"]["img_shape"] == it["img_metas"]["img_shape"]
+        monkeypatch.undo()
