@@ -40,14 +40,57 @@ class AdamW(torch.optim.AdamW):
         super().__init__(params, lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=amsgrad)
 
 
+class _RestArena:
+    """The parameters OUTSIDE the encoder arena (the head's ~120 tensors) as views into one flat fp32 buffer, with a flat
+    gradient buffer of the same layout that is filled from the autograd-produced `.grad`s by ONE multi-tensor copy per
+    step.  Lets the clip norm and Adam(amsgrad) of those parameters be the same two HIP launches as the encoder's instead
+    of the framework's foreach / fused-Adam chain (13 launches and ~2.5 ms of host time per step)."""
+
+    ALIGN = 64
+
+    def __init__(self, params):
+        self.params = list(params)
+        device = self.params[0].device
+        off, self.offsets = 0, []
+        for p in self.params:
+            off = (off + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+            self.offsets.append(off)
+            off += p.numel()
+        self.total = (off + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.flat = torch.zeros(self.total, device=device, dtype=torch.float32)
+        self.flat_grad = torch.zeros(self.total, device=device, dtype=torch.float32)
+        with torch.no_grad():
+            for p, o in zip(self.params, self.offsets):
+                v = self.flat[o:o + p.numel()].view(p.shape)
+                v.copy_(p.detach())
+                p.data = v
+        self.grad_views = [self.flat_grad[o:o + p.numel()].view(p.shape) for p, o in zip(self.params, self.offsets)]
+
+    def intact(self):
+        base = self.flat.untyped_storage().data_ptr()
+        ps = (self.params[0], self.params[len(self.params) // 2], self.params[-1])
+        return all(p.data.untyped_storage().data_ptr() == base for p in ps)
+
+    def gather_grads(self):
+        """autograd's per-tensor gradients -> the flat gradient buffer (parameters without a gradient: zeros)"""
+        have = [(v, p.grad) for v, p in zip(self.grad_views, self.params) if p.grad is not None]
+        if len(have) < len(self.params):
+            self.flat_grad.zero_()
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        return len(have)
+
+
 @OPTIMIZERS.register_module()
 class FlatAdam(torch.optim.Adam):
-    """Adam over [encoder arena as ONE tensor] + [remaining parameters].  `params` are the reference-style groups
-    (lists of the model's nn.Parameters with an `lr` each); every group whose parameters all live in the encoder arena
-    is replaced by the arena's flat tensor.  The arena is updated by ONE HIP kernel (`simvg_adam_step`: clip scale + Adam
-    amsgrad, 36 B per parameter), the head's ~120 tensors by torch's fused multi-tensor Adam; the optimizer state keeps
-    torch's keys (`step`, `exp_avg`, `exp_avg_sq`, `max_exp_avg_sq`), so `state_dict()` round-trips.
-    `clip_grad_norm(max_norm)` is the global-norm clip of apis/train.py:81-82 over the same set of gradients."""
+    """Adam over [encoder arena as ONE tensor] + [every other parameter as ONE tensor].  `params` are the reference-style
+    groups (lists of the model's nn.Parameters with an `lr` each); the group whose parameters all live in the encoder arena
+    is replaced by the arena's flat tensor, the remaining non-empty groups by a flat tensor each (`_RestArena`: the
+    parameters become views into it).  Each flat tensor is updated by ONE HIP kernel (`simvg_adam_step`: clip scale + Adam
+    amsgrad, 36 B per parameter); the optimizer state keeps torch's keys (`step`, `exp_avg`, `exp_avg_sq`,
+    `max_exp_avg_sq`) per flat tensor, so `state_dict()` round-trips.  `clip_grad_norm(max_norm)` is the global-norm clip of
+    apis/train.py:81-82 over the same set of gradients: the coefficient is applied INSIDE the Adam kernels (the `.grad`
+    tensors themselves stay unscaled)."""
 
     def __init__(self, params, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
         if weight_decay != 0:      # the fused kernel updates the WHOLE arena: parameters that never receive a gradient
@@ -65,7 +108,7 @@ class FlatAdam(torch.optim.Adam):
         self.flat = torch.nn.Parameter(arena.flat)
         self.flat.grad = arena.flat_grad
         self._clip = None
-        groups, self._rest, used_flat = [], [], False
+        groups, self._rest, self._rest_arenas, used_flat = [], [], [], False
         for g in params:
             g = dict(g)
             ps = list(g["params"])
@@ -80,13 +123,15 @@ class FlatAdam(torch.optim.Adam):
             else:
                 if any(id(p) in in_arena for p in ps):
                     raise ValueError("a param group mixes encoder-arena and other parameters")
-                self._rest += ps
+                if ps:
+                    ra = _RestArena(ps)
+                    ra.param = torch.nn.Parameter(ra.flat)
+                    ra.param.grad = ra.flat_grad
+                    self._rest_arenas.append(ra)
+                    self._rest += ps
+                    g["params"] = [ra.param]
             groups.append(g)      # empty groups (lan_enc) stay, so group indices match the reference's
-        try:      # single-pass multi-tensor kernel (p, g, m, v, vmax read once) instead of ~10 foreach passes
-            super().__init__(groups, lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=amsgrad,
-                             fused=True)
-        except (RuntimeError, ValueError):
-            super().__init__(groups, lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=amsgrad)
+        super().__init__(groups, lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=amsgrad)
 
     def zero_grad(self, set_to_none=True):
         for p in self._rest:
@@ -94,60 +139,68 @@ class FlatAdam(torch.optim.Adam):
         for p in self.arena.params.values():
             p.grad = None      # the arena re-attaches (and zeroes) its gradient views on the next backward
         self._clip = None
+        self._gathered = False
 
     def _check_arena(self):
         enc_arena = getattr(getattr(self, "_model_enc", None), "_arena", None)
-        if enc_arena is not self.arena or not self.arena.intact():
-            raise RuntimeError("the encoder re-created its parameter arena after this optimizer was built (model moved "
+        if enc_arena is not self.arena or not self.arena.intact() or not all(ra.intact() for ra in self._rest_arenas):
+            raise RuntimeError("the model re-created its parameter storage after this optimizer was built (model moved "
                                "to another device?): rebuild the optimizer")
 
+    def _gather(self):
+        if not getattr(self, "_gathered", False):
+            for ra in self._rest_arenas:
+                ra.gather_grads()
+            self._gathered = True
+
     def clip_grad_norm(self, max_norm):
-        """Global-norm clip (apis/train.py:81-82) without a host sync: the head's gradients are scaled now; the arena's
-        share of the scale is applied inside the fused Adam kernel of the following step() (its gradient buffer is left
-        unscaled -- it is zeroed by the next backward anyway).  Returns the total norm (device scalar)."""
+        """Global-norm clip (apis/train.py:81-82) without a host sync and without touching the gradients: the squared
+        norm of every flat gradient buffer is reduced deterministically on the device, the clip coefficient is applied
+        inside the Adam kernels of the following step().  Returns the total norm (device scalar)."""
         from .. import hip_ops as ops
         self._check_arena()
-        rest = [p.grad for p in self._rest if p.grad is not None]
+        self._gather()
         sq = torch.zeros(1, device=self.arena.flat.device, dtype=torch.float32)
         ops.sumsq_accum(self.arena.flat_grad, sq)
-        if rest:
-            norms = torch.stack(torch._foreach_norm(rest))
-            sq = sq + (norms * norms).sum()
-        total = sq.sqrt()
-        if rest:
-            coef = torch.clamp(max_norm / (total + 1e-6), max=1.0).reshape(())
-            torch._foreach_mul_(rest, coef)
+        for ra in self._rest_arenas:
+            ops.sumsq_accum(ra.flat_grad, sq)
+        total = sq.sqrt_()
         self._clip = (total, float(max_norm))
         return total.reshape(())
 
-    def step(self, closure=None):
+    def _flat_step(self, flat, grad, group):
         from .. import hip_ops as ops
-        self._check_arena()
-        group = next(g for g in self.param_groups if any(p is self.flat for p in g["params"]))
-        st = self.state[self.flat]
+        st = self.state[flat]
         if len(st) == 0:
             st["step"] = torch.tensor(0.0)
-            st["exp_avg"] = torch.zeros_like(self.arena.flat)
-            st["exp_avg_sq"] = torch.zeros_like(self.arena.flat)
+            st["exp_avg"] = torch.zeros_like(flat.data)
+            st["exp_avg_sq"] = torch.zeros_like(flat.data)
             if group["amsgrad"]:
-                st["max_exp_avg_sq"] = torch.zeros_like(self.arena.flat)
-        if st["step"].is_cuda:      # a fused optimizer's load_state_dict moves `step` to the parameter's device: bring the
-            st["step"] = st["step"].cpu()     # arena's counter home once, or every step would synchronise on int(...)
+                st["max_exp_avg_sq"] = torch.zeros_like(flat.data)
+        if st["step"].is_cuda:      # load_state_dict may move `step` to the parameter's device: bring the counter home once,
+            st["step"] = st["step"].cpu()     # or every step would synchronise on int(...)
         st["step"] += 1
         t = int(st["step"])
         b1, b2 = group["betas"]
         lr = float(group["lr"])
         total, max_norm = self._clip if self._clip is not None else (None, 0.0)
-        ops.adam_step(self.arena.flat, self.arena.flat_grad, st["exp_avg"], st["exp_avg_sq"], st.get("max_exp_avg_sq"),
+        ops.adam_step(flat.data, grad, st["exp_avg"], st["exp_avg_sq"], st.get("max_exp_avg_sq"),
                       lr / (1.0 - b1 ** t), (1.0 - b2 ** t) ** 0.5, b1, b2, group["eps"], group["weight_decay"],
                       total_norm=total, max_norm=max_norm)
+
+    def step(self, closure=None):
+        self._check_arena()
+        self._gather()
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p is self.flat:
+                    self._flat_step(p, self.arena.flat_grad, group)
+                else:
+                    ra = next(r for r in self._rest_arenas if r.param is p)
+                    self._flat_step(p, ra.flat_grad, group)
         self._clip = None
-        # the remaining (head) parameters: the framework's fused multi-tensor Adam; the flat parameter is hidden from it
-        self.flat.grad = None
-        try:
-            return super().step(closure)
-        finally:
-            self.flat.grad = self.arena.flat_grad
+        self._gathered = False
+        return None
 
 
 def build_optimizer(cfg, params, model=None):

@@ -285,8 +285,12 @@ class TwoStageLoader:
         worker = threading.Thread(target=produce, name="simvg-device-stage", daemon=True)
         worker.start()
         try:
+            import time
+            self.wait_s = 0.0                      # time the consumer spent waiting for a finished batch (diagnostic)
             while True:
+                t0 = time.perf_counter()
                 got = ready.get()
+                self.wait_s += time.perf_counter() - t0
                 if got is None:
                     break
                 if isinstance(got, BaseException):

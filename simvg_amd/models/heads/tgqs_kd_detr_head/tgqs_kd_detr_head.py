@@ -209,7 +209,12 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
             self._prep = ops.WeightPrep(entries, device)
             self._prep_dev, self._prep_ptrs = device, [p.data_ptr() for p in srcs]
         self._prep.run()
-        self._prep_version = version
+        # training: the optimizer may rewrite the parameters without moving their version counters (FlatAdam updates them
+        # through one flat tensor) -> the first eval forward after training always refreshes
+        self._prep_version = None if self.training else version
+
+    def mark_weights_dirty(self):
+        self._prep_version = None
 
     # ------------------------------------------------------------------ building blocks
     def _lin(self, x, key, relu=False, rows=None):

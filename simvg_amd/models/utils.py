@@ -112,9 +112,9 @@ class ExponentialMovingAverage(object):
 
     def _weights_changed(self):
         # the encoder keeps bf16 copies of its weights; make the next forward (eval included) refresh them
-        enc = getattr(getattr(self.model, "module", self.model), "vis_enc", None)
-        if enc is not None and hasattr(enc, "mark_weights_dirty"):
-            enc.mark_weights_dirty()
+        for m in getattr(self.model, "module", self.model).modules():
+            if hasattr(m, "mark_weights_dirty"):
+                m.mark_weights_dirty()
 
     def get_model_state(self):
         return {k: v.clone().detach() for k, v in self.model.state_dict().items()}

@@ -103,6 +103,8 @@ if os.environ.get("TRAIN"):
                     import pstats
                     prof.disable()
                     pstats.Stats(prof).sort_stats("tottime").print_stats(14)
+        if hasattr(loader, "wait_s"):
+            print(f"  consumer waited {loader.wait_s / (n / 64) * 1e3:.1f} ms per step for the loader thread")
         hg = getattr(model, "_head_graphs", None)
         if hg is not None:
             print("head graphs captured:", len(hg.graphs), "disabled:", hg.disabled, "default stream seen:", hg.default_stream_seen)
