@@ -104,6 +104,9 @@ class FlatAdam(torch.optim.Adam):
                                "model.vis_enc._ensure_engine(device) (or run one forward) first")
         self.arena = arena
         self._model_enc = enc
+        # modules that keep 16-bit copies of their weights: told after every step (the flat update does not move the
+        # parameters' version counters, which is what those modules watch in eval mode)
+        self._weight_watchers = [m.mark_weights_dirty for m in model.modules() if hasattr(m, "mark_weights_dirty")]
         in_arena = {id(p) for p in arena.params.values()}
         self.flat = torch.nn.Parameter(arena.flat)
         self.flat.grad = arena.flat_grad
@@ -200,6 +203,8 @@ class FlatAdam(torch.optim.Adam):
                     self._flat_step(p, ra.flat_grad, group)
         self._clip = None
         self._gathered = False
+        for mark in self._weight_watchers:
+            mark()
         return None
 
 

@@ -48,5 +48,5 @@ for ev in prof.events():
         ops[(ev.name, frame.split("/root/repo/")[-1][:90])] += kern
 tot = sum(ops.values())
 print("device launches issued by aten ops in one step:", tot)
-for (name, frame), n in ops.most_common(45):
+for (name, frame), n in ops.most_common(80):
     print(f"{n:4d}  {name:32s} {frame}")
