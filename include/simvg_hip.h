@@ -113,6 +113,13 @@ typedef struct simvg_gemm_f32_problem {
   const float* bias;
   const float* addend; long ld_addend; int addend_rows;
   int M, N, K, accumulate, act;
+  const float* A2; const float* B2;     /* optional second operands with A's / B's strides: the product uses A + A2 and
+                                         * B + B2 (q = (x + query_pos) W without materialising the sum) */
+  const float* mult; long ld_mult;      /* optional [M, N] factor applied after the activation (dropout multipliers) */
+  const float* gate; long ld_gate;      /* optional [M, N] gate: the value passes where gate > 0 (ReLU backward on the
+                                         * saved layer output).  With mult or gate the addend is added AFTER them:
+                                         * y = dropout(act(x W + b)) + residual (BaseTransformerLayer FFN,
+                                         * heads/tgqs_kd_detr_head/transformer.py:106-125) */
 } simvg_gemm_f32_problem;
 int simvg_gemm_f32_grouped(const simvg_gemm_f32_problem* problems, int count, simvg_stream_t stream);
 /* torch.nn.MultiheadAttention core (heads of 32) for <= 16 queries: softmax(scale q k^T + key_padding) [* dropout] v

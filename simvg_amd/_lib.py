@@ -19,7 +19,9 @@ class WeightDesc(C.Structure):
 class GemmF32Problem(C.Structure):      # simvg_gemm_f32_problem
     _fields_ = [("A", c_void_p), ("sam", c_long), ("sak", c_long), ("B", c_void_p), ("sbk", c_long), ("sbn", c_long),
                 ("C", c_void_p), ("ldc", c_long), ("bias", c_void_p), ("addend", c_void_p), ("ld_addend", c_long),
-                ("addend_rows", c_int), ("M", c_int), ("N", c_int), ("K", c_int), ("accumulate", c_int), ("act", c_int)]
+                ("addend_rows", c_int), ("M", c_int), ("N", c_int), ("K", c_int), ("accumulate", c_int), ("act", c_int),
+                ("A2", c_void_p), ("B2", c_void_p), ("mult", c_void_p), ("ld_mult", c_long), ("gate", c_void_p),
+                ("ld_gate", c_long)]
 
 
 _SIGS = {

@@ -20,6 +20,9 @@ struct simvg_gemm_f32_problem {
   const float* bias;
   const float* addend; long ld_addend; int addend_rows;
   int M, N, K, accumulate, act;
+  const float* A2; const float* B2;
+  const float* mult; long ld_mult;
+  const float* gate; long ld_gate;
 };
 
 namespace {
@@ -32,7 +35,27 @@ struct SGArgs {
   const float* addend; long lda2;     // optional C += addend[m % add_rows][n]
   int add_rows;
   int M, N, K, accumulate, act;
+  const float* A2;                    // optional second A operand with A's strides: the product uses A + A2 (q = (x + pos) W)
+  const float* B2;                    // same for B
+  const float* mult; long ldm;        // optional elementwise factor after the activation (dropout multipliers)
+  const float* gate; long ldg;        // optional gate: the value passes where gate > 0 (ReLU backward on the saved output)
 };
+
+// bias, [addend], activation, [* mult], [gate], store.  With `mult` or `gate` the addend is added AFTER them
+// (y = dropout(act(x W + b)) + residual); without, before the activation as it always was.
+__device__ __forceinline__ void sg_store(const SGArgs& a, float v, int m, int n) {
+  if (a.bias) v += a.bias[n];
+  const float add = a.addend ? a.addend[(long)(m % a.add_rows) * a.lda2 + n] : 0.f;
+  const bool post = a.mult != nullptr || a.gate != nullptr;
+  if (!post) v += add;
+  if (a.act == 2) v = fmaxf(v, 0.f);
+  else if (a.act == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));   // exact mode: libm erf
+  if (a.mult) v *= a.mult[(long)m * a.ldm + n];
+  if (a.gate) v = a.gate[(long)m * a.ldg + n] > 0.f ? v : 0.f;
+  if (post) v += add;
+  float* p = a.C + (long)m * a.ldc + n;
+  *p = a.accumulate ? *p + v : v;
+}
 
 constexpr int SG_LDS_FLOATS = 2 * 32 * 68;
 
@@ -53,10 +76,12 @@ __device__ __forceinline__ void gemm_f32_tile64(const SGArgs& a, int bx, int by,
       const int e = tid + 256 * i;
       int m, k;
       if (a.sak == 1) { k = e & 31; m = e >> 5; } else { m = e & 63; k = e >> 6; }
-      ra[i] = (m0 + m < a.M && k0 + k < a.K) ? a.A[(long)(m0 + m) * a.sam + (long)(k0 + k) * a.sak] : 0.f;
+      const long ia = (long)(m0 + m) * a.sam + (long)(k0 + k) * a.sak;
+      ra[i] = (m0 + m < a.M && k0 + k < a.K) ? (a.A2 ? a.A[ia] + a.A2[ia] : a.A[ia]) : 0.f;
       int n, kb;
       if (a.sbn == 1) { n = e & 63; kb = e >> 6; } else { kb = e & 31; n = e >> 5; }
-      rb[i] = (n0 + n < a.N && k0 + kb < a.K) ? a.B[(long)(k0 + kb) * a.sbk + (long)(n0 + n) * a.sbn] : 0.f;
+      const long ib = (long)(k0 + kb) * a.sbk + (long)(n0 + n) * a.sbn;
+      rb[i] = (n0 + n < a.N && k0 + kb < a.K) ? (a.B2 ? a.B[ib] + a.B2[ib] : a.B[ib]) : 0.f;
     }
   };
   fetch(0);
@@ -88,17 +113,10 @@ __device__ __forceinline__ void gemm_f32_tile64(const SGArgs& a, int bx, int by,
   for (int j = 0; j < 4; ++j) {
     const int n = n0 + j * 16 + (lane & 15);
     if (n >= a.N) continue;
-    const float bv = a.bias ? a.bias[n] : 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int m = m0 + wave * 16 + 4 * (lane >> 4) + r;
-      if (m >= a.M) continue;
-      float v = acc[j][r] + bv;
-      if (a.addend) v += a.addend[(long)(m % a.add_rows) * a.lda2 + n];
-      if (a.act == 2) v = fmaxf(v, 0.f);
-      else if (a.act == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));   // exact mode: libm erf
-      float* p = a.C + (long)m * a.ldc + n;
-      *p = a.accumulate ? *p + v : v;
+      if (m < a.M) sg_store(a, acc[j][r], m, n);
     }
   }
 }
@@ -128,6 +146,19 @@ __device__ __forceinline__ void gemm_f32_tile16(const SGArgs& a, int bx, int by,
   const float* Bp = a.B + (long)n * a.sbn;
   const bool avec = a.sak == 1 && (a.sam & 3) == 0 && (((unsigned long)a.A) & 15) == 0;
   const bool bvec = a.sbk == 1 && (a.sbn & 3) == 0 && (((unsigned long)a.B) & 15) == 0;
+  const bool avec2 = avec && (((unsigned long)a.A2) & 15) == 0, bvec2 = bvec && (((unsigned long)a.B2) & 15) == 0;
+  const float* Ap2 = a.A2 ? a.A2 + (long)m * a.sam : nullptr;
+  const float* Bp2 = a.B2 ? a.B2 + (long)n * a.sbn : nullptr;
+  auto ldA = [&](bool ok, int k) {
+    f32x4_t v = load_k4(Ap, a.sak, avec2, ok, k, a.K);
+    if (Ap2) { const f32x4_t w = load_k4(Ap2, a.sak, avec2, ok, k, a.K); v += w; }
+    return v;
+  };
+  auto ldB = [&](bool ok, int k) {
+    f32x4_t v = load_k4(Bp, a.sbk, bvec2, ok, k, a.K);
+    if (Bp2) { const f32x4_t w = load_k4(Bp2, a.sbk, bvec2, ok, k, a.K); v += w; }
+    return v;
+  };
   f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
   const int nsteps = (a.K + 15) >> 4;
   // wave w takes steps w, w+4, ...; two steps in flight (the next pair is loaded before the current pair is consumed)
@@ -135,15 +166,15 @@ __device__ __forceinline__ void gemm_f32_tile16(const SGArgs& a, int bx, int by,
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int st = wave + 4 * u;
-    av[u] = load_k4(Ap, a.sak, avec, mok && st < nsteps, st * 16 + 4 * g, a.K);
-    bv[u] = load_k4(Bp, a.sbk, bvec, nok && st < nsteps, st * 16 + 4 * g, a.K);
+    av[u] = ldA(mok && st < nsteps, st * 16 + 4 * g);
+    bv[u] = ldB(nok && st < nsteps, st * 16 + 4 * g);
   }
   for (int s = wave; s < nsteps; s += 8) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int st = s + 8 + 4 * u;
-      an[u] = load_k4(Ap, a.sak, avec, mok && st < nsteps, st * 16 + 4 * g, a.K);
-      bn[u] = load_k4(Bp, a.sbk, bvec, nok && st < nsteps, st * 16 + 4 * g, a.K);
+      an[u] = ldA(mok && st < nsteps, st * 16 + 4 * g);
+      bn[u] = ldB(nok && st < nsteps, st * 16 + 4 * g);
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -158,13 +189,7 @@ __device__ __forceinline__ void gemm_f32_tile16(const SGArgs& a, int bx, int by,
   const int ml = tid >> 4, nl = tid & 15;
   const int mo = by * 16 + ml, no = bx * 16 + nl;
   if (mo >= a.M || no >= a.N) return;
-  float v = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
-  if (a.bias) v += a.bias[no];
-  if (a.addend) v += a.addend[(long)(mo % a.add_rows) * a.lda2 + no];
-  if (a.act == 2) v = fmaxf(v, 0.f);
-  else if (a.act == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-  float* p = a.C + (long)mo * a.ldc + no;
-  *p = a.accumulate ? *p + v : v;
+  sg_store(a, part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid], mo, no);
 }
 
 __global__ __launch_bounds__(256) void gemm_f32_kernel(SGArgs a) {
@@ -361,7 +386,7 @@ extern "C" int simvg_gemm_f32(const float* A, long sam, long sak, const float* B
   SIMVG_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm_f32: empty problem");
   SIMVG_CHECK_ARG(act >= 0 && act <= 2, "gemm_f32: act must be 0 (none), 1 (gelu) or 2 (relu)");
   SGArgs a{A, sam, sak, B, sbk, sbn, C, ldc, bias, addend, ld_addend, addend_rows > 0 ? addend_rows : 1, M, N, K,
-           accumulate, act};
+           accumulate, act, nullptr, nullptr, nullptr, 0, nullptr, 0};
   constexpr int small_env = 32;      // <= 32 tiles of 64x64: the small-M kernel (sweep in profiles/r01_sweeps.md)
   if (cdiv(N, 64) * cdiv(M, 64) <= small_env)   // too few 64x64 tiles to fill the chip: one workgroup per 16x16 tile
     hipLaunchKernelGGL(gemm_f32_small_kernel, dim3(cdiv(N, 16), cdiv(M, 16)), dim3(256), 0, stream, a);
@@ -382,7 +407,8 @@ extern "C" int simvg_gemm_f32_grouped(const simvg_gemm_f32_problem* problems, in
     SIMVG_CHECK_ARG(q.M > 0 && q.N > 0 && q.K > 0, "gemm_f32_grouped: empty problem");
     SIMVG_CHECK_ARG(q.act >= 0 && q.act <= 2, "gemm_f32_grouped: act must be 0 (none), 1 (gelu) or 2 (relu)");
     g.p[i] = SGArgs{q.A, q.sam, q.sak, q.B, q.sbk, q.sbn, q.C, q.ldc, q.bias, q.addend, q.ld_addend,
-                    q.addend_rows > 0 ? q.addend_rows : 1, q.M, q.N, q.K, q.accumulate, q.act};
+                    q.addend_rows > 0 ? q.addend_rows : 1, q.M, q.N, q.K, q.accumulate, q.act,
+                    q.A2, q.B2, q.mult, q.ld_mult, q.gate, q.ld_gate};
     const int sm = cdiv(q.N, 64) * cdiv(q.M, 64) <= small_env;
     const int t = sm ? 16 : 64;
     g.small[i] = sm;

@@ -405,7 +405,9 @@ def gemm_f32(A, sam, sak, Bm, sbk, sbn, C, M, N, K, bias=None, addend=None, adde
 
 def gemm_f32_group(problems):
     """Independent gemm_f32 problems in ONE launch.  Each problem: dict(A, sam, sak, B, sbk, sbn, C, M, N, K[, bias,
-    addend, addend_rows, accumulate, act]) with the meaning of `gemm_f32`; at most 12 per launch (longer lists are split)."""
+    addend, addend_rows, accumulate, act, A2, B2, mult, gate]) with the meaning of `gemm_f32`; A2 / B2: second operands
+    (same strides) added to A / B on load; mult: [M, N] factor after the activation; gate: [M, N], the value passes where
+    gate > 0 (with mult or gate the addend is added after them).  At most 12 per launch (longer lists are split)."""
     lib = _lib.load()
     for i in range(0, len(problems), 12):
         chunk = problems[i:i + 12]
@@ -422,6 +424,11 @@ def gemm_f32_group(problems):
             d.addend_rows = q.get("addend_rows", 0)
             d.M, d.N, d.K = q["M"], q["N"], q["K"]
             d.accumulate, d.act = int(q.get("accumulate", False)), q.get("act", 0)
+            a2, b2, mu, ga = q.get("A2"), q.get("B2"), q.get("mult"), q.get("gate")
+            d.A2 = a2.data_ptr() if a2 is not None else None
+            d.B2 = b2.data_ptr() if b2 is not None else None
+            d.mult, d.ld_mult = (mu.data_ptr(), mu.stride(0)) if mu is not None else (None, 0)
+            d.gate, d.ld_gate = (ga.data_ptr(), ga.stride(0)) if ga is not None else (None, 0)
         t0 = _timer.start("gemm_f32_group") if _timer is not None else None
         rc = lib.simvg_gemm_f32_grouped(C.byref(arr), len(chunk), _stream())
         if t0 is not None:

@@ -180,24 +180,22 @@ class DecoderLayerFn(torch.autograd.Function):
             _, y, mean, rstd = ops.ln_fwd(x, g, b, eps=1e-5, out_lp=False, out_f32=True)
             return y, mean, rstd
 
-        # ---- self-attention: q = k = tgt + qpos, v = tgt
-        x_qk = tgt + qpos
+        # ---- self-attention: q = k = (tgt + qpos) W_qk (the sum is formed on the GEMM's operand load), v = tgt W_v
         qkv = _f32(M, 3 * E, device=dev)
-        ops.gemm_f32_group([ops.gp(x_qk, E, 1, Ws, 1, E, qkv, M, 2 * E, E, bias=bs),
+        ops.gemm_f32_group([ops.gp(tgt, E, 1, Ws, 1, E, qkv, M, 2 * E, E, bias=bs, A2=qpos),
                             ops.gp(tgt, E, 1, Ws[2 * E:], 1, E, qkv[:, 2 * E:], M, E, E, bias=bs[2 * E:])])
         dm0 = amask(nq)
         o, P0 = ops.attn_small_fwd(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], B, H, nq, nq, kpm=None, drop=dm0, kv_rows=0)
         r1 = _f32(M, E, device=dev)
         ops.gemm_f32(o, E, 1, Wso, 1, E, r1, M, E, E, bias=bso, addend=tgt, addend_rows=M)         # tgt + out_proj(o)
         t1, mean1, rstd1 = ln(r1, g0, b0)
-        # ---- cross-attention: q = t1 + qpos
-        xq = t1 + qpos
+        # ---- cross-attention: q = (t1 + qpos) W_q
         q = _f32(M, E, device=dev)
         if cfg.kind == "text":
             xk, xv = xk.contiguous(), xv.contiguous()
             R, Lk = xk.shape[0], cfg.Lk
             kv = _f32(R, 2 * E, device=dev)
-            ops.gemm_f32_group([ops.gp(xq, E, 1, Wc, 1, E, q, M, E, E, bias=bc),
+            ops.gemm_f32_group([ops.gp(t1, E, 1, Wc, 1, E, q, M, E, E, bias=bc, A2=qpos),
                                 ops.gp(xk, E, 1, Wc[E:], 1, E, kv, R, E, E, bias=bc[E:]),
                                 ops.gp(xv, E, 1, Wc[2 * E:], 1, E, kv[:, E:], R, E, E, bias=bc[2 * E:])])
             dm1 = amask(Lk)
@@ -208,7 +206,7 @@ class DecoderLayerFn(torch.autograd.Function):
             HW, R = Nv - 1, B * Nv
             pos2 = cfg.pos.reshape(-1, E)
             posk = _f32(pos2.shape[0], E, device=dev)
-            probs = [ops.gp(xq, E, 1, Wc, 1, E, q, M, E, E, bias=bc),
+            probs = [ops.gp(t1, E, 1, Wc, 1, E, q, M, E, E, bias=bc, A2=qpos),
                      ops.gp(pos2, E, 1, Wc[E:], 1, E, posk, pos2.shape[0], E, E)]
             if mem.dtype == ops.LP():
                 kv = ops.gemm_nt(mem, cfg.wb, bias=bc[E:], out_dtype=torch.float32)                  # [B*Nv, 2E]
@@ -223,25 +221,22 @@ class DecoderLayerFn(torch.autograd.Function):
         r2 = _f32(M, E, device=dev)
         ops.gemm_f32(o2, E, 1, Wco, 1, E, r2, M, E, E, bias=bco, addend=t1, addend_rows=M)
         t2, mean2, rstd2 = ln(r2, g1, b1n)
-        # ---- FFN: Linear, ReLU, dropout, Linear, dropout, + identity
-        h1 = _f32(M, Fd, device=dev)
-        ops.gemm_f32(t2, E, 1, W1, 1, E, h1, M, Fd, E, bias=b1, act=2)
-        r3 = _f32(M, E, device=dev)
+        # ---- FFN: Linear, ReLU, dropout, Linear, dropout, + identity; the dropout multipliers ride in the GEMM epilogues
+        h1d, r3 = _f32(M, Fd, device=dev), _f32(M, E, device=dev)
         if train and cfg.p_ffn > 0:
-            h1d, m1 = torch.native_dropout(h1, cfg.p_ffn, True)
-            h2 = _f32(M, E, device=dev)
-            ops.gemm_f32(h1d, Fd, 1, W2, 1, Fd, h2, M, E, Fd, bias=b2)
-            h2d, m2 = torch.native_dropout(h2, cfg.p_ffn, True)
-            torch.add(t2, h2d, out=r3)
+            m1, m2 = cfg.mask_fn((M, Fd), dev, cfg.p_ffn), cfg.mask_fn((M, E), dev, cfg.p_ffn)
+            ops.gemm_f32_group([ops.gp(t2, E, 1, W1, 1, E, h1d, M, Fd, E, bias=b1, act=2, mult=m1)])
+            ops.gemm_f32_group([ops.gp(h1d, Fd, 1, W2, 1, Fd, r3, M, E, Fd, bias=b2, mult=m2, addend=t2, addend_rows=M)])
         else:
-            h1d, m1, m2 = h1, None, None
-            ops.gemm_f32(h1, Fd, 1, W2, 1, Fd, r3, M, E, Fd, bias=b2, addend=t2, addend_rows=M)
+            m1 = m2 = None
+            ops.gemm_f32(t2, E, 1, W1, 1, E, h1d, M, Fd, E, bias=b1, act=2)
+            ops.gemm_f32(h1d, Fd, 1, W2, 1, Fd, r3, M, E, Fd, bias=b2, addend=t2, addend_rows=M)
         t3, mean3, rstd3 = ln(r3, g2, b2n)
         hs = meanP = rstdP = None
         if gP is not None:
             hs, meanP, rstdP = ln(t3, gP, bP)
-        ctx.save_for_backward(tgt, x_qk, qkv, P0, dm0, o, r1, mean1, rstd1, xq, q, kv, P1, dm1, o2, r2, mean2, rstd2, t2,
-                              h1, h1d, m1, m2, r3, mean3, rstd3, t3, meanP, rstdP, xk, xv, mem, pos2,
+        ctx.save_for_backward(tgt, qpos, qkv, P0, dm0, o, r1, mean1, rstd1, t1, q, kv, P1, dm1, o2, r2, mean2, rstd2, t2,
+                              h1d, m1, m2, r3, mean3, rstd3, t3, meanP, rstdP, xk, xv, mem, pos2,
                               Ws, Wso, g0, Wc, Wco, g1, W1, W2, g2, gP)
         ctx.cfg = cfg
         ctx.set_materialize_grads(False)
@@ -249,7 +244,7 @@ class DecoderLayerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_t3, d_hs):
-        (tgt, x_qk, qkv, P0, dm0, o, r1, mean1, rstd1, xq, q, kv, P1, dm1, o2, r2, mean2, rstd2, t2, h1, h1d, m1, m2, r3,
+        (tgt, qpos, qkv, P0, dm0, o, r1, mean1, rstd1, t1, q, kv, P1, dm1, o2, r2, mean2, rstd2, t2, h1d, m1, m2, r3,
          mean3, rstd3, t3, meanP, rstdP, xk, xv, mem, pos2, Ws, Wso, g0, Wc, Wco, g1, W1, W2, g2, gP) = ctx.saved_tensors
         cfg = ctx.cfg
         dev = tgt.device
@@ -276,16 +271,13 @@ class DecoderLayerFn(torch.autograd.Function):
         # ---- FFN
         d_r3 = _f32(M, E, device=dev)
         ops.ln_bwd(d_t3, r3, mean3, rstd3, g2, dg2, db2n, dx_f32=d_r3)
-        scale = 1.0 / (1.0 - cfg.p_ffn) if m2 is not None else 1.0
-        d_h2 = torch.ops.aten.native_dropout_backward(d_r3, m2, scale) if m2 is not None else d_r3
+        d_h2 = d_r3 * m2 if m2 is not None else d_r3
         d_h1 = _f32(M, Fd, device=dev)
         dW2, db2 = _f32(E, Fd, device=dev), _f32(1, E, device=dev)
-        ops.gemm_f32_group([ops.gp(d_h2, E, 1, W2, Fd, 1, d_h1, M, Fd, E),
+        # d(pre-activation) = (d_h2 W2) * dropout multiplier where the ReLU was open: h1d = relu(.) * m1 > 0 <=> both
+        ops.gemm_f32_group([ops.gp(d_h2, E, 1, W2, Fd, 1, d_h1, M, Fd, E, gate=h1d, mult=m1),
                             ops.gp(d_h2, 1, E, h1d, Fd, 1, dW2, E, Fd, M),
                             ops.gp(ones, 0, 1, d_h2, E, 1, db2, 1, E, M)])
-        if m1 is not None:
-            d_h1 = torch.ops.aten.native_dropout_backward(d_h1, m1, scale)
-        d_h1 = torch.ops.aten.threshold_backward(d_h1, h1, 0.0)
         d_t2 = _f32(M, E, device=dev)
         dW1, db1 = _f32(Fd, E, device=dev), _f32(1, Fd, device=dev)
         ops.gemm_f32_group([ops.gp(d_h1, Fd, 1, W1, E, 1, d_t2, M, E, Fd, addend=d_r3, addend_rows=M),
@@ -309,7 +301,7 @@ class DecoderLayerFn(torch.autograd.Function):
             dWc, dbc = _f32(3 * E, E, device=dev), _f32(1, 3 * E, device=dev)
             probs = [ops.gp(dq, E, 1, Wc, E, 1, dxq, M, E, E),
                      ops.gp(dq, E, 1, Wc, E, 1, d_t1, M, E, E, addend=d_r2, addend_rows=M),
-                     ops.gp(dq, 1, E, xq, E, 1, dWc, E, E, M),
+                     ops.gp(dq, 1, E, t1, E, 1, dWc, E, E, M, B2=qpos),
                      ops.gp(dkv, 1, 2 * E, xk, E, 1, dWc[E:], E, E, R),
                      ops.gp(dkv[:, E:], 1, 2 * E, xv, E, 1, dWc[2 * E:], E, E, R),
                      ops.gp(ones, 0, 1, dq, E, 1, dbc, 1, E, M),
@@ -334,7 +326,7 @@ class DecoderLayerFn(torch.autograd.Function):
                 dWc, dbc = _f32(3 * E, E, device=dev), _f32(1, 3 * E, device=dev)
             probs = [ops.gp(dq, E, 1, Wc, E, 1, dxq, M, E, E),
                      ops.gp(dq, E, 1, Wc, E, 1, d_t1, M, E, E, addend=d_r2, addend_rows=M),
-                     ops.gp(dq, 1, E, xq, E, 1, dWc, E, E, M),
+                     ops.gp(dq, 1, E, t1, E, 1, dWc, E, E, M, B2=qpos),
                      ops.gp(ones, 0, 1, dq, E, 1, dbc, 1, E, M)]
             if mem_bf:
                 ops.gemm_f32_group(probs)
@@ -367,7 +359,7 @@ class DecoderLayerFn(torch.autograd.Function):
         d_qpos = _f32(M, E, device=dev)
         dWs, dbs = _f32(3 * E, E, device=dev), _f32(1, 3 * E, device=dev)
         probs = [ops.gp(dqkv, 3 * E, 1, Ws, E, 1, d_qpos, M, E, 2 * E, addend=dxq, addend_rows=M),   # dqk W_qk + dxq
-                 ops.gp(dqkv, 1, 3 * E, x_qk, E, 1, dWs, 2 * E, E, M),
+                 ops.gp(dqkv, 1, 3 * E, tgt, E, 1, dWs, 2 * E, E, M, B2=qpos),
                  ops.gp(dqkv[:, 2 * E:], 1, 3 * E, tgt, E, 1, dWs[2 * E:], E, E, M),
                  ops.gp(ones, 0, 1, dqkv, 3 * E, 1, dbs, 1, 3 * E, M)]
         d_tgt = None

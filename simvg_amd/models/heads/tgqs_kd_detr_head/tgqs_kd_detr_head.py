@@ -115,6 +115,7 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
         self.register_buffer("criterion_empty_weight", torch.tensor([1.0, self.eos_coef]), persistent=False)
         self._prep = None
         self._prep_version = None
+        self._mask_state, self._mask_plan = None, {}
         self._const = {}
 
     # ------------------------------------------------------------------ parameters (reference schema)
@@ -229,14 +230,49 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
         shp = x.shape
         return LayerNormF32.apply(x.reshape(-1, shp[-1]), self._P(key + ".weight"), self._P(key + ".bias"), 1e-5).view(shp)
 
-    def _drop_mult(self, shape, device):
-        if not self.training or self.attn_dropout == 0:
+    def _drop_mult(self, shape, device, p=None):
+        """dropout multipliers (0 or 1/(1-p)) of one site.  All sites of a forward are slices of ONE generated buffer per
+        rate: the first forward of a geometry records how much each rate needs (`_mask_plan`), later ones draw the whole
+        step's multipliers in a single launch (`_begin_masks`) -- 20 launches per step otherwise."""
+        p = self.attn_dropout if p is None else p
+        if not self.training or p == 0:
             return None
-        key = ("ones", str(device), tuple(shape))
+        n = 1
+        for d in shape:
+            n *= int(d)
+        n_al = (n + 63) // 64 * 64
+        st = self._mask_state
+        if st is not None:
+            st["need"][p] = st["need"].get(p, 0) + n_al
+            buf = st["buf"].get(p)
+            if buf is not None and st["off"].get(p, 0) + n_al <= buf.numel():
+                o = st["off"].get(p, 0)
+                st["off"][p] = o + n_al
+                return buf[o:o + n].view(shape)
+        key = ("ones", str(device), n)
         ones = self._const.get(key)
         if ones is None:
-            ones = self._const[key] = torch.ones(shape, device=device)
-        return F.dropout(ones, self.attn_dropout, True)          # keep-mask / keep, one launch
+            ones = self._const[key] = torch.ones(n, device=device)
+        return F.dropout(ones, p, True).view(shape)
+
+    def _begin_masks(self, key, device):
+        if not self.training:
+            self._mask_state = None
+            return
+        plan = self._mask_plan.get(key, {})
+        bufs = {}
+        for p, total in plan.items():
+            ck = ("ones", str(device), total)
+            ones = self._const.get(ck)
+            if ones is None:
+                ones = self._const[ck] = torch.ones(total, device=device)
+            bufs[p] = F.dropout(ones, p, True)
+        self._mask_state = dict(key=key, need={}, off={}, buf=bufs)
+
+    def _end_masks(self):
+        st, self._mask_state = self._mask_state, None
+        if st is not None and len(self._mask_plan) < 64:
+            self._mask_plan[st["key"]] = dict(st["need"])
 
     def _dropout(self, x):
         return F.dropout(x, self.ffn_dropout, self.training) if self.training and self.ffn_dropout > 0 else x
@@ -294,6 +330,7 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
         device = enc_out.device
         E, nq, H = self.embed_dim, self.num_queries, self.heads
         HW = Nv - 1
+        self._begin_masks((str(device), B, Nv, T), device)
         hw = int(round(HW ** 0.5))
         enc_lp = getattr(enc_out, "lp", None)
         exact = enc_lp is None                      # precision="fp32" mode: fp32 memory rows as well
@@ -353,6 +390,7 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
         dec_logits = self._lin(hs, "class_embed_decoder")
         db = self._lin(self._lin(hs, "bbox_embed_decoder.layers.0", relu=True), "bbox_embed_decoder.layers.1", relu=True)
         dec_boxes = self._lin(db, "bbox_embed_decoder.layers.2").sigmoid()
+        self._end_masks()
         return dict(
             token_branch_output={"pred_logits": tok_logits[-1], "pred_boxes": tok_boxes[-1]},
             decoder_branch_output={"pred_logits": dec_logits[-1], "pred_boxes": dec_boxes[-1]},

@@ -188,24 +188,26 @@ def _mha_ref(xq, xk, xv, W, b, B, H, Lq, Lk, kpm=None, dm=None):
     return (w @ v).transpose(1, 2).reshape(B * Lq, E)
 
 
-def _ref_decoder_layer(tgt, qpos, P, B, H, nq, kind, xk=None, xv=None, mem=None, pos=None, kpm=None, post=None):
-    """post-norm DETR decoder layer in plain fp32 PyTorch (eval mode: no dropout); P = the 18 layer parameters"""
+def _ref_decoder_layer(tgt, qpos, P, B, H, nq, kind, xk=None, xv=None, mem=None, pos=None, kpm=None, post=None, masks=None):
+    """post-norm DETR decoder layer in plain fp32 PyTorch; P = the 18 layer parameters; masks = None (eval) or the dropout
+    multipliers (dm0, dm1 on the attention probabilities, m1 after the ReLU, m2 on the FFN output)"""
+    dm0, dm1, m1, m2 = masks if masks is not None else (None, None, 1.0, 1.0)
     (Ws, bs, Wso, bso, g0, b0, Wc, bc, Wco, bco, g1, b1n, W1, b1, W2, b2, g2, b2n) = P
     E = tgt.shape[1]
     x_qk = tgt + qpos
-    o = _mha_ref(x_qk, x_qk, tgt, Ws, bs, B, H, nq, nq)
+    o = _mha_ref(x_qk, x_qk, tgt, Ws, bs, B, H, nq, nq, dm=dm0)
     t1 = F.layer_norm(tgt + F.linear(o, Wso, bso), (E,), g0, b0, 1e-5)
     xq = t1 + qpos
     if kind == "text":
         Lk = xk.shape[0] // B
-        o2 = _mha_ref(xq, xk, xv, Wc, bc, B, H, nq, Lk, kpm=kpm)
+        o2 = _mha_ref(xq, xk, xv, Wc, bc, B, H, nq, Lk, kpm=kpm, dm=dm1)
     else:
         Nv = mem.shape[0] // B
         patches = mem.view(B, Nv, E)[:, 1:]
         keys = (patches + (pos[None] if pos.dim() == 2 else pos)).reshape(-1, E)
-        o2 = _mha_ref(xq, keys, patches.reshape(-1, E), Wc, bc, B, H, nq, Nv - 1, kpm=kpm)
+        o2 = _mha_ref(xq, keys, patches.reshape(-1, E), Wc, bc, B, H, nq, Nv - 1, kpm=kpm, dm=dm1)
     t2 = F.layer_norm(t1 + F.linear(o2, Wco, bco), (E,), g1, b1n, 1e-5)
-    t3 = F.layer_norm(t2 + F.linear(F.relu(F.linear(t2, W1, b1)), W2, b2), (E,), g2, b2n, 1e-5)
+    t3 = F.layer_norm(t2 + F.linear(F.relu(F.linear(t2, W1, b1)) * m1, W2, b2) * m2, (E,), g2, b2n, 1e-5)
     hs = F.layer_norm(t3, (E,), post[0], post[1], 1e-5) if post is not None else None
     return t3, hs
 
@@ -259,6 +261,80 @@ def test_decoder_layer_node_fwd_bwd(kind, nq, shared_pos):
             close(d.grad, c.grad, 1e-4, "grad " + n)
     if kind == "mem":
         assert float(ins_d[4].grad.view(B, Nv, E)[:, 0].abs().max()) == 0.0        # CLS rows are not keys: no gradient
+
+
+def test_gemm_f32_operand_sums_multiplier_and_gate():
+    """the optional pieces of a grouped problem: A + A2 / B + B2 formed on the operand load (both tile shapes, both operand
+    orientations), `mult` after the activation, `gate` on a saved output, addend added after them"""
+    from simvg_amd import hip_ops as ops
+    g = torch.Generator().manual_seed(23)
+    r = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    for M in (64, 1280):                                    # 16x16-tile and 64x64-tile kernels
+        x, x2, W, b = r(M, 256), r(M, 256), r(512, 256), r(512)
+        mult = (torch.rand(M, 512, generator=g) > 0.3).float().to(DEV) / 0.7
+        saved, res, dy = r(M, 512), r(M, 512), r(M, 512)
+        y0, y1, y2 = (torch.zeros(M, 512, device=DEV) for _ in range(3))
+        dW = torch.zeros(512, 256, device=DEV)
+        ops.gemm_f32_group([
+            ops.gp(x, 256, 1, W, 1, 256, y0, M, 512, 256, bias=b, A2=x2),                                          # (x + x2) W^T + b
+            ops.gp(x, 256, 1, W, 1, 256, y1, M, 512, 256, bias=b, act=2, mult=mult, addend=res, addend_rows=M),    # relu(.)*m + res
+            ops.gp(x, 256, 1, W, 1, 256, y2, M, 512, 256, gate=saved, mult=mult),                                  # gated
+            ops.gp(dy, 1, 512, x, 256, 1, dW, 512, 256, M, B2=x2)])                                                # dy^T (x + x2)
+        xc, x2c, Wc = x.cpu().double(), x2.cpu().double(), W.cpu().double()
+        close(y0, ((xc + x2c) @ Wc.t() + b.cpu().double()).float(), 2e-5, f"A2 M={M}")
+        close(y1, (F.relu(xc @ Wc.t() + b.cpu().double()) * mult.cpu().double() + res.cpu().double()).float(), 2e-5, f"mult M={M}")
+        close(y2, ((xc @ Wc.t()) * mult.cpu().double() * (saved.cpu() > 0).double()).float(), 2e-5, f"gate M={M}")
+        close(dW, (dy.cpu().double().t() @ (xc + x2c)).float(), 2e-5 * (M / 64) ** 0.5, f"B2 M={M}")
+
+
+@pytest.mark.parametrize("kind,nq", [("text", 3), ("mem", 2)])
+def test_decoder_layer_node_with_dropout_multipliers(kind, nq):
+    """training branch of the layer node: the four dropout sites take their multipliers from `mask_fn` (attention
+    probabilities, after the ReLU and on the FFN output through the GEMM epilogues) == the plain PyTorch layer with the
+    same multipliers, outputs and every gradient"""
+    from simvg_amd.models.heads.functions import DecoderLayerFn, LayerCfg
+    B, H, E, Fd, T, HW = 3, 8, 256, 512, 20, 16
+    Nv = HW + 1
+    g = torch.Generator().manual_seed(41 + nq)
+    r = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
+    tgt, qpos = r(B * nq, E), r(B * nq, E)
+    P = [r(3 * E, E, sc=E ** -0.5), r(3 * E, sc=0.1), r(E, E, sc=E ** -0.5), r(E, sc=0.1), 1 + r(E, sc=0.1), r(E, sc=0.1),
+         r(3 * E, E, sc=E ** -0.5), r(3 * E, sc=0.1), r(E, E, sc=E ** -0.5), r(E, sc=0.1), 1 + r(E, sc=0.1), r(E, sc=0.1),
+         r(Fd, E, sc=E ** -0.5), r(Fd, sc=0.1), r(E, Fd, sc=Fd ** -0.5), r(E, sc=0.1), 1 + r(E, sc=0.1), r(E, sc=0.1)]
+    post = [1 + r(E, sc=0.1), r(E, sc=0.1)]
+    xk = xv = mem = pos = None
+    Lk = T if kind == "text" else HW
+    if kind == "text":
+        xk, xv = r(B * T, E), r(B * T, E)
+    else:
+        mem, pos = r(B * Nv, E), r(HW, E)
+    keep = lambda *s: (torch.rand(*s, generator=g) > 0.1).float() / 0.9
+    masks = [keep(B, H, nq, nq), keep(B, H, nq, Lk), keep(B * nq, Fd), keep(B * nq, E)]
+    d_t3, d_hs = r(B * nq, E), r(B * nq, E)
+
+    def leaves(ts, dev):
+        return [None if t is None else t.clone().to(dev).requires_grad_(True) for t in ts]
+
+    ins_c = leaves([tgt, qpos, xk, xv, mem] + P + post, "cpu")
+    t3_ref, hs_ref = _ref_decoder_layer(ins_c[0], ins_c[1], ins_c[5:23], B, H, nq, kind, xk=ins_c[2], xv=ins_c[3], mem=ins_c[4],
+                                        pos=pos, post=ins_c[23:25], masks=masks)
+    torch.autograd.backward([t3_ref, hs_ref], [d_t3, d_hs])
+    ins_d = leaves([tgt, qpos, xk, xv, mem] + P + post, DEV)
+    order = iter([m.to(DEV) for m in masks])            # the node asks in the order: self-attn, cross-attn, ffn 1, ffn 2
+
+    def mask_fn(shape, dev, p=None):
+        m = next(order)
+        assert tuple(m.shape) == tuple(shape), (m.shape, shape)
+        return m
+
+    cfg = LayerCfg(B, H, nq, kind, Lk, pos=None if pos is None else pos.to(DEV), Nv=Nv if kind == "mem" else 0,
+                   p_attn=0.1, p_ffn=0.1, training=True, mask_fn=mask_fn)
+    t3, hs = DecoderLayerFn.apply(*ins_d, cfg)
+    torch.autograd.backward([t3, hs], [d_t3.to(DEV), d_hs.to(DEV)])
+    close(t3, t3_ref, 2e-5, "layer output"); close(hs, hs_ref, 2e-5, "post-normed output")
+    for i, (d, c) in enumerate(zip(ins_d, ins_c)):
+        if c is not None:
+            close(d.grad, c.grad, 1e-4, f"grad of input {i}")
 
 
 @pytest.mark.parametrize("B,nq,ncol,rescale", [(5, 1, 2, False), (4, 10, 2, True), (3, 7, 4, True)])
