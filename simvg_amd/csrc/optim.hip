@@ -66,38 +66,66 @@ struct AdamArgs {
   int amsgrad;
 };
 
+constexpr int STREAM_GRID = 768;      // 3 blocks of 256 threads per CU of an MI355X (256 CUs), all resident
+
 // (non-temporal loads / stores on the moment streams: no gain at 141 M parameters, -15 % at 370 M -- default policy)
+// U float4 chunks per thread and trip.  PHASED: the g / m / v loads of all U chunks first, then -- only for chunks that are
+// not all-zero -- p and vmax (two dependent round trips, 12 B instead of 20 B read for never-touched rows); !PHASED: all five
+// streams of all U chunks in flight at once.
+template <int U, bool PHASED>
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
   constexpr bool NT = false;
   float coef = 1.f;
   if (a.total_norm) coef = fminf(a.max_norm / (*a.total_norm + 1e-6f), 1.f);
   const float w1 = 1.f - a.beta1, w2 = 1.f - a.beta2;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.n4; i += (long)gridDim.x * 256) {
-    const f32x4_t g = ld4<NT>(a.g, i);
-    f32x4_t m = ld4<NT>(a.m, i), v = ld4<NT>(a.v, i);
-    // never-touched parameters (embedding rows of tokens that have not occurred yet: 49 M of ViT-B's 141 M parameters are
-    // the 64 010-row text table): g = m = v = 0 makes the update exactly zero and leaves the state unchanged -> skip the
-    // remaining 24 B of traffic.  (v = 0 implies vmax = 0; weight decay would move them, so only without it.)
-    if (a.weight_decay == 0.f && g[0] == 0.f && g[1] == 0.f && g[2] == 0.f && g[3] == 0.f && m[0] == 0.f && m[1] == 0.f &&
-        m[2] == 0.f && m[3] == 0.f && v[0] == 0.f && v[1] == 0.f && v[2] == 0.f && v[3] == 0.f)
-      continue;
-    f32x4_t p = ld4<NT>(a.p, i);
-    f32x4_t vm = a.amsgrad ? ld4<NT>(a.vmax, i) : v;
+  const long stride = (long)gridDim.x * 256;
+  for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < a.n4; i0 += stride * U) {
+    f32x4_t g[U], m[U], v[U], p[U], vm[U];
+    bool live[U];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float gk = g[k] * coef;
-      if (a.weight_decay != 0.f) gk = fmaf(a.weight_decay, p[k], gk);
-      m[k] = m[k] + w1 * (gk - m[k]);
-      v[k] = a.beta2 * v[k] + w2 * gk * gk;
-      float d2 = v[k];
-      if (a.amsgrad) { vm[k] = fmaxf(vm[k], v[k]); d2 = vm[k]; }
-      const float denom = sqrtf(d2) / a.bc2_sqrt + a.eps;
-      p[k] = p[k] - a.step_size * (m[k] / denom);
+    for (int u = 0; u < U; ++u) {
+      const long i = i0 + u * stride;
+      live[u] = i < a.n4;
+      if (live[u]) {
+        g[u] = ld4<NT>(a.g, i); m[u] = ld4<NT>(a.m, i); v[u] = ld4<NT>(a.v, i);
+        if (!PHASED) { p[u] = ld4<NT>(a.p, i); vm[u] = a.amsgrad ? ld4<NT>(a.vmax, i) : v[u]; }
+      }
     }
-    ((f32x4_t*)a.p)[i] = p;            // the parameters are re-read by the weight refresh right after: default policy
-    st4<NT>(a.m, i, m);
-    st4<NT>(a.v, i, v);
-    if (a.amsgrad) st4<NT>(a.vmax, i, vm);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      // never-touched parameters (embedding rows of tokens that have not occurred yet: 49 M of ViT-B's 141 M parameters are
+      // the 64 010-row text table): g = m = v = 0 makes the update exactly zero and leaves the state unchanged -> skip the
+      // rest of the traffic.  (v = 0 implies vmax = 0; weight decay would move them, so only without it.)
+      if (live[u] && a.weight_decay == 0.f && g[u][0] == 0.f && g[u][1] == 0.f && g[u][2] == 0.f && g[u][3] == 0.f &&
+          m[u][0] == 0.f && m[u][1] == 0.f && m[u][2] == 0.f && m[u][3] == 0.f && v[u][0] == 0.f && v[u][1] == 0.f &&
+          v[u][2] == 0.f && v[u][3] == 0.f)
+        live[u] = false;
+      if (PHASED && live[u]) {
+        const long i = i0 + u * stride;
+        p[u] = ld4<NT>(a.p, i);
+        vm[u] = a.amsgrad ? ld4<NT>(a.vmax, i) : v[u];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!live[u]) continue;
+      const long i = i0 + u * stride;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float gk = g[u][k] * coef;
+        if (a.weight_decay != 0.f) gk = fmaf(a.weight_decay, p[u][k], gk);
+        m[u][k] = m[u][k] + w1 * (gk - m[u][k]);
+        v[u][k] = a.beta2 * v[u][k] + w2 * gk * gk;
+        float d2 = v[u][k];
+        if (a.amsgrad) { vm[u][k] = fmaxf(vm[u][k], v[u][k]); d2 = vm[u][k]; }
+        const float denom = sqrtf(d2) / a.bc2_sqrt + a.eps;
+        p[u][k] = p[u][k] - a.step_size * (m[u][k] / denom);
+      }
+      ((f32x4_t*)a.p)[i] = p[u];       // the parameters are re-read by the weight refresh right after: default policy
+      st4<NT>(a.m, i, m[u]);
+      st4<NT>(a.v, i, v[u]);
+      if (a.amsgrad) st4<NT>(a.vmax, i, vm[u]);
+    }
   }
 }
 
@@ -107,7 +135,8 @@ extern "C" int simvg_sumsq(const float* x, long n, float* out_accum, float* part
   SIMVG_CHECK_ARG(x && out_accum && partial_ws && n > 0 && n % 4 == 0,
                   "sumsq: n must be a positive multiple of 4; a 2048-float workspace is required");
   const long n4 = n / 4;
-  const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+  // grid-stride over 3 resident blocks per CU (768 on MI355X): 84 us for 141 M floats against 106 us with 2048 blocks
+  const int grid = (int)((n4 + 255) / 256 < STREAM_GRID ? (n4 + 255) / 256 : STREAM_GRID);
   // read-once stream: non-temporal loads (5.1 -> 5.5 TB/s standalone; 3.7 TB/s before the 4-way unroll)
   hipLaunchKernelGGL(sumsq_kernel<true>, dim3(grid), dim3(256), 0, stream, x, n4, partial_ws);
   hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(64), 0, stream, partial_ws, grid, out_accum);
@@ -122,8 +151,12 @@ extern "C" int simvg_adam_step(float* param, const float* grad, float* exp_avg, 
   SIMVG_CHECK_ARG(bias_correction2_sqrt > 0.f, "adam_step: bias_correction2_sqrt must be > 0");
   AdamArgs a{param, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, n / 4, step_size, bias_correction2_sqrt, beta1, beta2, eps,
              weight_decay, total_norm, max_norm, max_exp_avg_sq != nullptr};
-  const int grid = (int)((a.n4 + 255) / 256 < 4096 ? (a.n4 + 255) / 256 : 4096);
-  hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, stream, a);
+  // 3 resident blocks per CU walking the nine streams in 3 MB strides: 880-980 us for ViT-B's 141 M parameters against
+  // 1150-1190 us with 4096 blocks (and every power-of-two grid); two chunks per thread in flight, loads phased around the
+  // zero-row test (sweep: profiles/r02_sweeps.md)
+  const long want = ((a.n4 + 255) / 256 + 1) / 2;
+  const int grid = (int)(want < STREAM_GRID ? want : STREAM_GRID);
+  hipLaunchKernelGGL((adam_kernel<2, true>), dim3(grid), dim3(256), 0, stream, a);
   SIMVG_LAUNCH_CHECK();
   return SIMVG_OK;
 }

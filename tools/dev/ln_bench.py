@@ -54,5 +54,9 @@ if which in ("all", "adam"):
     v.abs_(); vm.abs_()
     tn = torch.ones(1, device=dev)
     timed("adam_step amsgrad 141 M (dense)", lambda: ops.adam_step(p, gr, m, v, vm, 1e-4, 0.9, 0.9, 0.98, 1e-9, total_norm=tn, max_norm=0.15), n * 36.0, reps=10)
+    z = int(n * 0.65) // 4 * 4                       # ViT-B: the last 35 % of the arena is the (mostly untouched) text table
+    for t in (gr, m, v, vm):
+        t[z:].zero_()
+    timed("adam_step amsgrad 141 M (35 % untouched rows)", lambda: ops.adam_step(p, gr, m, v, vm, 1e-4, 0.9, 0.9, 0.98, 1e-9, total_norm=tn, max_norm=0.15), z * 36.0 + (n - z) * 12.0, reps=10)
     sq = torch.zeros(1, device=dev)
     timed("sumsq 141 M", lambda: ops.sumsq_accum(gr, sq), n * 4.0, reps=10)
