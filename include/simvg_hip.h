@@ -123,14 +123,19 @@ typedef struct simvg_gemm_f32_problem {
 } simvg_gemm_f32_problem;
 int simvg_gemm_f32_grouped(const simvg_gemm_f32_problem* problems, int count, simvg_stream_t stream);
 /* torch.nn.MultiheadAttention core (heads of 32) for <= 16 queries: softmax(scale q k^T + key_padding) [* dropout] v
- * (detrex MultiheadAttention wrapper; decoder layers transformer.py:167-186). */
+ * (detrex MultiheadAttention wrapper; decoder layers transformer.py:167-186).
+ * key_pos (optional): rows [Lk, E] (key_pos_rows_per_batch = 0: shared by the batch) or [B * Lk, E] (= Lk) of the PROJECTED
+ * key positional embedding, added to the K rows on load (K = (memory + key_pos) W_k^T = memory W_k^T + key_pos W_k^T); the
+ * backward's dk is then also the gradient of those rows. */
 int simvg_attn_small_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo,
                          float* P, const unsigned char* key_padding_mask, const float* drop_mult, int B, int H, int Lq,
-                         int Lk, int kv_rows_per_batch, float scale, simvg_stream_t stream);
+                         int Lk, int kv_rows_per_batch, float scale, const float* key_pos, int ld_key_pos,
+                         int key_pos_rows_per_batch, simvg_stream_t stream);
 int simvg_attn_small_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* P,
                          const unsigned char* key_padding_mask, const float* drop_mult, const float* dout, int lddo,
                          float* dq, int lddq, float* dk, int lddk, float* dv, int lddv, int B, int H, int Lq, int Lk,
-                         int kv_rows_per_batch, float scale, simvg_stream_t stream);
+                         int kv_rows_per_batch, float scale, const float* key_pos, int ld_key_pos,
+                         int key_pos_rows_per_batch, simvg_stream_t stream);
 
 /* exact-fp32 forward pieces (precision="fp32" inference mode: the reference computes in fp32, use_fp16=False in all
  * 53 configs): fp32 im2col and an fp32 encoder attention with the same modality-major row layout as simvg_attn_fwd. */

@@ -64,10 +64,10 @@ _SIGS = {
     "simvg_gemm_f32": [c_void_p, c_long, c_long, c_void_p, c_long, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long,
                        c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "simvg_attn_small_fwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
-                             c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
+                             c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_int, c_void_p],
     "simvg_attn_small_bwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                              c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
-                             c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
+                             c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_int, c_void_p],
     "simvg_match": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                     c_float, c_float, c_float, c_void_p],
     "simvg_soft_targets": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -239,6 +239,8 @@ struct SAArgs {
   float* dv; int lddv;
   int B, H, Lq, Lk, kv_rows;
   float scale;
+  const float* kpos; int ldkp, kpos_rows;   // optional key_pos rows [Lk or B*Lk, E] added to K on load (kpos_rows: rows per
+                                            // sample, 0 = one set shared by the batch)
 };
 
 constexpr int SHD = 32;
@@ -255,9 +257,11 @@ __global__ __launch_bounds__(256) void attn_small_fwd_kernel(SAArgs a) {
   for (int kk = tid; kk < a.Lk; kk += 256) {
     float kr[SHD];
     const float* kp = a.k + (long)(b * a.kv_rows + kk) * a.ldk + h * SHD;
+    const float* pp = a.kpos ? a.kpos + (long)(b * a.kpos_rows + kk) * a.ldkp + h * SHD : nullptr;
 #pragma unroll
     for (int d = 0; d < SHD; d += 4) {
-      const f32x4_t t = *(const f32x4_t*)(kp + d);
+      f32x4_t t = *(const f32x4_t*)(kp + d);
+      if (pp) t += *(const f32x4_t*)(pp + d);
       kr[d] = t[0]; kr[d + 1] = t[1]; kr[d + 2] = t[2]; kr[d + 3] = t[3];
     }
     const bool masked = a.kpm && a.kpm[b * a.Lk + kk];
@@ -359,7 +363,12 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(SAArgs a) {
     const int qi = e / SHD, d = e % SHD;
     float o = 0.f;
     const float* kp = a.k + (long)(b * a.kv_rows) * a.ldk + h * SHD + d;
-    for (int kk = 0; kk < a.Lk; ++kk) o += ds[qi * a.Lk + kk] * kp[(long)kk * a.ldk];
+    if (a.kpos) {
+      const float* pp = a.kpos + (long)(b * a.kpos_rows) * a.ldkp + h * SHD + d;
+      for (int kk = 0; kk < a.Lk; ++kk) o += ds[qi * a.Lk + kk] * (kp[(long)kk * a.ldk] + pp[(long)kk * a.ldkp]);
+    } else {
+      for (int kk = 0; kk < a.Lk; ++kk) o += ds[qi * a.Lk + kk] * kp[(long)kk * a.ldk];
+    }
     a.dq[(long)(b * a.Lq + qi) * a.lddq + h * SHD + d] = o;
   }
   // dK[k][d] = sum_q dS[q][k] Q[q][d]
@@ -426,12 +435,15 @@ extern "C" int simvg_gemm_f32_grouped(const simvg_gemm_f32_problem* problems, in
 extern "C" int simvg_attn_small_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                                     float* out, int ldo, float* P, const unsigned char* key_padding_mask,
                                     const float* drop_mult, int B, int H, int Lq, int Lk, int kv_rows_per_batch,
-                                    float scale, hipStream_t stream) {
+                                    float scale, const float* key_pos, int ld_key_pos, int key_pos_rows_per_batch,
+                                    hipStream_t stream) {
   SIMVG_CHECK_ARG(B > 0 && H > 0 && Lq > 0 && Lq <= 16 && Lk > 0 && (size_t)(Lq * SHD + Lq * Lk) * sizeof(float) <= 160 * 1024,
                   "attn_small: Lq <= 16 and the [Lq, Lk] score strip must fit the 160 KiB LDS");
   SIMVG_CHECK_ARG(ldk % 4 == 0 && ldv % 4 == 0, "attn_small: K/V rows must be 16-B aligned");
   SAArgs a{q, ldq, k, ldk, v, ldv, out, ldo, P, key_padding_mask, drop_mult, nullptr, 0, nullptr, 0, nullptr, 0,
-           nullptr, 0, B, H, Lq, Lk, kv_rows_per_batch > 0 ? kv_rows_per_batch : Lk, scale};
+           nullptr, 0, B, H, Lq, Lk, kv_rows_per_batch > 0 ? kv_rows_per_batch : Lk, scale, key_pos, ld_key_pos,
+           key_pos_rows_per_batch};
+  SIMVG_CHECK_ARG(!key_pos || ld_key_pos % 4 == 0, "attn_small: key_pos rows must be 16-B aligned");
   const size_t shm = (size_t)(Lq * SHD + Lq * Lk) * sizeof(float);
   static bool once = hipFuncSetAttribute((const void*)attn_small_fwd_kernel,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
@@ -445,13 +457,15 @@ extern "C" int simvg_attn_small_bwd(const float* q, int ldq, const float* k, int
                                     const float* P, const unsigned char* key_padding_mask, const float* drop_mult,
                                     const float* dout, int lddo, float* dq, int lddq, float* dk, int lddk, float* dv,
                                     int lddv, int B, int H, int Lq, int Lk, int kv_rows_per_batch, float scale,
+                                    const float* key_pos, int ld_key_pos, int key_pos_rows_per_batch,
                                     hipStream_t stream) {
   SIMVG_CHECK_ARG(B > 0 && H > 0 && Lq > 0 && Lq <= 16 && Lk > 0 &&
                   (size_t)(2 * Lq * SHD + 2 * Lq * Lk + Lq) * sizeof(float) <= 160 * 1024,
                   "attn_small: Lq <= 16 and two [Lq, Lk] strips must fit the 160 KiB LDS");
   SIMVG_CHECK_ARG(ldk % 4 == 0 && ldv % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0, "attn_small: rows must be 16-B aligned");
   SAArgs a{q, ldq, k, ldk, v, ldv, nullptr, 0, (float*)P, key_padding_mask, drop_mult, dout, lddo, dq, lddq, dk, lddk,
-           dv, lddv, B, H, Lq, Lk, kv_rows_per_batch > 0 ? kv_rows_per_batch : Lk, scale};
+           dv, lddv, B, H, Lq, Lk, kv_rows_per_batch > 0 ? kv_rows_per_batch : Lk, scale, key_pos, ld_key_pos,
+           key_pos_rows_per_batch};
   const size_t shm = (size_t)(2 * Lq * SHD + 2 * Lq * Lk + Lq) * sizeof(float);
   static bool once = hipFuncSetAttribute((const void*)attn_small_bwd_kernel,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;

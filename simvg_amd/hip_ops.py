@@ -441,22 +441,30 @@ def gp(A, sam, sak, Bm, sbk, sbn, Cm, M, N, K, **kw):
     return dict(A=A, sam=sam, sak=sak, B=Bm, sbk=sbk, sbn=sbn, C=Cm, M=M, N=N, K=K, **kw)
 
 
-def attn_small_fwd(q, k, v, B, H, Lq, Lk, kpm=None, drop=None, kv_rows=0):
+def attn_small_fwd(q, k, v, B, H, Lq, Lk, kpm=None, drop=None, kv_rows=0, kpos=None):
+    """kpos: projected key_pos rows [Lk, E] (shared) or [B * Lk, E], added to the K rows on load"""
     lib = _lib.load()
     E = H * 32
     out = torch.empty(B * Lq, E, device=q.device, dtype=torch.float32)
     P = torch.empty(B, H, Lq, Lk, device=q.device, dtype=torch.float32)
     rc = lib.simvg_attn_small_fwd(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out), out.stride(0),
-                                  _p(P), _p(kpm), _p(drop), B, H, Lq, Lk, kv_rows, 32 ** -0.5, _stream())
+                                  _p(P), _p(kpm), _p(drop), B, H, Lq, Lk, kv_rows, 32 ** -0.5, *_kpos_args(kpos, Lk), _stream())
     _lib.check(rc, "simvg_attn_small_fwd")
     return out, P
 
 
-def attn_small_bwd(q, k, v, P, dout, dq, dk, dv, B, H, Lq, Lk, kpm=None, drop=None, kv_rows=0):
+def _kpos_args(kpos, Lk):
+    if kpos is None:
+        return None, 0, 0
+    assert kpos.dim() == 2 and kpos.stride(1) == 1 and kpos.shape[0] % Lk == 0
+    return _p(kpos), kpos.stride(0), (Lk if kpos.shape[0] > Lk else 0)
+
+
+def attn_small_bwd(q, k, v, P, dout, dq, dk, dv, B, H, Lq, Lk, kpm=None, drop=None, kv_rows=0, kpos=None):
     lib = _lib.load()
     rc = lib.simvg_attn_small_bwd(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(P), _p(kpm), _p(drop),
                                   _p(dout), dout.stride(0), _p(dq), dq.stride(0), _p(dk), dk.stride(0), _p(dv),
-                                  dv.stride(0), B, H, Lq, Lk, kv_rows, 32 ** -0.5, _stream())
+                                  dv.stride(0), B, H, Lq, Lk, kv_rows, 32 ** -0.5, *_kpos_args(kpos, Lk), _stream())
     _lib.check(rc, "simvg_attn_small_bwd")
 
 

@@ -200,7 +200,7 @@ class DecoderLayerFn(torch.autograd.Function):
                                 ops.gp(xv, E, 1, Wc[2 * E:], 1, E, kv[:, E:], R, E, E, bias=bc[2 * E:])])
             dm1 = amask(Lk)
             o2, P1 = ops.attn_small_fwd(q, kv[:, :E], kv[:, E:], B, H, nq, Lk, kpm=cfg.kpm, drop=dm1, kv_rows=0)
-            pos2 = None
+            pos2 = posk = None
         else:
             Nv = cfg.Nv
             HW, R = Nv - 1, B * Nv
@@ -214,10 +214,10 @@ class DecoderLayerFn(torch.autograd.Function):
                 kv = _f32(R, 2 * E, device=dev)
                 probs.append(ops.gp(mem, mem.stride(0), 1, Wc[E:], 1, E, kv, R, 2 * E, E, bias=bc[E:]))
             ops.gemm_f32_group(probs)
-            kv.view(B, Nv, 2 * E)[:, 1:, :E].add_(posk.view(-1, HW, E))                              # key_pos, patch keys only
             dm1 = amask(HW)
-            # keys of sample b start at row b*Nv + 1: views that begin at row 1, batch stride Nv rows
-            o2, P1 = ops.attn_small_fwd(q, kv[1:, :E], kv[1:, E:], B, H, nq, HW, kpm=cfg.kpm, drop=dm1, kv_rows=Nv)
+            # keys of sample b start at row b*Nv + 1: views that begin at row 1, batch stride Nv rows; key_pos (patch keys
+            # only) joins the projected keys on the kernel's K load
+            o2, P1 = ops.attn_small_fwd(q, kv[1:, :E], kv[1:, E:], B, H, nq, HW, kpm=cfg.kpm, drop=dm1, kv_rows=Nv, kpos=posk)
         r2 = _f32(M, E, device=dev)
         ops.gemm_f32(o2, E, 1, Wco, 1, E, r2, M, E, E, bias=bco, addend=t1, addend_rows=M)
         t2, mean2, rstd2 = ln(r2, g1, b1n)
@@ -236,7 +236,7 @@ class DecoderLayerFn(torch.autograd.Function):
         if gP is not None:
             hs, meanP, rstdP = ln(t3, gP, bP)
         ctx.save_for_backward(tgt, qpos, qkv, P0, dm0, o, r1, mean1, rstd1, t1, q, kv, P1, dm1, o2, r2, mean2, rstd2, t2,
-                              h1d, m1, m2, r3, mean3, rstd3, t3, meanP, rstdP, xk, xv, mem, pos2,
+                              h1d, m1, m2, r3, mean3, rstd3, t3, meanP, rstdP, xk, xv, mem, pos2, posk,
                               Ws, Wso, g0, Wc, Wco, g1, W1, W2, g2, gP)
         ctx.cfg = cfg
         ctx.set_materialize_grads(False)
@@ -245,7 +245,8 @@ class DecoderLayerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_t3, d_hs):
         (tgt, qpos, qkv, P0, dm0, o, r1, mean1, rstd1, t1, q, kv, P1, dm1, o2, r2, mean2, rstd2, t2, h1d, m1, m2, r3,
-         mean3, rstd3, t3, meanP, rstdP, xk, xv, mem, pos2, Ws, Wso, g0, Wc, Wco, g1, W1, W2, g2, gP) = ctx.saved_tensors
+         mean3, rstd3, t3, meanP, rstdP, xk, xv, mem, pos2, posk, Ws, Wso, g0, Wc, Wco, g1, W1, W2, g2,
+         gP) = ctx.saved_tensors
         cfg = ctx.cfg
         dev = tgt.device
         M, E = tgt.shape
@@ -319,7 +320,7 @@ class DecoderLayerFn(torch.autograd.Function):
             dkv = _f32(R, 2 * E, device=dev)
             dkv.view(B, Nv, 2 * E)[:, 0].zero_()                                         # CLS rows: not keys, no gradient
             ops.attn_small_bwd(q, kv[1:, :E], kv[1:, E:], P1, d_o2, dq, dkv[1:, :E], dkv[1:, E:], B, H, nq, HW, kpm=cfg.kpm,
-                               drop=dm1, kv_rows=Nv)
+                               drop=dm1, kv_rows=Nv, kpos=posk)
             if mem_bf:
                 dWc, dbc = z[8 * E:8 * E + 3 * E * E].view(3 * E, E), z[8 * E + 3 * E * E:].view(1, 3 * E)
             else:
