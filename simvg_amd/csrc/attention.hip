@@ -108,7 +108,8 @@ __global__ __launch_bounds__(768) void attn_fwd_kernel(AttnArgs a) {
   __syncthreads();
 
   const float sc2 = a.scale * 1.44269504088896340736f;
-  for (int qb = wave; qb < nkt; qb += nwaves) {
+  // blockIdx.y: query strips dealt over gridDim.y workgroups of the same head (small B * H, see the host code)
+  for (int qb = wave + nwaves * blockIdx.y; qb < nkt; qb += nwaves * gridDim.y) {
     const int tq = qb * 16 + j;
     const lp_t* qp = a.qkv + tok_row(a, b, tq < N ? tq : N - 1) * a.ld + h * HD + 8 * g;
     const lpx8_t q0 = *(const lpx8_t*)qp, q1 = *(const lpx8_t*)(qp + 32);
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_t_kernel(AttnArgs a) {
   union { lpx8_t v; unsigned int u[4]; } ones;
   ones.u[0] = ones.u[1] = ones.u[2] = ones.u[3] = one2;
 
-  for (int qb = wave; qb < NKT; qb += nwaves) {
+  for (int qb = wave + nwaves * blockIdx.y; qb < NKT; qb += nwaves * gridDim.y) {
     const int tq = qb * 16 + j;
     const lp_t* qp = a.qkv + tok_row(a, b, tq < N ? tq : N - 1) * a.ld + h * HD + 8 * g;
     const lpx8_t q0 = *(const lpx8_t*)qp, q1 = *(const lpx8_t*)(qp + 32);
@@ -982,14 +983,17 @@ extern "C" int simvg_attn_fwd(const void* qkv, int ldqkv, void* out, int ldo, fl
   const size_t shm = (size_t)2 * npad * ROWB + npad * sizeof(float);
   static bool once = set_lds_limit(attn_fwd_kernel, 160 * 1024) && set_lds_limit(attn_fwd_t_kernel<27, 25, 768>, 160 * 1024);
   (void)once;
+  // few heads in flight (forward_test at B = 1 ... 4: B * H = 12 ... 48 workgroups on 256 CUs): the query strips of a head
+  // are dealt over up to 3 workgroups (each loads the head's K / V; one strip per wave instead of three in a row)
+  const int qsplit = B * H * 3 <= 256 ? std::min(3, cdiv(cdiv(N, 16), 12)) : 1;
   if (cdiv(N, 16) == 27 && Nv / 16 >= 25) {        // the path's geometry: 1 + (640/32)^2 vision + 20 text tokens
-    hipLaunchKernelGGL((attn_fwd_t_kernel<27, 25, 768>), dim3(B * H), dim3(768), shm, stream, a);
+    hipLaunchKernelGGL((attn_fwd_t_kernel<27, 25, 768>), dim3(B * H, qsplit), dim3(768), shm, stream, a);
     SIMVG_LAUNCH_CHECK();
     return SIMVG_OK;
   }
   // 12 waves per workgroup (3 per SIMD): the 27 query strips of a 421-token head take 3 rounds instead of 4 and the
   // MFMA / softmax-VALU / LDS phases of three waves overlap on every SIMD (512 threads: 112 us, 768: 95 us)
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H), dim3(768), shm, stream, a);
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H, qsplit), dim3(768), shm, stream, a);
   SIMVG_LAUNCH_CHECK();
   return SIMVG_OK;
 }

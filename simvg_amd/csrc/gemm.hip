@@ -352,6 +352,73 @@ __device__ __forceinline__ void stage_rows_k64(const lp_t* base, int ld, int row
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Latency kernel for problems that cannot fill the chip with big tiles (forward_test at B = 1 ... 8: M = 421 ... 3368 rows):
+// 64x64x64 tiles, 4 waves (each 16 rows x 64 columns), SIX-stage LDS ring of 16 KiB stages.  With one workgroup per CU at
+// most and 12 - 48 k-tiles per workgroup the time of such a GEMM is (k-tiles) x (time per k-tile); the 128x128 kernel above
+// waits for each k-tile's loads in full (one L2 / HBM round trip per k-tile, ~0.65 us).  Here the LDS-DMA of k-tile t + 5 is
+// issued in iteration t and a wave waits for its own 4 pieces of tile t only (counted vmcnt), so a k-tile costs its
+// 8 ds_read_b128 + 8 MFMAs + one barrier.
+// ------------------------------------------------------------------------------------------
+constexpr int LAT_NST = 6;
+constexpr int LAT_STAGE = (64 + 64) * BK * 2;      // 16 KiB
+
+__global__ __launch_bounds__(256) void gemm_nt_kernel_lat(GemmNTArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = (a.N + 63) / 64;
+  const int tm0 = (a.split + 63) / 64;
+  const int bid = blockIdx.x;
+  const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+  const int group = tile_m >= tm0;
+  const int row0 = group ? a.split + (tile_m - tm0) * 64 : tile_m * 64;
+  const int row_end = group ? a.M : a.split;
+  const int n0 = tile_n * 64;
+  const lp_t* W = a.W + (long)group * a.w_gstride;
+  f32x4_t acc[1][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[0][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int nk = a.K / BK;
+#define STA(s_) (smem + (s_) * LAT_STAGE)
+#define STB(s_) (smem + (s_) * LAT_STAGE + 64 * BK * 2)
+#define ISSUE(t_)                                                                              \
+  do {                                                                                         \
+    const int st__ = (t_) % LAT_NST;                                                           \
+    stage_tile_k64_n(a.A, a.lda, row0, row_end - 1, (t_) * BK, STA(st__), wave, lane, 2);      \
+    stage_tile_k64_n(W, a.ldw, n0, a.N - 1, (t_) * BK, STB(st__), wave, lane, 2);              \
+  } while (0)
+#pragma unroll
+  for (int t = 0; t < LAT_NST - 1; ++t)
+    if (t < nk) ISSUE(t);
+  for (int kt = 0; kt < nk; ++kt) {
+    // this wave's 4 pieces of tile kt have landed; up to LAT_NST - 2 younger tiles (4 pieces each) stay in flight
+    const int young = min(LAT_NST - 2, nk - 1 - kt);
+    if (young >= 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (young == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (young == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (young == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();            // everyone's pieces have, and everyone is past compute(kt - 1): its slot is free
+    if (kt + LAT_NST - 1 < nk) ISSUE(kt + LAT_NST - 1);
+    const char* sA = STA(kt % LAT_NST);
+    const char* sB = STB(kt % LAT_NST);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      lpx8_t fb[4];
+      const lpx8_t fa = read_frag_k64(sA, wave * 16 + (lane & 15), s * 4 + (lane >> 4));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = read_frag_k64(sB, j * 16 + (lane & 15), s * 4 + (lane >> 4));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[0][j] = mfma_lp(fb[j], fa, acc[0][j]);
+    }
+  }
+#undef STA
+#undef STB
+#undef ISSUE
+  gemm_nt_epilogue<1>(a, acc, group, row0, row_end, n0, wave, 0, lane);
+}
+
 // 256x256x64 tile with SIXTEEN waves (4 x 4, each 64x64; 4 waves per SIMD, 112 VGPRs): more waves cover the LDS-read and
 // rendezvous latencies of the one-workgroup-per-CU tile and issue the store-heavy epilogues 2x wider, at the price of 33 %
 // more LDS reads per MFMA (still ~50 % of the LDS bandwidth).  fc1 shape 124 vs 134 us, with fp32 residual epilogue
@@ -937,7 +1004,17 @@ extern "C" int simvg_gemm_nt(const void* A, int lda, const void* W, long w_gstri
     // 160-row tiles stage 23 % more bytes per FLOP: they have to win the quantisation estimate by 20 % to be chosen
     return (double)cdiv((int)tiles, 256) * bm * (bm == 160 ? 1.20 : 1.0);
   };
-  if (wide_ok && tile_cost(256) <= tile_cost(160)) {
+  // problems that cannot fill the chip with the big tiles (forward_test at B <= 4): the latency kernel, while its own 64x64
+  // tiles stay within two residency rounds (tools/dev/gemm_small_bench.py: B = 1: 107 -> 62 us for the four encoder shapes,
+  // B = 2: 108 -> 69, B = 4 out / fc2 18 / 54 -> 16 / 39; above 512 tiles the big-tile kernels win)
+  const long tiles64 = (long)(cdiv(split, 64) + cdiv(M - split, 64)) * cdiv(N, 64);
+  if (tiles64 <= 512) {
+    constexpr int SML = LAT_NST * LAT_STAGE;
+    static bool oncel = hipFuncSetAttribute((const void*)gemm_nt_kernel_lat, hipFuncAttributeMaxDynamicSharedMemorySize, SML) == hipSuccess;
+    (void)oncel;
+    const int tiles = (cdiv(split, 64) + cdiv(M - split, 64)) * cdiv(N, 64);
+    hipLaunchKernelGGL(gemm_nt_kernel_lat, dim3(tiles), dim3(256), SML, stream, a);
+  } else if (wide_ok && tile_cost(256) <= tile_cost(160)) {
     constexpr int SMW = 160 * 1024;      // ring 128 KiB; the 16-wave epilogue staging needs 136 KiB
     static bool oncew = hipFuncSetAttribute((const void*)gemm_nt_kernel_256sq_w16, hipFuncAttributeMaxDynamicSharedMemorySize, SMW) == hipSuccess;
     (void)oncew;

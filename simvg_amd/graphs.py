@@ -160,3 +160,97 @@ class HeadGraphs:
             preds = [dict(pred_bboxes=outs[9], pred_masks=None, predict_classes=outs[10]),
                      dict(pred_bboxes=outs[11], pred_masks=None, predict_classes=outs[12])]
         return losses, output, preds
+
+
+class InferenceGraphs:
+    """hipGraph replay of `MIXDETRMB._run` (encoder + head forward, eval mode) -- one graph per input signature.
+
+    `forward_test` at small batch is ~220 launches of a few microseconds each: the GPU finishes them faster than Python
+    issues them (B = 1: 2.9 ms per call eager against ~2 ms of kernel time after the small-problem GEMM / attention
+    changes).  A signature = (input shapes and dtypes, per-image `img_shape`s, the identity of the two modules' 16-bit weight
+    tables); it is captured after it has been seen `warm_calls` times, at most `max_graphs` signatures are kept, anything
+    else runs eagerly.  The 16-bit weight copies are refreshed EAGERLY before every replay (a no-op unless the master
+    weights moved: load_state_dict, EMA apply_shadow / restore, a training step), so the captured region holds no
+    weight-dependent decision.  The returned tensors are the graph's static outputs: consume them (the post-processing
+    does) before the next call with the same signature."""
+
+    def __init__(self, model, warm_calls=2, max_graphs=8, max_batch=16):
+        self.model, self.warm_calls, self.max_graphs, self.max_batch = model, warm_calls, max_graphs, max_batch
+        self.seen, self.graphs, self.disabled = {}, {}, False
+        self.replays = 0
+
+    def __deepcopy__(self, memo):      # a copied model captures its own graphs (the attribute is re-created lazily)
+        return None
+
+    def __reduce__(self):              # ... and so does an unpickled one
+        return (type(None), ())
+
+    def _signature(self, img, ids, mask, img_metas):
+        enc, head = self.model.vis_enc, self.model.head
+        return (tuple(img.shape), img.dtype, tuple(ids.shape), None if mask is None else (tuple(mask.shape), mask.dtype),
+                tuple(tuple(m["img_shape"][:2]) for m in img_metas),
+                tuple(img_metas[0].get("batch_input_shape", ())), id(getattr(enc, "_prep", None)), id(getattr(head, "_prep", None)),
+                getattr(enc, "precision", None))
+
+    def _refresh(self, device):
+        enc, head = self.model.vis_enc, self.model.head
+        if getattr(enc, "_prep", None) is not None:
+            enc._refresh_weights()
+        if getattr(head, "_prep", None) is not None:
+            head._refresh_weights(device)
+
+    def run(self, img, ids, img_metas, mask):
+        """-> the head's output dict (static tensors) or None (caller runs eagerly)"""
+        model = self.model
+        if self.disabled or model.training or torch.is_grad_enabled() or not img.is_cuda or img.shape[0] > self.max_batch:
+            return None
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        sig = self._signature(img, ids, mask, img_metas)
+        entry = self.graphs.get(sig)
+        if entry is None:
+            n = self.seen.get(sig, 0)
+            self.seen[sig] = n + 1
+            if n < self.warm_calls or len(self.graphs) >= self.max_graphs:
+                if len(self.seen) > 256:
+                    self.seen.clear()
+                return None
+            entry = self._capture(sig, img, ids, img_metas, mask)
+            if entry is None:
+                return None
+        g, s_img, s_ids, s_mask, out = entry
+        self._refresh(img.device)
+        s_img.copy_(img, non_blocking=True)
+        s_ids.copy_(ids, non_blocking=True)
+        if s_mask is not None:
+            s_mask.copy_(mask, non_blocking=True)
+        g.replay()
+        self.replays += 1
+        return out
+
+    def _capture(self, sig, img, ids, img_metas, mask):
+        model = self.model
+        try:
+            s_img, s_ids = img.clone(), ids.clone()
+            s_mask = None if mask is None else mask.clone()
+            metas = [dict(m) for m in img_metas]
+            cur = torch.cuda.current_stream(img.device)
+            side = torch.cuda.Stream(device=img.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                model._run(s_img, s_ids, metas, s_mask)          # workspaces / constants of this signature exist before capture
+            cur.wait_stream(side)
+            torch.cuda.synchronize(img.device)
+            self._refresh(img.device)
+            g = torch.cuda.CUDAGraph()
+            # thread_local: a loader thread may be issuing its own device work while this thread captures
+            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                out = model._run(s_img, s_ids, metas, s_mask)
+            torch.cuda.synchronize(img.device)
+        except Exception as e:      # noqa: BLE001  (a failed capture must never take inference down)
+            warnings.warn(f"inference graph capture failed ({type(e).__name__}: {e}); forward_test stays eager")
+            self.disabled = True
+            return None
+        entry = (g, s_img, s_ids, s_mask, out)
+        self.graphs[sig] = entry
+        return entry

@@ -95,7 +95,7 @@ class KeptLabels:
 
 @builder.MODELS.register_module()
 class MIXDETRMB(OneStageModel):
-    def __init__(self, word_emb, num_token, vis_enc, lan_enc, head, fusion, head_graph=False):
+    def __init__(self, word_emb, num_token, vis_enc, lan_enc, head, fusion, head_graph=False, infer_graph=True):
         super().__init__(word_emb, num_token, vis_enc, lan_enc, head, fusion)
         self.patch_size = vis_enc["patch_size"]
         # optional: replay the head (+ matcher + criterion) forward / backward as two hipGraphs once a training input
@@ -106,6 +106,10 @@ class MIXDETRMB(OneStageModel):
         env = os.environ.get("SIMVG_HEAD_GRAPH")
         self.head_graph = (bool(head_graph) or env == "1") and env != "0"
         self._head_graphs = None
+        # forward_test at batch <= 16 replays encoder + head as one hipGraph per input signature once the signature has
+        # repeated (simvg_amd/graphs.py::InferenceGraphs); `infer_graph=False` in the model cfg or SIMVG_INFER_GRAPH=0: eager
+        self.infer_graph = bool(infer_graph) and os.environ.get("SIMVG_INFER_GRAPH") != "0"
+        self._infer_graphs = None
         self._pp_const = {}
 
     def extract_visual_language(self, img, ref_expr_inds, text_attention_mask=None):
@@ -151,7 +155,14 @@ class MIXDETRMB(OneStageModel):
     @torch.no_grad()
     def forward_test(self, img, ref_expr_inds, img_metas, text_attention_mask=None, with_bbox=False, with_mask=False,
                      rescale=False):
-        output = self._run(img, ref_expr_inds, img_metas, text_attention_mask)
+        output = None
+        if self.infer_graph and img.is_cuda:
+            if self._infer_graphs is None:
+                from ...graphs import InferenceGraphs
+                self._infer_graphs = InferenceGraphs(self)
+            output = self._infer_graphs.run(img, ref_expr_inds, img_metas, text_attention_mask)
+        if output is None:
+            output = self._run(img, ref_expr_inds, img_metas, text_attention_mask)
         self._last_output = output
         return self._predict(output, img_metas, rescale)
 

@@ -100,3 +100,50 @@ def test_default_stream_training_never_captures():
         losses, _ = model(**batch, rescale=False)
         losses["loss_total"].backward()
     assert model._head_graphs.default_stream_seen and not model._head_graphs.graphs
+
+
+def test_graphed_forward_test_equals_eager_and_follows_the_weights():
+    """forward_test as one hipGraph per input signature (simvg_amd/graphs.py::InferenceGraphs): bit-identical boxes to the
+    eager path on fresh inputs, still after the master weights moved (load_state_dict -> the 16-bit copies are refreshed
+    before the replay), a second signature gets its own graph, and a deep copy of the model starts without graphs."""
+    from test_tools_gpu import _tiny_model, _batch
+    cfg, model = _tiny_model(5)
+    model.eval()
+
+    def infer(m, batch, graph):
+        m.infer_graph = graph
+        kw = {k: v for k, v in batch.items() if k != "gt_bbox"}
+        with torch.no_grad():
+            preds = m(**kw, return_loss=False, rescale=False)
+        return [p["pred_bboxes"].clone() for p in preds], {k: v.clone() for k, v in m._last_output["decoder_branch_output"].items()}
+
+    for step in range(5):
+        batch = _batch(cfg, B=2, seed=40 + step)
+        (b_e, o_e), (b_g, o_g) = infer(model, batch, False), infer(model, batch, True)
+        for a, b in zip(b_e, b_g):
+            assert torch.equal(a, b), step
+        for k in o_e:
+            assert torch.equal(o_e[k], o_g[k]), (step, k)
+    ig = model._infer_graphs
+    assert len(ig.graphs) == 1 and ig.replays >= 2 and not ig.disabled
+    # the weights move: every floating-point tensor of the state is perturbed and loaded back
+    sd = {k: (v + 0.01 * torch.randn_like(v) if v.is_floating_point() else v) for k, v in model.state_dict().items()}
+    model.load_state_dict(sd)
+    batch = _batch(cfg, B=2, seed=99)
+    before = ig.replays
+    (b_g, o_g), (b_e, o_e) = infer(model, batch, True), infer(model, batch, False)
+    assert ig.replays == before + 1
+    for k in o_e:
+        assert torch.equal(o_e[k], o_g[k]), k
+    # another batch size: its own signature, captured after two eager calls
+    for step in range(4):
+        batch3 = _batch(cfg, B=3, seed=60 + step)
+        (b_e, o_e), (b_g, o_g) = infer(model, batch3, False), infer(model, batch3, True)
+        for k in o_e:
+            assert torch.equal(o_e[k], o_g[k]), (step, k)
+    assert len(ig.graphs) == 2
+    twin = copy.deepcopy(model)
+    assert twin._infer_graphs is None
+    (b_t, o_t) = infer(twin, batch3, True)
+    for k in o_e:
+        assert torch.equal(o_e[k], o_t[k]), k

@@ -120,6 +120,7 @@ def test_probe_glds_lane_linear():
                                          (1684, 3072, 768, 1604), (640, 768, 3072, 512),
                                          (2370, 2304, 768, 2100), (2112, 3072, 128, 0),     # 256x256 tile path
                                          (2306, 4096, 64, 2100),      # 16 column tiles walked in groups of 6 / 6 / 4
+                                         (300, 7040, 64, 200),        # few rows, many columns: the 128x128 kernel
                                          (2230, 768, 256, 2000), (2048, 768, 3072, 0)])       # 160x256 tile path
 @pytest.mark.parametrize("mode", ["plain", "bias_gelu_aux", "residual_scale_f32", "relu_f32"])
 def test_gemm_nt(M, N, K, split, mode):
