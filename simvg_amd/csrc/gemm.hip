@@ -251,9 +251,14 @@ __device__ __forceinline__ void gemm_nt_epilogue_lds(const GemmNTArgs& a, f32x4_
   }
 }
 
+// 128x128x64 tiles, 4 waves (2 x 2, each 64x64), FOUR-stage LDS ring (4 x 32 KiB) with counted vmcnt: the mid-size kernel
+// (forward_test at B = 4 ... 16, and any problem with few rows and many columns).  Round 1's version of this kernel waited for
+// every k-tile's loads in full (~0.7 us per k-tile with one workgroup per CU); here two younger k-tiles stay in flight.
+constexpr int MID_NST = 4;
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int tiles_n = (a.N + BN - 1) / BN;
   const int tm0 = (a.split + BM - 1) / BM;
@@ -267,6 +272,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
 
 #define ldsA(c) (smem + (c) * 2 * TILE_BYTES)
 #define ldsB(c) (smem + TILE_BYTES + (c) * 2 * TILE_BYTES)
+#define ISSUE(t_)                                                                              \
+  do {                                                                                         \
+    const int st__ = (t_) % MID_NST;                                                           \
+    stage_tile_k64(a.A, a.lda, row0, row_end - 1, (t_) * BK, ldsA(st__), wave, lane);          \
+    stage_tile_k64(W, a.ldw, n0, a.N - 1, (t_) * BK, ldsB(st__), wave, lane);                  \
+  } while (0)
 
   f32x4_t acc[4][4];
 #pragma unroll
@@ -275,17 +286,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   const int nk = a.K / BK;
-  stage_tile_k64(a.A, a.lda, row0, row_end - 1, 0, ldsA(0), wave, lane);
-  stage_tile_k64(W, a.ldw, n0, a.N - 1, 0, ldsB(0), wave, lane);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
+#pragma unroll
+  for (int t = 0; t < MID_NST - 1; ++t)
+    if (t < nk) ISSUE(t);
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) {
-      stage_tile_k64(a.A, a.lda, row0, row_end - 1, (kt + 1) * BK, ldsA(cur ^ 1), wave, lane);
-      stage_tile_k64(W, a.ldw, n0, a.N - 1, (kt + 1) * BK, ldsB(cur ^ 1), wave, lane);
-    }
+    // this wave's 8 pieces of tile kt have landed; up to two younger tiles (8 pieces each) stay in flight
+    const int young = min(MID_NST - 2, nk - 1 - kt);
+    if (young >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (young == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + MID_NST - 1 < nk) ISSUE(kt + MID_NST - 1);
+    const int cur = kt % MID_NST;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       lpx8_t fa[4], fb[4];
@@ -301,10 +313,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
           // D[n_local][m_local]: lane holds 4 consecutive n for one m -> vector stores
           acc[i][j] = mfma_lp(fb[j], fa[i], acc[i][j]);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
   }
-
+#undef ISSUE
   gemm_nt_epilogue<4>(a, acc, group, row0, row_end, n0, wm, wn, lane);
 }
 
@@ -1007,6 +1017,7 @@ extern "C" int simvg_gemm_nt(const void* A, int lda, const void* W, long w_gstri
   // problems that cannot fill the chip with the big tiles (forward_test at B <= 4): the latency kernel, while its own 64x64
   // tiles stay within two residency rounds (tools/dev/gemm_small_bench.py: B = 1: 107 -> 62 us for the four encoder shapes,
   // B = 2: 108 -> 69, B = 4 out / fc2 18 / 54 -> 16 / 39; above 512 tiles the big-tile kernels win)
+  auto tiles128 = [&]() { return (long)(cdiv(split, 128) + cdiv(M - split, 128)) * cdiv(N, 128); };
   const long tiles64 = (long)(cdiv(split, 64) + cdiv(M - split, 64)) * cdiv(N, 64);
   if (tiles64 <= 512) {
     constexpr int SML = LAT_NST * LAT_STAGE;
@@ -1014,6 +1025,12 @@ extern "C" int simvg_gemm_nt(const void* A, int lda, const void* W, long w_gstri
     (void)oncel;
     const int tiles = (cdiv(split, 64) + cdiv(M - split, 64)) * cdiv(N, 64);
     hipLaunchKernelGGL(gemm_nt_kernel_lat, dim3(tiles), dim3(256), SML, stream, a);
+  } else if (tiles128() <= 256 && K >= 2048) {
+    // one residency round of 128x128 tiles and a long contraction (fc2 at B = 8: 55.5 -> 42.9 us; the short-K shapes and
+    // everything above one round are faster on the 16-wave kernels below)
+    static bool oncem2 = hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MID_NST * 2 * TILE_BYTES) == hipSuccess;
+    (void)oncem2;
+    hipLaunchKernelGGL(gemm_nt_kernel, dim3((int)tiles128()), dim3(256), MID_NST * 2 * TILE_BYTES, stream, a);
   } else if (wide_ok && tile_cost(256) <= tile_cost(160)) {
     constexpr int SMW = 160 * 1024;      // ring 128 KiB; the 16-wave epilogue staging needs 136 KiB
     static bool oncew = hipFuncSetAttribute((const void*)gemm_nt_kernel_256sq_w16, hipFuncAttributeMaxDynamicSharedMemorySize, SMW) == hipSuccess;
@@ -1034,7 +1051,9 @@ extern "C" int simvg_gemm_nt(const void* A, int lda, const void* W, long w_gstri
     hipLaunchKernelGGL(gemm_nt_kernel_256k32, dim3(tiles), dim3(512), 3 * STAGE3, stream, a);
   } else {
     const int tiles = (cdiv(split, BM) + cdiv(M - split, BM)) * cdiv(N, BN);
-    hipLaunchKernelGGL(gemm_nt_kernel, dim3(tiles), dim3(256), 4 * TILE_BYTES, stream, a);
+    static bool oncem = hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MID_NST * 2 * TILE_BYTES) == hipSuccess;
+    (void)oncem;
+    hipLaunchKernelGGL(gemm_nt_kernel, dim3(tiles), dim3(256), MID_NST * 2 * TILE_BYTES, stream, a);
   }
   SIMVG_LAUNCH_CHECK();
   return SIMVG_OK;

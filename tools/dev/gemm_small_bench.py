@@ -6,7 +6,7 @@ from simvg_amd import hip_ops as ops
 
 dev = "cuda"
 shapes = [("qkv", 2304, 768), ("out", 768, 768), ("fc1", 3072, 768), ("fc2", 768, 3072)]
-for B in (1, 2, 4, 8, 16):
+for B in (1, 2, 4, 8, 16, 32):
     M, SPLIT = B * 421, B * 401
     tot = 0.0
     for name, N, K in shapes:
