@@ -362,7 +362,8 @@ def main():
             infer[f"b{nb}"] = {"ms_per_call": round(ms, 3), "pairs_per_s": round(nb / ms * 1e3, 1)}
     model.train()
     if infer:
-        out["forward_test"] = dict(infer, note="MIXDETRMB.forward_test incl. post-processing, one synchronisation per call")
+        out["forward_test"] = dict(infer, note="MIXDETRMB.forward_test incl. post-processing, one synchronisation per call; batches <= 16 replay "
+                                   "encoder + head as one hipGraph per input signature (simvg_amd/graphs.py::InferenceGraphs)")
     if a.breakdown:
         tot = dt * 1e3
         for k, d in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
