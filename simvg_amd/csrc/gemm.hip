@@ -251,9 +251,9 @@ __device__ __forceinline__ void gemm_nt_epilogue_lds(const GemmNTArgs& a, f32x4_
   }
 }
 
-// 128x128x64 tiles, 4 waves (2 x 2, each 64x64), FOUR-stage LDS ring (4 x 32 KiB) with counted vmcnt: the mid-size kernel
-// (forward_test at B = 4 ... 16, and any problem with few rows and many columns).  Round 1's version of this kernel waited for
-// every k-tile's loads in full (~0.7 us per k-tile with one workgroup per CU); here two younger k-tiles stay in flight.
+// 128x128x64 tiles, 4 waves (2 x 2, each 64x64), FOUR-stage LDS ring (4 x 32 KiB) with counted vmcnt: the fallback for
+// problems with few rows and many columns (M < 512 and more than 800 64x64 tiles) and for N that is no multiple of 256 at
+// M < 512.  Round 1's version waited for every k-tile's loads in full; here two younger k-tiles stay in flight.
 constexpr int MID_NST = 4;
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -364,15 +364,16 @@ __device__ __forceinline__ void stage_rows_k64(const lp_t* base, int ld, int row
 
 // ------------------------------------------------------------------------------------------
 // Latency kernel for problems that cannot fill the chip with big tiles (forward_test at B = 1 ... 8: M = 421 ... 3368 rows):
-// 64x64x64 tiles, 4 waves (each 16 rows x 64 columns), SIX-stage LDS ring of 16 KiB stages.  With one workgroup per CU at
-// most and 12 - 48 k-tiles per workgroup the time of such a GEMM is (k-tiles) x (time per k-tile); the 128x128 kernel above
-// waits for each k-tile's loads in full (one L2 / HBM round trip per k-tile, ~0.65 us).  Here the LDS-DMA of k-tile t + 5 is
-// issued in iteration t and a wave waits for its own 4 pieces of tile t only (counted vmcnt), so a k-tile costs its
-// 8 ds_read_b128 + 8 MFMAs + one barrier.
+// 64x64x64 tiles, 4 waves (each 16 rows x 64 columns), LAT_NST-stage LDS ring of 16 KiB stages, counted vmcnt (a wave waits for
+// its own 4 pieces of the oldest k-tile only).  With few workgroups per CU the time of such a GEMM is (k-tiles) x (time per
+// k-tile) + launch / prologue / epilogue; the 128x128 kernel of round 1 waited for each k-tile's loads in full (~0.7 us per
+// k-tile, one workgroup per CU).  Sweep (tools/dev/gemm_small_bench.py): a THREE-stage ring (48 KiB: three workgroups resident
+// per CU, so one workgroup's prologue / epilogue hides behind the others' main loops) beats the six-stage ring (96 KiB, one
+// workgroup per CU) at every size -- B = 1: 48.6 vs 61.7 us for the four encoder shapes, B = 8: 128.6 vs 227.1 us.
 // ------------------------------------------------------------------------------------------
-constexpr int LAT_NST = 6;
 constexpr int LAT_STAGE = (64 + 64) * BK * 2;      // 16 KiB
 
+template <int LAT_NST>
 __global__ __launch_bounds__(256) void gemm_nt_kernel_lat(GemmNTArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -404,8 +405,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel_lat(GemmNTArgs a) {
   for (int kt = 0; kt < nk; ++kt) {
     // this wave's 4 pieces of tile kt have landed; up to LAT_NST - 2 younger tiles (4 pieces each) stay in flight
     const int young = min(LAT_NST - 2, nk - 1 - kt);
-    if (young >= 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (young == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    if (LAT_NST >= 6 && young >= 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (LAT_NST >= 5 && young == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else if (young == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (young == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1014,23 +1015,15 @@ extern "C" int simvg_gemm_nt(const void* A, int lda, const void* W, long w_gstri
     // 160-row tiles stage 23 % more bytes per FLOP: they have to win the quantisation estimate by 20 % to be chosen
     return (double)cdiv((int)tiles, 256) * bm * (bm == 160 ? 1.20 : 1.0);
   };
-  // problems that cannot fill the chip with the big tiles (forward_test at B <= 4): the latency kernel, while its own 64x64
-  // tiles stay within two residency rounds (tools/dev/gemm_small_bench.py: B = 1: 107 -> 62 us for the four encoder shapes,
-  // B = 2: 108 -> 69, B = 4 out / fc2 18 / 54 -> 16 / 39; above 512 tiles the big-tile kernels win)
-  auto tiles128 = [&]() { return (long)(cdiv(split, 128) + cdiv(M - split, 128)) * cdiv(N, 128); };
+  // problems that cannot fill the chip with the big tiles (forward_test at B <= 8): the latency kernel while its 64x64 tiles
+  // fit about one residency round of 3 workgroups per CU (tools/dev/gemm_small_bench.py, us for qkv / out / fc1 / fc2:
+  // B = 1: 21.7 19.6 20.6 45.5 -> 10.1 8.6 10.5 19.4;  B = 2: 18.8 17.1 19.1 53.1 -> 11.1 9.6 13.2 20.2;
+  // B = 4 out, fc2: 17.5 54.0 -> 10.5 25.6;  B = 8 out, fc2: 18.3 55.5 -> 14.7 38.5; above ~800 tiles the big-tile kernels win)
   const long tiles64 = (long)(cdiv(split, 64) + cdiv(M - split, 64)) * cdiv(N, 64);
-  if (tiles64 <= 512) {
-    constexpr int SML = LAT_NST * LAT_STAGE;
-    static bool oncel = hipFuncSetAttribute((const void*)gemm_nt_kernel_lat, hipFuncAttributeMaxDynamicSharedMemorySize, SML) == hipSuccess;
+  if (tiles64 <= 800) {
+    static bool oncel = hipFuncSetAttribute((const void*)gemm_nt_kernel_lat<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * LAT_STAGE) == hipSuccess;
     (void)oncel;
-    const int tiles = (cdiv(split, 64) + cdiv(M - split, 64)) * cdiv(N, 64);
-    hipLaunchKernelGGL(gemm_nt_kernel_lat, dim3(tiles), dim3(256), SML, stream, a);
-  } else if (tiles128() <= 256 && K >= 2048) {
-    // one residency round of 128x128 tiles and a long contraction (fc2 at B = 8: 55.5 -> 42.9 us; the short-K shapes and
-    // everything above one round are faster on the 16-wave kernels below)
-    static bool oncem2 = hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MID_NST * 2 * TILE_BYTES) == hipSuccess;
-    (void)oncem2;
-    hipLaunchKernelGGL(gemm_nt_kernel, dim3((int)tiles128()), dim3(256), MID_NST * 2 * TILE_BYTES, stream, a);
+    hipLaunchKernelGGL(gemm_nt_kernel_lat<3>, dim3((int)tiles64), dim3(256), 3 * LAT_STAGE, stream, a);
   } else if (wide_ok && tile_cost(256) <= tile_cost(160)) {
     constexpr int SMW = 160 * 1024;      // ring 128 KiB; the 16-wave epilogue staging needs 136 KiB
     static bool oncew = hipFuncSetAttribute((const void*)gemm_nt_kernel_256sq_w16, hipFuncAttributeMaxDynamicSharedMemorySize, SMW) == hipSuccess;
