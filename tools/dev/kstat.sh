@@ -8,10 +8,11 @@ import csv, glob, sys, re
 f = glob.glob('/tmp/kstat/**/*kernel_stats.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 tot = sum(int(r['TotalDurationNs']) for r in rows)
-print(f"sum of kernel time per step: {tot / 13e6:.3f} ms (13 steps)")
+steps = max(1, sum(int(r['Calls']) for r in rows if 'adam_kernel' in r['Name']) // 2)      # two Adam launches per step
+print(f"sum of kernel time per step: {tot / steps / 1e6:.3f} ms ({steps} steps incl. set-up and warm-up)")
 pat = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] else None
 for r in rows[:40] if pat is None else rows:
     n = re.sub(r'\(anonymous namespace\)::', '', r['Name'])
     if pat is None or re.search(pat, n):
-        print(f"{n[:90]:90s} {int(r['Calls']):5d} {float(r['AverageNs'])/1e3:9.1f} us {int(r['TotalDurationNs'])/13e6:7.3f} ms/step")
+        print(f"{n[:90]:90s} {int(r['Calls']):5d} {float(r['AverageNs'])/1e3:9.1f} us {int(r['TotalDurationNs'])/steps/1e6:7.3f} ms/step")
 PY
