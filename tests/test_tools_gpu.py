@@ -245,3 +245,13 @@ def test_training_overfits_a_fixed_batch(head_graph):
     else:
         assert model._head_graphs is None
     assert first > 20.0 and last < 4.0 and acc >= 87.5, (first, last, acc)
+
+
+def test_inference_time_tool(capsys):
+    """tools/misc/inference_time.py: the reference's single-sample latency protocol on the tiny config (synthetic val split)"""
+    sys.path.insert(0, os.path.join(ROOT, "tools", "misc"))
+    import inference_time
+    ms, macs, params = inference_time.main(["--config", CFG, "--test_samples_number", "12"])
+    out = capsys.readouterr().out
+    assert "inference_time = " in out and "ms/iter" in out and "total_macs:" in out and "total_params:" in out
+    assert 0.0 < ms < 1000.0 and macs > 0 and params > 0
