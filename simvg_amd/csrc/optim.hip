@@ -68,7 +68,7 @@ struct AdamArgs {
 
 constexpr int STREAM_GRID = 768;      // 3 blocks of 256 threads per CU of an MI355X (256 CUs), all resident
 
-// (non-temporal loads / stores on the moment streams: no gain at 141 M parameters, -15 % at 370 M -- default policy)
+// (non-temporal loads / stores on the moment streams: no gain at 141 M elements, -15 % at 370 M -- default policy)
 // U float4 chunks per thread and trip.  PHASED: the g / m / v loads of all U chunks first, then -- only for chunks that are
 // not all-zero -- p and vmax (two dependent round trips, 12 B instead of 20 B read for never-touched rows); !PHASED: all five
 // streams of all U chunks in flight at once.
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      // never-touched parameters (embedding rows of tokens that have not occurred yet: 49 M of ViT-B's 141 M parameters are
+      // never-touched parameters (embedding rows of tokens that have not occurred yet: 49 M of the 223 M elements of ViT-B's arena are
       // the 64 010-row text table): g = m = v = 0 makes the update exactly zero and leaves the state unchanged -> skip the
       // rest of the traffic.  (v = 0 implies vmax = 0; weight decay would move them, so only without it.)
       if (live[u] && a.weight_decay == 0.f && g[u][0] == 0.f && g[u][1] == 0.f && g[u][2] == 0.f && g[u][3] == 0.f &&
@@ -135,7 +135,7 @@ extern "C" int simvg_sumsq(const float* x, long n, float* out_accum, float* part
   SIMVG_CHECK_ARG(x && out_accum && partial_ws && n > 0 && n % 4 == 0,
                   "sumsq: n must be a positive multiple of 4; a 2048-float workspace is required");
   const long n4 = n / 4;
-  // grid-stride over 3 resident blocks per CU (768 on MI355X): 84 us for 141 M floats against 106 us with 2048 blocks
+  // grid-stride over 3 resident blocks per CU (768 on MI355X): 84 us for 141 M floats against 106 us with 2048 blocks (the ViT-B arena is 223 M)
   const int grid = (int)((n4 + 255) / 256 < STREAM_GRID ? (n4 + 255) / 256 : STREAM_GRID);
   // read-once stream: non-temporal loads (5.1 -> 5.5 TB/s standalone; 3.7 TB/s before the 4-way unroll)
   hipLaunchKernelGGL(sumsq_kernel<true>, dim3(grid), dim3(256), 0, stream, x, n4, partial_ws);
@@ -151,7 +151,7 @@ extern "C" int simvg_adam_step(float* param, const float* grad, float* exp_avg, 
   SIMVG_CHECK_ARG(bias_correction2_sqrt > 0.f, "adam_step: bias_correction2_sqrt must be > 0");
   AdamArgs a{param, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, n / 4, step_size, bias_correction2_sqrt, beta1, beta2, eps,
              weight_decay, total_norm, max_norm, max_exp_avg_sq != nullptr};
-  // 3 resident blocks per CU walking the nine streams in 3 MB strides: 880-980 us for ViT-B's 141 M parameters against
+  // 3 resident blocks per CU walking the nine streams in 3 MB strides: 880-980 us for 141 M elements against
   // 1150-1190 us with 4096 blocks (and every power-of-two grid); two chunks per thread in flight, loads phased around the
   // zero-row test (sweep: profiles/r02_sweeps.md)
   const long want = ((a.n4 + 255) / 256 + 1) / 2;
