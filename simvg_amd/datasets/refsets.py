@@ -286,11 +286,14 @@ class TwoStageLoader:
         worker.start()
         try:
             import time
-            self.wait_s = 0.0                      # time the consumer spent waiting for a finished batch (diagnostic)
+            self.wait_s, self.first_wait_s = 0.0, None    # time the consumer spent waiting for finished batches (diagnostic)
             while True:
                 t0 = time.perf_counter()
                 got = ready.get()
-                self.wait_s += time.perf_counter() - t0
+                if self.first_wait_s is None:      # the epoch's pipeline fill (workers start decoding when iteration begins)
+                    self.first_wait_s = time.perf_counter() - t0
+                else:
+                    self.wait_s += time.perf_counter() - t0
                 if got is None:
                     break
                 if isinstance(got, BaseException):

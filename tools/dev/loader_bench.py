@@ -88,7 +88,11 @@ if os.environ.get("TRAIN"):
                     import cProfile
                     prof = cProfile.Profile()
                     prof.enable()
+                t_second = None
                 for batch in loader:
+                    if n == 64:                                    # steady state: from the second step on
+                        torch.cuda.synchronize()
+                        t_second = time.perf_counter()
                     b = extract_data(batch, dev)
                     losses, _ = model(b["img"], b["ref_expr_inds"], b["img_metas"], return_loss=True,
                                       text_attention_mask=b["text_attention_mask"], gt_bbox=b["gt_bbox"], rescale=False)
@@ -104,9 +108,12 @@ if os.environ.get("TRAIN"):
                     prof.disable()
                     pstats.Stats(prof).sort_stats("tottime").print_stats(14)
         if hasattr(loader, "wait_s"):
-            print(f"  consumer waited {loader.wait_s / (n / 64) * 1e3:.1f} ms per step for the loader thread")
+            print(f"  consumer waited {loader.first_wait_s * 1e3:.1f} ms for the first batch of the epoch, then "
+                  f"{loader.wait_s / max(n / 64 - 1, 1) * 1e3:.2f} ms per step for the loader thread")
         hg = getattr(model, "_head_graphs", None)
         if hg is not None:
             print("head graphs captured:", len(hg.graphs), "disabled:", hg.disabled, "default stream seen:", hg.default_stream_seen)
-        print(f"training from JPEG files, workers {workers}, background device stage {background}: {n / dt:7.1f} pairs/s "
-              f"({dt / (n / 64) * 1e3:5.1f} ms per step)", flush=True)
+        steady = (n - 64) / (t0 + dt - t_second) if t_second is not None and n > 64 else float("nan")
+        print(f"training from JPEG files, workers {workers}, background device stage {background}: {n / dt:7.1f} pairs/s over the "
+              f"epoch incl. its pipeline fill ({dt / (n / 64) * 1e3:5.1f} ms per step), {steady:7.1f} pairs/s from the second step on",
+              flush=True)
