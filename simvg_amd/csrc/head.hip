@@ -421,7 +421,10 @@ extern "C" int simvg_gemm_f32(const float* A, long sam, long sak, const float* B
   SIMVG_CHECK_ARG(act >= 0 && act <= 2, "gemm_f32: act must be 0 (none), 1 (gelu) or 2 (relu)");
   SGArgs a{A, sam, sak, B, sbk, sbn, C, ldc, bias, addend, ld_addend, addend_rows > 0 ? addend_rows : 1, M, N, K,
            accumulate, act, nullptr, nullptr, nullptr, 0, nullptr, 0};
-  constexpr int small_env = 32;      // <= 32 tiles of 64x64: the small-M kernel (sweep in profiles/r01_sweeps.md)
+  // <= 128 tiles of 64x64: the small-M kernel (one workgroup per 16x16 tile, K split over its waves).  32 in round 1 (tuned at
+  // num_queries = 1); at num_queries = 10 (M = 640 rows) the K = 2048 FFN problems have 40 - 320 such tiles and ran 27+ us each on
+  // the 64x64 kernel: 32 -> 128 is 34.2 -> 32.7 ms per step there, no change at num_queries = 1 (profiles/r02_sweeps.md)
+  constexpr int small_env = 128;
   if (cdiv(N, 64) * cdiv(M, 64) <= small_env)   // too few 64x64 tiles to fill the chip: one workgroup per 16x16 tile
     hipLaunchKernelGGL(gemm_f32_small_kernel, dim3(cdiv(N, 16), cdiv(M, 16)), dim3(256), 0, stream, a);
   else
@@ -432,7 +435,10 @@ extern "C" int simvg_gemm_f32(const float* A, long sam, long sak, const float* B
 
 extern "C" int simvg_gemm_f32_grouped(const simvg_gemm_f32_problem* problems, int count, hipStream_t stream) {
   SIMVG_CHECK_ARG(problems != nullptr && count > 0 && count <= SG_MAX, "gemm_f32_grouped: 1..12 problems");
-  constexpr int small_env = 32;      // <= 32 tiles of 64x64: the small-M kernel (sweep in profiles/r01_sweeps.md)
+  // <= 128 tiles of 64x64: the small-M kernel (one workgroup per 16x16 tile, K split over its waves).  32 in round 1 (tuned at
+  // num_queries = 1); at num_queries = 10 (M = 640 rows) the K = 2048 FFN problems have 40 - 320 such tiles and ran 27+ us each on
+  // the 64x64 kernel: 32 -> 128 is 34.2 -> 32.7 ms per step there, no change at num_queries = 1 (profiles/r02_sweeps.md)
+  constexpr int small_env = 128;
   SGGroup g;
   g.count = count;
   int total = 0;
