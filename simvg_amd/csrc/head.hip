@@ -297,22 +297,28 @@ __global__ __launch_bounds__(256) void attn_small_fwd_kernel(SAArgs a) {
   // out[qi][d] = sum_k P'[qi][k] V[k][d]: thread (part, d) adds keys part, part + 8, ... (a key row is one coalesced 128-B read
   // of the 32 d-lanes); the 8 partial sums meet in LDS.  (One thread per (qi, d) walking all keys was 10 of the kernel's 15 us
   // with num_queries = 1: 32 active threads, 400 dependent strided reads each.)
-  float* red = sc + a.Lq * a.Lk;        // [8][32]
+  float* red = sc + a.Lq * a.Lk;        // [8][Lq][32]
   {
     const int part = tid >> 5, d = tid & 31;
     const float* vp = a.v + (long)(b * a.kv_rows) * a.ldv + h * SHD + d;
-    for (int qi = 0; qi < a.Lq; ++qi) {
-      float o = 0.f;
-      for (int kk = part; kk < a.Lk; kk += 8) o += sc[qi * a.Lk + kk] * vp[(long)kk * a.ldv];
-      red[part * SHD + d] = o;
-      __syncthreads();
-      if (tid < SHD) {
-        float t = 0.f;
+    float o[16];
 #pragma unroll
-        for (int p8 = 0; p8 < 8; ++p8) t += red[p8 * SHD + tid];
-        a.out[(long)(b * a.Lq + qi) * a.ldo + h * SHD + tid] = t;
-      }
-      __syncthreads();
+    for (int qi = 0; qi < 16; ++qi) o[qi] = 0.f;
+    for (int kk = part; kk < a.Lk; kk += 8) {            // a V row is read once for all queries
+      const float vv = vp[(long)kk * a.ldv];
+#pragma unroll
+      for (int qi = 0; qi < 16; ++qi)
+        if (qi < a.Lq) o[qi] += sc[qi * a.Lk + kk] * vv;
+    }
+#pragma unroll
+    for (int qi = 0; qi < 16; ++qi)
+      if (qi < a.Lq) red[(part * a.Lq + qi) * SHD + d] = o[qi];
+    __syncthreads();
+    for (int e = tid; e < a.Lq * SHD; e += 256) {
+      float t = 0.f;
+#pragma unroll
+      for (int p8 = 0; p8 < 8; ++p8) t += red[p8 * a.Lq * SHD + e];
+      a.out[(long)(b * a.Lq + e / SHD) * a.ldo + h * SHD + (e % SHD)] = t;
     }
   }
 }
@@ -374,26 +380,29 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(SAArgs a) {
   __syncthreads();
   // dQ[qi][d] = sum_k dS[qi][k] K[k][d]: keys dealt over 8 thread groups as in the forward's P V product
   {
-    float* red = rs + a.Lq;               // [8][32]
+    float* red = rs + a.Lq;               // [8][Lq][32]
     const int part = tid >> 5, d = tid & 31;
     const float* kp = a.k + (long)(b * a.kv_rows) * a.ldk + h * SHD + d;
     const float* pp = a.kpos ? a.kpos + (long)(b * a.kpos_rows) * a.ldkp + h * SHD + d : nullptr;
-    for (int qi = 0; qi < a.Lq; ++qi) {
-      float o = 0.f;
-      if (pp) {
-        for (int kk = part; kk < a.Lk; kk += 8) o += ds[qi * a.Lk + kk] * (kp[(long)kk * a.ldk] + pp[(long)kk * a.ldkp]);
-      } else {
-        for (int kk = part; kk < a.Lk; kk += 8) o += ds[qi * a.Lk + kk] * kp[(long)kk * a.ldk];
-      }
-      red[part * SHD + d] = o;
-      __syncthreads();
-      if (tid < SHD) {
-        float t = 0.f;
+    float o[16];
 #pragma unroll
-        for (int p8 = 0; p8 < 8; ++p8) t += red[p8 * SHD + tid];
-        a.dq[(long)(b * a.Lq + qi) * a.lddq + h * SHD + tid] = t;
-      }
-      __syncthreads();
+    for (int qi = 0; qi < 16; ++qi) o[qi] = 0.f;
+    for (int kk = part; kk < a.Lk; kk += 8) {
+      float kv = kp[(long)kk * a.ldk];
+      if (pp) kv += pp[(long)kk * a.ldkp];
+#pragma unroll
+      for (int qi = 0; qi < 16; ++qi)
+        if (qi < a.Lq) o[qi] += ds[qi * a.Lk + kk] * kv;
+    }
+#pragma unroll
+    for (int qi = 0; qi < 16; ++qi)
+      if (qi < a.Lq) red[(part * a.Lq + qi) * SHD + d] = o[qi];
+    __syncthreads();
+    for (int e = tid; e < a.Lq * SHD; e += 256) {
+      float t = 0.f;
+#pragma unroll
+      for (int p8 = 0; p8 < 8; ++p8) t += red[p8 * a.Lq * SHD + e];
+      a.dq[(long)(b * a.Lq + e / SHD) * a.lddq + h * SHD + (e % SHD)] = t;
     }
   }
   // dK[k][d] = sum_q dS[q][k] Q[q][d]
@@ -468,14 +477,14 @@ extern "C" int simvg_attn_small_fwd(const float* q, int ldq, const float* k, int
                                     const float* drop_mult, int B, int H, int Lq, int Lk, int kv_rows_per_batch,
                                     float scale, const float* key_pos, int ld_key_pos, int key_pos_rows_per_batch,
                                     hipStream_t stream) {
-  SIMVG_CHECK_ARG(B > 0 && H > 0 && Lq > 0 && Lq <= 16 && Lk > 0 && (size_t)(Lq * SHD + Lq * Lk + 8 * SHD) * sizeof(float) <= 160 * 1024,
+  SIMVG_CHECK_ARG(B > 0 && H > 0 && Lq > 0 && Lq <= 16 && Lk > 0 && (size_t)(Lq * SHD + Lq * Lk + 8 * Lq * SHD) * sizeof(float) <= 160 * 1024,
                   "attn_small: Lq <= 16 and the [Lq, Lk] score strip must fit the 160 KiB LDS");
   SIMVG_CHECK_ARG(ldk % 4 == 0 && ldv % 4 == 0, "attn_small: K/V rows must be 16-B aligned");
   SAArgs a{q, ldq, k, ldk, v, ldv, out, ldo, P, key_padding_mask, drop_mult, nullptr, 0, nullptr, 0, nullptr, 0,
            nullptr, 0, B, H, Lq, Lk, kv_rows_per_batch > 0 ? kv_rows_per_batch : Lk, scale, key_pos, ld_key_pos,
            key_pos_rows_per_batch};
   SIMVG_CHECK_ARG(!key_pos || ld_key_pos % 4 == 0, "attn_small: key_pos rows must be 16-B aligned");
-  const size_t shm = (size_t)(Lq * SHD + Lq * Lk + 8 * SHD) * sizeof(float);
+  const size_t shm = (size_t)(Lq * SHD + Lq * Lk + 8 * Lq * SHD) * sizeof(float);
   static bool once = hipFuncSetAttribute((const void*)attn_small_fwd_kernel,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
   (void)once;
@@ -491,13 +500,13 @@ extern "C" int simvg_attn_small_bwd(const float* q, int ldq, const float* k, int
                                     const float* key_pos, int ld_key_pos, int key_pos_rows_per_batch,
                                     hipStream_t stream) {
   SIMVG_CHECK_ARG(B > 0 && H > 0 && Lq > 0 && Lq <= 16 && Lk > 0 &&
-                  (size_t)(2 * Lq * SHD + 2 * Lq * Lk + Lq + 8 * SHD) * sizeof(float) <= 160 * 1024,
+                  (size_t)(2 * Lq * SHD + 2 * Lq * Lk + Lq + 8 * Lq * SHD) * sizeof(float) <= 160 * 1024,
                   "attn_small: Lq <= 16 and two [Lq, Lk] strips must fit the 160 KiB LDS");
   SIMVG_CHECK_ARG(ldk % 4 == 0 && ldv % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0, "attn_small: rows must be 16-B aligned");
   SAArgs a{q, ldq, k, ldk, v, ldv, nullptr, 0, (float*)P, key_padding_mask, drop_mult, dout, lddo, dq, lddq, dk, lddk,
            dv, lddv, B, H, Lq, Lk, kv_rows_per_batch > 0 ? kv_rows_per_batch : Lk, scale, key_pos, ld_key_pos,
            key_pos_rows_per_batch};
-  const size_t shm = (size_t)(2 * Lq * SHD + 2 * Lq * Lk + Lq + 8 * SHD) * sizeof(float);
+  const size_t shm = (size_t)(2 * Lq * SHD + 2 * Lq * Lk + Lq + 8 * Lq * SHD) * sizeof(float);
   static bool once = hipFuncSetAttribute((const void*)attn_small_bwd_kernel,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
   (void)once;
