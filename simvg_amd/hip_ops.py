@@ -505,11 +505,14 @@ def soft_targets(logits, boxes, match_idx, tboxes, tcount):
     B, nq, _ = logits.shape
     TM = tboxes.shape[1]
     dev = logits.device
-    pboxes = torch.zeros(B, TM, 4, device=dev)
-    plabels = torch.zeros(B, TM, device=dev, dtype=torch.int32)
-    pcount = torch.zeros(B, device=dev, dtype=torch.int32)
-    pweight = torch.zeros(B, TM, device=dev)
-    scal = torch.zeros(4, device=dev)
+    # the five zero-initialised outputs are slices of ONE fill (int32 zeros and fp32 zeros share the bit pattern)
+    n_box, n_tm = B * TM * 4, B * TM
+    buf = torch.zeros(n_box + 2 * n_tm + B + 4, device=dev)
+    pboxes = buf[:n_box].view(B, TM, 4)
+    pweight = buf[n_box:n_box + n_tm].view(B, TM)
+    scal = buf[n_box + n_tm:n_box + n_tm + 4]
+    plabels = buf[n_box + n_tm + 4:n_box + 2 * n_tm + 4].view(torch.int32).view(B, TM)
+    pcount = buf[n_box + 2 * n_tm + 4:].view(torch.int32)
     rc = lib.simvg_soft_targets(_p(logits), _p(boxes), _p(match_idx), _p(tboxes), _p(tcount), _p(pboxes), _p(plabels),
                                 _p(pcount), _p(pweight), _p(scal), B, nq, TM, _stream())
     _lib.check(rc, "simvg_soft_targets")
@@ -522,7 +525,10 @@ def criterion(logits, boxes, match_idx, tboxes, tlabels, num_boxes, wdist, coef_
     lib = _lib.load()
     L, B, nq, _ = logits.shape
     TM = tboxes.shape[1]
-    dlogits, dboxes = torch.empty_like(logits), torch.empty_like(boxes)
+    # both gradients in one buffer: the backward's scaling by the upstream gradient is then one launch (Criterion.backward)
+    nl, nb = logits.numel(), boxes.numel()
+    grads = torch.empty(nl + nb, device=logits.device, dtype=logits.dtype)
+    dlogits, dboxes = grads[:nl].view(logits.shape), grads[nl:].view(boxes.shape)
     out = torch.empty(1 + 3 * L, device=logits.device)
     rc = lib.simvg_criterion(_p(logits), _p(boxes), _p(match_idx), _p(tboxes), _p(tlabels), _p(num_boxes), _p(wdist),
                              _p(dlogits), _p(dboxes), _p(out), L, B, nq, TM, coef_mode, coef, eos_coef, weights[0],
