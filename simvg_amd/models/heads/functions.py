@@ -76,7 +76,13 @@ class LinearLP(torch.autograd.Function):
         dyb = ops.cast_lp(dy.float().contiguous(), scale=S)
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
-            dx = ops.gemm_nt(dyb, wT, out_dtype=torch.float32, alpha=1.0 / S)            # [M,K] fp32
+            # x is the leading rows of a larger row-major buffer (the vision rows of the encoder output, text rows behind
+            # them): the gradient is written into the leading rows of an fp32 buffer of the WHOLE extent, so that
+            # SplitEncoderOutput.backward can fill in the remaining rows instead of copying these 83 MB
+            M, K = x.shape
+            rows_total = x.untyped_storage().nbytes() // (x.element_size() * K) if x.is_contiguous() and x.storage_offset() == 0 else M
+            full = torch.empty(max(rows_total, M), K, device=dy.device, dtype=torch.float32)
+            dx = ops.gemm_nt(dyb, wT, out=full[:M], alpha=1.0 / S)                       # [M,K] fp32
         if ctx.needs_input_grad[1]:
             dW = torch.zeros(ctx.shapeW, device=dy.device, dtype=torch.float32)
             db = torch.zeros(ctx.shapeW[0], device=dy.device, dtype=torch.float32) if ctx.needs_input_grad[2] else None
@@ -139,13 +145,40 @@ def _f32(*shape, device):
 
 
 class LayerCfg:
-    """non-tensor arguments of `DecoderLayerFn` (geometry, cross-attention flavour and its gradient-free operands)"""
+    """non-tensor arguments of `DecoderLayerFn` (geometry, cross-attention flavour and its gradient-free operands);
+    mem_grad: the `SharedMemoryGrad` holder of the 16-bit memory rows, or None (the layer returns its own d(mem))"""
 
     def __init__(self, B, H, nq, kind, Lk, kpm=None, pos=None, wb=None, wbT=None, Nv=0, p_attn=0.0, p_ffn=0.0,
-                 training=False, mask_fn=None):
+                 training=False, mask_fn=None, mem_grad=None):
         self.B, self.H, self.nq, self.kind, self.Lk = B, H, nq, kind, Lk
         self.kpm, self.pos, self.wb, self.wbT, self.Nv = kpm, pos, wb, wbT, Nv
         self.p_attn, self.p_ffn, self.training, self.mask_fn = p_attn, p_ffn, training, mask_fn
+        self.mem_grad = mem_grad
+
+
+class SharedMemoryGrad(torch.autograd.Function):
+    """The image memory is read by every decoder layer; autograd would add the layers' [B*Nv, E] fp32 gradients pairwise
+    (two 83 MB passes for three layers).  `mem, holder = SharedMemoryGrad.join(mem)`: the layers that get `holder`
+    (LayerCfg.mem_grad) accumulate their d(mem) into ONE buffer through the GEMM epilogue (C = residual + alpha A W^T, in
+    place) and return no gradient for `mem`; this node, which the engine runs once all of them are done, hands the buffer on."""
+
+    @staticmethod
+    def forward(ctx, mem, holder):
+        ctx.holder = holder
+        ctx.set_materialize_grads(False)
+        return mem.view_as(mem)
+
+    @staticmethod
+    def backward(ctx, g):
+        buf = ctx.holder.pop("buf", None)
+        if buf is None:
+            return g, None
+        return (buf if g is None else buf + g), None
+
+    @staticmethod
+    def join(mem):
+        holder = {}
+        return SharedMemoryGrad.apply(mem, holder), holder
 
 
 class DecoderLayerFn(torch.autograd.Function):
@@ -334,7 +367,13 @@ class DecoderLayerFn(torch.autograd.Function):
                 S = ops.grad_scale()                                                     # 16-bit operand dkv * S
                 dkvb = ops.cast_lp(dkv, scale=S)
                 if need[4]:
-                    dmem = ops.gemm_nt(dkvb, cfg.wbT, out_dtype=torch.float32, alpha=1.0 / S)   # [R, E] fp32, true gradient
+                    acc = cfg.mem_grad
+                    if acc is None:
+                        dmem = ops.gemm_nt(dkvb, cfg.wbT, out_dtype=torch.float32, alpha=1.0 / S)   # [R, E] fp32, true gradient
+                    elif acc.get("buf") is None:
+                        acc["buf"] = ops.gemm_nt(dkvb, cfg.wbT, out_dtype=torch.float32, alpha=1.0 / S)
+                    else:       # a later layer's backward already left its share: buf += dkv W (residual epilogue, in place)
+                        ops.gemm_nt(dkvb, cfg.wbT, out=acc["buf"], residual=acc["buf"], alpha=1.0 / S)
                 ops.gemm_tn(dkvb, mem, dWc[E:], db=dbc[0, E:], out_scale=1.0 / S)
             else:
                 if need[4]:
@@ -411,11 +450,16 @@ class SplitEncoderOutput(torch.autograd.Function):
     def backward(ctx, dvis, dtext, dcls):
         B, Nv, T, D = ctx.geo
         ref = dvis if dvis is not None else (dtext if dtext is not None else dcls)
-        d = torch.empty(B * (Nv + T), D, device=ref.device, dtype=torch.float32)
-        if dvis is not None:
-            d[:B * Nv] = dvis
+        rows = B * (Nv + T)
+        if dvis is not None and dvis.dtype == torch.float32 and dvis.is_contiguous() and dvis.storage_offset() == 0 \
+                and tuple(dvis.shape) == (B * Nv, D) and dvis.untyped_storage().nbytes() >= rows * D * 4:
+            d = dvis.new_empty(0).set_(dvis.untyped_storage(), 0, (rows, D))      # LinearLP.backward left room for the text rows
         else:
-            d[:B * Nv].zero_()
+            d = torch.empty(rows, D, device=ref.device, dtype=torch.float32)
+            if dvis is not None:
+                d[:B * Nv] = dvis
+            else:
+                d[:B * Nv].zero_()
         if dtext is not None:
             d[B * Nv:] = dtext
         else:

@@ -16,7 +16,8 @@ import torch.nn.functional as F
 
 from ... import builder
 from .... import hip_ops as ops
-from ..functions import (Criterion, DecoderLayerFn, LayerCfg, LayerNormF32, LinearLP, LinearF32, SplitEncoderOutput)
+from ..functions import (Criterion, DecoderLayerFn, LayerCfg, LayerNormF32, LinearLP, LinearF32, SharedMemoryGrad,
+                         SplitEncoderOutput)
 
 
 def _xavier(*shape):
@@ -379,10 +380,13 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
         qpos_d = query_embed.reshape(B * nq, E)
         tgt = torch.zeros(B * nq, E, device=device)
         hs = []
+        mem_grad = None
+        if not exact and mem.requires_grad and torch.is_grad_enabled():
+            mem, mem_grad = SharedMemoryGrad.join(mem)            # one accumulator for the layers' memory gradients
         for i in range(self.num_decoder_layers):
             # K = (mem + pos) Wk^T + bk = mem Wk^T + bk + pos Wk^T ; V = mem Wv^T + bv   (key_pos only on K)
             wb, wbT = (None, None) if exact else (self.wb[f"kv{i}"], self.wb[f"kvT{i}"])
-            cfg_m = self._layer_cfg(B, "mem", HW, kpm=img_kpm, pos=pos2d, wb=wb, wbT=wbT, Nv=Nv)
+            cfg_m = self._layer_cfg(B, "mem", HW, kpm=img_kpm, pos=pos2d, wb=wb, wbT=wbT, Nv=Nv, mem_grad=mem_grad)
             tgt, h = self._decoder_layer(f"transformer.decoder.layers.{i}.", tgt, qpos_d, cfg_m, mem=mem,
                                          post="transformer.decoder.post_norm_layer")
             hs.append(h)
