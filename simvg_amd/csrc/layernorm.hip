@@ -719,6 +719,9 @@ __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __re
   } while (0)
 
 static inline int ln_wide_rpb(int M) { return std::max(16, cdiv(M, 508)); }
+// narrow rows: 32 rows per block (4 waves x 8 rows) at training sizes; the decoder head's [B * num_queries, 256] problems have
+// 64 - 640 rows in all -- 4 rows per block (one per wave) so that they spread over 16 - 160 blocks instead of 2 - 20
+static inline int ln_narrow_rpb(int M) { return M <= 2048 ? 4 : 32; }
 
 extern "C" int simvg_ln_fwd(const void* x, int x_is_bf16, int ldx, const float* gamma, const float* beta,
                             int group_stride, void* y_bf16, int ldy, float* y_f32, int ldy32, float* mean,
@@ -779,7 +782,7 @@ extern "C" int simvg_ln_bwd(const void* dy_bf16, int dy_is_f32, int lddy, const 
   // global atomics
   // rows per block: the wide two-stage kernel gets its grid into one residency round (2 blocks per CU; >= 16 rows),
   // 32 for the generic wave-per-row kernels (sweeps: profiles/r01_sweeps.md)
-  const int rpb = (D >= 2048 && partial_ws) ? ln_wide_rpb(M) : 32;
+  const int rpb = (D >= 2048 && partial_ws) ? ln_wide_rpb(M) : ln_narrow_rpb(M);
   const int blocks0 = cdiv(split, rpb), blocks1 = cdiv(M - split, rpb);
   const dim3 grid(blocks0 + blocks1), block(256);
   const size_t shm = (size_t)2 * D * sizeof(float);
@@ -868,6 +871,6 @@ extern "C" int simvg_ln_bwd(const void* dy_bf16, int dy_is_f32, int lddy, const 
 
 extern "C" long simvg_ln_bwd_ws_floats(int M, int D, int split) {
   if (split == 0) split = M;
-  const int rpb = D >= 2048 ? ln_wide_rpb(M) : 32;
+  const int rpb = D >= 2048 ? ln_wide_rpb(M) : ln_narrow_rpb(M);
   return (long)(cdiv(split, rpb) + cdiv(M - split, rpb)) * 2 * D;
 }
