@@ -257,3 +257,20 @@ def test_reference_signature_checkpoint_roundtrip(tmp_path):
     with pytest.raises(AssertionError):
         load_pretrained_checkpoint(m3, ema3, str(tmp_path / "ddp.pth"))
     assert load_pretrained_checkpoint(ML.MockVG(), None, str(tmp_path / "ddp.pth")) == (-1, 40.0, 0.0)
+
+
+def test_analytic_forward_macs_equal_the_baseline_table():
+    """tools/misc/inference_time.py::forward_macs counts the GEMM-like work of one forward_test; 2 x MACs must be the
+    algorithmic FLOPs per pair of BASELINE.md section 2 (80.44 GFLOP for ViT-B/32 @640, 274.78 for ViT-L/32)"""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tools", "misc"))
+    import bench
+    import inference_time
+    from simvg_amd.models import build_model
+    for vit, gflop in (("base", 80.44), ("large", 274.78)):
+        model = build_model(bench.model_cfg(vit=vit))
+        assert abs(2 * inference_time.forward_macs(model, 20) / 1e9 - gflop) < 0.01, vit
+        assert abs(3 * 2 * inference_time.forward_macs(model, 20) - bench.FLOP_PER_PAIR_FWD_BWD[vit]) < 0.02e9, vit
