@@ -4,6 +4,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 B=${1:-1}
 python tools/dev/infer_loop.py $B 100
 rm -rf /tmp/ik && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ik -o p -- python tools/dev/infer_loop.py $B 100 > /tmp/ik.log 2>&1
+mkdir -p gpurun_out/infer && cp $(find /tmp/ik -name "*kernel_stats.csv" | head -1) gpurun_out/infer/b${B}_kernel_stats.csv
 python - <<'PY'
 import csv, glob, re
 f = glob.glob('/tmp/ik/**/*kernel_stats.csv', recursive=True)[0]
