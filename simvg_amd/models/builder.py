@@ -43,6 +43,21 @@ class Registry:
         return cls(**kwargs)
 
 
+class skip_init:
+    """`with skip_init(): model = build_model(cfg)` -- the large random initialisations (truncated-normal encoder weights, Xavier
+    head weights) are left as uninitialised memory.  ONLY for callers that load every parameter right afterwards
+    (`load_state_dict(strict=True)`): building ViT-L otherwise spends tens of seconds of single-threaded CPU time on
+    values that are overwritten."""
+    active = False
+
+    def __enter__(self):
+        self._prev, skip_init.active = skip_init.active, True
+        return self
+
+    def __exit__(self, *exc):
+        skip_init.active = self._prev
+
+
 VIS_ENCODERS = Registry("VIS_ENCS")
 LAN_ENCODERS = Registry("LAN_ENCS")
 MODELS = Registry("MODELS")

@@ -22,7 +22,8 @@ from ..functions import (Criterion, DecoderLayerFn, LayerCfg, LayerNormF32, Line
 
 def _xavier(*shape):
     t = torch.empty(*shape)
-    nn.init.xavier_uniform_(t)
+    if not builder.skip_init.active:
+        nn.init.xavier_uniform_(t)
     return t
 
 

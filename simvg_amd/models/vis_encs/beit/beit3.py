@@ -50,6 +50,8 @@ def _set_param(root, key, tensor):
 
 def _trunc_normal(shape, std=0.02):
     t = torch.empty(shape)
+    if builder.skip_init.active:
+        return t
     nn.init.trunc_normal_(t, mean=0.0, std=std, a=-std, b=std)   # modeling_utils.py:17-18
     return t
 

@@ -17,18 +17,32 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+_SD_CACHE = {}
+
+
+def _state_dict(fx, cfg):
+    """the fixture's weights (a pure function of geometry + seed; generating ViT-L's takes 10 - 30 s of CPU time, and three or four
+    tests use each fixture, in test-function-major order): all nine are kept (~13 GB of host memory)"""
+    from oracle import weights as W
+    key = (fx["vit"], fx["num_queries"], fx["img_size"], fx["wseed"], bool(fx.get("refinit")))
+    if key not in _SD_CACHE:
+        _SD_CACHE[key] = W.reference_init_state_dict(cfg, fx["wseed"]) if fx.get("refinit") else W.golden_state_dict(cfg, fx["wseed"])
+    return _SD_CACHE[key]
+
+
 def _build(fx):
     from oracle import ref_loader, simvg_cpu as O, weights as W
     from simvg_amd.models import build_model
+    from simvg_amd.models.builder import skip_init
     cfg = O.make_cfg(fx["vit"], fx["num_queries"], fx["img_size"])
     mcfg = ref_loader.model_cfg("base" if fx["vit"] == "tiny" else fx["vit"], fx["num_queries"], fx["img_size"])
     if fx["vit"] == "tiny":
         mcfg["vis_enc"]["encoder_cfg"] = dict(embed_dim=cfg.embed_dim, heads=cfg.heads, ffn_dim=cfg.ffn_dim, layers=cfg.layers)
         mcfg["vis_enc"]["drop_path_rate"] = 0.0
         mcfg["head"]["in_channels"] = cfg.embed_dim
-    model = build_model(mcfg)
-    sd = W.reference_init_state_dict(cfg, fx["wseed"]) if fx.get("refinit") else W.golden_state_dict(cfg, fx["wseed"])
-    model.load_state_dict(sd, strict=True)
+    with skip_init():                    # every parameter is loaded (strict) right below
+        model = build_model(mcfg)
+    model.load_state_dict(_state_dict(fx, cfg), strict=True)
     batch = W.synthetic_batch(cfg, fx["B"], fx["iseed"], fx["grec"])
     return model.to(DEV), batch, cfg
 
