@@ -33,6 +33,17 @@ CASES = {
     # reference-style initialisation (what training from scratch / the benchmark uses)
     "base_nq1_refinit":       ("base", 1, 640, 2, False, 16, 26),
     "base_nq10_grec_refinit": ("base", 10, 640, 3, True, 17, 27),
+    # branch_loss_weight = {"decoder": 1.0}: every *_twostage_1 config, pretrian-mixed / pretrain-cocoall (BASELINE config 4's
+    # named workload) and the six finetune_* configs (e.g. configs/single/ViT-large/refcoco/refcoco_twostage_1.py:98,
+    # configs/mix/ViT-base/pretrian-mixed.py:103); the token branch then runs forward only and gets no gradient
+    "base_nq1_deconly":       ("base", 1, 640, 2, False, 31, 41, {"decoder": 1.0}),
+    "large_nq1_deconly":      ("large", 1, 640, 2, False, 32, 42, {"decoder": 1.0}),
+    "base_nq10_grec_deconly": ("base", 10, 640, 3, True, 33, 43, {"decoder": 1.0}),
+    "tiny_nq1_deconly":       ("tiny", 1, 128, 2, False, 34, 44, {"decoder": 1.0}),
+    # ViT-L's one-stage / two-stage-2 loss weights (configs/single/ViT-large/refcoco/refcoco_onestage.py:96)
+    "large_nq1_w104":         ("large", 1, 640, 2, False, 35, 45, {"decoder": 1.0, "balanced_distill": {"token": 1.0, "distill": 0.4}}),
+    "large_nq10_grec_w104_refinit": ("large", 10, 640, 3, True, 36, 46,
+                                     {"decoder": 1.0, "balanced_distill": {"token": 1.0, "distill": 0.4}}),
 }
 
 GRAD_KEYS = [  # sampled gradient probes (first 16 elements + norm)
@@ -63,9 +74,9 @@ def _summ(t, n=64):
                 idx=idx, vals=t[idx].clone())
 
 
-def build_reference(vit, nq, img_size, cfg):
+def build_reference(vit, nq, img_size, cfg, blw=None):
     M = ref_loader.load()
-    mcfg = ref_loader.model_cfg("base" if vit == "tiny" else vit, nq, img_size, cfg.patch_size)
+    mcfg = ref_loader.model_cfg("base" if vit == "tiny" else vit, nq, img_size, cfg.patch_size, blw)
     if vit == "tiny":
         beit3_mod = sys.modules["simvg.models.vis_encs.beit.beit3"]
         from .leaf import EncoderConfig
@@ -84,10 +95,11 @@ def build_reference(vit, nq, img_size, cfg):
 
 
 def run_case(name, check_only=False):
-    vit, nq, img_size, B, grec, wseed, iseed = CASES[name]
-    cfg = O.make_cfg(vit, nq, img_size)
+    vit, nq, img_size, B, grec, wseed, iseed = CASES[name][:7]
+    blw = CASES[name][7] if len(CASES[name]) > 7 else None
+    cfg = O.cfg_from_branch_loss_weight(O.make_cfg(vit, nq, img_size), blw)
     t0 = time.time()
-    model = build_reference(vit, nq, img_size, cfg)
+    model = build_reference(vit, nq, img_size, cfg, blw)
     refinit = name.endswith("_refinit")
     sd = W.reference_init_state_dict(cfg, wseed) if refinit else W.golden_state_dict(cfg, wseed)
     missing = model.load_state_dict(sd, strict=True)
@@ -122,6 +134,9 @@ def run_case(name, check_only=False):
     losses2["loss_total"].backward()
 
     def chk(a, b, what, tol=2e-5):
+        if a is None or b is None:       # the decoder-only head has no token branch: both sides must say so
+            assert a is None and b is None, f"[{name}] {what}: one side is None"
+            return 0.0
         err = float((a.detach() - b.detach()).abs().max()) if a.numel() else 0.0
         scale = max(1.0, float(b.detach().abs().max())) if b.numel() else 1.0
         assert err <= tol * scale, f"[{name}] restatement mismatch on {what}: {err}"
@@ -133,6 +148,7 @@ def run_case(name, check_only=False):
     errs["tok_boxes"] = chk(out2["tok_boxes"], hout["outputs_coord_token_branch"], "tok_boxes")
     errs["dec_logits"] = chk(out2["dec_logits"], hout["outputs_class_decoder_branch"], "dec_logits")
     errs["dec_boxes"] = chk(out2["dec_boxes"], hout["outputs_coord_decoder_branch"], "dec_boxes")
+    assert list(losses2) == list(losses), (list(losses2), list(losses))      # same keys, same (insertion) order
     for k in losses:
         errs[k] = chk(losses2[k], losses[k], k)
     if not grec:
@@ -140,6 +156,9 @@ def run_case(name, check_only=False):
             errs[f"pred{i}"] = chk(pred2[i]["pred_bboxes"], pred[i]["pred_bboxes"], f"pred_bboxes[{i}]", 1e-4)
     else:
         for i in (0, 1):
+            if pred[i]["pred_bboxes"] is None or pred2[i]["pred_bboxes"] is None:
+                assert pred[i]["pred_bboxes"] is None and pred2[i]["pred_bboxes"] is None, i
+                continue
             for a, b in zip(pred2[i]["pred_bboxes"], pred[i]["pred_bboxes"]):
                 chk(a["boxes"], b["boxes"], "grec boxes", 1e-4)
                 chk(a["scores"], b["scores"], "grec scores")
@@ -149,6 +168,7 @@ def run_case(name, check_only=False):
         if g is None:
             assert g2 is None or float(g2.abs().max()) == 0.0, k
             continue
+        assert g2 is not None, f"[{name}] the reference has a gradient for {k}, the restatement has none"
         gerr = max(gerr, chk(g2, g, "grad " + k, 5e-5))
     errs["grad_max"] = gerr
     print(f"[{name}] restatement == reference; max errs:", {k: f"{v:.2e}" for k, v in errs.items()})
@@ -158,10 +178,12 @@ def run_case(name, check_only=False):
     tiny = vit == "tiny"
     fx = dict(
         name=name, refinit=refinit, vit=vit, num_queries=nq, img_size=img_size, B=B, grec=grec, wseed=wseed, iseed=iseed,
-        torch_version=torch.__version__,
+        torch_version=torch.__version__, branch_loss_weight=blw,
+        no_grad_params=sorted(k for k, g in ref_grads.items() if g is None),
         losses={k: float(v) for k, v in losses.items()},
-        tok_logits=hout["outputs_class_token_branch"].detach().clone(),
-        tok_boxes=hout["outputs_coord_token_branch"].detach().clone(),
+        tok_logits=None if hout["outputs_class_token_branch"] is None else hout["outputs_class_token_branch"].detach().clone(),
+        tok_boxes=None if hout["outputs_coord_token_branch"] is None else hout["outputs_coord_token_branch"].detach().clone(),
+        token_features=_summ(hout["token_features"], 512),
         dec_logits=hout["outputs_class_decoder_branch"].detach().clone(),
         dec_boxes=hout["outputs_coord_decoder_branch"].detach().clone(),
         img_feat=img_feat.detach().clone() if tiny else _summ(img_feat, 4096),
@@ -176,12 +198,14 @@ def run_case(name, check_only=False):
         grads={k: dict(norm=float(ref_grads[k].norm()), head=ref_grads[k].reshape(-1)[:16].clone(),
                        summ=_summ(ref_grads[k], 64)) for k in GRAD_KEYS if k in ref_grads and ref_grads[k] is not None},
     )
-    if not grec:
-        fx["pred_decoder"] = pred[0]["pred_bboxes"].clone()
-        fx["pred_token"] = pred[1]["pred_bboxes"].clone()
-    else:
-        fx["pred_decoder"] = [{k: v.clone() for k, v in d.items()} for d in pred[0]["pred_bboxes"]]
-        fx["pred_token"] = [{k: v.clone() for k, v in d.items()} for d in pred[1]["pred_bboxes"]]
+    for i, key in enumerate(["pred_decoder", "pred_token"]):
+        pb = pred[i]["pred_bboxes"]
+        if pb is None:
+            fx[key] = None
+        elif not grec:
+            fx[key] = pb.clone()
+        else:
+            fx[key] = [{k: v.clone() for k, v in d.items()} for d in pb]
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     path = os.path.join(GOLDEN_DIR, name + ".pt")
     torch.save(fx, path)

@@ -216,9 +216,15 @@ def load_pipelines():
     return m
 
 
-def model_cfg(vit_type="base", num_queries=1, img_size=640, patch_size=32):
+def model_cfg(vit_type="base", num_queries=1, img_size=640, patch_size=32, branch_loss_weight=None):
     """cfg.model of configs/single/ViT-{base,large}/refcoco/refcoco_onestage.py:68-105
-    (grefcoco: num_queries=10), with pretrain=None (no checkpoint in this image)."""
+    (grefcoco: num_queries=10), with pretrain=None (no checkpoint in this image).  branch_loss_weight: the head's loss
+    branches; default = ViT-B one-stage's; {"decoder": 1.0} = *_twostage_1 / pretrian-mixed / finetune_* (e.g.
+    configs/single/ViT-large/refcoco/refcoco_twostage_1.py:98); ViT-L one-stage uses token 1.0 / distill 0.4
+    (configs/single/ViT-large/refcoco/refcoco_onestage.py:96)."""
+    import copy
+    blw = copy.deepcopy(branch_loss_weight) if branch_loss_weight is not None else \
+        {"decoder": 1.0, "balanced_distill": {"token": 2.0, "distill": 1.0}}
     return dict(
         type="MIXDETRMB",
         vis_enc=dict(type="BEIT3", img_size=img_size, patch_size=patch_size, vit_type=vit_type,
@@ -229,7 +235,7 @@ def model_cfg(vit_type="base", num_queries=1, img_size=640, patch_size=32):
                   in_channels=768 if vit_type == "base" else 1024, embed_dim=256, decoder_freeze=False,
                   num_classes=1, aux_loss=True, num_encoder_layers=6, num_decoder_layers=3,
                   only_decoder=True, text_embed_aug=False,
-                  branch_loss_weight={"decoder": 1.0, "balanced_distill": {"token": 2.0, "distill": 1.0}},
+                  branch_loss_weight=blw,
                   distill_type="hard_weighted", prepare_target_mode="score_iou_weighted",
                   share_predicthead=False, num_token_mlp_layers=1, mlp_aux_loss=False,
                   text_guided_query_generation=True, num_tgqg_layers=2),

@@ -41,9 +41,24 @@ def make_cfg(vit_type="base", num_queries=1, img_size=640, patch_size=32, max_to
                dec_layers=3, dec_ffn=2048, tgqg_layers=2, tgqg_ffn=512, num_classes=1,
                eos_coef=0.1, cost_class=1.0, cost_bbox=5.0, cost_giou=2.0,
                w_class=1.0, w_bbox=5.0, w_giou=2.0, w_decoder=1.0, w_token=2.0, w_distill=1.0,
-               **enc)
+               branches=("decoder", "balanced_distill"), **enc)
     cfg.update(over)
     return SimpleNamespace(**cfg)
+
+
+def cfg_from_branch_loss_weight(cfg, branch_loss_weight):
+    """head kwarg `branch_loss_weight` (e.g. {"decoder": 1.0} of the *_twostage_1 / pre-training configs, or ViT-L's
+    {"decoder": 1.0, "balanced_distill": {"token": 1.0, "distill": 0.4}}) -> the restatement's cfg fields."""
+    if branch_loss_weight is None:
+        return cfg
+    assert set(branch_loss_weight) <= {"decoder", "balanced_distill"} and branch_loss_weight
+    cfg.branches = tuple(k for k in ("decoder", "balanced_distill") if k in branch_loss_weight)
+    if "decoder" in branch_loss_weight:
+        cfg.w_decoder = float(branch_loss_weight["decoder"])
+    if "balanced_distill" in branch_loss_weight:
+        cfg.w_token = float(branch_loss_weight["balanced_distill"]["token"])
+        cfg.w_distill = float(branch_loss_weight["balanced_distill"]["distill"])
+    return cfg
 
 
 # ----------------------------------------------------------------------------------------
@@ -273,10 +288,14 @@ def head_forward_general(sd, cfg, img_feat, text_feat, cls_feat, text_mask, img_
                       torch.zeros_like(qe), text, qe, tpos, text_mask.bool(), return_intermediate=False)
     query_embed = g[0] + filt + qe
     tok = query_embed + cls                                               # Q5
-    # ---- token branch (:411-420), num_token_mlp_layers=1, return_intermediate=True
-    tok = _mlp(sd, p + "mlp", tok, 1)[None]                               # [1,B,nq,E]
-    tok_logits = F.linear(tok, sd[p + "class_embed_token.weight"], sd[p + "class_embed_token.bias"])
-    tok_boxes = _mlp(sd, p + "bbox_embed_token", tok, 3).sigmoid()
+    # ---- token branch (:403-420), num_token_mlp_layers=1, return_intermediate=True; skipped -- None outputs, in
+    # forward_test too -- when branch_loss_weight is {"decoder": w} alone (:403-409)
+    if tuple(cfg.branches) == ("decoder",):
+        tok_logits = tok_boxes = None
+    else:
+        tok = _mlp(sd, p + "mlp", tok, 1)[None]                           # [1,B,nq,E]
+        tok_logits = F.linear(tok, sd[p + "class_embed_token.weight"], sd[p + "class_embed_token.bias"])
+        tok_boxes = _mlp(sd, p + "bbox_embed_token", tok, 3).sigmoid()
     # ---- decoder branch (:425-428)
     hs = decoder_stack(sd, p + "transformer.decoder.", cfg.dec_layers, cfg.head_heads,
                        torch.zeros_like(query_embed), mem, query_embed, pos, masks.flatten(1),
@@ -376,19 +395,29 @@ def prepare_soft_targets(gt_bbox, dec_logits, dec_boxes, img_metas, cfg):
 
 
 def head_forward_train(sd, cfg, out, gt_bbox, img_metas, world_size=1):
-    """forward_train, branches "decoder" + "balanced_distill" (tgqs_kd_detr_head.py:456-572)."""
+    """forward_train (tgqs_kd_detr_head.py:456-572): the "decoder" (:483-487) and "balanced_distill" (:489-509) blocks
+    are independent `if`s over branch_loss_weight's keys (cfg.branches); a block that is absent leaves its term at the
+    constant 0 of :474-480 and adds no entry to the loss dict; loss_total = the sum (:571)."""
     tg, tp = prepare_soft_targets(gt_bbox, out["dec_logits"][-1], out["dec_boxes"][-1], img_metas, cfg)
-    ld = set_criterion(out["dec_logits"], out["dec_boxes"], tg, cfg, world_size)
-    loss_dgt = cfg.w_decoder * sum(ld.values())
-    w = torch.mean(torch.cat([t["weight"] for t in tp]))                    # Q8 (detached)
-    tl, tbx = out["tok_logits"][-1:], out["tok_boxes"][-1:]
-    lt = set_criterion(tl, tbx, tg, cfg, world_size)
-    loss_tgt = cfg.w_token * sum(lt.values()) * (1 - w)
-    lk = set_criterion(tl, tbx, tp, cfg, world_size)
-    loss_kd = cfg.w_distill * sum(lk.values()) * w
-    return dict(loss_dgt=loss_dgt, loss_tgt=loss_tgt, loss_kd=loss_kd, loss_distill_w=w,
-                loss_total=loss_dgt + loss_tgt + loss_kd), dict(dec=ld, tok_gt=lt, tok_kd=lk,
-                                                                targets_gt=tg, targets_pred=tp)
+    losses, detail = {}, dict(targets_gt=tg, targets_pred=tp)
+    total = torch.tensor(0.0)
+    if "decoder" in cfg.branches:
+        ld = set_criterion(out["dec_logits"], out["dec_boxes"], tg, cfg, world_size)
+        losses["loss_dgt"] = cfg.w_decoder * sum(ld.values())
+        total = total + losses["loss_dgt"]
+        detail["dec"] = ld
+    if "balanced_distill" in cfg.branches:
+        w = torch.mean(torch.cat([t["weight"] for t in tp]))                # Q8 (detached)
+        tl, tbx = out["tok_logits"][-1:], out["tok_boxes"][-1:]
+        lt = set_criterion(tl, tbx, tg, cfg, world_size)
+        losses["loss_tgt"] = cfg.w_token * sum(lt.values()) * (1 - w)
+        lk = set_criterion(tl, tbx, tp, cfg, world_size)
+        losses["loss_kd"] = cfg.w_distill * sum(lk.values()) * w
+        losses["loss_distill_w"] = w
+        total = total + losses["loss_tgt"] + losses["loss_kd"]
+        detail.update(tok_gt=lt, tok_kd=lk)
+    losses["loss_total"] = total
+    return losses, detail
 
 
 # ----------------------------------------------------------------------------------------
@@ -436,7 +465,10 @@ def model_forward(sd, cfg, img, ids, img_metas, text_attention_mask, dp_scales=N
 def forward_test(sd, cfg, img, ids, img_metas, text_attention_mask, rescale=False):
     out = model_forward(sd, cfg, img, ids, img_metas, text_attention_mask)
     grec = img_metas[0].get("target", None) is not None
-    pt = get_predictions(out["tok_logits"][-1], out["tok_boxes"][-1], img_metas, rescale, grec)
+    if out["tok_logits"] is None:          # get_predictions on a {"pred_logits": None} output (mix_detr_mb.py:128-129,162-163)
+        pt = dict(pred_bboxes=None, pred_masks=None, predict_classes=None)
+    else:
+        pt = get_predictions(out["tok_logits"][-1], out["tok_boxes"][-1], img_metas, rescale, grec)
     pd = get_predictions(out["dec_logits"][-1], out["dec_boxes"][-1], img_metas, rescale, grec)
     return [pd, pt], out
 

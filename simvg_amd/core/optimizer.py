@@ -72,7 +72,23 @@ class _RestArena:
         return all(p.data.untyped_storage().data_ptr() == base for p in ps)
 
     def gather_grads(self):
-        """autograd's per-tensor gradients -> the flat gradient buffer (parameters without a gradient: zeros)"""
+        """autograd's per-tensor gradients -> the flat gradient buffer.  A parameter whose `.grad` is None contributes
+        zeros: per-tensor Adam SKIPS such a parameter (no moment decay, no step count, no state), and the fused kernel does
+        exactly that for an element whose gradient and moments are all zero (the update is exactly zero and nothing is
+        written) -- i.e. for a parameter that NEVER receives a gradient (the token branch under branch_loss_weight=
+        {"decoder": w}, `mask_token`).  A parameter graded on some steps only would differ (its moments would decay and its
+        bias correction would use the arena's step count), so the set of graded parameters is pinned at the first step and
+        a change raises instead of silently departing from torch.optim.Adam."""
+        mask = tuple(p.grad is not None for p in self.params)
+        if getattr(self, "_graded", None) is None:
+            self._graded = mask
+        elif mask != self._graded:
+            changed = [i for i, (a, b) in enumerate(zip(mask, self._graded)) if a != b]
+            raise RuntimeError(
+                f"FlatAdam: {len(changed)} parameter(s) changed between 'has a gradient' and 'has none' after the first "
+                "step (first: index %d, shape %s).  The fused update shares one step count per flat tensor; use "
+                "optimizer_config.flat=False (per-tensor torch Adam) for models whose graded set varies"
+                % (changed[0], tuple(self.params[changed[0]].shape)))
         have = [(v, p.grad) for v, p in zip(self.grad_views, self.params) if p.grad is not None]
         if len(have) < len(self.params):
             self.flat_grad.zero_()

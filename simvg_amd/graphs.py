@@ -70,7 +70,7 @@ class training_stream:
 
 
 class _HeadStep(torch.nn.Module):
-    """enc_out, text mask, packed targets -> (loss_total, 4 logged loss terms, 4 prediction tensors[, post-processed boxes
+    """enc_out, text mask, packed targets -> (loss_total, the configured logged loss terms, 4 prediction tensors[, post-processed boxes
     and classes of both branches]); parameters = the head's.  Only `loss_total` is differentiable: the other outputs are
     detached, so the replayed backward takes one incoming gradient instead of materialising zeros for eight."""
 
@@ -87,17 +87,14 @@ class _HeadStep(torch.nn.Module):
         out = self.head.forward_fused(enc_out, B, Nv, T, self.img_metas, text_mask)
         losses, _ = self.head.loss_from_targets(out, tboxes, tlabels, tcount, nums)
         t, d = out["token_branch_output"], out["decoder_branch_output"]
-        res = (losses["loss_total"], losses["loss_dgt"].detach(), losses["loss_tgt"].detach(), losses["loss_kd"].detach(),
-               losses["loss_distill_w"].detach(), t["pred_logits"].detach(), t["pred_boxes"].detach(),
-               d["pred_logits"].detach(), d["pred_boxes"].detach())
+        logged = tuple(losses[k].detach() for k in self.head.loss_keys if k != "loss_total")
+        res = (losses["loss_total"],) + logged + (t["pred_logits"].detach(), t["pred_boxes"].detach(),
+                                                  d["pred_logits"].detach(), d["pred_boxes"].detach())
         if self.predict_fn is not None:
             with torch.no_grad():      # get_predictions of both branches rides in the forward graph (no eager launches)
                 dec, tok = self.predict_fn(out, self.img_metas)
             res = res + (dec["pred_bboxes"], dec["predict_classes"], tok["pred_bboxes"], tok["predict_classes"])
         return res
-
-
-LOSS_KEYS = ("loss_total", "loss_dgt", "loss_tgt", "loss_kd", "loss_distill_w")
 
 
 class HeadGraphs:
@@ -152,13 +149,17 @@ class HeadGraphs:
                 return None
             self.graphs[sig] = g
         outs = g(enc_out, enc_out.lp, text_mask, tboxes, tlabels, tcount, nums)
-        losses = dict(zip(LOSS_KEYS, outs[:5]))
-        output = dict(token_branch_output={"pred_logits": outs[5], "pred_boxes": outs[6]},
-                      decoder_branch_output={"pred_logits": outs[7], "pred_boxes": outs[8]})
+        keys = [k for k in self.head.loss_keys if k != "loss_total"]      # the head's configured branches (reference order)
+        n = 1 + len(keys)
+        named = dict(zip(["loss_total"] + keys, outs[:n]))
+        losses = {k: named[k] for k in self.head.loss_keys}
+        outs = outs[n:]
+        output = dict(token_branch_output={"pred_logits": outs[0], "pred_boxes": outs[1]},
+                      decoder_branch_output={"pred_logits": outs[2], "pred_boxes": outs[3]})
         preds = None
-        if len(outs) > 9:
-            preds = [dict(pred_bboxes=outs[9], pred_masks=None, predict_classes=outs[10]),
-                     dict(pred_bboxes=outs[11], pred_masks=None, predict_classes=outs[12])]
+        if len(outs) > 4:
+            preds = [dict(pred_bboxes=outs[4], pred_masks=None, predict_classes=outs[5]),
+                     dict(pred_bboxes=outs[6], pred_masks=None, predict_classes=outs[7])]
         return losses, output, preds
 
 

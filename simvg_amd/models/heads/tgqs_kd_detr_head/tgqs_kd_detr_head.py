@@ -5,8 +5,10 @@ same constructor kwargs, `forward_train` / `forward_test` / `inference`), of the
 `transformer.py:93-235` and of `core/criterion/criterion.py:62-271`, with all arithmetic in hand-written
 gfx950 kernels: 16-bit MFMA GEMMs for the B*(1+HW) memory rows, exact-fp32 MFMA GEMMs / LayerNorm / attention
 for the [B*nq, 256] query rows, and an on-device Hungarian matcher + criterion (no host round trips).
-Only the branches the reference configs execute are built ("decoder" + "balanced_distill", `hard_weighted`,
-`score_iou_weighted`, TGQG on; SURVEY.md 8(a) "dead branches").  state_dict keys match Appendix B.
+Only the branches the reference configs execute are built: `branch_loss_weight` with "decoder" and / or
+"balanced_distill" (32 configs use both; the 13 two-stage stage-1, 2 pre-training and 6 fine-tuning configs use
+{"decoder": 1.0} alone, `tgqs_kd_detr_head.py:483-509`: independent `if` blocks), `hard_weighted`,
+`score_iou_weighted`, TGQG on; SURVEY.md 8(a) "dead branches".  state_dict keys match Appendix B.
 """
 import math
 
@@ -93,7 +95,8 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
         if not only_decoder: unsupported.append("only_decoder=False")
         if not text_guided_query_generation: unsupported.append("text_guided_query_generation=False")
         if prepare_target_mode != "score_iou_weighted": unsupported.append("prepare_target_mode=" + prepare_target_mode)
-        if set(branch_loss_weight) != {"decoder", "balanced_distill"}: unsupported.append(f"branch_loss_weight={set(branch_loss_weight)}")
+        if not branch_loss_weight or not set(branch_loss_weight) <= {"decoder", "balanced_distill"}:
+            unsupported.append(f"branch_loss_weight={set(branch_loss_weight)}")
         if num_token_mlp_layers != 1 or mlp_aux_loss or share_predicthead or decoder_freeze or not aux_loss or num_classes != 1:
             unsupported.append("token-MLP / predict-head / aux options")
         if embed_dim != 256:
@@ -372,11 +375,15 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
                                          post=pre + "post_norm_layer" if last else None)
         query_embed = g.view(B, nq, E) + filt[:, None, :] + qe[None]
         tok = (query_embed + cls[:, None, :]).reshape(B * nq, E)                      # Q5
-        # ---- token branch (:411-420)
-        tok = self._lin(tok, "mlp.layers.0")
-        tok_logits = self._lin(tok, "class_embed_token").view(1, B, nq, -1)
-        tb = self._lin(self._lin(tok, "bbox_embed_token.layers.0", relu=True), "bbox_embed_token.layers.1", relu=True)
-        tok_boxes = self._lin(tb, "bbox_embed_token.layers.2").sigmoid().view(1, B, nq, 4)
+        # ---- token branch (:411-420); with branch_loss_weight == {"decoder": w} the reference skips it, in forward_test
+        # as well: the token prediction is {"pred_logits": None, "pred_boxes": None} and `token_features` the pre-MLP sum (:403-409)
+        if set(self.branch_loss_weight) == {"decoder"}:
+            tok_logits = tok_boxes = None
+        else:
+            tok = self._lin(tok, "mlp.layers.0")
+            tok_logits = self._lin(tok, "class_embed_token").view(1, B, nq, -1)
+            tb = self._lin(self._lin(tok, "bbox_embed_token.layers.0", relu=True), "bbox_embed_token.layers.1", relu=True)
+            tok_boxes = self._lin(tb, "bbox_embed_token.layers.2").sigmoid().view(1, B, nq, 4)
         # ---- decoder branch (:425-428)
         qpos_d = query_embed.reshape(B * nq, E)
         tgt = torch.zeros(B * nq, E, device=device)
@@ -397,11 +404,12 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
         dec_boxes = self._lin(db, "bbox_embed_decoder.layers.2").sigmoid()
         self._end_masks()
         return dict(
-            token_branch_output={"pred_logits": tok_logits[-1], "pred_boxes": tok_boxes[-1]},
+            token_branch_output={"pred_logits": None if tok_logits is None else tok_logits[-1],
+                                 "pred_boxes": None if tok_boxes is None else tok_boxes[-1]},
             decoder_branch_output={"pred_logits": dec_logits[-1], "pred_boxes": dec_boxes[-1]},
             outputs_class_decoder_branch=dec_logits, outputs_coord_decoder_branch=dec_boxes,
             outputs_class_token_branch=tok_logits, outputs_coord_token_branch=tok_boxes,
-            token_features=tok.view(1, B, nq, E), decoder_features=hs)
+            token_features=tok.view(1, B, nq, E) if tok_logits is not None else tok.view(B, nq, E), decoder_features=hs)
 
     # ------------------------------------------------------------------ targets + losses (:207-268, 456-572)
     def _pack_targets(self, gt_bbox, img_metas, device, return_counts=False):
@@ -460,28 +468,45 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
         tboxes, tlabels, tcount, nums = self.prepare_targets(gt_bbox, img_metas, output["outputs_class_decoder_branch"].device)
         return self.loss_from_targets(output, tboxes, tlabels, tcount, nums)
 
+    @property
+    def loss_keys(self):
+        """keys of forward_train's loss dict, in the reference's insertion order (:483-509, :571)"""
+        keys = []
+        if "decoder" in self.branch_loss_weight:
+            keys.append("loss_dgt")
+        if "balanced_distill" in self.branch_loss_weight:
+            keys += ["loss_tgt", "loss_kd", "loss_distill_w"]
+        return tuple(keys) + ("loss_total",)
+
     def loss_from_targets(self, output, tboxes, tlabels, tcount, nums):
+        """forward_train's loss composition (:483-509, :571): the "decoder" and "balanced_distill" blocks are independent;
+        a block that is not configured contributes neither a dict entry nor a gradient (with {"decoder": 1.0} alone the
+        token branch -- input_cls_proj, mlp, class_embed_token, bbox_embed_token -- receives none, as in the reference)."""
         dl, dbx = output["outputs_class_decoder_branch"], output["outputs_coord_decoder_branch"]
-        tl, tbx = output["outputs_class_token_branch"][-1:], output["outputs_coord_token_branch"][-1:]
         dl_d, dbx_d = dl.detach().contiguous(), dbx.detach().contiguous()
         m_dec = ops.match(dl_d, dbx_d, tboxes, tlabels, tcount, self.cost)
-        pboxes, plabels, pcount, pweight, scal = ops.soft_targets(dl_d[-1], dbx_d[-1], m_dec[-1], tboxes, tcount)
-        wd = scal[0:1]
         bw = self.branch_loss_weight
-        loss_dgt, t_dec = Criterion.apply(dl, dbx, m_dec, tboxes, tlabels, nums[0:1], None, 0, float(bw["decoder"]),
-                                          self.eos_coef, self.loss_w)
-        tl_d, tbx_d = tl.detach().contiguous(), tbx.detach().contiguous()
-        m_tg = ops.match(tl_d, tbx_d, tboxes, tlabels, tcount, self.cost)
-        loss_tgt, t_tg = Criterion.apply(tl, tbx, m_tg, tboxes, tlabels, nums[0:1], wd, 1,
-                                         float(bw["balanced_distill"]["token"]), self.eos_coef, self.loss_w)
-        m_kd = ops.match(tl_d, tbx_d, pboxes, plabels, pcount, self.cost)
-        loss_kd, t_kd = Criterion.apply(tl, tbx, m_kd, pboxes, plabels, nums[1:2], wd, 2,
-                                        float(bw["balanced_distill"]["distill"]), self.eos_coef, self.loss_w)
-        losses = dict(loss_dgt=loss_dgt, loss_tgt=loss_tgt, loss_kd=loss_kd, loss_distill_w=wd[0],
-                      loss_total=loss_dgt + loss_tgt + loss_kd)
-        detail = dict(match_dec=m_dec, match_tok_gt=m_tg, match_tok_kd=m_kd, terms_dec=t_dec, terms_tok_gt=t_tg,
-                      terms_tok_kd=t_kd, targets=(tboxes, tcount), targets_pred=(pboxes, pcount, pweight),
-                      device_counts=scal[1:3])
+        losses, detail, total = {}, dict(match_dec=m_dec, targets=(tboxes, tcount)), None
+        if "decoder" in bw:
+            loss_dgt, detail["terms_dec"] = Criterion.apply(dl, dbx, m_dec, tboxes, tlabels, nums[0:1], None, 0,
+                                                            float(bw["decoder"]), self.eos_coef, self.loss_w)
+            losses["loss_dgt"] = total = loss_dgt
+        if "balanced_distill" in bw:
+            tl, tbx = output["outputs_class_token_branch"][-1:], output["outputs_coord_token_branch"][-1:]
+            pboxes, plabels, pcount, pweight, scal = ops.soft_targets(dl_d[-1], dbx_d[-1], m_dec[-1], tboxes, tcount)
+            wd = scal[0:1]
+            tl_d, tbx_d = tl.detach().contiguous(), tbx.detach().contiguous()
+            m_tg = ops.match(tl_d, tbx_d, tboxes, tlabels, tcount, self.cost)
+            loss_tgt, t_tg = Criterion.apply(tl, tbx, m_tg, tboxes, tlabels, nums[0:1], wd, 1,
+                                             float(bw["balanced_distill"]["token"]), self.eos_coef, self.loss_w)
+            m_kd = ops.match(tl_d, tbx_d, pboxes, plabels, pcount, self.cost)
+            loss_kd, t_kd = Criterion.apply(tl, tbx, m_kd, pboxes, plabels, nums[1:2], wd, 2,
+                                            float(bw["balanced_distill"]["distill"]), self.eos_coef, self.loss_w)
+            losses.update(loss_tgt=loss_tgt, loss_kd=loss_kd, loss_distill_w=wd[0])
+            total = loss_tgt + loss_kd if total is None else total + loss_tgt + loss_kd
+            detail.update(match_tok_gt=m_tg, match_tok_kd=m_kd, terms_tok_gt=t_tg, terms_tok_kd=t_kd,
+                          targets_pred=(pboxes, pcount, pweight), device_counts=scal[1:3])
+        losses["loss_total"] = total
         return losses, detail
 
     # ------------------------------------------------------------------ reference entry points
