@@ -33,6 +33,10 @@ def build(force=False, verbose=True, lowp=None):
         raise ValueError("SIMVG_LOWP must be fp16 or bf16")
     suffix = "_bf16" if lowp == "bf16" else ""
     flags = FLAGS + (["-DSIMVG_LOWP_BF16"] if lowp == "bf16" else [])
+    # development variants (instrumented kernels, tools/dev): extra compiler flags into a library of their own
+    if os.environ.get("SIMVG_EXTRA_FLAGS"):
+        flags = flags + os.environ["SIMVG_EXTRA_FLAGS"].split()
+        suffix += os.environ.get("SIMVG_LIB_SUFFIX", "_dev")
     lib = os.path.join(LIBDIR, f"libsimvg_hip{suffix}.so")
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
