@@ -3,6 +3,7 @@ reference on the GPU, at training-size launches; then isolated timings of both."
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
+os.environ.setdefault("SIMVG_ATTN_STREAM", "1")
 from simvg_amd import hip_ops as ops
 
 dev = torch.device("cuda", 0)
