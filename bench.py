@@ -196,6 +196,9 @@ def main():
     ap.add_argument("--roofline-every", type=int, default=4,
                     help="bracket the gemm_nt launches with HIP events in one of every N timed steps (each event pair "
                          "costs the stream ~2 x 3 us of serialisation; N=1 times every launch of every step)")
+    ap.add_argument("--dump-params", default=None,
+                    help="after the timed steps: write {name: (sum, abs-sum, 8 sampled values)} of every parameter to this file "
+                         "(torch.save; tests compare a reduced run with an unreduced one)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -289,6 +292,15 @@ def main():
     loss_val = float(losses["loss_total"].detach())
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
     p50 = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
+    if rank == 0 and a.dump_params:
+        torch.cuda.synchronize()
+        digest = {}
+        for n, p in model.named_parameters():
+            t = p.detach().double().reshape(-1)
+            k = min(8, t.numel())          # integer arithmetic: a float32 linspace rounds past the end of a 49 M element tensor
+            idx = torch.tensor([(t.numel() - 1) * e // max(k - 1, 1) for e in range(k)], device=t.device)
+            digest[n] = (float(t.sum()), float(t.abs().sum()), t[idx].cpu(), t.numel())
+        torch.save(dict(params=digest, loss=loss_val, reducer=dict(reducer.last_stats, active=reducer.active)), a.dump_params)
     if rank != 0:
         if use_dist:
             dist.destroy_process_group()
@@ -331,6 +343,7 @@ def main():
                      "timed_steps": sampled_steps,
                      "share_of_step": round(g["ms"] / (dt * 1e3 * sampled_steps / a.steps), 4)},
     }
+    out["reducer"] = dict(reducer.last_stats, active=reducer.active) if reducer.active else {"active": False, "world": world}
     out["roofline_attn"] = {
         "kernel": f"encoder self-attention (QK^T + key-padding softmax + PV; {_lowp} MFMA 16x16x32), B={B} x {H} heads x {iso['N']} tokens x {hd}",
         "bound": "mfma", "achieved": round(iso["fwd_tf"], 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -34,6 +34,9 @@ typedef struct ihipStream_t* simvg_stream_t; /* == hipStream_t */
 
 /* ---- library ---- */
 int simvg_version(void);
+/* sha256[:32] of the csrc/ sources (+ variant flags) this library was built from; the Python binding compares it with the
+ * sources it finds beside it and refuses a stale library (simvg_amd/build.py, simvg_amd/_lib.py) */
+const char* simvg_source_hash(void);
 const char* simvg_last_error(void);
 int simvg_lowp_format(void); /* 1 = IEEE fp16, 2 = bfloat16 */
 

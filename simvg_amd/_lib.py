@@ -89,6 +89,21 @@ class SimvgHipError(RuntimeError):
     pass
 
 
+def _check_source_hash(lib):
+    """A stale library (sources edited after the build, an old .so that travelled with a snapshot) must not run silently:
+    the embedded hash has to equal the hash of csrc/ next to this file.  Development variants (SIMVG_HIP_LIB) are built with
+    extra flags that are part of their hash and are not re-derived here; SIMVG_SKIP_SOURCE_CHECK=1 disables the check."""
+    if os.environ.get("SIMVG_HIP_LIB") or os.environ.get("SIMVG_SKIP_SOURCE_CHECK") == "1":
+        return
+    if not os.path.isdir(os.path.join(_HERE, "csrc")):
+        return                                              # a binary-only installation has nothing to compare with
+    from .build import source_hash
+    built, now = lib.simvg_source_hash().decode(), source_hash()
+    if built != now:
+        raise SimvgHipError(f"{LIB_PATH} was built from other sources (library {built}, csrc/ now {now}): "
+                            "run `python -m simvg_amd.build`")
+
+
 def load():
     global _lib
     if _lib is not None:
@@ -105,6 +120,9 @@ def load():
     lib.simvg_last_error.restype = C.c_char_p
     lib.simvg_last_error.argtypes = []
     lib.simvg_version.restype = c_int
+    lib.simvg_source_hash.restype = C.c_char_p
+    lib.simvg_source_hash.argtypes = []
+    _check_source_hash(lib)
     lib.simvg_lowp_format.restype = c_int
     lib.simvg_lowp_format.argtypes = []
     lib.simvg_ln_bwd_ws_floats.restype = c_long
@@ -119,7 +137,7 @@ def lowp_format():
 
 
 def exported_symbols():
-    return sorted(_SIGS) + ["simvg_last_error", "simvg_version", "simvg_lowp_format", "simvg_ln_bwd_ws_floats"]
+    return sorted(_SIGS) + ["simvg_last_error", "simvg_version", "simvg_source_hash", "simvg_lowp_format", "simvg_ln_bwd_ws_floats"]
 
 
 def check(rc, what):

@@ -11,7 +11,13 @@ extern "C" void simvg_set_error(const char* msg) {
   g_err[sizeof(g_err) - 1] = 0;
 }
 extern "C" const char* simvg_last_error(void) { return g_err; }
-extern "C" int simvg_version(void) { return 2; }
+extern "C" int simvg_version(void) { return 3; }
+// sha256[:32] of csrc/*.hip + csrc/*.h (+ the variant's compiler flags) the library was built from (simvg_amd/build.py);
+// `simvg_amd._lib.load()` refuses a library whose hash differs from the sources next to it
+#ifndef SIMVG_SOURCE_HASH
+#define SIMVG_SOURCE_HASH "unknown"
+#endif
+extern "C" const char* simvg_source_hash(void) { return SIMVG_SOURCE_HASH; }
 
 namespace {
 // out[64][4] = D fragment of one v_mfma_f32_16x16x32_bf16 with A[i][k] = a[i*32+k], B[k][j] = b[k*16+j]

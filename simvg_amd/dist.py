@@ -34,6 +34,13 @@ class GradReducer:
         self._all_ids, self._ids_done, self._text_rows = None, False, None
         self.last_sparse_rows = 0
         self.last_late = 0          # head gradients that missed the early message in the last step (diagnostic)
+        # which branches the last step took (tests / bench line): messages sent, averaging inside the collective, ids gathered
+        # with all_gather_into_tensor, rows of the sparse text-table message
+        self.last_stats = {}
+        self._n_msgs = 0
+        # SIMVG_DIST_CHECK=1: verify every step (one host synchronisation) that all ranks hold the same gathered id list --
+        # the sparse text-row exchange is correct only then (rows are matched by position in that list)
+        self.check_ids = os.environ.get("SIMVG_DIST_CHECK") == "1"
         # RCCL averages inside the collective (ncclAvg): no separate 1/world pass over the 640 MB of gradients; gloo (CPU
         # tests) has no AVG -> SUM, then one division per message
         self._avg = dist.is_initialized() and dist.get_backend() == "nccl"
@@ -110,6 +117,7 @@ class GradReducer:
                 self._lowp.append((t, msg))
                 t = msg
             self.pending.append(dist.all_reduce(t, op=op, async_op=True))
+            self._n_msgs += 1
             if not self._avg:
                 self._scale.append(t)
 
@@ -124,9 +132,26 @@ class GradReducer:
         self._head = (grads, flat)
         self._launch(flat)
 
+    def _assert_same_ids(self, ids):
+        """every rank must hold the SAME gathered id list, in the same order: row r of the compact message belongs to
+        ids[r] on every rank.  An order-sensitive checksum is gathered from every rank and compared."""
+        w = torch.arange(1, ids.numel() + 1, device=ids.device, dtype=ids.dtype)
+        c = (ids * w).sum().reshape(1)                     # order-sensitive checksum (int64, wraps consistently)
+        if self._avg:
+            every = torch.empty(self.world, dtype=c.dtype, device=c.device)
+            dist.all_gather_into_tensor(every, c)
+        else:
+            parts = [torch.empty_like(c) for _ in range(self.world)]
+            dist.all_gather(parts, c)
+            every = torch.cat(parts)
+        if bool((every != every[0]).any()):
+            raise RuntimeError("GradReducer: the ranks hold different gathered token-id lists; the sparse text-row exchange "
+                               "would mix rows (SIMVG_DENSE_EMBED_REDUCE=1 selects the dense message)")
+
     def begin(self):
         self.pending, self._scale, self._head, self._lowp = [], [], None, []
         self._all_ids, self._ids_done, self._text_rows = None, False, None
+        self._n_msgs = 0
 
     def finish(self):
         """Call after loss.backward(): waits for every message, averages, scatters the head gradients back."""
@@ -157,6 +182,12 @@ class GradReducer:
             torch._foreach_copy_(late, [v.view_as(g) for g, v in zip(late, late_flat.split([g.numel() for g in late]))])
         if self._text_rows is not None:
             table, ids, rows = self._text_rows
+            if self.check_ids:
+                self._assert_same_ids(ids)
             table.index_copy_(0, ids, rows)
+        self.last_stats = dict(messages=self._n_msgs, avg_in_collective=bool(self._avg),
+                               ids_gathered=self._all_ids is not None, gather_into_tensor=bool(self._avg and self._all_ids is not None),
+                               sparse_rows=int(self._text_rows[1].numel()) if self._text_rows is not None else 0,
+                               message_dtype="bf16" if self.message_dtype is not None else "fp32", world=self.world)
         self.pending, self._scale, self._head, self._lowp = [], [], None, []
         self._all_ids, self._ids_done, self._text_rows = None, False, None

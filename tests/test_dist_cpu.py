@@ -56,7 +56,7 @@ def _rank_ids(rank, g, uneven):
 
 
 def _worker(rank, world, port, out, uneven=False, message=None):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SIMVG_DIST_CHECK="1")   # + the same-id-list assertion
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from simvg_amd.dist import GradReducer
     torch.manual_seed(0)

@@ -95,3 +95,44 @@ def test_two_ranks_average_to_the_single_process_gradient_on_the_global_batch():
     # rounding; a wrong normaliser or a missed message would show as O(1)
     assert errs[0][0] <= 6e-2, errs[0]
     assert sum(e for e, _ in errs) / len(errs) <= 1e-2
+
+
+def test_bench_under_torchrun_takes_the_rccl_branches_and_matches_the_unreduced_run(tmp_path):
+    """`bench.py --gpus 1` launched the way the driver launches N > 1 (torch.distributed.run, backend nccl = RCCL), with
+    SIMVG_FORCE_REDUCE=1 so that the one-rank job runs the whole exchange: ReduceOp.AVG inside the collective,
+    all_gather_into_tensor of the token ids, the sparse text-row message, the per-layer messages issued from inside the
+    backward on the training stream; SIMVG_DIST_CHECK=1 adds the same-id-list assertion.  An all-reduce over one rank is the
+    identity, so three optimizer steps must leave the same parameters as the plain single-process run (up to the
+    summation order of the weight-gradient atomics: 1e-6 of each tensor's abs-sum)."""
+    import json
+    import subprocess
+    root = os.path.dirname(HERE)
+    common = ["--steps", "3", "--warmup", "0", "--batch", "4", "--batches", "2", "--no-cpu-baseline", "--no-forward-test"]
+    env = dict(os.environ, SIMVG_FORCE_REDUCE="1", SIMVG_DIST_CHECK="1", MASTER_ADDR="127.0.0.1")
+    f_red, f_plain = str(tmp_path / "reduced.pt"), str(tmp_path / "plain.pt")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", *common, "--dump-params", f_red],
+                       capture_output=True, text=True, env=env, cwd=root, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    red = line["reducer"]
+    assert red["active"] and red["avg_in_collective"] and red["gather_into_tensor"] and red["sparse_rows"] == 4 * 20
+    assert red["messages"] >= 12 + 2 and line["n_gpus"] == 1          # 12 layer messages + head + embeddings (+ sparse rows)
+    env2 = {k: v for k, v in os.environ.items() if k not in ("SIMVG_FORCE_REDUCE", "RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", *common, "--dump-params", f_plain],
+                        capture_output=True, text=True, env=env2, cwd=root, timeout=900)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    a, b = torch.load(f_red, weights_only=False), torch.load(f_plain, weights_only=False)
+    assert not b["reducer"]["active"]
+    assert abs(a["loss"] - b["loss"]) <= 1e-3 * abs(b["loss"])
+    # Adam normalises the update: an element whose gradient is noise-sized (summation order of the weight-gradient atomics) may
+    # move by a full lr per step in either run, so samples are compared against the largest possible move (3 steps x lr 5e-4)
+    # and the tensors' abs-sums relatively
+    worst_sum = worst_val = 0.0
+    for n, (s1, a1, v1, numel) in a["params"].items():
+        s2, a2, v2, _ = b["params"][n]
+        # abs-sum: 0.2 % of the tensor, plus 5 % of its elements moving by the three steps' maximum (zero-initialised biases)
+        worst_sum = max(worst_sum, abs(a1 - a2) / (2e-3 * a2 + 0.05 * numel * 1.5e-3))
+        worst_val = max(worst_val, float((v1 - v2).abs().max()))
+    print(f"reduced vs plain after 3 steps: abs-sum difference / allowance {worst_sum:.2f}, sampled values {worst_val:.2e}")
+    assert worst_sum <= 1.0 and worst_val <= 1.6e-3, (worst_sum, worst_val)
