@@ -86,7 +86,10 @@ def test_full_size_inference_properties(vit, B, nq, grec):
         if "decoder" in k:
             assert mx <= 1e-3, (k, mx)
         else:
-            assert mean <= 1e-3 and mx <= 2e-3, (k, mx, mean)
+            # the token branch at full batch on TRAINED-SCALE weights: 99 % of the boxes within the north_star's 1e-3, the tail
+            # of the maximum over the batch (measured 1.2e-3 ... 1.25e-3) above it -- stated in README / DESIGN in these words;
+            # reference-initialised weights (what bench.py runs) stay below 7e-5 (tests/test_model_gpu.py)
+            assert p99 <= 1e-3 and mean <= 1e-3 and mx <= 2e-3, (k, mx, p99, mean)
         assert d2 <= 1e-3, (k, d2)
 
 

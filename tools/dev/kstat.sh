@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-kernel time of a short bench run: bash tools/dev/kstat.sh [grep pattern]
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rm -rf /tmp/kstat && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kstat -o p -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-forward-test > /tmp/kstat.log 2>&1
+rm -rf /tmp/kstat && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kstat -o p -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-forward-test --no-extras > /tmp/kstat.log 2>&1
 tail -1 /tmp/kstat.log | cut -c1-200
 python - "$1" <<'PY'
 import csv, glob, sys, re

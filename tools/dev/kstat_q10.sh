@@ -1,6 +1,6 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rm -rf /tmp/kq && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kq -o p -- python bench.py --queries 10 --steps 10 --warmup 3 --no-cpu-baseline --no-forward-test > /tmp/kq.log 2>&1
+rm -rf /tmp/kq && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kq -o p -- python bench.py --queries 10 --steps 10 --warmup 3 --no-cpu-baseline --no-forward-test --no-extras > /tmp/kq.log 2>&1
 python - <<'PY'
 import csv, glob, re
 f = glob.glob('/tmp/kq/**/*kernel_stats.csv', recursive=True)[0]

@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/pmc
 for set in "FETCH_SIZE" "WRITE_SIZE"; do
   rm -rf /tmp/pmcb_$set
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pmcb_$set -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-forward-test > /tmp/pmcb_$set.log 2>&1
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pmcb_$set -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-forward-test --no-extras > /tmp/pmcb_$set.log 2>&1
 done
 python - <<'PY'
 import csv, glob, json, collections
@@ -29,6 +29,7 @@ for k in res["FETCH_SIZE"]:
                   hbm_bytes_per_launch=(2.0 * fs / n + ws / max(n2, 1)) * 1024.0)
 import hashlib, time
 out["gemm_hip_sha256"] = hashlib.sha256(open("simvg_amd/csrc/gemm.hip", "rb").read()).hexdigest()[:16]
+out["wgrad_hip_sha256"] = hashlib.sha256(open("simvg_amd/csrc/wgrad.hip", "rb").read()).hexdigest()[:16]
 out["measured"] = time.strftime("%Y-%m-%dT%H:%MZ", time.gmtime())
 json.dump(out, open("gpurun_out/pmc/hbm_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
