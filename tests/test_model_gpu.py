@@ -115,9 +115,9 @@ def test_forward_train_matches_reference(golden, name):
     model.zero_grad(set_to_none=True)
     losses["loss_total"].backward()
     params = dict(model.named_parameters())
-    # fp16 build, EVERY fixture (harsh weights included): per-tensor direction cosine >= 0.99, relative L2 on the 64 sampled
-    # entries <= 1.2e-1, norm within 3e-2.  Measured worst over all parameters: cosine 0.9964 / L2 8.6e-2 (large_nq1), norm 1.9e-2
-    # (tiny_nq10_grec; <= 6.2e-3 on the reference geometries); reference-init fixtures cosine >= 0.9994, norm <= 2.4e-3.
+    # fp16 build, EVERY fixture (harsh weights included): per-tensor direction cosine >= 0.995, relative L2 on the 64 sampled
+    # entries <= 1.0e-1, norm within 1e-2 (2.5e-2 on the tiny geometry); reference-init fixtures: cosine >= 0.999, L2 <= 5e-2,
+    # norm <= 4e-3.  Measured worst cases are printed below and quoted at the assertion.
     # bf16 build: reference-init fixtures as above with L2 1.5e-1 / norm 6e-2; on the harsh fixtures its 1e-2 box deviations flip
     # pieces of the piecewise-smooth box losses (L1 sign, GIoU max/min, assignment near-ties), so only direction (cosine >= 0.85)
     # and magnitude (20 %) are checked there.
@@ -137,7 +137,13 @@ def test_forward_train_matches_reference(golden, name):
             cos = float((got * ref["vals"]).sum() / (got.norm() * ref["vals"].norm() + 1e-20))
         worst = [max(worst[0], e), min(worst[1], cos), max(worst[2], en)]
         if _fp16():
-            ok = e <= 1.2e-1 and cos >= 0.99 and en <= 3e-2
+            # asserted = measured worst case over all fixtures (round 3: cosine 0.99637 and L2 8.6e-2 on large_nq1, norm 2.0e-2
+            # on tiny_nq10_grec, <= 6.8e-3 on the reference geometries; reference-initialised fixtures: 0.99942 / 3.7e-2 / 2.4e-3)
+            # plus a margin for the run-to-run summation order of the weight-gradient atomics
+            if strict:
+                ok = e <= 5e-2 and cos >= 0.999 and en <= 4e-3
+            else:
+                ok = e <= 1.0e-1 and cos >= 0.995 and en <= (2.5e-2 if fx["vit"] == "tiny" else 1e-2)
         else:
             ok = (e <= 1.5e-1 and cos >= 0.99 and en <= 6e-2) if strict else (cos >= 0.85 and en <= 0.20)
         if not ok:
