@@ -242,6 +242,18 @@ int simvg_probe_mfma(const void* a_lp, const void* b_lp, float* out, simvg_strea
 int simvg_probe_tr16(const int* byte_addr, void* out_i16, simvg_stream_t stream);
 int simvg_probe_glds(const void* src_i16, const int* perm, void* out_i16, simvg_stream_t stream);
 
+/* ---- random multipliers of the training step (csrc/rng.hip) ---------------------------------------------------------------
+ * Dropout / DropPath multipliers (0 or 1 / keep) from Philox4x32-10, element i a pure function of (seed, offset, i).
+ * Replaces torchscale DropPath (reference beit3_base.py:146-151: per-sample Bernoulli(1 - p) / (1 - p)) and the nn.Dropout /
+ * attention-dropout draws of the DETR decoder layers (heads/tgqs_kd_detr_head/transformer.py:106-125).  keep_seg != NULL: device
+ * table of keep probabilities, element i uses keep_seg[i / seg] (one DropPath rate per encoder layer).  state != NULL: two
+ * device words {epoch, ticket}, zero-initialised by the caller and owned by one stream; the epoch enters the counter and is
+ * incremented by the launch itself -- for launches recorded into a hipGraph, whose scalar arguments are frozen. */
+int simvg_dropout_mult(float* out, long n, float keep, const float* keep_seg, long seg, unsigned long long seed,
+                       unsigned long long offset, unsigned long long* state, simvg_stream_t stream);
+/* the same generator evaluated on the host: out[4] = Philox4x32-10(ctr[4], key[2]) (known-answer tests) */
+int simvg_philox4x32(const unsigned* ctr, const unsigned* key, unsigned* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,18 @@ __device__ __forceinline__ lpx8_t pack8(const float* lo, const float* hi) {
   return r.v;
 }
 
+// The backward kernels are VALU-issue-bound (a wave64 VALU instruction holds its SIMD's issue port for 4 cycles: 930 VALU against
+// 164 MFMAs per 16-query strip of dQ, profiles/r03_sweeps.md): the per-score arithmetic  ds = exp2(s c - lse) (dp - delta)  is
+// written on pairs so that hipcc emits v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 (same IEEE operations, half the instructions)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void ds_pair(float s0, float s1, f32x2_t c, f32x2_t nl, float dp0, float dp1, f32x2_t dl, float& p0,
+                                        float& p1, float& ds0, float& ds1) {
+  const f32x2_t t = __builtin_elementwise_fma((f32x2_t){s0, s1}, c, nl);
+  const f32x2_t p = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+  const f32x2_t d = p * ((f32x2_t){dp0, dp1} - dl);
+  p0 = p[0]; p1 = p[1]; ds0 = d[0]; ds1 = d[1];
+}
+
 __device__ __forceinline__ void fill_key_bias(const AttnArgs& a, int b, int N, int npad, float* bias) {
   for (int k = threadIdx.x; k < npad; k += blockDim.x) {
     bool masked = k >= N;
@@ -423,14 +435,16 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_dq_t_kernel(AttnArgs a) {
       dp = mfma_lp(cva, d0, dp);
       sa = mfma_lp(ckb, q1, sa);
       dp = mfma_lp(cvb, d1, dp);
-      float ds[4];
+      float ds[4], pu[4];
+      const f32x2_t c2 = {sc2, sc2}, dl2 = {dl, dl};
       if (kt >= KFULL) {
         const f32x4_t kb = *(const f32x4_t*)(bias + kt * 16 + 4 * g);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ds[r] = __builtin_amdgcn_exp2f(fmaf(sa[r], sc2, kb[r] + nlse2)) * (dp[r] - dl);
+        ds_pair(sa[0], sa[1], c2, (f32x2_t){kb[0] + nlse2, kb[1] + nlse2}, dp[0], dp[1], dl2, pu[0], pu[1], ds[0], ds[1]);
+        ds_pair(sa[2], sa[3], c2, (f32x2_t){kb[2] + nlse2, kb[3] + nlse2}, dp[2], dp[3], dl2, pu[2], pu[3], ds[2], ds[3]);
       } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ds[r] = __builtin_amdgcn_exp2f(fmaf(sa[r], sc2, nlse2)) * (dp[r] - dl);
+        const f32x2_t nl2 = {nlse2, nlse2};
+        ds_pair(sa[0], sa[1], c2, nl2, dp[0], dp[1], dl2, pu[0], pu[1], ds[0], ds[1]);
+        ds_pair(sa[2], sa[3], c2, nl2, dp[2], dp[3], dl2, pu[2], pu[3], ds[2], ds[3]);
       }
       dsb[kt] = (u32x2_t){pack_lp2(ds[0], ds[1]), pack_lp2(ds[2], ds[3])};
       __builtin_amdgcn_sched_barrier(0);
@@ -603,12 +617,11 @@ __device__ __forceinline__ void dkv_strip(const char* ldsQ, const char* ldsDO, c
       dp = mfma_lp(dc[hh][1], v1, dp);
       const f32x4_t l4 = *(const f32x4_t*)(nlse_s + qt * 16 + 4 * g);
       const f32x4_t d4 = *(const f32x4_t*)(dl_s + qt * 16 + 4 * g);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float pr = __builtin_amdgcn_exp2f(fmaf(sa[r], sc2, MASKED ? l4[r] + kbias : l4[r]));
-        p[hh][r] = pr;
-        ds[hh][r] = pr * (dp[r] - d4[r]);
-      }
+      const f32x2_t c2 = {sc2, sc2};
+      ds_pair(sa[0], sa[1], c2, (f32x2_t){MASKED ? l4[0] + kbias : l4[0], MASKED ? l4[1] + kbias : l4[1]}, dp[0], dp[1],
+              (f32x2_t){d4[0], d4[1]}, p[hh][0], p[hh][1], ds[hh][0], ds[hh][1]);
+      ds_pair(sa[2], sa[3], c2, (f32x2_t){MASKED ? l4[2] + kbias : l4[2], MASKED ? l4[3] + kbias : l4[3]}, dp[2], dp[3],
+              (f32x2_t){d4[2], d4[3]}, p[hh][2], p[hh][3], ds[hh][2], ds[hh][3]);
     }
     union { lpx8_t v; unsigned int u[4]; } pf;
     pf.u[0] = pack_lp2_raw(p[0][0], p[0][1]); pf.u[1] = pack_lp2_raw(p[0][2], p[0][3]);

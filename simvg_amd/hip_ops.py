@@ -283,6 +283,37 @@ def ln_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, split=0, dx_lp=None, gelu_u=
     _lib.check(rc, "simvg_ln_bwd")
 
 
+def _philox_key():
+    """A fresh 64-bit Philox key per call from torch's default CPU generator (a host-side draw, no device launch): `torch.manual_seed`
+    / `set_random_seed` make the masks reproducible and ranks seeded differently draw different masks, exactly as with the
+    framework's own dropout."""
+    hi, lo = torch.randint(0, 1 << 31, (2,)).tolist()
+    return (hi << 31) | lo
+
+
+_philox_epochs = {}
+
+
+def dropout_mult(n, device, keep=None, keep_seg=None, seg=0, out=None):
+    """n multipliers, 0 or 1 / keep (csrc/rng.hip, Philox4x32-10).  keep: scalar keep probability; keep_seg: device tensor of
+    keep probabilities, element i uses keep_seg[i // seg].  While the current stream is being captured into a hipGraph the
+    launch gets a device-side epoch (one per device, owned by the training stream), so replays draw fresh multipliers."""
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty(n, device=device, dtype=torch.float32)
+    state = None
+    if torch.cuda.is_current_stream_capturing():
+        state = _philox_epochs.get(out.device)
+        if state is None:
+            raise RuntimeError("dropout_mult: first call on this device happens inside a graph capture; run one eager step first")
+    elif out.device not in _philox_epochs:
+        _philox_epochs[out.device] = torch.zeros(2, device=out.device, dtype=torch.int64)
+    rc = lib.simvg_dropout_mult(_p(out), n, float(keep if keep is not None else 1.0), _p(keep_seg), int(seg), _philox_key(), 0,
+                                _p(state), _stream())
+    _lib.check(rc, "simvg_dropout_mult")
+    return out
+
+
 def attn_fwd(qkv, B, H, Nv, Nt, pad=None, out=None, scale=None):
     """qkv: [M, 3*D] lp, modality-major rows.  Returns (out [M,D] lp, lse [B*H, N] fp32)."""
     lib = _lib.load()

@@ -254,11 +254,7 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
                 o = st["off"].get(p, 0)
                 st["off"][p] = o + n_al
                 return buf[o:o + n].view(shape)
-        key = ("ones", str(device), n)
-        ones = self._const.get(key)
-        if ones is None:
-            ones = self._const[key] = torch.ones(n, device=device)
-        return F.dropout(ones, p, True).view(shape)
+        return ops.dropout_mult(n, device, keep=1.0 - p).view(shape)
 
     def _begin_masks(self, key, device):
         if not self.training:
@@ -267,20 +263,13 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
         plan = self._mask_plan.get(key, {})
         bufs = {}
         for p, total in plan.items():
-            ck = ("ones", str(device), total)
-            ones = self._const.get(ck)
-            if ones is None:
-                ones = self._const[ck] = torch.ones(total, device=device)
-            bufs[p] = F.dropout(ones, p, True)
+            bufs[p] = ops.dropout_mult(total, device, keep=1.0 - p)       # csrc/rng.hip: one launch for all sites of the step
         self._mask_state = dict(key=key, need={}, off={}, buf=bufs)
 
     def _end_masks(self):
         st, self._mask_state = self._mask_state, None
         if st is not None and len(self._mask_plan) < 64:
             self._mask_plan[st["key"]] = dict(st["need"])
-
-    def _dropout(self, x):
-        return F.dropout(x, self.ffn_dropout, self.training) if self.training and self.ffn_dropout > 0 else x
 
     _LAYER_KEYS = ("attentions.0.attn.in_proj_weight", "attentions.0.attn.in_proj_bias", "attentions.0.attn.out_proj.weight",
                    "attentions.0.attn.out_proj.bias", "norms.0.weight", "norms.0.bias",

@@ -479,13 +479,13 @@ class BEIT3(nn.Module):
     def _drop_path_scales(self, B, device):
         if not self.training or all(p == 0.0 for p in self.drop_path_probs):
             return None
-        # two independent draws per layer (beit3_base.py:148-149,166-167); all layers' masks come from ONE Bernoulli
-        # launch over a [L, 2, B] tensor of per-layer keep probabilities plus one scaling launch
+        # two independent draws per layer (beit3_base.py:148-149,166-167); all layers' multipliers come from ONE launch of the
+        # Philox kernel over a [L, 2, B] table with one keep probability per layer
         keep = getattr(self, "_dp_keep", None)
         if keep is None or keep.device != device:
             keep = self._dp_keep = torch.tensor([1.0 - p for p in self.drop_path_probs], dtype=torch.float32).to(device)
-        k3 = keep[:, None, None].expand(len(self.drop_path_probs), 2, B)
-        m = torch.bernoulli(k3) / k3
+        L = len(self.drop_path_probs)
+        m = ops.dropout_mult(L * 2 * B, device, keep_seg=keep, seg=2 * B).view(L, 2, B)     # csrc/rng.hip: Bernoulli(keep) / keep
         return [(None, None) if p == 0.0 else (m[i, 0], m[i, 1]) for i, p in enumerate(self.drop_path_probs)]
 
     def encode(self, image, question, padding_mask=None, dp_scales=None):

@@ -54,3 +54,18 @@ def test_product_refuses_cpu_tensors():
     from simvg_amd import hip_ops, _lib
     with pytest.raises(_lib.SimvgHipError):
         hip_ops.gemm_nt(torch.zeros(4, 64, dtype=hip_ops.LP()), torch.zeros(4, 64, dtype=hip_ops.LP()))
+
+
+def test_philox_known_answers():
+    """csrc/rng.hip evaluates Philox4x32-10 on the host through the same inline function the kernel uses: the three
+    known-answer vectors of the Random123 distribution (kat_vectors: philox4x32 10)."""
+    import ctypes as C
+    from simvg_amd import _lib
+    lib = _lib.load()
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        c, k, o = (C.c_uint * 4)(*ctr), (C.c_uint * 2)(*key), (C.c_uint * 4)()
+        assert lib.simvg_philox4x32(c, k, o) == 0
+        assert tuple(o) == want, (ctr, [hex(x) for x in o])

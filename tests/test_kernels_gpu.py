@@ -488,3 +488,39 @@ def test_weight_prep():
             assert torch.equal(dst, m.to(LPD()))
         if dst_t is not None:
             assert torch.equal(dst_t, m.t().contiguous().to(LPD()))
+
+
+def test_dropout_multipliers_philox():
+    """csrc/rng.hip: multipliers are 0 or 1 / keep with the right frequency, a pure function of (key, index) -- the key of
+    every call is drawn from torch's CPU generator, so `torch.manual_seed` reproduces the sequence of masks -- and the
+    per-segment table gives every encoder layer its own DropPath rate (torchscale DropPath: Bernoulli(1 - p) / (1 - p))."""
+    ops = _ops()
+    torch.manual_seed(77)
+    n = 1 << 20
+    a = ops.dropout_mult(n, DEV, keep=0.9)
+    b = ops.dropout_mult(n, DEV, keep=0.9)
+    torch.manual_seed(77)
+    a2 = ops.dropout_mult(n, DEV, keep=0.9)
+    b2 = ops.dropout_mult(n + 3, DEV, keep=0.9)            # a ragged length: the shared prefix is the same stream
+    assert torch.equal(a, a2) and torch.equal(b, b2[:n]) and not torch.equal(a, b)
+    vals = torch.unique(a)
+    assert vals.numel() == 2 and float(vals[0]) == 0.0 and abs(float(vals[1]) - 1 / 0.9) < 1e-6
+    frac = float((a > 0).float().mean())
+    assert abs(frac - 0.9) < 4 * (0.9 * 0.1 / n) ** 0.5 + 1e-4, frac                    # 4 sigma
+    assert abs(float(a.mean()) - 1.0) < 2e-3                                           # unbiased
+    # no correlation between neighbours / between the four words of a counter
+    k = (a > 0).float()
+    for lag in (1, 2, 3, 4, 64):
+        c = float(((k[:-lag] - 0.9) * (k[lag:] - 0.9)).mean()) / (0.9 * 0.1)
+        assert abs(c) < 6e-3, (lag, c)
+    # DropPath table: L layers x 2 draws x B samples, one keep probability per layer
+    L, B = 12, 4096
+    keep = torch.linspace(1.0, 0.9, L).to(DEV)
+    m = ops.dropout_mult(L * 2 * B, DEV, keep_seg=keep, seg=2 * B).view(L, 2 * B)
+    assert bool((m[0] == 1.0).all())                                                     # keep = 1: never dropped
+    for i in range(1, L):
+        kp = float(keep[i])
+        f = float((m[i] > 0).float().mean())
+        assert abs(f - kp) < 4 * (kp * (1 - kp) / (2 * B)) ** 0.5 + 1e-3, (i, f, kp)
+        nz = m[i][m[i] > 0]
+        assert abs(float(nz[0]) - 1 / kp) < 1e-5
