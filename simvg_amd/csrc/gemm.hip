@@ -497,6 +497,221 @@ __global__ __launch_bounds__(1024) void gemm_nt_kernel_256sq_w16(GemmNTArgs a) {
 }
 
 
+// ------------------------------------------------------------------------------------------
+// PERSISTENT form of the 256x256x64 / 16-wave kernel for 16-bit outputs with a plain (+bias) epilogue -- QKV, fc1, the dgrad
+// of fc2: launches whose 16-bit output is as large as their operands.  One workgroup per CU walks tiles v, v + G, v + 2G ...
+// (same XCD-contiguous order as the hardware dispatch of the one-tile kernel) and never drains its stores:
+//   * k-tile 0 of the NEXT tile is put in flight under the last MFMAs of this one, so the next tile starts warm (issuing
+//     k-tile 1 as well needs a barrier before the epilogue -- every wave must have left the ring's other stage -- and
+//     measured 2 % slower: without it the early waves of a SIMD convert and store while the late ones still own the MFMA pipe);
+//   * the epilogue stages through a 32 KiB region of its own (2 KiB per wave, 16-bit, XOR-swizzled) -- the ring stays
+//     loadable -- and its 8 stores per wave are left in flight: CDNA4 counts stores in vmcnt, in order with the loads, so the
+//     next tile's wait for its first k-tile is counted PAST them (FIFO of a wave at the top of a tile, oldest first:
+//     L0 B S -> vmcnt(8); at k-tile 1: S L1 -> vmcnt(0)): the stores have the epilogue plus one MFMA interval to retire;
+//   * the bias (B: 4 loads, not tracked by the compiler) is the accumulators' initial value, so the epilogue reads no global memory;
+//   * a tile with rows beyond the row group masks stores per lane, which the compiler may branch around: such a tile ends with
+//     vmcnt(0) (an uncounted store would make the next waits too permissive).
+// ------------------------------------------------------------------------------------------
+constexpr int PQ_STAGE = (256 + BNQ) * BK * 2;     // 64 KiB
+constexpr int PQ_STG = 2 * PQ_STAGE;                // staging: wave w owns [PQ_STG + 2048 w, +2048)
+constexpr int PQ_SMEM = PQ_STG + 16 * 2048;         // 160 KiB
+constexpr int PQ_NS = 8;                            // stores per wave and tile
+
+struct PQTile { int row0, row_end, n0, group; };
+
+__device__ __forceinline__ PQTile pq_decode(const GemmNTArgs& a, int v, int ntot, int tiles_n, int tm0) {
+  const int bid = xcd_remap(v, ntot);
+  int tm, tn;
+  tile_order(bid, ntot / tiles_n, tiles_n, a.gn, tm, tn);
+  PQTile t;
+  t.group = tm >= tm0;
+  t.row0 = t.group ? a.split + (tm - tm0) * 256 : tm * 256;
+  t.row_end = t.group ? a.M : a.split;
+  t.n0 = tn * BNQ;
+  return t;
+}
+
+template <int N_> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
+template <int N_> __device__ __forceinline__ void lgkm_wait() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N_) : "memory");
+  __builtin_amdgcn_sched_barrier(0);         // register-only instructions (MFMA, packs) must not be hoisted above the wait
+}
+// a load the compiler does not track (its own wait before the first use would be vmcnt(0) across the loop's back edge): the
+// caller waits with a counted vmcnt and pins the registers afterwards
+__device__ __forceinline__ f32x4_t gload_x4_untracked(const float* p) {
+  f32x4_t v;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void lds_write_b64_asm(unsigned addr, u32x2_t v) {
+  asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ lpx8_t as_frag(u32x4_t v) { return __builtin_bit_cast(lpx8_t, v); }
+
+// All LDS traffic of this kernel is inline asm (common.h: hipcc drains vmcnt in front of compiler-visible LDS accesses that
+// follow a buffer-form LDS-DMA), all DMA addressing is (SGPR descriptor of the tile) + (4 loop-invariant lane offsets).
+#ifdef SIMVG_PQ_PROFILE
+#define PQ_T(k_) do { if (prof && wave == 0 && lane == 0 && tix < 8) prof[((long)blockIdx.x * 8 + tix) * 8 + (k_)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PQ_T(k_) do { } while (0)
+#endif
+__global__ __launch_bounds__(1024) void gemm_nt_kernel_256sq_p(GemmNTArgs a, int ntot, unsigned long long* prof) {
+  constexpr int MI = 4;
+  int tix = 0;
+  (void)tix; (void)prof;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;   // 4 x 4 waves
+  const int tiles_n = a.N / BNQ;
+  const int tm0 = (a.split + 255) / 256;
+  const int nk = a.K / BK;                   // even, >= 2 (launcher)
+  // LDS-DMA: piece p = 2 wave + i holds rows 8 p .. 8 p + 7 of an operand's 256 x 64 k-tile, lane -> row 8 p + (lane >> 3),
+  // 16-B slot (lane & 7) ^ (row & 7) of the row (the XOR is on the SOURCE address: the LDS image is lane-linear)
+  const int din = lane >> 3, dslot = (lane & 7) ^ din;
+  int voffA[2], voffW[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    voffA[i] = ((wave * 2 + i) * 8 + din) * a.lda * 2 + dslot * 16;
+    voffW[i] = ((wave * 2 + i) * 8 + din) * a.ldw * 2 + dslot * 16;
+  }
+  // fragment reads: row (lane & 15) of a 16-row block, slot (4 s + (lane >> 4)) ^ (row & 7)
+  const int c0 = (lane >> 4) ^ (lane & 7);
+  const unsigned fA0 = lds_addr(smem) + (wm * 64 + (lane & 15)) * 128 + c0 * 16, fA1 = fA0 ^ 64;
+  const unsigned fB0 = lds_addr(smem) + 256 * BK * 2 + (wn * 64 + (lane & 15)) * 128 + c0 * 16, fB1 = fB0 ^ 64;
+
+  struct Desc { __amdgpu_buffer_rsrc_t A, W; const float* bias; };
+  auto make_desc = [&](const PQTile& t) {
+    Desc d;
+    d.A = __builtin_amdgcn_make_buffer_rsrc((void*)(a.A + (long)t.row0 * a.lda), 0, (int)((long)(t.row_end - t.row0) * a.lda * 2), 0x00020000);
+    d.W = __builtin_amdgcn_make_buffer_rsrc((void*)(a.W + (long)t.group * a.w_gstride + (long)t.n0 * a.ldw), 0, BNQ * a.ldw * 2, 0x00020000);
+    d.bias = a.bias ? a.bias + (long)t.group * a.bias_gstride + t.n0 : nullptr;
+    return d;
+  };
+  auto issue = [&](const Desc& d, int kt, int st) {
+    char* sA = smem + st * PQ_STAGE + wave * 2048;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(d.A, LDS_PTR(sA + i * 1024), 16, voffA[i], kt * (BK * 2), 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(d.W, LDS_PTR(sA + 256 * BK * 2 + i * 1024), 16, voffW[i], kt * (BK * 2), 0, 0);
+  };
+  // the bias enters as the accumulators' initial value: bn[j] = bias of columns n0 + wn * 64 + j * 16 + 4 (lane >> 4) .. + 3
+  f32x4_t bn[4];
+  auto load_bias = [&](const Desc& d) {
+    if (d.bias) {
+      const float* bp = d.bias + wn * 64 + 4 * (lane >> 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bn[j] = gload_x4_untracked(bp + j * 16);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bn[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+
+  int v = blockIdx.x;
+  PQTile cur = pq_decode(a, v, ntot, tiles_n, tm0);
+  Desc dcur = make_desc(cur);
+  issue(dcur, 0, 0);
+  issue(dcur, 1, 1);
+  load_bias(dcur);
+  bool pend = false;                         // PQ_NS stores of the previous tile are the youngest entries of this wave's FIFO
+  bool first = true;
+  for (;;) {
+    const int vn = v + (int)gridDim.x;
+    const bool has_next = vn < ntot;
+    PQTile nxt = cur;
+    if (has_next) nxt = pq_decode(a, vn, ntot, tiles_n, tm0);
+    const Desc dnxt = make_desc(nxt);
+    // FIFO, oldest first: L0 [L1] B [S] (L1: first tile only): everything but the stores has to be here
+    PQ_T(0);
+    if (pend) vm_wait<PQ_NS>(); else vm_wait<0>();
+    PQ_T(1);
+    asm volatile("" : "+v"(bn[0]), "+v"(bn[1]), "+v"(bn[2]), "+v"(bn[3]));
+    f32x4_t acc[MI][4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[i][j] = bn[j];
+        asm volatile("" : "+v"(acc[i][j]));   // copies now: bn's registers are free during the main loop
+      }
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt == 1) PQ_T(2);
+      if (kt >= 1) vm_wait<0>();             // k-tile 0: waited for above;  k-tile 1: FIFO = [S] L1, the stores have to be through
+      if (kt == 1) PQ_T(3);
+      __builtin_amdgcn_s_barrier();          // k-tile kt has landed for everyone, everyone is past the MFMAs of kt - 1
+      if (kt >= 1 || !first) {               // (the first tile's k-tile 1 was issued by the prologue)
+        if (kt + 1 < nk) issue(dcur, kt + 1, (kt + 1) & 1);
+        else if (has_next) issue(dnxt, 0, 0);
+      }
+      const unsigned so = (kt & 1) * PQ_STAGE;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const unsigned pa = (s ? fA1 : fA0) + so, pb = (s ? fB1 : fB0) + so;
+        u32x4_t fb[4], fa[2];
+        fb[0] = lds_b128_asm<0>(pb); fb[1] = lds_b128_asm<2048>(pb); fb[2] = lds_b128_asm<4096>(pb); fb[3] = lds_b128_asm<6144>(pb);
+        fa[0] = lds_b128_asm<0>(pa);
+        fa[1] = lds_b128_asm<2048>(pa);
+        lgkm_wait<1>();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[0][j] = mfma_lp(as_frag(fb[j]), as_frag(fa[0]), acc[0][j]);
+        __builtin_amdgcn_sched_barrier(0);
+        fa[0] = lds_b128_asm<4096>(pa);
+        lgkm_wait<1>();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[1][j] = mfma_lp(as_frag(fb[j]), as_frag(fa[1]), acc[1][j]);
+        __builtin_amdgcn_sched_barrier(0);
+        fa[1] = lds_b128_asm<6144>(pa);
+        lgkm_wait<1>();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[2][j] = mfma_lp(as_frag(fb[j]), as_frag(fa[0]), acc[2][j]);
+        lgkm_wait<0>();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[3][j] = mfma_lp(as_frag(fb[j]), as_frag(fa[1]), acc[3][j]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    PQ_T(4);
+    if (has_next) load_bias(dnxt);
+    PQ_T(5);
+    // ---- epilogue of `cur`: 16 bit -> wave-private staging -> row-wise 16-B stores, left in flight
+    {
+      const unsigned stg = lds_addr(smem) + PQ_STG + wave * 2048;
+      const int er = lane & 15, ecg = lane >> 4;         // accumulator layout: row er, columns 4 ecg .. + 3 of each 16 x 16 block
+      const int rr = lane >> 3, rq = lane & 7;           // read-out layout: rows rr and rr + 8, 16-B chunk rq
+      lp_t* cp = (lp_t*)a.C + (long)(cur.row0 + wm * 64 + rr) * a.ldc + cur.n0 + wn * 64 + rq * 8;
+      const int mleft = cur.row_end - (cur.row0 + wm * 64 + rr);
+      // 8-B chunk j * 4 + ecg of row er is stored at chunk ^ er (the 16 rows of a store's lane group hit 16 different banks);
+      // the 16-B chunk rq of row r is then found at chunk rq ^ (r >> 1), its halves swapped for odd r
+      const unsigned wa = stg + er * 128, ra = stg + rr * 128 + ((rq ^ (rr >> 1)) << 4);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4_t x = acc[i][j];
+          lds_write_b64_asm(wa + (((j * 4 + ecg) ^ er) << 3), (u32x2_t){pack_lp2(x[0], x[1]), pack_lp2(x[2], x[3])});
+        }
+        lgkm_wait<0>();                                  // wave-private slice: only this wave's writes matter
+        u32x4_t d0 = lds_b128_asm<0>(ra);
+        u32x4_t d1 = lds_b128_asm<0>(ra ^ 1088);         // row + 8: offset 1024, chunk ^ 4
+        lgkm_wait<0>();                                  // (also: the next pass overwrites the slice)
+        if (rr & 1) { d0 = (u32x4_t){d0[2], d0[3], d0[0], d0[1]}; d1 = (u32x4_t){d1[2], d1[3], d1[0], d1[1]}; }
+        if (i * 16 < mleft) *(u32x4_t*)(cp + (long)(i * 16) * a.ldc) = d0;
+        if (i * 16 + 8 < mleft) *(u32x4_t*)(cp + (long)(i * 16 + 8) * a.ldc) = d1;
+      }
+    }
+    PQ_T(6);
+    ++tix;
+    pend = true;
+    if (cur.row0 + 256 > cur.row_end) { vm_wait<0>(); pend = false; }    // lane-masked stores are not countable
+    if (!has_next) break;
+    cur = nxt;
+    dcur = dnxt;
+    v = vn;
+    first = false;
+  }
+}
+
 // 160x256x64 tile with sixteen waves: 2 (M) x 8 (N), each 80x32 = acc[5][2] -- the 16-wave layout for the N = 768 problems
 // (160 rows do not split over 4 M-waves).  7 fragment reads per 10 MFMAs (8-wave layout: 9 per 20).
 // THREE-stage LDS ring (3 x 52 KiB = 156 KiB, the double buffer left 54 KiB of the CU's LDS unused): the
@@ -990,6 +1205,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const lp_t* Y, int ldy, flo
 
 }  // namespace
 
+// the persistent 256x256 kernel: 16-bit output, bias-only epilogue, an even number of k-tiles
+static bool persist_ok(const GemmNTArgs& a) {
+  static const bool off = getenv("SIMVG_GEMM_PERSIST") && atoi(getenv("SIMVG_GEMM_PERSIST")) == 0;
+  return !off && !a.c_f32 && !a.aux && !a.res && !a.row_scale && a.act == 0 && a.alpha == 1.f && (a.K / BK) % 2 == 0 && a.ldc % 8 == 0;
+}
+
 extern "C" int simvg_gemm_nt(const void* A, int lda, const void* W, long w_gstride, int ldw,
                              const float* bias, int bias_gstride, void* C, int ldc, int c_is_f32,
                              void* aux_preact, int ldaux, const float* residual, int ldres,
@@ -1024,6 +1245,13 @@ extern "C" int simvg_gemm_nt(const void* A, int lda, const void* W, long w_gstri
     static bool oncel = hipFuncSetAttribute((const void*)gemm_nt_kernel_lat<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * LAT_STAGE) == hipSuccess;
     (void)oncel;
     hipLaunchKernelGGL(gemm_nt_kernel_lat<3>, dim3((int)tiles64), dim3(256), 3 * LAT_STAGE, stream, a);
+  } else if (wide_ok && tile_cost(256) <= tile_cost(160) && persist_ok(a)) {
+    static bool oncep = hipFuncSetAttribute((const void*)gemm_nt_kernel_256sq_p, hipFuncAttributeMaxDynamicSharedMemorySize, PQ_SMEM) == hipSuccess;
+    (void)oncep;
+    const int tiles = (cdiv(split, 256) + cdiv(M - split, 256)) * cdiv(N, BNQ);
+    static const int cus = [] { int dev = 0, n = 256; hipGetDevice(&dev); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n & ~7; }();
+    static unsigned long long* prof = getenv("SIMVG_PQ_PROF_PTR") ? (unsigned long long*)strtoull(getenv("SIMVG_PQ_PROF_PTR"), nullptr, 0) : nullptr;
+    hipLaunchKernelGGL(gemm_nt_kernel_256sq_p, dim3(tiles < cus ? tiles : cus), dim3(1024), PQ_SMEM, stream, a, tiles, prof);
   } else if (wide_ok && tile_cost(256) <= tile_cost(160)) {
     constexpr int SMW = 160 * 1024;      // ring 128 KiB; the 16-wave epilogue staging needs 136 KiB
     static bool oncew = hipFuncSetAttribute((const void*)gemm_nt_kernel_256sq_w16, hipFuncAttributeMaxDynamicSharedMemorySize, SMW) == hipSuccess;

@@ -120,9 +120,10 @@ def test_probe_glds_lane_linear():
                                          (1684, 3072, 768, 1604), (640, 768, 3072, 512),
                                          (2370, 2304, 768, 2100), (2112, 3072, 128, 0),     # 256x256 tile path
                                          (2306, 4096, 64, 2100),      # 16 column tiles walked in groups of 6 / 6 / 4
+                                         (7000, 3072, 128, 6500),     # 336 tiles: persistent workgroups take two tiles, ragged row groups
                                          (300, 7040, 64, 200),        # few rows, many columns: the 128x128 kernel
                                          (2230, 768, 256, 2000), (2048, 768, 3072, 0)])       # 160x256 tile path
-@pytest.mark.parametrize("mode", ["plain", "bias_gelu_aux", "residual_scale_f32", "relu_f32"])
+@pytest.mark.parametrize("mode", ["plain", "bias", "bias_gelu_aux", "residual_scale_f32", "relu_f32"])
 def test_gemm_nt(M, N, K, split, mode):
     ops = _ops()
     g = torch.Generator().manual_seed(M + N + K)
@@ -142,6 +143,9 @@ def test_gemm_nt(M, N, K, split, mode):
     if mode == "plain":
         out = ops.gemm_nt(ad, wd, split=split)
         assert_close(out, ref_lin(False), LPTOL(), "gemm plain")
+    elif mode == "bias":         # with "plain": the epilogue of the persistent 256x256 kernel (bias = accumulator start value)
+        out = ops.gemm_nt(ad, wd, bias=bd, split=split)
+        assert_close(out, ref_lin(True), LPTOL(), "gemm bias")
     elif mode == "bias_gelu_aux":
         aux = torch.empty(M, N, device=DEV, dtype=LPD())
         out = ops.gemm_nt(ad, wd, bias=bd, split=split, act=1, aux_preact=aux)

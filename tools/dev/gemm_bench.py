@@ -8,8 +8,11 @@ M, SPLIT = 26944, 25664
 shapes = [("qkv", 2304, 768), ("out", 768, 768), ("fc1", 3072, 768), ("fc2", 768, 3072)]
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 which = sys.argv[2] if len(sys.argv) > 2 else "nt"
+only = sys.argv[3] if len(sys.argv) > 3 else None
 dev = "cuda"
 for name, N, K in shapes:
+    if only and name != only:
+        continue
     a = (torch.randn(M, K, device=dev) * 1.0).to(ops.LP())
     w = (torch.randn(2, N, K, device=dev) * K ** -0.5).to(ops.LP())
     bias = torch.randn(2, N, device=dev)
