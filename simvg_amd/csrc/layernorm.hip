@@ -427,6 +427,130 @@ __global__ __launch_bounds__(256) void ln_bwd_pf_kernel(const lp_t* __restrict__
   }
 }
 
+// Narrow rows, many loads in flight (round 3).  The wave-per-row kernels above keep 12 columns of every array in a lane
+// (188 / 148 VGPRs -> 7-12 waves per CU with two rows each in flight: ~100 / 70 KB per CU, and by Little's law 4.1 / 2.1 TB/s
+// at the ~6.5 us loaded latency -- the Adam pass reaches 6.8 TB/s with ~300 KB per CU in flight).  Here a ROW is shared by the
+// NW = D / 256 waves of a block, each lane owning 4 consecutive columns: a row in flight costs 4 (16-bit x) to 10 (fp32 x +
+// dres) registers, so a block keeps 2 R rows in flight in raw form (two batches of R rows: the loads of batch b + 2 are issued
+// as soon as batch b is finished) at ~5 blocks per CU.  The two row sums cross the waves through LDS, one barrier per BATCH
+// (partials double-buffered by batch parity); dgamma / dbeta partials go to the workspace of the two-stage reduction.
+// (The same form for the 3072-wide ffn_layernorm backward -- 12 waves per row, 80 VGPRs, two blocks per CU -- measured 147 us
+// against the 142 us of ln_bwd_ffn_kernel below: that kernel is bound by its ~33 VALU operations per element, two of them
+// transcendental, not by loads in flight.  Deeper per-wave load rings (4-8 batches, buffer loads, branch-free bodies) did not
+// survive hipcc: its wait-count pass closes a ring that crosses the loop's back edge with vmcnt(0) / vmcnt(1), and the
+// bodies' register allocation spilled the raw rows.  What carries these kernels is blocks per CU, not ring depth.)
+template <typename TIn, bool RES, int NW, int R>
+__global__ __launch_bounds__(NW * 64) void ln_bwd_tile_kernel(const lp_t* __restrict__ dy, int lddy, const TIn* __restrict__ x, int ldx,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              const float* __restrict__ gamma, int gstride,
+                                                              lp_t* __restrict__ out_bf16, int ldob,
+                                                              const float* __restrict__ dres, float* __restrict__ out_f32, int ldof,
+                                                              lp_t* __restrict__ out_scaled, int ldos, const float* __restrict__ row_scale,
+                                                              int rps0, int rps1, int M, int split, int rows_per_block, int blocks0,
+                                                              float* __restrict__ partial, float pscale) {
+  constexpr int D = NW * 256;
+  constexpr bool XF = sizeof(TIn) == 4;
+  __shared__ float part[2][R][NW][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int blk = blockIdx.x;
+  const int g = blk >= blocks0;
+  const int r_begin = g ? split + (blk - blocks0) * rows_per_block : blk * rows_per_block;
+  const int r_end = min(r_begin + rows_per_block, g ? M : split);
+  const int c = tid * 4;
+  const f32x4_t gv = *(const f32x4_t*)(gamma + (long)g * gstride + c);
+  f32x4_t ag = {0.f, 0.f, 0.f, 0.f}, ab = {0.f, 0.f, 0.f, 0.f};
+  constexpr float invD = 1.f / (float)D;
+  f32x4_t xf[2][XF ? R : 1], rq[2][RES ? R : 1];
+  u32x2_t xb[2][XF ? 1 : R], dq[2][R];
+  auto fetch = [&](int b, int slot) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int row = r_begin + b * R + r;
+      if (row < r_end) {
+        if constexpr (XF) xf[slot][r] = *(const f32x4_t*)((const float*)x + (long)row * ldx + c);
+        else xb[slot][r] = *(const u32x2_t*)((const lp_t*)x + (long)row * ldx + c);
+        dq[slot][r] = *(const u32x2_t*)(dy + (long)row * lddy + c);
+        if constexpr (RES) rq[slot][r] = *(const f32x4_t*)(dres + (long)row * ldof + c);
+      }
+    }
+  };
+  auto unpack_row = [&](int slot, int r, float mu, float rs, float (&xh)[4], float (&dyv)[4]) {
+    float xv[4];
+    if constexpr (XF) { const f32x4_t t = xf[slot][r]; xv[0] = t[0]; xv[1] = t[1]; xv[2] = t[2]; xv[3] = t[3]; }
+    else { const u32x2_t t = xb[slot][r]; unpack_lp2(t[0], xv[0], xv[1]); unpack_lp2(t[1], xv[2], xv[3]); }
+    const u32x2_t d = dq[slot][r];
+    unpack_lp2(d[0], dyv[0], dyv[1]);
+    unpack_lp2(d[1], dyv[2], dyv[3]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xh[k] = (xv[k] - mu) * rs;
+  };
+  const int nb = (r_end - r_begin + R - 1) / R;
+  if (nb > 0) fetch(0, 0);
+  if (nb > 1) fetch(1, 1);
+  auto batch = [&](int b, int slot) {
+    float mu[R], rs[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int row = r_begin + b * R + r;
+      mu[r] = rs[r] = 0.f;
+      if (row < r_end) {
+        mu[r] = mean[row];
+        rs[r] = rstd[row];
+        float xh[4], dyv[4];
+        unpack_row(slot, r, mu[r], rs[r], xh, dyv);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float dg = dyv[k] * gv[k];
+          s1 += dg;
+          s2 += dg * xh[k];
+          ag[k] += dyv[k] * xh[k];
+          ab[k] += dyv[k];
+        }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        if (lane == 0) { part[slot][r][wave][0] = s1; part[slot][r][wave][1] = s2; }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int row = r_begin + b * R + r;
+      if (row < r_end) {
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { c1 += part[slot][r][w][0]; c2 += part[slot][r][w][1]; }
+        c1 *= invD;
+        c2 *= invD;
+        float xh[4], dyv[4], dx[4];
+        unpack_row(slot, r, mu[r], rs[r], xh, dyv);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dx[k] = rs[r] * (dyv[k] * gv[k] - c1 - xh[k] * c2);
+        if constexpr (RES) {
+          const f32x4_t t = rq[slot][r];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) dx[k] += t[k];
+          *(f32x4_t*)(out_f32 + (long)row * ldof + c) = (f32x4_t){dx[0], dx[1], dx[2], dx[3]};
+          if (out_scaled) {
+            const float scl = row_scale ? row_scale[g ? (row - split) / rps1 : row / rps0] : 1.f;
+            float t2[4] = {dx[0] * scl, dx[1] * scl, dx[2] * scl, dx[3] * scl};
+            st4_lp(out_scaled + (long)row * ldos + c, t2);
+          }
+        } else {
+          st4_lp(out_bf16 + (long)row * ldob + c, dx);
+        }
+      }
+    }
+    if (b + 2 < nb) fetch(b + 2, slot);
+  };
+  int b = 0;
+  for (; b + 1 < nb; b += 2) { batch(b, 0); batch(b + 1, 1); }
+  if (b < nb) batch(b, 0);
+  float* pp = partial + (long)blk * 2 * D;
+  *(f32x4_t*)(pp + c) = ag * pscale;
+  *(f32x4_t*)(pp + D + c) = ab * pscale;
+}
+
 // Wide rows (D >= 2048, e.g. the 3072-wide ffn_layernorm): the 4 waves of a block share ONE row (each lane owns
 // D/1024 float4 column groups), so the row costs 12 instead of 48+ live registers per array and the kernel runs at
 // full occupancy; the two row statistics cross waves through 32 B of LDS (one barrier per row, double-buffered).
@@ -719,6 +843,21 @@ __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __re
   } while (0)
 
 static inline int ln_wide_rpb(int M) { return std::max(16, cdiv(M, 508)); }
+// ln_bwd_tile_kernel: R rows per batch (two batches in flight); rows per block so that the grid is ~ LN_TILE_BLOCKS blocks
+// (sweep at M = 26 944, us residual-stream / sub-LN instance incl. the reduction launch, +-5 us run to run: R = 2/4, 3/6, 4/8, 5/10 at
+// 1280 blocks: 60.5/41.0, 60.5-68.7/41.3, 72.6/46.0, 72.8/52.9;  R = 3/6 at 1024, 1536, 2048, 2560 blocks: 60.1/41.7, 71.4/42.9,
+// 69.9/43.0, 70.6/45.2;  the wave-per-row kernels: 88.3 / 64.5)
+#ifndef LN_TILE_R_RES
+#define LN_TILE_R_RES 3
+#endif
+#ifndef LN_TILE_R_SUB
+#define LN_TILE_R_SUB 6
+#endif
+#ifndef LN_TILE_BLOCKS
+#define LN_TILE_BLOCKS 1024
+#endif
+static inline int ln_tile_rpb(int M, int R) { return std::max(2 * R, cdiv(cdiv(M, LN_TILE_BLOCKS), R) * R); }
+static inline bool ln_tile_off() { static const bool off = getenv("SIMVG_LN_TILE") && atoi(getenv("SIMVG_LN_TILE")) == 0; return off; }
 // narrow rows: 32 rows per block (4 waves x 8 rows) at training sizes; the decoder head's [B * num_queries, 256] problems have
 // 64 - 640 rows in all -- 4 rows per block (one per wave) so that they spread over 16 - 160 blocks instead of 2 - 20
 static inline int ln_narrow_rpb(int M) { return M <= 2048 ? 4 : 32; }
@@ -828,6 +967,23 @@ extern "C" int simvg_ln_bwd(const void* dy_bf16, int dy_is_f32, int lddy, const 
     const bool res = !x_is_bf16 && dres && dx_f32 && !dx_bf16;
     const bool sub = x_is_bf16 && dx_bf16 && !dx_f32 && !dres;
     const int nit_pf = (D + 255) / 256;
+    if (dy_bf16 && !gelu_u_bf16 && partial_ws && (D == 768 || D == 1024) && (res || sub) && M >= 1024 && !ln_tile_off()) {
+      const int R = res ? LN_TILE_R_RES : LN_TILE_R_SUB;
+      const int rpb_t = ln_tile_rpb(M, R);
+      const int tb0 = cdiv(split, rpb_t), tb1 = cdiv(M - split, rpb_t);
+#define TCALL(T_, RES_, NW_, R_)                                                                                        \
+      hipLaunchKernelGGL((ln_bwd_tile_kernel<T_, RES_, NW_, R_>), dim3(tb0 + tb1), dim3(NW_ * 64), 0, stream,          \
+                         (const lp_t*)dy_bf16, lddy, (const T_*)x, ldx, mean, rstd, gamma, group_stride, (lp_t*)dx_bf16, lddxb, \
+                         dres, dx_f32, lddxf, (lp_t*)dx_scaled_bf16, lddxs, row_scale, rps0, rps1, M, split, rpb_t, tb0,  \
+                         partial_ws, param_scale)
+      if (res) { if (D == 768) TCALL(float, true, 3, LN_TILE_R_RES); else TCALL(float, true, 4, LN_TILE_R_RES); }
+      else { if (D == 768) TCALL(lp_t, false, 3, LN_TILE_R_SUB); else TCALL(lp_t, false, 4, LN_TILE_R_SUB); }
+#undef TCALL
+      hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(D, 64), 4), dim3(1024), 0, stream, partial_ws, dgamma, dbeta,
+                         group_stride, D, tb0, tb1);
+      SIMVG_LAUNCH_CHECK();
+      return SIMVG_OK;
+    }
     if (dy_bf16 && !gelu_u_bf16 && !partial_ws && (nit_pf == 3 || nit_pf == 4) && (res || sub)) {
       // rows per block: the whole grid in ONE residency round (2-3 blocks of 4 waves per CU) -- with 32 rows the 842
       // blocks of a B=64 step took two rounds, the second one a third full (sweep: 32 -> 93.7 / 64.9 us, 53-64 ->
@@ -872,5 +1028,10 @@ extern "C" int simvg_ln_bwd(const void* dy_bf16, int dy_is_f32, int lddy, const 
 extern "C" long simvg_ln_bwd_ws_floats(int M, int D, int split) {
   if (split == 0) split = M;
   const int rpb = D >= 2048 ? ln_wide_rpb(M) : ln_narrow_rpb(M);
-  return (long)(cdiv(split, rpb) + cdiv(M - split, rpb)) * 2 * D;
+  long blocks = cdiv(split, rpb) + cdiv(M - split, rpb);
+  if (D == 768 || D == 1024) {      // ln_bwd_tile_kernel's grid (the smaller R gives the larger one)
+    const int rt = ln_tile_rpb(M, std::min(LN_TILE_R_RES, LN_TILE_R_SUB));
+    blocks = std::max<long>(blocks, cdiv(split, rt) + cdiv(M - split, rt));
+  }
+  return blocks * 2 * D;
 }

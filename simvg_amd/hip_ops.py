@@ -264,7 +264,10 @@ def ln_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, split=0, dx_lp=None, gelu_u=
            dx_scaled=None, row_scale=None, rows_per_sample=(1, 1), dy_scale=1.0, param_scale=1.0):
     lib = _lib.load()
     # two-stage dgamma/dbeta reduction pays for wide rows only (measured: profiles/r01_sweeps.md)
-    ws = _ln_workspace(dy.shape[0], dy.shape[1], split, dy.device) if (dy.shape[0] >= 1024 and dy.shape[1] >= 2048) else None
+    # (and for the many-rows-in-flight kernel of the 768 / 1024-wide 16-bit-dy instances, csrc/layernorm.hip: ln_bwd_tile_kernel)
+    ws = None
+    if dy.shape[0] >= 1024 and (dy.shape[1] >= 2048 or (dy.shape[1] in (768, 1024) and dy.dtype != torch.float32)):
+        ws = _ln_workspace(dy.shape[0], dy.shape[1], split, dy.device)
     _chk(dy, None, "dy")
     M, D = dy.shape
     gs = gamma.stride(0) if gamma.dim() == 2 else 0
