@@ -200,7 +200,10 @@ def bf16_line(a):
         env.pop(k, None)
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
-        j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if not lines:       # e.g. a bf16 library older than csrc/ (simvg_amd/_lib.py refuses it): say so instead of an IndexError
+            return {"error": "bf16 sub-run printed no line: " + (r.stderr.strip().splitlines() or ["no stderr"])[-1][:300]}
+        j = json.loads(lines[-1])
         return {"dtype": j["dtype"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "steps": j["steps"],
                 "roofline_frac_gemm_nt": j["roofline"]["frac"], "box_parity": "held to 1.5e-2 L1 (harsh fixtures measure 4e-3 / 1.1e-2): "
                 "tests/test_model_gpu.py::_box_tol; the fp16 line above is the one that meets 1e-3",
