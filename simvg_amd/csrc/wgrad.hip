@@ -22,6 +22,8 @@
 // conflict-free without any address swizzle (the MFMA contraction index <-> stage row assignment is free as long as both
 // operands use the same one), so fragment addresses are one per-lane base plus compile-time immediates and the global
 // reads stay whole, unpermuted rows.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -33,7 +35,14 @@ struct WgradXArgs {
   float* db; int db_gstride;
   int M, N, K, split;
   float out_scale;
+  unsigned long long* prof;       // development builds (-DSIMVG_WG_PROFILE): s_memtime at the role boundaries of stages 8..23
 };
+#ifdef SIMVG_WG_PROFILE
+#define WG_T(k_) do { if (a.prof && blockIdx.x == 8 && lane == 0 && (wave & 3) == 0 && t >= 8 && t < 24)                 \
+    a.prof[((wave >> 2) * 16 + (t - 8)) * 8 + (k_)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WG_T(k_) do { } while (0)
+#endif
 
 // The LDS reads of the main loop are inline asm (common.h: lds_tr16_asm / lds_wait_all): the compiler would otherwise
 // drain the ring with `s_waitcnt vmcnt(0)` right after every stage is issued, which is what the first wgrad kernel did.
@@ -55,6 +64,13 @@ struct WgradXArgs {
 //        before the barrier that closes interval 3t + 2 -- the end of MFMA(t) / LOADb(t) / LOADa(t) for g = 0 / 1 / 2;
 //   WAR: stage t + 3 lands in the buffer of stage t - 1, last read (group 2, LOADb(t - 1)) in interval 3t; the earliest
 //        DMA into it is issued in interval 3t + 1 (group 0's LOADb(t)).
+// Round-3 timeline (tools/dev/wgrad_profile.py, -DSIMVG_WG_PROFILE, shader cycles per 32-row stage of the fc1 shape): 2850 in all;
+// per wave: fragment-read issue 390, LDS-DMA issue 380-460 (3-4 pieces at ~130 each: the CU's L2 -> LDS path takes 1 KiB per ~17
+// cycles and four waves issue at once), rest of LOADb 210-450 (the bias column sums live in group 0), 24 MFMAs 510-600, and
+// 920 waiting at the three barriers -- the interval is set by LOADb (600-900), not by the MFMA role (384 ideal).  Moving all or
+// part of the DMA issue between the MFMAs (60-100 cycles per piece there) made the MFMA role the long one (680-740) and every shape
+// 5-6 % slower (fc1 165 -> 173-175 us); what this structure would need is the DMA issue spread evenly over the three roles
+// (a WAR hazard forbids it in group 0's LOADa) or dedicated producer waves (the accumulators of 8 consumer waves do not fit).
 template <int A, int B, int WI, int WJ>
 __global__ __launch_bounds__(A * B * 64) void wgrad_x_kernel(WgradXArgs a) {
   constexpr int NW = A * B, NST = 4;
@@ -159,6 +175,7 @@ __global__ __launch_bounds__(A * B * 64) void wgrad_x_kernel(WgradXArgs a) {
     for (int k = 0; k < grp3; ++k) __builtin_amdgcn_s_barrier();        // phase shift of this wave's group
     for (int t = 0; t < nt; ++t) {
       // ---------------- LOADa(t): fragment reads
+      WG_T(0);
       const unsigned sb_ = lds0 + (unsigned)(t % NST) * STAGE;
       const unsigned an = sb_ + fb_n, ak = sb_ + fb_k;
       u32x2_t ry[WI][2], rx[WJ][2];
@@ -170,10 +187,13 @@ __global__ __launch_bounds__(A * B * 64) void wgrad_x_kernel(WgradXArgs a) {
 #undef RD_X
       u32x4_t csv;
       if (cs_lane) csv = lds_b128_asm<0>(sb_ + cs_off);
+      WG_T(1);
       if (grp3 == 2 && t + 1 < nt) wait_oldest(min(nt - 2 - t, 1));     // stage t + 1 (t + 3 not issued yet)
       __builtin_amdgcn_s_barrier();
-      // ---------------- LOADb(t): reads complete, bias partial sums, DMA of stage t + 3
+      WG_T(2);
+      // ---------------- LOADb(t): reads complete, bias partial sums
       if (t + 3 < nt) issue(t + 3);
+      WG_T(3);
       lds_wait_all();
 #pragma unroll
       for (int i = 0; i < WI; ++i) lds_pin(ry[i][0], ry[i][1]);
@@ -194,8 +214,10 @@ __global__ __launch_bounds__(A * B * 64) void wgrad_x_kernel(WgradXArgs a) {
           cs[2 * e + 1] += hi;
         }
       }
+      WG_T(4);
       if (grp3 == 1 && t + 1 < nt) wait_oldest(min(nt - 2 - t, 2));
       __builtin_amdgcn_s_barrier();
+      WG_T(5);
       // ---------------- MFMA(t)
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -203,8 +225,10 @@ __global__ __launch_bounds__(A * B * 64) void wgrad_x_kernel(WgradXArgs a) {
 #pragma unroll
         for (int j = 0; j < WJ; ++j) acc[i][j] = mfma_lp(fy[i], fx[j], acc[i][j]);
       __builtin_amdgcn_s_setprio(0);
+      WG_T(6);
       if (grp3 == 0 && t + 1 < nt) wait_oldest(min(nt - 2 - t, 2));
       __builtin_amdgcn_s_barrier();
+      WG_T(7);
     }
     for (int k = grp3; k < 2; ++k) __builtin_amdgcn_s_barrier();
     // ---- flush: fp32 atomics into dW[grp] (lanes 0-15 of a 16-lane group cover 64 contiguous bytes of one row)
@@ -256,7 +280,8 @@ bool launch(const WgradXArgs& a, hipStream_t stream, int nsub = 1) {
 bool simvg_wgrad_x(const void* dY, int lddy, const void* X, int ldx, float* dW, long dw_gstride, int lddw, float* db,
                    int db_gstride, int M, int N, int K, int split, float out_scale, hipStream_t stream) {
   if (M < 4096 || (lddy & 7) || (ldx & 7)) return false;
-  WgradXArgs a{(const lp_t*)dY, lddy, (const lp_t*)X, ldx, dW, dw_gstride, lddw, db, db_gstride, M, N, K, split, out_scale};
+  static unsigned long long* prof = getenv("SIMVG_WG_PROF_PTR") ? (unsigned long long*)strtoull(getenv("SIMVG_WG_PROF_PTR"), nullptr, 0) : nullptr;
+  WgradXArgs a{(const lp_t*)dY, lddy, (const lp_t*)X, ldx, dW, dw_gstride, lddw, db, db_gstride, M, N, K, split, out_scale, prof};
   auto fits = [&](int tn, int tk) {
     return N % tn == 0 && K % tk == 0 && (N / tn) * (K / tk) == 32 && ((tn / (K / tk)) % 8) == 0;
   };

@@ -6,6 +6,7 @@ from simvg_amd import hip_ops as ops
 dev = "cuda"
 LP = ops.LP()
 B = int(os.environ.get("B", 64))
+REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 M, SPLIT = B * 421, B * 401
 for name, N, K in [("qkv", 2304, 768), ("fc1", 3072, 768), ("fc2", 768, 3072), ("out", 768, 768)]:
     dy = torch.randn(M, N, device=dev).to(LP)
@@ -17,8 +18,8 @@ for name, N, K in [("qkv", 2304, 768), ("fc1", 3072, 768), ("fc2", 768, 3072), (
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(50):
+    for _ in range(REPS):
         ops.gemm_tn(dy, x, dw, split=SPLIT, db=db)
     e1.record(); torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) / 50 * 1e3
+    us = e0.elapsed_time(e1) / REPS * 1e3
     print(f"wgrad {name:4s} [{M}x{N}x{K}] {us:7.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TFLOP/s", flush=True)
