@@ -240,13 +240,21 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     import torch.distributed as dist
+    # SIMVG_BENCH_SHARE_DEVICE=1 (tests only): every rank on cuda:0 over gloo -- the control flow of a world > 1 run (barriers,
+    # who leaves when, which side measurements are skipped) on a one-GPU box; RCCL refuses two ranks per device
+    share = os.environ.get("SIMVG_BENCH_SHARE_DEVICE") == "1"
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     use_dist = world > 1 or os.environ.get("SIMVG_FORCE_REDUCE") == "1"
     if use_dist:
         if os.environ.get("NCCL_DEBUG") == "VERSION":    # RCCL prints its version banner on STDOUT: keep stdout to the one JSON line
             os.environ.pop("NCCL_DEBUG")
-        dist.init_process_group("nccl", device_id=device)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
     from simvg_amd.models import build_model
     from simvg_amd.dist import GradReducer
     from simvg_amd.core import build_optimizer
@@ -336,10 +344,16 @@ def main():
             idx = torch.tensor([(t.numel() - 1) * e // max(k - 1, 1) for e in range(k)], device=t.device)
             digest[n] = (float(t.sum()), float(t.abs().sum()), t[idx].cpu(), t.numel())
         torch.save(dict(params=digest, loss=loss_val, reducer=dict(reducer.last_stats, active=reducer.active)), a.dump_params)
+    if use_dist:
+        # every rank leaves the job here: nothing below this line may contain a collective (the extra measurements of rank 0 are
+        # single-process by construction: with world > 1 they are skipped, see `extras`)
+        dist.barrier()
+        dist.destroy_process_group()
     if rank != 0:
-        if use_dist:
-            dist.destroy_process_group()
         return
+    # side measurements (extra bracketed steps, isolated attention, forward_test, bf16 sub-run, CPU baseline) only in a
+    # single-process run: at world > 1 a step contains collectives, and the other ranks have left
+    extras = not a.no_extras and not use_dist
     from simvg_amd import _lib as _simvg_lib
     _lowp = _simvg_lib.lowp_format()      # "fp16" (default build) or "bf16": the MFMA operand / storage format, fp32 accumulate
     pairs = world * B * a.steps
@@ -355,7 +369,7 @@ def main():
     H, hd = (12, 64) if a.vit == "base" else (16, 64)
     Nv_tok, T_tok = (640 // 32) ** 2 + 1, 20
     extra = {}
-    if not a.no_extras:
+    if extras:
         # wgrad / LayerNorm / Adam launches bracketed by HIP events in four EXTRA steps after the timed region (bracketing ~150
         # more launches per step inside it would cost the headline 0.2 ms per step)
         with training_stream(device):
@@ -367,7 +381,7 @@ def main():
             hip_ops.set_timer(None)
         extra = t2.summary()
     with training_stream(device):
-        iso = attention_roofline(B, H, Nv_tok, T_tok, hd, device) if not a.no_extras else None
+        iso = attention_roofline(B, H, Nv_tok, T_tok, hd, device) if extras else None
     situ = {k: summ[k] for k in ("attn_fwd", "attn_bwd") if k in summ}
     out = {
         "metric": "image-text pairs/sec (whole node), RefCOCO 640x640 bs=64/GPU, 1/2/4/8 MI355X",
@@ -385,6 +399,11 @@ def main():
                                "16-wave 160x256x64 with a 3-stage ring for N = 768, global_load_lds, LDS-staged coalesced epilogue)", "bound": "mfma",
                      "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                     "sustained_mfma_ceiling": {"value": 1930.0, "unit": "TFLOP/s", "frac_of_it": round(ach / 1930.0, 4),
+                                                "source": "tools/dev/probes/mfma_power.hip (profiles/r03_sweeps.md): a register-only loop of "
+                                                          "v_mfma_f32_16x16x32_f16 on random operands, 16 waves per CU, sustains 1917-1933 TFLOP/s "
+                                                          "(package at 1.31-1.34 kW, sclk 1.75-2.0 GHz); 2424 on all-zero operands -- the 2.5 PFLOP/s "
+                                                          "peak is a 2.4 GHz figure the part does not hold on real data"},
                      "algorithmic_bytes_per_launch": round(g["bytes"] / g["calls"]),
                      "launches": g["calls"], "avg_launch_us": round(g["ms"] / g["calls"] * 1e3, 2),
                      "timed_steps": sampled_steps,
@@ -431,7 +450,7 @@ def main():
     model.eval()
     infer = {}
     with torch.no_grad(), training_stream(device):
-        for nb, reps in (() if (a.no_forward_test or a.no_extras) else ((1, 20), (8, 20), (B, 5))):
+        for nb, reps in (() if (a.no_forward_test or not extras) else ((1, 20), (8, 20), (B, 5))):
             bb = synthetic_batch(nb, 4242, device)
             kw = dict(return_loss=False, text_attention_mask=bb["text_attention_mask"], with_bbox=True, with_mask=False, rescale=False)
             for _ in range(3):
@@ -454,15 +473,13 @@ def main():
             gb = d["bytes"] / (d["ms"] * 1e-3) / 1e9
             print(f"[breakdown] {k:34s} calls/step {d['calls'] / a.steps:7.1f}  ms/step {d['ms'] / a.steps:8.3f} "
                   f"({100 * d['ms'] / tot:5.1f} %)  {tf:8.1f} TFLOP/s  {gb:8.1f} GB/s(algorithmic)", file=sys.stderr)
-    if world == 1 and not a.no_extras and _lowp == "fp16" and not os.environ.get("SIMVG_HIP_LIB"):
+    if extras and _lowp == "fp16" and not os.environ.get("SIMVG_HIP_LIB"):
         out["bf16_line"] = bf16_line(a)
-    if world == 1 and not a.no_cpu_baseline and not a.no_extras and a.vit == "base" and a.queries == 1:
+    if extras and not a.no_cpu_baseline and a.vit == "base" and a.queries == 1:
         try:
             out["cpu_baseline"] = cpu_baseline()
         except Exception as e:   # the oracle is a checker; never let it take the GPU number down
             out["cpu_baseline"] = {"error": repr(e)}
-    if use_dist:
-        dist.destroy_process_group()
     print(json.dumps(out), flush=True)
 
 

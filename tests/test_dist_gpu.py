@@ -136,3 +136,28 @@ def test_bench_under_torchrun_takes_the_rccl_branches_and_matches_the_unreduced_
         worst_val = max(worst_val, float((v1 - v2).abs().max()))
     print(f"reduced vs plain after 3 steps: abs-sum difference / allowance {worst_sum:.2f}, sampled values {worst_val:.2e}")
     assert worst_sum <= 1.0 and worst_val <= 1.6e-3, (worst_sum, worst_val)
+
+
+def test_bench_with_two_ranks_finishes_and_reports_the_whole_job(tmp_path):
+    """The driver's N > 1 launch line with two ranks on the one GPU of the test box (gloo, SIMVG_BENCH_SHARE_DEVICE=1): rank 0
+    prints ONE line for the whole job (n_gpus 2, global batch 2 x B, value = pairs of both ranks / max time), the other rank
+    leaves without printing, nothing after the timed region waits for a rank that has left (the side measurements of a
+    single-process run are skipped), and the reducer reports one message per layer + head + embeddings."""
+    import json
+    import subprocess
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, SIMVG_BENCH_SHARE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--batch", "4", "--batches", "2"],
+                       capture_output=True, text=True, env=env, cwd=root, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 8 and line["config"]["parallelism"] == "dp2"
+    assert line["scaling"] == "weak" and line["value"] > 0
+    assert abs(line["value"] - 8 * 3 / (line["ms_per_step"] * 3e-3)) <= 0.02 * line["value"]
+    assert line["reducer"]["active"] and line["reducer"]["messages"] >= 12 + 2
+    for k in ("cpu_baseline", "bf16_line", "forward_test", "roofline_wgrad"):
+        assert k not in line
