@@ -179,6 +179,7 @@ class InferenceGraphs:
         self.model, self.warm_calls, self.max_graphs, self.max_batch = model, warm_calls, max_graphs, max_batch
         self.seen, self.graphs, self.disabled = {}, {}, False
         self.replays = 0
+        self._gen = None                   # generation of the weight buffers the kept graphs were captured against
 
     def __deepcopy__(self, memo):      # a copied model captures its own graphs (the attribute is re-created lazily)
         return None
@@ -190,8 +191,13 @@ class InferenceGraphs:
         enc, head = self.model.vis_enc, self.model.head
         return (tuple(img.shape), img.dtype, tuple(ids.shape), None if mask is None else (tuple(mask.shape), mask.dtype),
                 tuple(tuple(m["img_shape"][:2]) for m in img_metas),
-                tuple(img_metas[0].get("batch_input_shape", ())), id(getattr(enc, "_prep", None)), id(getattr(head, "_prep", None)),
-                getattr(enc, "precision", None))
+                tuple(img_metas[0].get("batch_input_shape", ())), getattr(enc, "precision", None)) + self._generation()
+
+    def _generation(self):
+        """(serial number of the encoder's, of the head's 16-bit weight buffers): a captured graph's launches point into exactly
+        these buffers; when either set is rebuilt (FlatAdam re-pointing p.data, a device move) older graphs are dropped"""
+        enc, head = self.model.vis_enc, self.model.head
+        return (getattr(getattr(enc, "_prep", None), "generation", 0), getattr(getattr(head, "_prep", None), "generation", 0))
 
     def _refresh(self, device):
         enc, head = self.model.vis_enc, self.model.head
@@ -201,13 +207,19 @@ class InferenceGraphs:
             head._refresh_weights(device)
 
     def run(self, img, ids, img_metas, mask):
-        """-> the head's output dict (static tensors) or None (caller runs eagerly)"""
+        """-> the head's output dict or None (caller runs eagerly).  The tensors of the dict are the graph's STATIC outputs: the next
+        replay of the same signature overwrites them (`MIXDETRMB._last_output` aliases them; the predictions `forward_test` returns
+        are computed from them into fresh tensors and stay valid)."""
         model = self.model
         if self.disabled or model.training or torch.is_grad_enabled() or not img.is_cuda or img.shape[0] > self.max_batch:
             return None
         if torch.cuda.is_current_stream_capturing():
             return None
         sig = self._signature(img, ids, mask, img_metas)
+        gen = sig[-2:]
+        if self._gen != gen:               # graphs of older weight buffers: their pointers are stale, and they would hold the slots
+            self.graphs = {k: v for k, v in self.graphs.items() if k[-2:] == gen}
+            self._gen = gen
         entry = self.graphs.get(sig)
         if entry is None:
             n = self.seen.get(sig, 0)

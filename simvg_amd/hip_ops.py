@@ -29,7 +29,7 @@ def grad_scale():
     removed where parameter gradients are written (`out_scale` / `param_scale` / `alpha` arguments), so `.grad` tensors
     are true gradients, and because S is a power of two the results do not depend on it as long as nothing leaves fp16's
     normal range.  S follows the gradient the encoder receives (`GradScaleTracker`: the largest |d loss / d encoder
-    output| of the previous step is brought to ~2^6, three orders of magnitude below the saturation value 65504), starting
+    output| of the step before last is brought to ~2^6, three orders of magnitude below the saturation value 65504), starting
     from 2^10; `set_grad_scale(v)` pins it.  bf16 builds: always 1."""
     global _GRAD_SCALE
     if _GRAD_SCALE is None:
@@ -48,16 +48,22 @@ def set_grad_scale(v):
 
 
 class GradScaleTracker:
-    """Keeps S where the incoming gradient needs it WITHOUT a host synchronisation: `observe(dout)` (called at the entry of
-    the encoder backward) queues max|dout| -> pinned host memory behind an event; `update()` (called at the next training
-    forward, a whole step later) reads it if the copy has completed and sets S = 2^floor(log2(64 / max|dout|)), clamped to
-    [1, 2^24].  A step whose gradient jumps by > 2^9 before the scale follows saturates (stores clamp at +-65504, no inf)."""
+    """Keeps S where the incoming gradient needs it, DETERMINISTICALLY: `observe(dout)` (called at the entry of the encoder
+    backward of step k) queues max|dout| -> pinned host memory behind an event, into slot k % 2; `update()` (called at the
+    training forward of step k + 2) waits for exactly that event and sets S = 2^floor(log2(64 / max|dout|)), clamped to
+    [1, 2^24].  So the scale of step n is a function of the gradient of step n - 2 and of nothing else -- not of whether a copy
+    happened to have completed (an earlier version polled the event).  The wait is on work queued two steps earlier: it blocks
+    only a host that is more than a step ahead of the device, which costs no throughput.  A step whose gradient jumps by > 2^9
+    before the scale follows saturates (stores clamp at +-65504, no inf).  S itself is process-wide (`grad_scale()`); with
+    several training models in one process the last update wins -- results do not depend on S inside fp16's normal range."""
 
     TARGET = 64.0
 
     def __init__(self):
         self._host = None
-        self._event = None
+        self._events = [None, None]
+        self._seen = 0                     # observations queued so far
+        self._used = 0                     # observations consumed so far
 
     def __deepcopy__(self, memo):          # events / pinned buffers are per-instance runtime state, never copied
         return GradScaleTracker()
@@ -66,26 +72,32 @@ class GradScaleTracker:
         return {}
 
     def __setstate__(self, state):
-        self._host, self._event = None, None
+        self.__init__()
 
     def observe(self, dout):
         if LP() != torch.float16 or _GRAD_SCALE_PINNED or torch.cuda.is_current_stream_capturing():
             return
         if self._host is None:
-            self._host = torch.zeros(1, dtype=torch.float32).pin_memory()
-            self._event = torch.cuda.Event()
-        elif not self._event.query():
-            return                         # the previous observation has not been read back yet: keep it
-        self._host.copy_(torch.linalg.vector_norm(dout.reshape(-1), float("inf")).reshape(1), non_blocking=True)
-        self._event.record()
-        self._fresh = True
+            self._host = torch.zeros(2, dtype=torch.float32).pin_memory()
+        if self._seen - self._used >= 2:   # two backwards without a training forward in between (gradient accumulation):
+            self._used = self._seen - 1    # the oldest unread observation is dropped, by count -- still timing-independent
+        slot = self._seen % 2
+        self._host[slot:slot + 1].copy_(torch.linalg.vector_norm(dout.reshape(-1), float("inf")).reshape(1), non_blocking=True)
+        ev = self._events[slot] or torch.cuda.Event()
+        ev.record()
+        self._events[slot] = ev
+        self._seen += 1
 
     def update(self):
         global _GRAD_SCALE
-        if self._host is None or _GRAD_SCALE_PINNED or not getattr(self, "_fresh", False) or not self._event.query():
+        if self._host is None or _GRAD_SCALE_PINNED:
             return
-        self._fresh = False
-        amax = float(self._host[0])
+        if self._seen - self._used < 2:    # the observation of the step before last is the newest one that is used
+            return
+        slot = self._used % 2
+        self._events[slot].synchronize()
+        self._used += 1
+        amax = float(self._host[slot])
         if amax > 0.0 and amax == amax and amax != float("inf"):
             import math
             k = min(24, max(0, math.floor(math.log2(self.TARGET / amax))))
@@ -399,8 +411,14 @@ def cast_lp(src, dst=None, scale=1.0):
 class WeightPrep:
     """Batched fp32 -> 16-bit (+ transposed) conversion of many weight matrices in ONE launch."""
 
+    _generations = 0
+
     def __init__(self, entries, device):
         # entries: list of (src fp32 2-D tensor, dst lp | None, dst_t lp | None)
+        # generation: a process-wide serial number -- what captured graphs key on to know which set of 16-bit buffers their
+        # launches point into (an id() can be handed to a later object)
+        WeightPrep._generations += 1
+        self.generation = WeightPrep._generations
         n = len(entries)
         arr = (_lib.WeightDesc * n)()
         tiles = 0

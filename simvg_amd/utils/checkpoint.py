@@ -61,19 +61,22 @@ def load_pretrained_checkpoint(model, model_ema=None, finetune_from=None, amp=Fa
 
 
 def load_checkpoint(model, model_ema=None, resume_from=None, load_from=None, amp=False, optimizer=None, scheduler=None):
-    """-> (start_epoch, best_d_acc, best_miou, strict_ok) (reference :86-120).  `resume_from` continues a run (epoch,
-    optimizer, scheduler, EMA shadow); `load_from` takes the weights only."""
+    """-> (start_epoch, best_d_acc, best_miou, has_ema) (reference :86-120).  `resume_from` continues a run (epoch,
+    optimizer, scheduler, EMA shadow); `load_from` takes the weights only.  has_ema: the file carried an `ema_state_dict` and it
+    was assigned to `model_ema.shadow`; when it is False the caller's shadow still holds whatever it was built from (the reference
+    raises a NameError on such a file, :100-101) -- tools/train.py and tools/test.py restart the shadow from the loaded weights."""
     assert resume_from is None or load_from is None
     path = resume_from if resume_from is not None else load_from
     ckpt = _read(path, model)
     weights = _plain(ckpt["state_dict"])
-    strict_ok = True
     try:
         model.load_state_dict(weights, strict=True)
-    except RuntimeError:
-        strict_ok = False
+    except RuntimeError as e:
+        if is_main():
+            get_root_logger().info(f"{path}: strict load failed ({str(e).splitlines()[0]} ...); loading the matching keys only")
         model.load_state_dict(weights, strict=False)
-    if model_ema is not None and "ema_state_dict" in ckpt:
+    has_ema = model_ema is not None and "ema_state_dict" in ckpt
+    if has_ema:
         model_ema.shadow = _plain(ckpt["ema_state_dict"])
     for obj, key in ((optimizer, "optimizer"), (scheduler, "scheduler")):
         if obj is None or ckpt.get(key) is None:
@@ -87,7 +90,7 @@ def load_checkpoint(model, model_ema=None, resume_from=None, load_from=None, amp
                 get_root_logger().info(f"optimizer state in {path} does not match this optimizer ({e}); skipped")
     start_epoch = ckpt["epoch"] if (resume_from is not None and "epoch" in ckpt) else -1
     best = log_loaded_info(ckpt, path) if is_main() else (0.0, 0.0)
-    return start_epoch, best[0], best[1], strict_ok
+    return start_epoch, best[0], best[1], has_ema
 
 
 def save_checkpoint(work_dir, interval, model, model_ema, optimizer, scheduler, checkpoint):

@@ -254,6 +254,14 @@ def test_reference_signature_checkpoint_roundtrip(tmp_path):
     m3 = ML.MockVG(); ema3 = ExponentialMovingAverage(m3, 0.999)
     start, _, _, flag = load_checkpoint(m3, ema3, load_from=str(tmp_path / "ddp.pth"))
     assert start == -1 and flag and all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m3.state_dict().values()))
+    # a file without a shadow: the 4th value says so (the caller restarts its EMA from the loaded weights), weights still load
+    ck2 = {k: v for k, v in ck.items() if k != "ema_state_dict"}
+    torch.save(ck2, tmp_path / "noema.pth")
+    m4 = ML.MockVG(); ema4 = ExponentialMovingAverage(m4, 0.999)
+    before = {k: v.clone() for k, v in ema4.shadow.items()}
+    assert load_checkpoint(m4, ema4, load_from=str(tmp_path / "noema.pth"))[3] is False
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m4.state_dict().values()))
+    assert all(torch.equal(before[k], ema4.shadow[k]) for k in before)          # untouched: NOT the loaded weights
     with pytest.raises(AssertionError):
         load_pretrained_checkpoint(m3, ema3, str(tmp_path / "ddp.pth"))
     assert load_pretrained_checkpoint(ML.MockVG(), None, str(tmp_path / "ddp.pth")) == (-1, 40.0, 0.0)

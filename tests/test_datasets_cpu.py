@@ -180,3 +180,21 @@ def test_two_stage_loader_runs_the_host_stage_in_seeded_workers(mini):
         for batch in loader2:
             again += [(os.path.basename(i["img_metas"]["filename"]), i["img_metas"]["expression"]) for i in batch]
     assert again == seen                                       # same seed -> same order and the same expression draws
+
+
+def test_decode_image_applies_the_exif_orientation(tmp_path):
+    """mmcv.imfrombytes(flag='color') = cv2.imdecode(IMREAD_COLOR), which rotates by the EXIF orientation tag (reference
+    loading.py:157-160): a 40 x 20 JPEG tagged "rotate 90 CW" (6) must come out 40 high and 20 wide, its red left edge on top."""
+    import numpy as np
+    from PIL import Image
+    from simvg_amd.datasets.loading import decode_image
+    a = np.zeros((20, 40, 3), np.uint8)
+    a[:, :8] = (255, 0, 0)                         # red band at the LEFT of the stored raster
+    exif = Image.Exif()
+    exif[0x0112] = 6                               # the viewer has to rotate the raster 90 degrees clockwise
+    Image.fromarray(a).save(tmp_path / "o6.jpg", quality=95, exif=exif.tobytes())
+    Image.fromarray(a).save(tmp_path / "plain.jpg", quality=95)
+    plain, turned = decode_image(str(tmp_path / "plain.jpg")), decode_image(str(tmp_path / "o6.jpg"))
+    assert plain.shape == (20, 40, 3) and turned.shape == (40, 20, 3)
+    assert plain[:, :6, 2].mean() > 200 and plain[:, 12:, 2].mean() < 40          # BGR: red is channel 2
+    assert turned[:6, :, 2].mean() > 200 and turned[12:, :, 2].mean() < 40       # left edge -> top edge

@@ -147,3 +147,33 @@ def test_graphed_forward_test_equals_eager_and_follows_the_weights():
     (b_t, o_t) = infer(twin, batch3, True)
     for k in o_e:
         assert torch.equal(o_e[k], o_t[k]), k
+
+
+def test_inference_graphs_of_rebuilt_weight_buffers_are_dropped():
+    """Captured graphs are keyed on the serial numbers of the 16-bit weight buffers their launches point into.  When those buffers
+    are rebuilt (here: the head's preparation object is discarded, as FlatAdam re-pointing p.data does) the old graphs leave the
+    table -- they neither replay against freed memory nor occupy the slots -- and the signature is captured again."""
+    from test_tools_gpu import _tiny_model, _batch
+    cfg, model = _tiny_model(6)
+    model.eval()
+    model.infer_graph = True
+
+    def infer(batch):
+        kw = {k: v for k, v in batch.items() if k != "gt_bbox"}
+        with torch.no_grad():
+            return [p["pred_bboxes"].clone() for p in model(**kw, return_loss=False, rescale=False)]
+
+    batch = _batch(cfg, B=2, seed=7)
+    for _ in range(4):
+        ref = infer(batch)
+    ig = model._infer_graphs
+    assert len(ig.graphs) == 1
+    (old_sig,) = ig.graphs
+    gen0 = model.head._prep.generation
+    model.head._prep = None                                   # the next call rebuilds the head's 16-bit buffers
+    for _ in range(4):
+        got = infer(batch)
+    assert model.head._prep.generation > gen0
+    assert old_sig not in ig.graphs and len(ig.graphs) == 1   # the stale graph is gone, the signature was captured again
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)

@@ -15,7 +15,7 @@ sys.path.insert(0, osp.dirname(osp.dirname(osp.abspath(__file__))))
 from simvg_amd.apis import set_random_seed                                           # noqa: E402
 from simvg_amd.config import Config, DictAction                                      # noqa: E402
 from simvg_amd.runtime import Session                                                # noqa: E402
-from simvg_amd.utils import load_checkpoint, load_pretrained_checkpoint              # noqa: E402
+from simvg_amd.utils import get_root_logger, is_main, load_checkpoint, load_pretrained_checkpoint   # noqa: E402
 
 
 def parse_args(argv=None):
@@ -36,7 +36,13 @@ def report(cfg):
     loaders = [run.loader(run.dataset(s)) for s in splits]
     run.build(train_set)
     if cfg.load_from:
-        load_checkpoint(run.model, run.ema, load_from=cfg.load_from)
+        has_ema = load_checkpoint(run.model, run.ema, load_from=cfg.load_from)[3]
+        if run.ema is not None and not has_ema:
+            # no shadow in the file (the reference fails with a NameError here): evaluate the loaded weights in both passes
+            # rather than a shadow of weights that were never loaded, and say so
+            run.fresh_ema()
+            if is_main():
+                get_root_logger().info(f"{cfg.load_from} carries no ema_state_dict: the `_ema` results below are those of the plain weights")
     elif cfg.finetune_from:
         load_pretrained_checkpoint(run.model, None, cfg.finetune_from, amp=cfg.use_fp16)
     results = {}

@@ -80,8 +80,8 @@ class TrainingRun(Session):
         elif cfg.finetune_from:      # weights only, non-strict
             load_pretrained_checkpoint(self.model, self.ema, cfg.finetune_from, amp=cfg.use_fp16)
         elif cfg.load_from:          # weights + EMA + the best metrics; a checkpoint without a shadow restarts the EMA
-            self.last_epoch, self.best[0], self.best[1], had_ema = load_checkpoint(self.model, self.ema, load_from=cfg.load_from)
-            if not had_ema:
+            self.last_epoch, self.best[0], self.best[1], has_ema = load_checkpoint(self.model, self.ema, load_from=cfg.load_from)
+            if not has_ema:          # the file carried no shadow: the EMA starts from the weights just loaded
                 self.fresh_ema()
 
     def validate(self, epoch):
