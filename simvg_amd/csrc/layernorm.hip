@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIn* __restrict__ x, 
 // What remains above the 66 us of the same kernel without the activation is VALU: the erf GELU + LayerNorm are ~35 VALU
 // operations per element (a persistent variant with the next row's loads in flight measured the same 88 us).
 template <int NIT8, bool GELU>
-__global__ __launch_bounds__(256) void ln_fwd_wide_kernel(const lp_t* __restrict__ x, int ldx, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256, NIT8 <= 6 ? 4 : 3) void ln_fwd_wide_kernel(const lp_t* __restrict__ x, int ldx, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, int gstride, lp_t* __restrict__ y,
                                                           int ldy, float* __restrict__ mean, float* __restrict__ rstd, int M,
                                                           int split, float eps) {
@@ -114,24 +114,33 @@ __global__ __launch_bounds__(256) void ln_fwd_wide_kernel(const lp_t* __restrict
   u32x4_t raw[NIT8];
 #pragma unroll
   for (int it = 0; it < NIT8; ++it) raw[it] = __builtin_nontemporal_load((const u32x4_t*)(xr + it * 512));
-  float v[NIT8][8];
-  float s = 0.f;
+  // two values per register pair: the arithmetic below is packed fp32 (v_pk_fma / v_pk_mul / v_pk_add: one issue slot for two
+  // values) -- this kernel is bound by VALU issue, not by HBM, once the activation is evaluated here
+  hw_f32x2_t v[NIT8][4];
+  hw_f32x2_t s2 = {0.f, 0.f};
 #pragma unroll
   for (int it = 0; it < NIT8; ++it) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      unpack_lp2(raw[it][k], v[it][2 * k], v[it][2 * k + 1]);
-      if (GELU) { v[it][2 * k] = gelu_erf(v[it][2 * k]); v[it][2 * k + 1] = gelu_erf(v[it][2 * k + 1]); }
+      float lo, hi;
+      unpack_lp2(raw[it][k], lo, hi);
+      v[it][k] = (hw_f32x2_t){lo, hi};
+      if (GELU) {
+        hw_f32x2_t cdf, pdf;
+        gelu_parts2(v[it][k], cdf, pdf);
+        v[it][k] = v[it][k] * cdf;
+      }
     }
-    s += ((v[it][0] + v[it][1]) + (v[it][2] + v[it][3])) + ((v[it][4] + v[it][5]) + (v[it][6] + v[it][7]));
+    s2 += (v[it][0] + v[it][1]) + (v[it][2] + v[it][3]);
   }
-  const float mu = wave_sum(s) * (1.f / (float)D);
-  float q = 0.f;
+  const float mu = wave_sum(s2[0] + s2[1]) * (1.f / (float)D);
+  const hw_f32x2_t mu2 = {mu, mu};
+  hw_f32x2_t q2 = {0.f, 0.f};
 #pragma unroll
   for (int it = 0; it < NIT8; ++it)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { const float d = v[it][k] - mu; q += d * d; }
-  const float rs = rsqrtf(wave_sum(q) * (1.f / (float)D) + eps);
+    for (int k = 0; k < 4; ++k) { const hw_f32x2_t d = v[it][k] - mu2; q2 = __builtin_elementwise_fma(d, d, q2); }
+  const float rs = rsqrtf(wave_sum(q2[0] + q2[1]) * (1.f / (float)D) + eps);
   if (lane == 0) {
     if (mean) mean[row] = mu;
     if (rstd) rstd[row] = rs;
@@ -139,17 +148,20 @@ __global__ __launch_bounds__(256) void ln_fwd_wide_kernel(const lp_t* __restrict
   const float* gm = gamma + (long)g * gstride + lane * 8;
   const float* bt = beta + (long)g * gstride + lane * 8;
   lp_t* yr = y + (long)row * ldy + lane * 8;
+  const hw_f32x2_t rs2 = {rs, rs};
 #pragma unroll
   for (int it = 0; it < NIT8; ++it) {
     const f32x4_t g0 = *(const f32x4_t*)(gm + it * 512), g1 = *(const f32x4_t*)(gm + it * 512 + 4);
     const f32x4_t b0 = *(const f32x4_t*)(bt + it * 512), b1 = *(const f32x4_t*)(bt + it * 512 + 4);
-    float o[8];
+    const hw_f32x2_t gg[4] = {{g0[0], g0[1]}, {g0[2], g0[3]}, {g1[0], g1[1]}, {g1[2], g1[3]}};
+    const hw_f32x2_t bb[4] = {{b0[0], b0[1]}, {b0[2], b0[3]}, {b1[0], b1[1]}, {b1[2], b1[3]}};
+    unsigned w[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      o[k] = (v[it][k] - mu) * rs * g0[k] + b0[k];
-      o[4 + k] = (v[it][4 + k] - mu) * rs * g1[k] + b1[k];
+      const hw_f32x2_t o = __builtin_elementwise_fma((v[it][k] - mu2) * rs2, gg[k], bb[k]);
+      w[k] = pack_lp2(o[0], o[1]);
     }
-    *(u32x4_t*)(yr + it * 512) = (u32x4_t){pack_lp2(o[0], o[1]), pack_lp2(o[2], o[3]), pack_lp2(o[4], o[5]), pack_lp2(o[6], o[7])};
+    *(u32x4_t*)(yr + it * 512) = (u32x4_t){w[0], w[1], w[2], w[3]};
   }
 }
 
