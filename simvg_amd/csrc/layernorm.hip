@@ -712,6 +712,8 @@ __global__ __launch_bounds__(256) void ln_bwd_ffn_kernel(const lp_t* __restrict_
                                                          lp_t* __restrict__ out, int ldo, int M, int D, int split,
                                                          int rows_per_block, int blocks0, float* __restrict__ partial,
                                                          float pscale) {
+  // D == NITW * 1024 (launcher).  The arithmetic is packed fp32, two values per instruction: the kernel is bound by VALU issue
+  // (GELU, GELU' and the LayerNorm backward are ~33 operations per element, two of them transcendental)
   __shared__ float part[2][4][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int blk = blockIdx.x;
@@ -719,16 +721,15 @@ __global__ __launch_bounds__(256) void ln_bwd_ffn_kernel(const lp_t* __restrict_
   const int r_begin = g ? split + (blk - blocks0) * rows_per_block : blk * rows_per_block;
   const int r_end = min(r_begin + rows_per_block, g ? M : split);
   const float* gm = gamma + (long)g * gstride;
-  float gv[NITW][4], ag[NITW][4], ab[NITW][4];
+  hw_f32x2_t gv[NITW][2], ag[NITW][2], ab[NITW][2];
 #pragma unroll
   for (int it = 0; it < NITW; ++it) {
     const int c = (it * 256 + tid) * 4;
+    const f32x4_t t = *(const f32x4_t*)(gm + c);
+    gv[it][0] = (hw_f32x2_t){t[0], t[1]};
+    gv[it][1] = (hw_f32x2_t){t[2], t[3]};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { ag[it][k] = 0.f; ab[it][k] = 0.f; gv[it][k] = 0.f; }
-    if (c < D) {
-      const f32x4_t t = *(const f32x4_t*)(gm + c);
-      gv[it][0] = t[0]; gv[it][1] = t[1]; gv[it][2] = t[2]; gv[it][3] = t[3];
-    }
+    for (int h = 0; h < 2; ++h) { ag[it][h] = (hw_f32x2_t){0.f, 0.f}; ab[it][h] = (hw_f32x2_t){0.f, 0.f}; }
   }
   const float invD = 1.f / (float)D;
   u32x2_t dq[2][NITW], uq[2][NITW];
@@ -739,57 +740,54 @@ __global__ __launch_bounds__(256) void ln_bwd_ffn_kernel(const lp_t* __restrict_
 #pragma unroll
     for (int it = 0; it < NITW; ++it) {
       const int c = (it * 256 + tid) * 4;
-      if (c < D) {
-        dq[slot][it] = *(const u32x2_t*)(dy + (long)row * lddy + c);
-        uq[slot][it] = *(const u32x2_t*)(u + (long)row * ldu + c);
-      }
+      dq[slot][it] = *(const u32x2_t*)(dy + (long)row * lddy + c);
+      uq[slot][it] = *(const u32x2_t*)(u + (long)row * ldu + c);
     }
   };
   if (r_begin < r_end) fetch(r_begin, 0);
   if (r_begin + 1 < r_end) fetch(r_begin + 1, 1);
   auto row_body = [&](int row, int par) {
     const float mu = mu_q[par], rs = rs_q[par];
-    float xh[NITW][4], dyv[NITW][4], uv[NITW][4];
-    float s1 = 0.f, s2 = 0.f;
+    const hw_f32x2_t mu2 = {mu, mu}, rs2 = {rs, rs};
+    hw_f32x2_t xh[NITW][2], dg[NITW][2], uv[NITW][2];
+    hw_f32x2_t s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
 #pragma unroll
     for (int it = 0; it < NITW; ++it) {
-      const int c = (it * 256 + tid) * 4;
-      const bool in = c < D;
       const u32x2_t dr = dq[par][it], ur = uq[par][it];
-      float dv[4], uu[4];
-      unpack_lp2(dr[0], dv[0], dv[1]);
-      unpack_lp2(dr[1], dv[2], dv[3]);
-      unpack_lp2(ur[0], uu[0], uu[1]);
-      unpack_lp2(ur[1], uu[2], uu[3]);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        dyv[it][k] = in ? dv[k] : 0.f;
-        float cdf, pdf;
-        gelu_parts(uu[k], cdf, pdf);
-        uv[it][k] = fmaf(uu[k], pdf, cdf);                      // GELU'(u)
-        xh[it][k] = in ? (uu[k] * cdf - mu) * rs : 0.f;         // LayerNorm input g = u * Phi(u), normalised
-        const float dg = dyv[it][k] * gv[it][k];
-        s1 += dg;
-        s2 += dg * xh[it][k];
-        ag[it][k] += dyv[it][k] * xh[it][k];
-        ab[it][k] += dyv[it][k];
+      for (int h = 0; h < 2; ++h) {
+        float d0, d1, u0, u1;
+        unpack_lp2(dr[h], d0, d1);
+        unpack_lp2(ur[h], u0, u1);
+        const hw_f32x2_t dv = {d0, d1}, uu = {u0, u1};
+        hw_f32x2_t cdf, pdf;
+        gelu_parts2(uu, cdf, pdf);
+        uv[it][h] = __builtin_elementwise_fma(uu, pdf, cdf);         // GELU'(u)
+        xh[it][h] = (uu * cdf - mu2) * rs2;                            // LayerNorm input g = u * Phi(u), normalised
+        dg[it][h] = dv * gv[it][h];
+        s1 += dg[it][h];
+        s2 = __builtin_elementwise_fma(dg[it][h], xh[it][h], s2);
+        ag[it][h] = __builtin_elementwise_fma(dv, xh[it][h], ag[it][h]);
+        ab[it][h] += dv;
       }
     }
     if (row + 2 < r_end) fetch(row + 2, par);
-    s1 = wave_sum(s1); s2 = wave_sum(s2);
-    if (lane == 0) { part[par][wave][0] = s1; part[par][wave][1] = s2; }
+    const float t1 = wave_sum(s1[0] + s1[1]), t2 = wave_sum(s2[0] + s2[1]);
+    if (lane == 0) { part[par][wave][0] = t1; part[par][wave][1] = t2; }
     __syncthreads();
     const float c1 = ((part[par][0][0] + part[par][1][0]) + (part[par][2][0] + part[par][3][0])) * invD;
     const float c2 = ((part[par][0][1] + part[par][1][1]) + (part[par][2][1] + part[par][3][1])) * invD;
+    const hw_f32x2_t c1v = {c1, c1}, nc2 = {-c2, -c2};
 #pragma unroll
     for (int it = 0; it < NITW; ++it) {
       const int c = (it * 256 + tid) * 4;
-      if (c < D) {
-        float dx[4];
+      unsigned w[2];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) dx[k] = rs * (dyv[it][k] * gv[it][k] - c1 - xh[it][k] * c2) * uv[it][k];
-        st4_lp(out + (long)row * ldo + c, dx);
+      for (int h = 0; h < 2; ++h) {
+        const hw_f32x2_t dx = (rs2 * (__builtin_elementwise_fma(xh[it][h], nc2, dg[it][h]) - c1v)) * uv[it][h];
+        w[h] = pack_lp2(dx[0], dx[1]);
       }
+      *(u32x2_t*)(out + (long)row * ldo + c) = (u32x2_t){w[0], w[1]};
     }
   };
   // two rows per trip so that the prefetch slot is a compile-time index (a runtime-indexed register array would go
@@ -801,10 +799,8 @@ __global__ __launch_bounds__(256) void ln_bwd_ffn_kernel(const lp_t* __restrict_
 #pragma unroll
   for (int it = 0; it < NITW; ++it) {
     const int c = (it * 256 + tid) * 4;
-    if (c < D) {
-      *(f32x4_t*)(pp + c) = (f32x4_t){ag[it][0], ag[it][1], ag[it][2], ag[it][3]} * pscale;
-      *(f32x4_t*)(pp + D + c) = (f32x4_t){ab[it][0], ab[it][1], ab[it][2], ab[it][3]} * pscale;
-    }
+    *(f32x4_t*)(pp + c) = (f32x4_t){ag[it][0][0], ag[it][0][1], ag[it][1][0], ag[it][1][1]} * pscale;
+    *(f32x4_t*)(pp + D + c) = (f32x4_t){ab[it][0][0], ab[it][0][1], ab[it][1][0], ab[it][1][1]} * pscale;
   }
 }
 
@@ -960,7 +956,7 @@ extern "C" int simvg_ln_bwd(const void* dy_bf16, int dy_is_f32, int lddy, const 
                        (const lp_t*)gelu_u_bf16, ldu, dres, dx_f32, lddxf, (lp_t*)dx_scaled_bf16, lddxs, row_scale, \
                        rps0, rps1, M, D, split, rpb, blocks0, partial_ws, param_scale)
     const bool ffn = x_is_bf16 && gelu_u_bf16 && gelu_u_bf16 == x && dx_bf16 && !dx_f32 && !dres && partial_ws &&
-                     (nitw == 3 || nitw == 4);
+                     (nitw == 3 || nitw == 4) && D == nitw * 1024;
 #define FCALL_FFN(N_)                                                                                                   \
     hipLaunchKernelGGL((ln_bwd_ffn_kernel<N_>), grid, block, 0, stream, (const lp_t*)dy_bf16, lddy, (const lp_t*)x,  \
                        ldx, mean, rstd, gamma, group_stride, (lp_t*)dx_bf16, lddxb, M, D, split, rpb, blocks0, partial_ws, param_scale)
