@@ -69,3 +69,37 @@ def test_philox_known_answers():
         c, k, o = (C.c_uint * 4)(*ctr), (C.c_uint * 2)(*key), (C.c_uint * 4)()
         assert lib.simvg_philox4x32(c, k, o) == 0
         assert tuple(o) == want, (ctr, [hex(x) for x in o])
+
+
+def _header_arity():
+    """{entry point: number of parameters} parsed from include/simvg_hip.h"""
+    src = open(os.path.join(ROOT, "include", "simvg_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
+    out = {}
+    for m in re.finditer(r"\b(simvg_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+        args = m.group(2).strip()
+        out[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
+    return out
+
+
+def test_ctypes_binding_and_the_integration_stub_have_the_headers_arity():
+    """every argtypes list of simvg_amd/_lib.py has as many entries as the declaration in include/simvg_hip.h has parameters (a
+    missing trailing argument is read from a garbage register, not refused), and so does the ctypes stub INTEGRATION.md shows a
+    maintainer"""
+    from simvg_amd import _lib
+    arity = _header_arity()
+    assert len(arity) >= 40
+    for name, sig in _lib._SIGS.items():
+        assert name in arity, name
+        assert len(sig) == arity[name], (name, len(sig), arity[name])
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"lib\.simvg_ln_fwd\.argtypes = \[(.*?)\]", doc, flags=re.S)
+    assert m and m.group(1).count("ctypes.") == arity["simvg_ln_fwd"], (m and m.group(1).count("ctypes."), arity["simvg_ln_fwd"])
+    call = re.search(r"rc = lib\.simvg_ln_fwd\((.*?)\)\n", doc, flags=re.S).group(1)
+    depth, n = 0, 1
+    for ch in call:
+        depth += ch in "([" 
+        depth -= ch in ")]"
+        n += (ch == "," and depth == 0)
+    assert n == arity["simvg_ln_fwd"], n
