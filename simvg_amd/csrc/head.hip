@@ -254,22 +254,46 @@ __global__ __launch_bounds__(256) void attn_small_fwd_kernel(SAArgs a) {
   for (int e = tid; e < a.Lq * SHD; e += 256)
     qs[e] = a.q[(long)(b * a.Lq + e / SHD) * a.ldq + h * SHD + (e % SHD)] * a.scale;
   __syncthreads();
-  for (int kk = tid; kk < a.Lk; kk += 256) {
-    float kr[SHD];
-    const float* kp = a.k + (long)(b * a.kv_rows + kk) * a.ldk + h * SHD;
-    const float* pp = a.kpos ? a.kpos + (long)(b * a.kpos_rows + kk) * a.ldkp + h * SHD : nullptr;
+  // scores: 8 consecutive lanes share a key -- lane c of the group reads the 16-B chunk c of the key's 128-B head slice, so one
+  // wave instruction consumes 8 whole 128-B segments (one thread per key row read its 128 B in 8 instructions whose lanes were
+  // 2 KiB apart: every segment was fetched by 8 instructions and lived in L1 in between; the kernel took 40 us for the 52 MB of
+  // a 400-key layer at B = 64)
+  constexpr int KB = 13;                 // 13 x 32 = 416 keys per pass: ALL of a pass's loads are issued before the first is used
+  f32x4_t tv[KB];                        // the V rows of the first pass are requested together with its K rows: their latency
+  {                                      // passes under the score / softmax phases (the decoder's 400 keys are one pass)
+    const int c4 = (tid & 7) * 4;
+    for (int k0 = 0; k0 < a.Lk; k0 += 32 * KB) {      // (one load -> use per trip exposed the memory latency 13 times)
+      f32x4_t t[KB];
+      if (k0 == 0) {
 #pragma unroll
-    for (int d = 0; d < SHD; d += 4) {
-      f32x4_t t = *(const f32x4_t*)(kp + d);
-      if (pp) t += *(const f32x4_t*)(pp + d);
-      kr[d] = t[0]; kr[d + 1] = t[1]; kr[d + 2] = t[2]; kr[d + 3] = t[3];
-    }
-    const bool masked = a.kpm && a.kpm[b * a.Lk + kk];
-    for (int qi = 0; qi < a.Lq; ++qi) {
-      float s = 0.f;
+        for (int u = 0; u < KB; ++u) {
+          const int kk = u * 32 + (tid >> 3);
+          tv[u] = kk < a.Lk ? *(const f32x4_t*)(a.v + (long)(b * a.kv_rows + kk) * a.ldv + h * SHD + c4) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        }
+      }
 #pragma unroll
-      for (int d = 0; d < SHD; ++d) s += qs[qi * SHD + d] * kr[d];
-      sc[qi * a.Lk + kk] = masked ? -INFINITY : s;
+      for (int u = 0; u < KB; ++u) {
+        const int kk = k0 + u * 32 + (tid >> 3);
+        t[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (kk < a.Lk) {
+          t[u] = *(const f32x4_t*)(a.k + (long)(b * a.kv_rows + kk) * a.ldk + h * SHD + c4);
+          if (a.kpos) t[u] += *(const f32x4_t*)(a.kpos + (long)(b * a.kpos_rows + kk) * a.ldkp + h * SHD + c4);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < KB; ++u) {
+        const int kk = k0 + u * 32 + (tid >> 3);
+        const bool in = kk < a.Lk;
+        const bool masked = in && a.kpm && a.kpm[b * a.Lk + kk];
+        for (int qi = 0; qi < a.Lq; ++qi) {
+          const f32x4_t q4 = *(const f32x4_t*)(qs + qi * SHD + c4);
+          float sv = (q4[0] * t[u][0] + q4[1] * t[u][1]) + (q4[2] * t[u][2] + q4[3] * t[u][3]);
+          sv += __shfl_xor(sv, 1, 64);
+          sv += __shfl_xor(sv, 2, 64);
+          sv += __shfl_xor(sv, 4, 64);
+          if (in && c4 == 0) sc[qi * a.Lk + kk] = masked ? -INFINITY : sv;
+        }
+      }
     }
   }
   __syncthreads();
@@ -294,36 +318,49 @@ __global__ __launch_bounds__(256) void attn_small_fwd_kernel(SAArgs a) {
     }
   }
   __syncthreads();
-  // out[qi][d] = sum_k P'[qi][k] V[k][d]: thread (part, d) adds keys part, part + 8, ... (a key row is one coalesced 128-B read
-  // of the 32 d-lanes); the 8 partial sums meet in LDS.  (One thread per (qi, d) walking all keys was 10 of the kernel's 15 us
-  // with num_queries = 1: 32 active threads, 400 dependent strided reads each.)
-  float* red = sc + a.Lq * a.Lk;        // [8][Lq][32]
+  // out[qi][d] = sum_k P'[qi][k] V[k][d], in the layout of the score phase: 8 lanes share a key, lane c holds 4 of its 32 values
+  // (16-B loads, all of a pass issued before the first is used: the earlier one-float-per-lane walk over 50 keys per thread was
+  // the longest part of the kernel -- 4-byte loads, 8 in flight).  The 32 key slots of the block meet in LDS.
+  float* red = sc + a.Lq * a.Lk;        // [32][Lq][32]
   {
-    const int part = tid >> 5, d = tid & 31;
-    const float* vp = a.v + (long)(b * a.kv_rows) * a.ldv + h * SHD + d;
-    float o[16];
+    const int slot = tid >> 3, c4 = (tid & 7) * 4;
+    f32x4_t o[16];
 #pragma unroll
-    for (int qi = 0; qi < 16; ++qi) o[qi] = 0.f;
-    for (int kk = part; kk < a.Lk; kk += 8) {            // a V row is read once for all queries
-      const float vv = vp[(long)kk * a.ldv];
+    for (int qi = 0; qi < 16; ++qi) o[qi] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < a.Lk; k0 += 32 * KB) {
+      f32x4_t t[KB];
 #pragma unroll
-      for (int qi = 0; qi < 16; ++qi)
-        if (qi < a.Lq) o[qi] += sc[qi * a.Lk + kk] * vv;
+      for (int u = 0; u < KB; ++u) {
+        const int kk = k0 + u * 32 + slot;
+        if (k0 == 0) t[u] = tv[u];
+        else t[u] = kk < a.Lk ? *(const f32x4_t*)(a.v + (long)(b * a.kv_rows + kk) * a.ldv + h * SHD + c4) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < KB; ++u) {
+        const int kk = k0 + u * 32 + slot;
+        if (kk < a.Lk) {
+#pragma unroll
+          for (int qi = 0; qi < 16; ++qi)
+            if (qi < a.Lq) o[qi] += sc[qi * a.Lk + kk] * t[u];
+        }
+      }
     }
 #pragma unroll
     for (int qi = 0; qi < 16; ++qi)
-      if (qi < a.Lq) red[(part * a.Lq + qi) * SHD + d] = o[qi];
+      if (qi < a.Lq) *(f32x4_t*)(red + (slot * a.Lq + qi) * SHD + c4) = o[qi];
     __syncthreads();
     for (int e = tid; e < a.Lq * SHD; e += 256) {
       float t = 0.f;
 #pragma unroll
-      for (int p8 = 0; p8 < 8; ++p8) t += red[p8 * a.Lq * SHD + e];
+      for (int p32 = 0; p32 < 32; ++p32) t += red[p32 * a.Lq * SHD + e];
       a.out[(long)(b * a.Lq + e / SHD) * a.ldo + h * SHD + (e % SHD)] = t;
     }
   }
 }
 
 __global__ __launch_bounds__(256) void attn_small_bwd_kernel(SAArgs a) {
+  // Same thread layout as the forward: 8 consecutive lanes share a key, lane c holds 4 of the 32 values of its head slice (16-B
+  // loads and stores, every 128-B segment touched by one instruction; the loads of a pass of 13 x 32 keys are issued together).
   extern __shared__ float sm[];
   float* qs = sm;                           // [Lq][32] (unscaled)
   float* dos = qs + a.Lq * SHD;             // [Lq][32]
@@ -332,6 +369,8 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(SAArgs a) {
   float* rs = pd + a.Lq * a.Lk;             // [Lq] rowsum(dP * P)
   const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int slot = tid >> 3, c4 = (tid & 7) * 4;
+  constexpr int KB = 13;
   for (int e = tid; e < a.Lq * SHD; e += 256) {
     const long r = (long)(b * a.Lq + e / SHD);
     qs[e] = a.q[r * a.ldq + h * SHD + (e % SHD)];
@@ -339,31 +378,35 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(SAArgs a) {
   }
   __syncthreads();
   // dP = (dO . V^T) * drop ; dV = (P*drop)^T dO
-  for (int kk = tid; kk < a.Lk; kk += 256) {
-    float vr[SHD], dvr[SHD];
-    const float* vp = a.v + (long)(b * a.kv_rows + kk) * a.ldv + h * SHD;
+  for (int k0 = 0; k0 < a.Lk; k0 += 32 * KB) {
+    f32x4_t t[KB];
 #pragma unroll
-    for (int d = 0; d < SHD; d += 4) {
-      const f32x4_t t = *(const f32x4_t*)(vp + d);
-      vr[d] = t[0]; vr[d + 1] = t[1]; vr[d + 2] = t[2]; vr[d + 3] = t[3];
-      dvr[d] = dvr[d + 1] = dvr[d + 2] = dvr[d + 3] = 0.f;
+    for (int u = 0; u < KB; ++u) {
+      const int kk = k0 + u * 32 + slot;
+      t[u] = kk < a.Lk ? *(const f32x4_t*)(a.v + (long)(b * a.kv_rows + kk) * a.ldv + h * SHD + c4) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
-    for (int qi = 0; qi < a.Lq; ++qi) {
-      const long pi = ((long)blockIdx.x * a.Lq + qi) * a.Lk + kk;
-      const float p = a.P[pi];
-      const float dm = a.drop ? a.drop[pi] : 1.f;
-      float dp = 0.f;
 #pragma unroll
-      for (int d = 0; d < SHD; ++d) {
-        dp += dos[qi * SHD + d] * vr[d];
-        dvr[d] += p * dm * dos[qi * SHD + d];
+    for (int u = 0; u < KB; ++u) {
+      const int kk = k0 + u * 32 + slot;
+      const bool in = kk < a.Lk;
+      f32x4_t dvr = {0.f, 0.f, 0.f, 0.f};
+      for (int qi = 0; qi < a.Lq; ++qi) {
+        const long pi = ((long)blockIdx.x * a.Lq + qi) * a.Lk + (in ? kk : 0);
+        const float p = a.P[pi];
+        const float dm = a.drop ? a.drop[pi] : 1.f;
+        const f32x4_t d4 = *(const f32x4_t*)(dos + qi * SHD + c4);
+        float dp = (d4[0] * t[u][0] + d4[1] * t[u][1]) + (d4[2] * t[u][2] + d4[3] * t[u][3]);
+        dp += __shfl_xor(dp, 1, 64);
+        dp += __shfl_xor(dp, 2, 64);
+        dp += __shfl_xor(dp, 4, 64);
+        dvr += (p * dm) * d4;
+        if (in && c4 == 0) {
+          ds[qi * a.Lk + kk] = dp * dm;   // dP wrt softmax output
+          pd[qi * a.Lk + kk] = p;
+        }
       }
-      ds[qi * a.Lk + kk] = dp * dm;   // dP wrt softmax output
-      pd[qi * a.Lk + kk] = p;
+      if (in) *(f32x4_t*)(a.dv + (long)(b * a.kv_rows + kk) * a.lddv + h * SHD + c4) = dvr;
     }
-    float* gp = a.dv + (long)(b * a.kv_rows + kk) * a.lddv + h * SHD;
-#pragma unroll
-    for (int d = 0; d < SHD; d += 4) *(f32x4_t*)(gp + d) = (f32x4_t){dvr[d], dvr[d + 1], dvr[d + 2], dvr[d + 3]};
   }
   __syncthreads();
   for (int qi = wave; qi < a.Lq; qi += 4) {
@@ -378,46 +421,49 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(SAArgs a) {
     ds[e] = pd[e] * (ds[e] - rs[qi]) * a.scale;      // dS * scale (masked keys: P = 0 -> 0)
   }
   __syncthreads();
-  // dQ[qi][d] = sum_k dS[qi][k] K[k][d]: keys dealt over 8 thread groups as in the forward's P V product
+  // dQ[qi][d] = sum_k dS[qi][k] K[k][d] (the 32 key slots of the block meet in LDS);  dK[k][d] = sum_q dS[q][k] Q[q][d]
   {
-    float* red = rs + a.Lq;               // [8][Lq][32]
-    const int part = tid >> 5, d = tid & 31;
-    const float* kp = a.k + (long)(b * a.kv_rows) * a.ldk + h * SHD + d;
-    const float* pp = a.kpos ? a.kpos + (long)(b * a.kpos_rows) * a.ldkp + h * SHD + d : nullptr;
-    float o[16];
+    float* red = rs + a.Lq;               // [32][Lq][32]
+    f32x4_t o[16];
 #pragma unroll
-    for (int qi = 0; qi < 16; ++qi) o[qi] = 0.f;
-    for (int kk = part; kk < a.Lk; kk += 8) {
-      float kv = kp[(long)kk * a.ldk];
-      if (pp) kv += pp[(long)kk * a.ldkp];
+    for (int qi = 0; qi < 16; ++qi) o[qi] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < a.Lk; k0 += 32 * KB) {
+      f32x4_t t[KB];
 #pragma unroll
-      for (int qi = 0; qi < 16; ++qi)
-        if (qi < a.Lq) o[qi] += ds[qi * a.Lk + kk] * kv;
+      for (int u = 0; u < KB; ++u) {
+        const int kk = k0 + u * 32 + slot;
+        t[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (kk < a.Lk) {
+          t[u] = *(const f32x4_t*)(a.k + (long)(b * a.kv_rows + kk) * a.ldk + h * SHD + c4);
+          if (a.kpos) t[u] += *(const f32x4_t*)(a.kpos + (long)(b * a.kpos_rows + kk) * a.ldkp + h * SHD + c4);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < KB; ++u) {
+        const int kk = k0 + u * 32 + slot;
+        if (kk < a.Lk) {
+          f32x4_t dkr = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int qi = 0; qi < 16; ++qi)
+            if (qi < a.Lq) {
+              const float sv = ds[qi * a.Lk + kk];
+              o[qi] += sv * t[u];
+              dkr += sv * *(const f32x4_t*)(qs + qi * SHD + c4);
+            }
+          *(f32x4_t*)(a.dk + (long)(b * a.kv_rows + kk) * a.lddk + h * SHD + c4) = dkr;
+        }
+      }
     }
 #pragma unroll
     for (int qi = 0; qi < 16; ++qi)
-      if (qi < a.Lq) red[(part * a.Lq + qi) * SHD + d] = o[qi];
+      if (qi < a.Lq) *(f32x4_t*)(red + (slot * a.Lq + qi) * SHD + c4) = o[qi];
     __syncthreads();
     for (int e = tid; e < a.Lq * SHD; e += 256) {
       float t = 0.f;
 #pragma unroll
-      for (int p8 = 0; p8 < 8; ++p8) t += red[p8 * a.Lq * SHD + e];
+      for (int p32 = 0; p32 < 32; ++p32) t += red[p32 * a.Lq * SHD + e];
       a.dq[(long)(b * a.Lq + e / SHD) * a.lddq + h * SHD + (e % SHD)] = t;
     }
-  }
-  // dK[k][d] = sum_q dS[q][k] Q[q][d]
-  for (int kk = tid; kk < a.Lk; kk += 256) {
-    float acc[SHD];
-#pragma unroll
-    for (int d = 0; d < SHD; ++d) acc[d] = 0.f;
-    for (int qi = 0; qi < a.Lq; ++qi) {
-      const float s = ds[qi * a.Lk + kk];
-#pragma unroll
-      for (int d = 0; d < SHD; ++d) acc[d] += s * qs[qi * SHD + d];
-    }
-    float* gp = a.dk + (long)(b * a.kv_rows + kk) * a.lddk + h * SHD;
-#pragma unroll
-    for (int d = 0; d < SHD; d += 4) *(f32x4_t*)(gp + d) = (f32x4_t){acc[d], acc[d + 1], acc[d + 2], acc[d + 3]};
   }
 }
 
@@ -477,14 +523,14 @@ extern "C" int simvg_attn_small_fwd(const float* q, int ldq, const float* k, int
                                     const float* drop_mult, int B, int H, int Lq, int Lk, int kv_rows_per_batch,
                                     float scale, const float* key_pos, int ld_key_pos, int key_pos_rows_per_batch,
                                     hipStream_t stream) {
-  SIMVG_CHECK_ARG(B > 0 && H > 0 && Lq > 0 && Lq <= 16 && Lk > 0 && (size_t)(Lq * SHD + Lq * Lk + 8 * Lq * SHD) * sizeof(float) <= 160 * 1024,
+  SIMVG_CHECK_ARG(B > 0 && H > 0 && Lq > 0 && Lq <= 16 && Lk > 0 && (size_t)(Lq * SHD + Lq * Lk + 32 * Lq * SHD) * sizeof(float) <= 160 * 1024,
                   "attn_small: Lq <= 16 and the [Lq, Lk] score strip must fit the 160 KiB LDS");
   SIMVG_CHECK_ARG(ldk % 4 == 0 && ldv % 4 == 0, "attn_small: K/V rows must be 16-B aligned");
   SAArgs a{q, ldq, k, ldk, v, ldv, out, ldo, P, key_padding_mask, drop_mult, nullptr, 0, nullptr, 0, nullptr, 0,
            nullptr, 0, B, H, Lq, Lk, kv_rows_per_batch > 0 ? kv_rows_per_batch : Lk, scale, key_pos, ld_key_pos,
            key_pos_rows_per_batch};
   SIMVG_CHECK_ARG(!key_pos || ld_key_pos % 4 == 0, "attn_small: key_pos rows must be 16-B aligned");
-  const size_t shm = (size_t)(Lq * SHD + Lq * Lk + 8 * Lq * SHD) * sizeof(float);
+  const size_t shm = (size_t)(Lq * SHD + Lq * Lk + 32 * Lq * SHD) * sizeof(float);
   static bool once = hipFuncSetAttribute((const void*)attn_small_fwd_kernel,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
   (void)once;
@@ -500,13 +546,13 @@ extern "C" int simvg_attn_small_bwd(const float* q, int ldq, const float* k, int
                                     const float* key_pos, int ld_key_pos, int key_pos_rows_per_batch,
                                     hipStream_t stream) {
   SIMVG_CHECK_ARG(B > 0 && H > 0 && Lq > 0 && Lq <= 16 && Lk > 0 &&
-                  (size_t)(2 * Lq * SHD + 2 * Lq * Lk + Lq + 8 * Lq * SHD) * sizeof(float) <= 160 * 1024,
+                  (size_t)(2 * Lq * SHD + 2 * Lq * Lk + Lq + 32 * Lq * SHD) * sizeof(float) <= 160 * 1024,
                   "attn_small: Lq <= 16 and two [Lq, Lk] strips must fit the 160 KiB LDS");
   SIMVG_CHECK_ARG(ldk % 4 == 0 && ldv % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0, "attn_small: rows must be 16-B aligned");
   SAArgs a{q, ldq, k, ldk, v, ldv, nullptr, 0, (float*)P, key_padding_mask, drop_mult, dout, lddo, dq, lddq, dk, lddk,
            dv, lddv, B, H, Lq, Lk, kv_rows_per_batch > 0 ? kv_rows_per_batch : Lk, scale, key_pos, ld_key_pos,
            key_pos_rows_per_batch};
-  const size_t shm = (size_t)(2 * Lq * SHD + 2 * Lq * Lk + Lq + 8 * Lq * SHD) * sizeof(float);
+  const size_t shm = (size_t)(2 * Lq * SHD + 2 * Lq * Lk + Lq + 32 * Lq * SHD) * sizeof(float);
   static bool once = hipFuncSetAttribute((const void*)attn_small_bwd_kernel,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
   (void)once;
