@@ -136,7 +136,8 @@ __device__ __forceinline__ f32x4_t load_k4(const float* base, long sk, bool vec,
     if (k + i < K) v[i] = base[(long)(k + i) * sk];
   return v;
 }
-__device__ __forceinline__ void gemm_f32_tile16(const SGArgs& a, int bx, int by, float* smem) {
+template <int U>      // U 16-k steps of a wave in flight (loaded before the previous U are consumed)
+__device__ __forceinline__ void gemm_f32_tile16_u(const SGArgs& a, int bx, int by, float* smem) {
   float (*part)[256] = (float (*)[256])smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
@@ -161,27 +162,28 @@ __device__ __forceinline__ void gemm_f32_tile16(const SGArgs& a, int bx, int by,
   };
   f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
   const int nsteps = (a.K + 15) >> 4;
-  // wave w takes steps w, w+4, ...; two steps in flight (the next pair is loaded before the current pair is consumed)
-  f32x4_t av[2], bv[2], an[2], bn[2];
+  // wave w takes steps w, w+4, ...; U steps in flight (the next U are loaded before the current U are consumed): the loop is a
+  // chain of memory latencies, K = 2048 (the FFN's second Linear) is 32 steps per wave -- 16 round trips at U = 2 (33 us), 4 at U = 8
+  f32x4_t av[U], bv[U], an[U], bn[U];
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < U; ++u) {
     const int st = wave + 4 * u;
     av[u] = ldA(mok && st < nsteps, st * 16 + 4 * g);
     bv[u] = ldB(nok && st < nsteps, st * 16 + 4 * g);
   }
-  for (int s = wave; s < nsteps; s += 8) {
+  for (int s = wave; s < nsteps; s += 4 * U) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int st = s + 8 + 4 * u;
+    for (int u = 0; u < U; ++u) {
+      const int st = s + 4 * U + 4 * u;
       an[u] = ldA(mok && st < nsteps, st * 16 + 4 * g);
       bn[u] = ldB(nok && st < nsteps, st * 16 + 4 * g);
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][i], bv[u][i], acc, 0, 0, 0);
 #pragma unroll
-    for (int u = 0; u < 2; ++u) { av[u] = an[u]; bv[u] = bn[u]; }
+    for (int u = 0; u < U; ++u) { av[u] = an[u]; bv[u] = bn[u]; }
   }
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) part[wave][(4 * g + rr) * 16 + r] = acc[rr];
@@ -190,6 +192,11 @@ __device__ __forceinline__ void gemm_f32_tile16(const SGArgs& a, int bx, int by,
   const int mo = by * 16 + ml, no = bx * 16 + nl;
   if (mo >= a.M || no >= a.N) return;
   sg_store(a, part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid], mo, no);
+}
+
+__device__ __forceinline__ void gemm_f32_tile16(const SGArgs& a, int bx, int by, float* smem) {
+  if (a.K >= 1024) gemm_f32_tile16_u<8>(a, bx, by, smem);
+  else gemm_f32_tile16_u<2>(a, bx, by, smem);
 }
 
 __global__ __launch_bounds__(256) void gemm_f32_kernel(SGArgs a) {
