@@ -92,6 +92,69 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIn* __restrict__ x, 
 }
 
 
+// Narrow rows at training sizes, RW rows per wave: the kernel above keeps one 3-4 KB row per wave in flight, which at full
+// occupancy is ~96 KB per CU -- bound by loads in flight (Little), like the backward kernels were.  Here a wave issues the loads of
+// RW rows back to back (raw form) and then normalises them one after the other; width (D = NIT * 256) and output (16 bit) are
+// compile-time, straight-line code, so hipcc counts its own waits.
+template <typename TIn, int NIT, int RW>
+__global__ __launch_bounds__(256) void ln_fwd_rows_kernel(const TIn* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, int gstride, lp_t* __restrict__ y, int ldy,
+                                                          float* __restrict__ mean, float* __restrict__ rstd, int M, int split, float eps) {
+  constexpr int D = NIT * 256;
+  constexpr bool XF = sizeof(TIn) == 4;
+  const int lane = threadIdx.x & 63;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
+  if (row0 >= M) return;
+  f32x4_t xf[RW][XF ? NIT : 1];
+  u32x2_t xb[RW][XF ? 1 : NIT];
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int row = min(row0 + r, M - 1);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = (it * 64 + lane) * 4;
+      if constexpr (XF) xf[r][it] = *(const f32x4_t*)((const float*)x + (long)row * ldx + c);
+      else xb[r][it] = *(const u32x2_t*)((const lp_t*)x + (long)row * ldx + c);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int row = row0 + r;
+    if (row >= M) break;
+    float v[NIT][4];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      if constexpr (XF) { const f32x4_t t = xf[r][it]; v[it][0] = t[0]; v[it][1] = t[1]; v[it][2] = t[2]; v[it][3] = t[3]; }
+      else { unpack_lp2(xb[r][it][0], v[it][0], v[it][1]); unpack_lp2(xb[r][it][1], v[it][2], v[it][3]); }
+      s += (v[it][0] + v[it][1]) + (v[it][2] + v[it][3]);
+    }
+    const float mu = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const float d = v[it][k] - mu; q += d * d; }
+    const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+    if (lane == 0) {
+      if (mean) mean[row] = mu;
+      if (rstd) rstd[row] = rs;
+    }
+    const int g = row >= split;
+    const float* gm = gamma + (long)g * gstride;
+    const float* bt = beta + (long)g * gstride;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = (it * 64 + lane) * 4;
+      const f32x4_t gv = *(const f32x4_t*)(gm + c), bv = *(const f32x4_t*)(bt + c);
+      float o[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = (v[it][k] - mu) * rs * gv[k] + bv[k];
+      st4_lp(y + (long)row * ldy + c, o);
+    }
+  }
+}
+
 // Wide 16-bit rows (D = NIT8 * 512: the 3072 / 4096-wide ffn_layernorm, whose input is the fc1 pre-activation u and whose
 // LayerNorm input gelu(u) is recomputed here).  The generic kernel above guards every 256-column slice with `c < D` and
 // tests the run-time gelu flag inside the slice loop; each slice's load then sits in its own exec-masked block, hipcc
@@ -850,6 +913,10 @@ __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __re
     else { CALL(16); }                                               \
   } while (0)
 
+#ifndef LN_FWD_RW
+#define LN_FWD_RW 2
+#endif
+static inline bool ln_rows_off() { static const bool off = getenv("SIMVG_LN_ROWS") && atoi(getenv("SIMVG_LN_ROWS")) == 0; return off; }
 static inline int ln_wide_rpb(int M) { return std::max(16, cdiv(M, 508)); }
 // ln_bwd_tile_kernel: R rows per batch (two batches in flight); rows per block so that the grid is ~ LN_TILE_BLOCKS blocks
 // (sweep at M = 26 944, us residual-stream / sub-LN instance incl. the reduction launch, +-5 us run to run: R = 2/4, 3/6, 4/8, 5/10 at
@@ -897,6 +964,18 @@ extern "C" int simvg_ln_fwd(const void* x, int x_is_bf16, int ldx, const float* 
       SIMVG_LAUNCH_CHECK();
       return SIMVG_OK;
     }
+  }
+  if (y_bf16 && !y_f32 && !x_is_gelu_preact && (D == 768 || D == 1024) && M >= 1024 && group_stride % 4 == 0 && !ln_rows_off()) {
+    constexpr int RW = LN_FWD_RW;
+    const dim3 rgrid(cdiv(M, 4 * RW));
+#define RCALL(T_, N_)                                                                                                  \
+    hipLaunchKernelGGL((ln_fwd_rows_kernel<T_, N_, RW>), rgrid, block, 0, stream, (const T_*)x, ldx, gamma, beta,      \
+                       group_stride, (lp_t*)y_bf16, ldy, mean, rstd, M, split, eps)
+    if (x_is_bf16) { if (D == 768) RCALL(lp_t, 3); else RCALL(lp_t, 4); }
+    else { if (D == 768) RCALL(float, 3); else RCALL(float, 4); }
+#undef RCALL
+    SIMVG_LAUNCH_CHECK();
+    return SIMVG_OK;
   }
 #define CALL(N_)                                                                                                   \
   if (x_is_bf16)                                                                                                   \
