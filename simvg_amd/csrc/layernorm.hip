@@ -163,68 +163,82 @@ __global__ __launch_bounds__(256) void ln_fwd_rows_kernel(const TIn* __restrict_
 // back-to-back before any arithmetic, each lane owns 8 consecutive columns per slice (16-B loads and stores): 113 -> 85 us.
 // What remains above the 66 us of the same kernel without the activation is VALU: the erf GELU + LayerNorm are ~35 VALU
 // operations per element (a persistent variant with the next row's loads in flight measured the same 88 us).
-template <int NIT8, bool GELU>
+#ifndef LN_WIDE_RW
+#define LN_WIDE_RW 1
+#endif
+// RW rows per wave (raw 16-bit rows all requested before the first is normalised).  A wave per row keeps 6-8 KB in flight, ~96 KB
+// per CU at 4 waves per SIMD, and the kernel runs at the ~4.2 TB/s that allows; RW = 2 would double it, but the fp32 row (48
+// registers) + a second raw row (24) + the activation's temporaries do not fit 128 VGPRs: 90 us with spills against 78 us
+// (without the activation 72 vs 74 us), so RW stays 1 here -- the narrow kernel above is where two rows per wave pay
+template <int NIT8, bool GELU, int RW>
 __global__ __launch_bounds__(256, NIT8 <= 6 ? 4 : 3) void ln_fwd_wide_kernel(const lp_t* __restrict__ x, int ldx, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, int gstride, lp_t* __restrict__ y,
                                                           int ldy, float* __restrict__ mean, float* __restrict__ rstd, int M,
                                                           int split, float eps) {
   constexpr int D = NIT8 * 512;
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
-  const int g = row >= split;
-  const lp_t* xr = x + (long)row * ldx + lane * 8;
-  u32x4_t raw[NIT8];
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
+  if (row0 >= M) return;
+  u32x4_t raw[RW][NIT8];
 #pragma unroll
-  for (int it = 0; it < NIT8; ++it) raw[it] = __builtin_nontemporal_load((const u32x4_t*)(xr + it * 512));
-  // two values per register pair: the arithmetic below is packed fp32 (v_pk_fma / v_pk_mul / v_pk_add: one issue slot for two
-  // values) -- this kernel is bound by VALU issue, not by HBM, once the activation is evaluated here
-  hw_f32x2_t v[NIT8][4];
-  hw_f32x2_t s2 = {0.f, 0.f};
+  for (int r = 0; r < RW; ++r) {
+    const lp_t* xr = x + (long)min(row0 + r, M - 1) * ldx + lane * 8;
 #pragma unroll
-  for (int it = 0; it < NIT8; ++it) {
+    for (int it = 0; it < NIT8; ++it) raw[r][it] = __builtin_nontemporal_load((const u32x4_t*)(xr + it * 512));
+  }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float lo, hi;
-      unpack_lp2(raw[it][k], lo, hi);
-      v[it][k] = (hw_f32x2_t){lo, hi};
-      if (GELU) {
-        hw_f32x2_t cdf, pdf;
-        gelu_parts2(v[it][k], cdf, pdf);
-        v[it][k] = v[it][k] * cdf;
+  for (int r = 0; r < RW; ++r) {
+    const int row = row0 + r;
+    if (row >= M) break;
+    const int g = row >= split;
+    // two values per register pair: the arithmetic below is packed fp32 (v_pk_fma / v_pk_mul / v_pk_add: one issue slot for two values)
+    hw_f32x2_t v[NIT8][4];
+    hw_f32x2_t s2 = {0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < NIT8; ++it) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float lo, hi;
+        unpack_lp2(raw[r][it][k], lo, hi);
+        v[it][k] = (hw_f32x2_t){lo, hi};
+        if (GELU) {
+          hw_f32x2_t cdf, pdf;
+          gelu_parts2(v[it][k], cdf, pdf);
+          v[it][k] = v[it][k] * cdf;
+        }
       }
+      s2 += (v[it][0] + v[it][1]) + (v[it][2] + v[it][3]);
     }
-    s2 += (v[it][0] + v[it][1]) + (v[it][2] + v[it][3]);
-  }
-  const float mu = wave_sum(s2[0] + s2[1]) * (1.f / (float)D);
-  const hw_f32x2_t mu2 = {mu, mu};
-  hw_f32x2_t q2 = {0.f, 0.f};
+    const float mu = wave_sum(s2[0] + s2[1]) * (1.f / (float)D);
+    const hw_f32x2_t mu2 = {mu, mu};
+    hw_f32x2_t q2 = {0.f, 0.f};
 #pragma unroll
-  for (int it = 0; it < NIT8; ++it)
+    for (int it = 0; it < NIT8; ++it)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { const hw_f32x2_t d = v[it][k] - mu2; q2 = __builtin_elementwise_fma(d, d, q2); }
-  const float rs = rsqrtf(wave_sum(q2[0] + q2[1]) * (1.f / (float)D) + eps);
-  if (lane == 0) {
-    if (mean) mean[row] = mu;
-    if (rstd) rstd[row] = rs;
-  }
-  const float* gm = gamma + (long)g * gstride + lane * 8;
-  const float* bt = beta + (long)g * gstride + lane * 8;
-  lp_t* yr = y + (long)row * ldy + lane * 8;
-  const hw_f32x2_t rs2 = {rs, rs};
-#pragma unroll
-  for (int it = 0; it < NIT8; ++it) {
-    const f32x4_t g0 = *(const f32x4_t*)(gm + it * 512), g1 = *(const f32x4_t*)(gm + it * 512 + 4);
-    const f32x4_t b0 = *(const f32x4_t*)(bt + it * 512), b1 = *(const f32x4_t*)(bt + it * 512 + 4);
-    const hw_f32x2_t gg[4] = {{g0[0], g0[1]}, {g0[2], g0[3]}, {g1[0], g1[1]}, {g1[2], g1[3]}};
-    const hw_f32x2_t bb[4] = {{b0[0], b0[1]}, {b0[2], b0[3]}, {b1[0], b1[1]}, {b1[2], b1[3]}};
-    unsigned w[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const hw_f32x2_t o = __builtin_elementwise_fma((v[it][k] - mu2) * rs2, gg[k], bb[k]);
-      w[k] = pack_lp2(o[0], o[1]);
+      for (int k = 0; k < 4; ++k) { const hw_f32x2_t d = v[it][k] - mu2; q2 = __builtin_elementwise_fma(d, d, q2); }
+    const float rs = rsqrtf(wave_sum(q2[0] + q2[1]) * (1.f / (float)D) + eps);
+    if (lane == 0) {
+      if (mean) mean[row] = mu;
+      if (rstd) rstd[row] = rs;
     }
-    *(u32x4_t*)(yr + it * 512) = (u32x4_t){w[0], w[1], w[2], w[3]};
+    const float* gm = gamma + (long)g * gstride + lane * 8;
+    const float* bt = beta + (long)g * gstride + lane * 8;
+    lp_t* yr = y + (long)row * ldy + lane * 8;
+    const hw_f32x2_t rs2 = {rs, rs};
+#pragma unroll
+    for (int it = 0; it < NIT8; ++it) {
+      const f32x4_t g0 = *(const f32x4_t*)(gm + it * 512), g1 = *(const f32x4_t*)(gm + it * 512 + 4);
+      const f32x4_t b0 = *(const f32x4_t*)(bt + it * 512), b1 = *(const f32x4_t*)(bt + it * 512 + 4);
+      const hw_f32x2_t gg[4] = {{g0[0], g0[1]}, {g0[2], g0[3]}, {g1[0], g1[1]}, {g1[2], g1[3]}};
+      const hw_f32x2_t bb[4] = {{b0[0], b0[1]}, {b0[2], b0[3]}, {b1[0], b1[1]}, {b1[2], b1[3]}};
+      unsigned w[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const hw_f32x2_t o = __builtin_elementwise_fma((v[it][k] - mu2) * rs2, gg[k], bb[k]);
+        w[k] = pack_lp2(o[0], o[1]);
+      }
+      *(u32x4_t*)(yr + it * 512) = (u32x4_t){w[0], w[1], w[2], w[3]};
+    }
   }
 }
 
@@ -948,8 +962,8 @@ extern "C" int simvg_ln_fwd(const void* x, int x_is_bf16, int ldx, const float* 
   const dim3 grid(cdiv(M, 4)), block(256);
   if (x_is_bf16 && y_bf16 && !y_f32 && D % 512 == 0 && D >= 1024 && ldx % 8 == 0 && ldy % 8 == 0 && group_stride % 4 == 0) {
 #define WCALL(N_, G_)                                                                                                  \
-    hipLaunchKernelGGL((ln_fwd_wide_kernel<N_, G_>), grid, block, 0, stream, (const lp_t*)x, ldx, gamma, beta,        \
-                       group_stride, (lp_t*)y_bf16, ldy, mean, rstd, M, split, eps)
+    hipLaunchKernelGGL((ln_fwd_wide_kernel<N_, G_, LN_WIDE_RW>), dim3(cdiv(M, 4 * LN_WIDE_RW)), block, 0, stream,      \
+                       (const lp_t*)x, ldx, gamma, beta, group_stride, (lp_t*)y_bf16, ldy, mean, rstd, M, split, eps)
     const int n8 = D / 512;
     bool done = true;
     if (x_is_gelu_preact) {
