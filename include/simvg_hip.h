@@ -164,6 +164,11 @@ int simvg_match(const float* logits, const float* boxes, const float* tboxes, co
 int simvg_soft_targets(const float* logits, const float* boxes, const int* match, const float* tboxes, const int* tcount,
                        float* pboxes, int* plabels, int* pcount, float* pweight, float* scalars4, int B, int nq, int TM,
                        simvg_stream_t stream);
+/* GT packing of prepare_soft_targets (tgqs_kd_detr_head.py:215-234: pixel xyxy / (w,h,w,h) -> cxcywh rows of the [B, max_targets, 4]
+ * target array, zero elsewhere; per-image counts).  table (device memory, uploaded by the host in one copy): n_rows records
+ * {const float* src (device pointer to 4 floats, or NULL: use box), float box[4], float w, float h, int dst_row, int pad} (40 bytes)
+ * followed by B int32 counts. */
+int simvg_pack_targets(const void* table, int n_rows, float* boxes, int* count, int B, int max_targets, simvg_stream_t stream);
 int simvg_criterion(const float* logits, const float* boxes, const int* match, const float* tboxes, const int* tlabels,
                     const float* num_boxes, const float* weights_distill, float* dlogits, float* dboxes, float* out,
                     int L, int B, int nq, int TM, int coef_mode, float coef, float eos_coef, float w_class, float w_bbox,

@@ -79,6 +79,7 @@ _SIGS = {
     "simvg_attn_f32_fwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
     "simvg_dropout_mult": [c_void_p, c_long, c_float, c_void_p, c_long, C.c_ulonglong, C.c_ulonglong, c_void_p, c_void_p],
     "simvg_philox4x32": [c_void_p, c_void_p, c_void_p],
+    "simvg_pack_targets": [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "simvg_probe_mfma": [c_void_p, c_void_p, c_void_p, c_void_p],
     "simvg_probe_tr16": [c_void_p, c_void_p, c_void_p],
     "simvg_probe_glds": [c_void_p, c_void_p, c_void_p, c_void_p],

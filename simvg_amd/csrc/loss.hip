@@ -378,6 +378,39 @@ extern "C" int simvg_soft_targets(const float* logits, const float* boxes, const
   return SIMVG_OK;
 }
 
+// ---- target packing (prepare_soft_targets :215-234): xyxy pixel boxes -> normalised cxcywh rows of the [B, max_targets, 4] target
+// array, one launch instead of the framework's cat / div / add / sub / stack / index_put / zeros chain.  The host uploads ONE table:
+// n rows {source pointer or inline box, image w / h, destination row} followed by the B per-image counts.
+namespace {
+struct PackRow { const float* src; float box[4]; float w, h; int dst; int pad; };      // 40 bytes
+__global__ __launch_bounds__(256) void pack_targets_kernel(const PackRow* __restrict__ rows, int n, float* __restrict__ boxes,
+                                                           int* __restrict__ count, int B, int TM) {
+  const int* counts_src = (const int*)(rows + n);
+  for (int i = threadIdx.x; i < B * TM * 4; i += 256) boxes[i] = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) count[b] = counts_src[b];
+  __syncthreads();
+  for (int r = threadIdx.x; r < n; r += 256) {
+    const PackRow q = rows[r];
+    float x0, y0, x1, y1;
+    if (q.src) { x0 = q.src[0]; y0 = q.src[1]; x1 = q.src[2]; y1 = q.src[3]; }
+    else { x0 = q.box[0]; y0 = q.box[1]; x1 = q.box[2]; y1 = q.box[3]; }
+    x0 = x0 / q.w; y0 = y0 / q.h; x1 = x1 / q.w; y1 = y1 / q.h;          // the reference's order: normalise, then convert
+    float* o = boxes + (long)q.dst * 4;
+    o[0] = (x0 + x1) / 2.f;
+    o[1] = (y0 + y1) / 2.f;
+    o[2] = x1 - x0;
+    o[3] = y1 - y0;
+  }
+}
+}  // namespace
+
+extern "C" int simvg_pack_targets(const void* table, int n_rows, float* boxes, int* count, int B, int max_targets, hipStream_t stream) {
+  SIMVG_CHECK_ARG(table && boxes && count && n_rows >= 0 && B > 0 && max_targets > 0, "pack_targets: bad arguments");
+  hipLaunchKernelGGL(pack_targets_kernel, dim3(1), dim3(256), 0, stream, (const PackRow*)table, n_rows, boxes, count, B, max_targets);
+  SIMVG_LAUNCH_CHECK();
+  return SIMVG_OK;
+}
+
 extern "C" int simvg_criterion(const float* logits, const float* boxes, const int* match, const float* tboxes,
                                const int* tlabels, const float* num_boxes, const float* weights_distill,
                                float* dlogits, float* dboxes, float* out, int L, int B, int nq, int TM,

@@ -520,6 +520,52 @@ def attn_small_bwd(q, k, v, P, dout, dq, dk, dv, B, H, Lq, Lk, kpm=None, drop=No
     _lib.check(rc, "simvg_attn_small_bwd")
 
 
+class _PackRing:
+    """pinned staging buffers for the one host->device copy of `pack_targets`: a slot is rewritten only after the copy that read it
+    has completed (the host may run steps ahead of the device)"""
+    SLOTS = 8
+
+    def __init__(self):
+        self.bufs, self.events, self.i = [None] * self.SLOTS, [None] * self.SLOTS, 0
+
+    def stage(self, raw, device):
+        k = self.i % self.SLOTS
+        self.i += 1
+        if self.events[k] is not None:
+            self.events[k].synchronize()
+        if self.bufs[k] is None or self.bufs[k].numel() < len(raw):
+            self.bufs[k] = torch.empty(max(4096, 2 * len(raw)), dtype=torch.uint8).pin_memory()
+        pin = self.bufs[k][:len(raw)]
+        pin.copy_(torch.frombuffer(raw, dtype=torch.uint8))
+        dev = pin.to(device, non_blocking=True)
+        ev = self.events[k] or torch.cuda.Event()
+        ev.record()
+        self.events[k] = ev
+        return dev
+
+
+_pack_ring = _PackRing()
+
+
+def pack_targets(rows, counts, B, TM, device):
+    """rows: list of (device tensor holding an fp32 xyxy box at `offset` elements | None, offset, (x0, y0, x1, y1) | None, w, h,
+    destination row); counts: B ints.  -> (boxes [B, TM, 4] fp32 normalised cxcywh, count [B] int32), one copy + one launch."""
+    import struct
+    lib = _lib.load()
+    raw = bytearray()
+    for src, off, box, w, h, dst in rows:
+        ptr = 0 if src is None else src.data_ptr() + 4 * off
+        bx = box if box is not None else (0.0, 0.0, 0.0, 0.0)
+        raw += struct.pack("<q4fffii", ptr, bx[0], bx[1], bx[2], bx[3], float(w), float(h), int(dst), 0)
+    raw += struct.pack(f"<{B}i", *counts)
+    table = _pack_ring.stage(raw, device)
+    boxes = torch.empty(B, TM, 4, device=device, dtype=torch.float32)
+    count = torch.empty(B, device=device, dtype=torch.int32)
+    rc = lib.simvg_pack_targets(_p(table), len(rows), _p(boxes), _p(count), B, TM, _stream())
+    _lib.check(rc, "simvg_pack_targets")
+    return boxes, count
+
+
 def match(logits, boxes, tboxes, tlabels, tcount, cost=(1.0, 5.0, 2.0)):
     """logits [L,B,nq,2], boxes [L,B,nq,4] fp32 -> int32 [L,B,nq] matched target index or -1."""
     lib = _lib.load()

@@ -403,10 +403,11 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
     # ------------------------------------------------------------------ targets + losses (:207-268, 456-572)
     def _pack_targets(self, gt_bbox, img_metas, device, return_counts=False):
         """GT -> normalised cxcywh target arrays (prepare_soft_targets :215-234; drops category_id == -1 entries).
-        Counts / indices come from host metadata (shapes, img_metas); the boxes themselves stay where they are
-        (CPU or HBM) and are packed with device ops -- no device-to-host synchronisation."""
+        Counts / indices come from host metadata (shapes, img_metas); boxes in HBM are read where they are (the table carries
+        their addresses), host boxes travel inside the table: one host->device copy and one launch (`simvg_pack_targets`), no
+        device-to-host synchronisation."""
         B, TM = len(gt_bbox), self.max_targets
-        rows, dst, whwh, counts = [], [], [], []
+        rows, counts = [], []
         for b, (tb, meta) in enumerate(zip(gt_bbox, img_metas)):
             tb = tb if torch.is_tensor(tb) else torch.as_tensor(tb, dtype=torch.float32)
             h, w = meta["img_shape"][:2]
@@ -419,18 +420,23 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
             if len(keep) > TM:
                 raise ValueError(f"more than {TM} targets in one image")
             if keep:
-                sel = tb if len(keep) == int(tb.shape[0]) else tb[keep]       # no gather launch when nothing is dropped
-                rows.append(sel.to(device=device, dtype=torch.float32, non_blocking=True))
-                dst += [b * TM + j for j in range(len(keep))]
-                whwh += [[w, h, w, h]] * len(keep)
+                on_dev = tb.is_cuda and tb.device == device and tb.dtype == torch.float32 and tb.stride(-1) == 1
+                if not on_dev:            # host boxes (the file loader's) travel inside the table; other device layouts are normalised first
+                    vals = tb.detach().to(dtype=torch.float32).cpu().tolist() if not tb.is_cuda else None
+                    if vals is None:
+                        tb, on_dev = tb.to(device=device, dtype=torch.float32).contiguous(), True
+                for j, i in enumerate(keep):
+                    if on_dev:
+                        rows.append((tb, i * tb.stride(0), None, w, h, b * TM + j))      # (tensor, element offset of the row)
+                    else:
+                        rows.append((None, 0, vals[i], w, h, b * TM + j))
             counts.append(len(keep))
-        boxes = torch.zeros(B * TM, 4, device=device)
-        if rows:
-            t = torch.cat(rows, 0) / torch.tensor(whwh, dtype=torch.float32).to(device, non_blocking=True)
-            cx = torch.stack([(t[:, 0] + t[:, 2]) / 2, (t[:, 1] + t[:, 3]) / 2, t[:, 2] - t[:, 0], t[:, 3] - t[:, 1]], -1)
-            boxes[torch.tensor(dst, dtype=torch.long).to(device, non_blocking=True)] = cx
-        count = torch.tensor(counts, dtype=torch.int32).to(device, non_blocking=True)
-        out = (boxes.view(B, TM, 4), torch.zeros(B, TM, dtype=torch.int32, device=device), count)
+        boxes, count = ops.pack_targets(rows, counts, B, TM, device)
+        key = ("tlabels", str(device), B, TM)
+        labels = self._const.get(key)
+        if labels is None:
+            labels = self._const[key] = torch.zeros(B, TM, dtype=torch.int32, device=device)
+        out = (boxes, labels, count)
         return out + (counts,) if return_counts else out
 
     def prepare_targets(self, gt_bbox, img_metas, device):

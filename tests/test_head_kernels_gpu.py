@@ -370,3 +370,51 @@ def test_postprocess_kernel_vs_torch(B, nq, ncol, rescale):
     assert torch.equal(box.cpu(), box_ref)
     assert torch.equal(best_label.cpu(), labels_ref[torch.arange(B), best])
     close(scores, scores_ref, 1e-6, "scores")
+
+
+def test_pack_targets_matches_the_reference_formula():
+    """`simvg_pack_targets` (one copy + one launch) against prepare_soft_targets' arithmetic (tgqs_kd_detr_head.py:215-234): boxes
+    in HBM (views of one batch tensor, as the loaders hand them over), boxes on the host, multi-target lists with dropped
+    (category_id == -1) entries and images without a target -- bit-identical rows, zeros elsewhere, counts per image."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_tools_gpu import _tiny_model
+    _, model = _tiny_model(3)
+    head = model.head
+    TM = head.max_targets
+    g = torch.Generator().manual_seed(5)
+    B = 6
+    xy = torch.rand(B, 3, 2, generator=g) * 300
+    wh = 20 + torch.rand(B, 3, 2, generator=g) * 200
+    allb = torch.cat([xy, xy + wh], -1)                                   # [B, 3, 4] pixel xyxy
+    shapes = [(480, 640), (640, 480), (333, 517), (640, 640), (512, 400), (200, 300)]
+    metas, gts, ref = [], [], torch.zeros(B, TM, 4)
+    counts = []
+    for b in range(B):
+        h, w = shapes[b]
+        if b % 3 == 0:            # single box given as a 1-D tensor (RefCOCO): a view of the batch tensor in HBM
+            gts.append(allb.to(DEV)[b, 0])
+            metas.append(dict(img_shape=(h, w, 3)))
+            kept = [allb[b, 0]]
+        elif b % 3 == 1:          # GRefCOCO list on the host, second entry is a no-target placeholder
+            gts.append(allb[b].clone())
+            metas.append(dict(img_shape=(h, w, 3), target=[dict(category_id=1), dict(category_id=-1), dict(category_id=3)]))
+            kept = [allb[b, 0], allb[b, 2]]
+        else:                     # GRefCOCO list in HBM, nothing kept
+            gts.append(allb[b].to(DEV))
+            metas.append(dict(img_shape=(h, w, 3), target=[dict(category_id=-1)] * 3))
+            kept = []
+        counts.append(len(kept))
+        for j, bx in enumerate(kept):
+            t = bx / torch.tensor([w, h, w, h], dtype=torch.float32)
+            ref[b, j] = torch.stack([(t[0] + t[2]) / 2, (t[1] + t[3]) / 2, t[2] - t[0], t[3] - t[1]])
+    boxes, labels, count, host_counts = head._pack_targets(gts, metas, torch.device(DEV), return_counts=True)
+    torch.cuda.synchronize()
+    assert host_counts == counts and count.cpu().tolist() == counts
+    assert labels.shape == (B, TM) and int(labels.abs().sum()) == 0
+    assert torch.equal(boxes.cpu(), ref)
+    # the staging ring survives more calls than it has slots
+    for _ in range(20):
+        b2 = head._pack_targets(gts, metas, torch.device(DEV))[0]
+    assert torch.equal(b2.cpu(), ref)
