@@ -407,6 +407,18 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
         their addresses), host boxes travel inside the table: one host->device copy and one launch (`simvg_pack_targets`), no
         device-to-host synchronisation."""
         B, TM = len(gt_bbox), self.max_targets
+        rows, counts = self._target_rows(gt_bbox, img_metas, device)
+        boxes, count = ops.pack_targets(rows, counts, B, TM, device)
+        key = ("tlabels", str(device), B, TM)
+        labels = self._const.get(key)
+        if labels is None:
+            labels = self._const[key] = torch.zeros(B, TM, dtype=torch.int32, device=device)
+        out = (boxes, labels, count)
+        return out + (counts,) if return_counts else out
+
+    def _target_rows(self, gt_bbox, img_metas, device):
+        """host side of the packing: -> (table rows for `hip_ops.pack_targets`, number of kept targets per image)"""
+        TM = self.max_targets
         rows, counts = [], []
         for b, (tb, meta) in enumerate(zip(gt_bbox, img_metas)):
             tb = tb if torch.is_tensor(tb) else torch.as_tensor(tb, dtype=torch.float32)
@@ -431,13 +443,7 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
                     else:
                         rows.append((None, 0, vals[i], w, h, b * TM + j))
             counts.append(len(keep))
-        boxes, count = ops.pack_targets(rows, counts, B, TM, device)
-        key = ("tlabels", str(device), B, TM)
-        labels = self._const.get(key)
-        if labels is None:
-            labels = self._const[key] = torch.zeros(B, TM, dtype=torch.int32, device=device)
-        out = (boxes, labels, count)
-        return out + (counts,) if return_counts else out
+        return rows, counts
 
     def prepare_targets(self, gt_bbox, img_metas, device):
         """Everything the criterion needs that is known BEFORE the forward: packed targets and the two loss normalisers
@@ -445,6 +451,10 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
         for the pseudo-target set of the KD term (k = #matched queries = min(num_queries, #GT) per image).  Keeping this
         outside `loss_from_targets` leaves the latter free of collectives and host copies (CUDA-graph capturable)."""
         tboxes, tlabels, tcount, counts = self._pack_targets(gt_bbox, img_metas, device, return_counts=True)
+        return tboxes, tlabels, tcount, self.target_normalisers(counts, device)
+
+    def target_normalisers(self, counts, device):
+        """[num_boxes of the GT target set, of the KD pseudo-target set], averaged over the ranks (criterion.py:245-249)"""
         n_gt = float(sum(counts))
         n_kd = float(sum(min(self.num_queries, c) for c in counts))
         key = ("nums", str(device), n_gt, n_kd)
@@ -457,7 +467,7 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
             nums = nums.clone()
             torch.distributed.all_reduce(nums)
             nums = nums / torch.distributed.get_world_size()
-        return tboxes, tlabels, tcount, nums
+        return nums
 
     def loss(self, output, gt_bbox, img_metas):
         tboxes, tlabels, tcount, nums = self.prepare_targets(gt_bbox, img_metas, output["outputs_class_decoder_branch"].device)

@@ -203,8 +203,12 @@ def _nums_worker(rank, world, port, out):
     else:              # 1 + 1 targets: k = 2, pseudo = 2
         metas = [dict(img_shape=(64, 64, 3), target=[dict(category_id=1)]), dict(img_shape=(64, 64, 3), target=[dict(category_id=1)])]
         gt = [torch.tensor([[1.0, 2, 30, 40]]), torch.tensor([[3.0, 3, 9, 9]])]
-    tboxes, tlabels, tcount, nums = head.prepare_targets(gt, metas, torch.device("cpu"))
-    out[rank] = (nums.tolist(), tcount.tolist())
+    # the host side of prepare_targets (which entries are kept, the two normalisers and their all-reduce); the packing itself is a
+    # device launch (tests/test_head_kernels_gpu.py::test_pack_targets_matches_the_reference_formula)
+    rows, counts = head._target_rows(gt, metas, torch.device("cpu"))
+    assert len(rows) == sum(counts) and all(r[0] is None and len(r[2]) == 4 for r in rows)
+    nums = head.target_normalisers(counts, torch.device("cpu"))
+    out[rank] = (nums.tolist(), counts)
     dist.destroy_process_group()
 
 
