@@ -195,7 +195,9 @@ __device__ __forceinline__ void gemm_f32_tile16_u(const SGArgs& a, int bx, int b
 }
 
 __device__ __forceinline__ void gemm_f32_tile16(const SGArgs& a, int bx, int by, float* smem) {
-  if (a.K >= 1024) gemm_f32_tile16_u<8>(a, bx, by, smem);
+  // deep pipelining only where a k4 group is ONE 16-B load (both operands K-contiguous: the forward Linears); the strided
+  // operands of a weight gradient take four loads per group, and eight of those in flight per operand ran slower (45 vs 40 us)
+  if (a.K >= 1024 && a.sak == 1 && a.sbk == 1) gemm_f32_tile16_u<8>(a, bx, by, smem);
   else gemm_f32_tile16_u<2>(a, bx, by, smem);
 }
 
