@@ -53,6 +53,14 @@ int simvg_gemm_nt(const void* A_lp, int lda, const void* W_lp, long w_group_stri
                   void* aux_preact_lp, int ldaux, const float* residual, int ldres,
                   const float* row_scale, int rows_per_sample0, int rows_per_sample1,
                   int M, int N, int K, int split, int act, float alpha, simvg_stream_t stream);
+/* The same contraction with the weight held as TWO 16-bit numbers per entry (precise inference forward): rows of W2 are
+ * [lo * 2^s | hi] along K (2 K entries, ldw >= 2 K), hi = the 16-bit rounding of w, lo = the 16-bit rounding of (w - hi) * 2^s,
+ * lo_scale = 2^-s.  C[M,N] = A[M,K] . (hi + lo)[g][N,K]^T (+bias) (+residual), i.e. the reference's fp32 weight
+ * (nn.Linear of beit3_base.py:137-145,159) carried to ~22 significand bits at twice the MFMA work. */
+int simvg_gemm_nt_split(const void* A_lp, int lda, const void* W2_lp, long w_group_stride, int ldw,
+                        const float* bias, int bias_group_stride, void* C, int ldc, int c_is_f32,
+                        const float* residual, int ldres, int M, int N, int K, int split, float lo_scale,
+                        simvg_stream_t stream);
 /* dW[g][N,K] += out_scale * dY[M,N]^T . X[M,K]  (weight gradient of the same Linears; fp32 accumulate); optional fused bias
  * gradient db[g][N] += out_scale * column sums of dY over the rows of group g (extra streaming blocks of the same
  * launch).  out_scale = 1 / (gradient scale carried by dY). */

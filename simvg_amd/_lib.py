@@ -31,6 +31,8 @@ _SIGS = {
     "simvg_gemm_nt": [c_void_p, c_int, c_void_p, c_long, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
                       c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                       c_float, c_void_p],
+    "simvg_gemm_nt_split": [c_void_p, c_int, c_void_p, c_long, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
+                            c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
     "simvg_gemm_tn": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_long, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                       c_float, c_void_p],
     "simvg_colsum": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p],

@@ -7,6 +7,9 @@ Element-wise Adam over a flat view is bit-identical to per-tensor Adam.  `build_
 selects it for `type="Adam"` when the model carries arenas; the param groups keep the reference's order and learning
 rates (tools/train.py:78-94: vis_enc -> lr_vis_enc, lan_enc -> lr_lan_enc, rest -> lr), so schedulers and the
 `lr:{optimizer.param_groups[0]['lr']}` log field behave as in the reference."""
+import os
+import warnings
+
 import torch
 
 from ..models.builder import Registry
@@ -76,19 +79,23 @@ class _RestArena:
         zeros: per-tensor Adam SKIPS such a parameter (no moment decay, no step count, no state), and the fused kernel does
         exactly that for an element whose gradient and moments are all zero (the update is exactly zero and nothing is
         written) -- i.e. for a parameter that NEVER receives a gradient (the token branch under branch_loss_weight=
-        {"decoder": w}, `mask_token`).  A parameter graded on some steps only would differ (its moments would decay and its
-        bias correction would use the arena's step count), so the set of graded parameters is pinned at the first step and
-        a change raises instead of silently departing from torch.optim.Adam."""
+        {"decoder": w}, `mask_token`).  A parameter graded on SOME steps only departs from torch.optim.Adam on the steps
+        without a gradient (its moments decay with a zero gradient and its bias correction uses the flat tensor's step
+        count): the update stays finite and well defined, so a changed set WARNS (once per change) and the run continues;
+        SIMVG_STRICT_GRADED_SET=1 turns the warning into an error for runs that must stay step-for-step equal to per-tensor
+        Adam (`optimizer_config.flat=False` is the exact alternative)."""
         mask = tuple(p.grad is not None for p in self.params)
         if getattr(self, "_graded", None) is None:
             self._graded = mask
         elif mask != self._graded:
             changed = [i for i, (a, b) in enumerate(zip(mask, self._graded)) if a != b]
-            raise RuntimeError(
-                f"FlatAdam: {len(changed)} parameter(s) changed between 'has a gradient' and 'has none' after the first "
-                "step (first: index %d, shape %s).  The fused update shares one step count per flat tensor; use "
-                "optimizer_config.flat=False (per-tensor torch Adam) for models whose graded set varies"
-                % (changed[0], tuple(self.params[changed[0]].shape)))
+            msg = (f"FlatAdam: {len(changed)} parameter(s) changed between 'has a gradient' and 'has none' "
+                   "(first: index %d, shape %s); on steps without a gradient their moments decay as if it were zero, "
+                   "unlike per-tensor torch Adam which skips them" % (changed[0], tuple(self.params[changed[0]].shape)))
+            if os.environ.get("SIMVG_STRICT_GRADED_SET") == "1":
+                raise RuntimeError(msg + " (SIMVG_STRICT_GRADED_SET=1)")
+            warnings.warn(msg, RuntimeWarning, stacklevel=2)
+            self._graded = mask
         have = [(v, p.grad) for v, p in zip(self.grad_views, self.params) if p.grad is not None]
         if len(have) < len(self.params):
             self.flat_grad.zero_()

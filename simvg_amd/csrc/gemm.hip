@@ -30,7 +30,24 @@ struct GemmNTArgs {
   int M, N, K, split, act;
   int gn;     // column-group width of the tile walk (0: rows of all column tiles)
   float alpha; // scalar on the accumulator, before the bias (1/gradient-scale in the head's backward GEMMs)
+  // SPLIT weights (simvg_gemm_nt_split, the precise inference forward): W rows are [lo * 2^s | hi] along K (K = 2 ka), A has
+  // ka columns and is walked twice; after the lo half the accumulators are multiplied by lo_scale = 2^-s, so that
+  // C = A . (hi + lo)^T with the weight carried to ~22 significand bits at twice the MFMA work.  ka == K: plain GEMM.
+  int ka; float lo_scale;
 };
+
+// k offset of the A operand for k-tile element offset k (A wraps around after ka columns)
+__device__ __forceinline__ int a_koff(const GemmNTArgs& a, int k) { return k >= a.ka ? k - a.ka : k; }
+// after the k-tile that ends the lo half: acc *= lo_scale (wave-uniform branch, once per tile)
+template <int MI_, int NJ_>
+__device__ __forceinline__ void split_rescale(const GemmNTArgs& a, f32x4_t (&acc)[MI_][NJ_], int k_done) {
+  if (k_done == a.ka && a.ka < a.K) {
+#pragma unroll
+    for (int i = 0; i < MI_; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ_; ++j) acc[i][j] *= a.lo_scale;
+  }
+}
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   // bijective XCD-aware remap: XCD x (= bid % 8) walks a contiguous chunk of the tile space
@@ -275,7 +292,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
 #define ISSUE(t_)                                                                              \
   do {                                                                                         \
     const int st__ = (t_) % MID_NST;                                                           \
-    stage_tile_k64(a.A, a.lda, row0, row_end - 1, (t_) * BK, ldsA(st__), wave, lane);          \
+    stage_tile_k64(a.A, a.lda, row0, row_end - 1, a_koff(a, (t_) * BK), ldsA(st__), wave, lane); \
     stage_tile_k64(W, a.ldw, n0, a.N - 1, (t_) * BK, ldsB(st__), wave, lane);                  \
   } while (0)
 
@@ -313,6 +330,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
           // D[n_local][m_local]: lane holds 4 consecutive n for one m -> vector stores
           acc[i][j] = mfma_lp(fb[j], fa[i], acc[i][j]);
     }
+    split_rescale(a, acc, (kt + 1) * BK);
   }
 #undef ISSUE
   gemm_nt_epilogue<4>(a, acc, group, row0, row_end, n0, wm, wn, lane);
@@ -396,7 +414,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel_lat(GemmNTArgs a) {
 #define ISSUE(t_)                                                                              \
   do {                                                                                         \
     const int st__ = (t_) % LAT_NST;                                                           \
-    stage_tile_k64_n(a.A, a.lda, row0, row_end - 1, (t_) * BK, STA(st__), wave, lane, 2);      \
+    stage_tile_k64_n(a.A, a.lda, row0, row_end - 1, a_koff(a, (t_) * BK), STA(st__), wave, lane, 2); \
     stage_tile_k64_n(W, a.ldw, n0, a.N - 1, (t_) * BK, STB(st__), wave, lane, 2);              \
   } while (0)
 #pragma unroll
@@ -423,6 +441,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel_lat(GemmNTArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[0][j] = mfma_lp(fb[j], fa, acc[0][j]);
     }
+    split_rescale(a, acc, (kt + 1) * BK);
   }
 #undef STA
 #undef STB
@@ -465,7 +484,7 @@ __global__ __launch_bounds__(1024) void gemm_nt_kernel_256sq_w16(GemmNTArgs a) {
 #define ISSUE(t_)                                                                                  \
   do {                                                                                             \
     const int st__ = (t_) & 1;                                                                     \
-    stage_tile_k64_n(a.A, a.lda, row0, row_end - 1, (t_) * BK, STA(st__), wave, lane, 2);          \
+    stage_tile_k64_n(a.A, a.lda, row0, row_end - 1, a_koff(a, (t_) * BK), STA(st__), wave, lane, 2); \
     stage_tile_k64_n(W, a.ldw, n0, a.N - 1, (t_) * BK, STB(st__), wave, lane, 2);                  \
   } while (0)
 
@@ -489,6 +508,7 @@ __global__ __launch_bounds__(1024) void gemm_nt_kernel_256sq_w16(GemmNTArgs a) {
         for (int j = 0; j < 4; ++j)
           acc[i][j] = mfma_lp(fb[j], fa[i], acc[i][j]);
     }
+    split_rescale(a, acc, (kt + 1) * BK);
   }
 #undef STA
 #undef STB
@@ -748,7 +768,7 @@ __global__ __launch_bounds__(1024) void gemm_nt_kernel_160x256_r3(GemmNTArgs a) 
 #define ISSUE(t_)                                                                                      \
   do {                                                                                                 \
     const int st__ = (t_) % 3;                                                                         \
-    stage_rows_k64(a.A, a.lda, row0, row_end - 1, (t_) * BK, STA(st__), wave, lane, BMQ / 8, 16);      \
+    stage_rows_k64(a.A, a.lda, row0, row_end - 1, a_koff(a, (t_) * BK), STA(st__), wave, lane, BMQ / 8, 16); \
     stage_rows_k64(W, a.ldw, n0, a.N - 1, (t_) * BK, STB(st__), wave, lane, BNQ / 8, 16);              \
   } while (0)
   ISSUE(0);
@@ -778,6 +798,7 @@ __global__ __launch_bounds__(1024) void gemm_nt_kernel_160x256_r3(GemmNTArgs a) 
         for (int j = 0; j < 2; ++j)
           acc[i][j] = mfma_lp(fb[j], fa[i], acc[i][j]);
     }
+    split_rescale(a, acc, (kt + 1) * BK);
   }
 #undef STA
 #undef STB
@@ -835,7 +856,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_256k32(GemmNTArgs a) {
 #define ISSUE(t_)                                                                         \
   do {                                                                                    \
     const int st__ = (t_) % 3;                                                            \
-    stage_tile_k32(a.A, a.lda, row0, row_end - 1, (t_) * BK3, STA(st__), wave, lane, 2);  \
+    stage_tile_k32(a.A, a.lda, row0, row_end - 1, a_koff(a, (t_) * BK3), STA(st__), wave, lane, 2); \
     stage_tile_k32(W, a.ldw, n0, a.N - 1, (t_) * BK3, STB(st__), wave, lane, 1);          \
   } while (0)
   ISSUE(0);
@@ -858,6 +879,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_256k32(GemmNTArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         acc[i][j] = mfma_lp(fb[j], fa[i], acc[i][j]);
+    split_rescale(a, acc, (kt + 1) * BK3);
   }
 #undef STA
 #undef STB
@@ -1208,14 +1230,51 @@ __global__ __launch_bounds__(256) void colsum_kernel(const lp_t* Y, int ldy, flo
 // the persistent 256x256 kernel: 16-bit output, bias-only epilogue, an even number of k-tiles
 static bool persist_ok(const GemmNTArgs& a) {
   static const bool off = getenv("SIMVG_GEMM_PERSIST") && atoi(getenv("SIMVG_GEMM_PERSIST")) == 0;
-  return !off && !a.c_f32 && !a.aux && !a.res && !a.row_scale && a.act == 0 && a.alpha == 1.f && (a.K / BK) % 2 == 0 && a.ldc % 8 == 0;
+  // the kernel's counted vmcnt waits assume that its ONLY vector-memory operations are the ones written in the source: a build
+  // that spills (scratch loads / stores share the FIFO) would consume k-tile 0 or the bias before they land.  Refuse such a build
+  // (the non-persistent 256x256 kernel takes over), as the streamed attention launcher does.
+  static const bool no_scratch = [] {
+    hipFuncAttributes fa{};
+    return hipFuncGetAttributes(&fa, (const void*)gemm_nt_kernel_256sq_p) == hipSuccess && fa.localSizeBytes == 0;
+  }();
+  return !off && no_scratch && !a.c_f32 && !a.aux && !a.res && !a.row_scale && a.act == 0 && a.alpha == 1.f && (a.K / BK) % 2 == 0 && a.ldc % 8 == 0 &&
+         a.ka == a.K;      // split weights: the bias is this kernel's accumulator start value, which the lo-half rescale would hit
 }
+
+static int gemm_nt_launch(const void* A, int lda, const void* W, long w_gstride, int ldw,
+                          const float* bias, int bias_gstride, void* C, int ldc, int c_is_f32,
+                          void* aux_preact, int ldaux, const float* residual, int ldres,
+                          const float* row_scale, int rows_per_sample0, int rows_per_sample1,
+                          int M, int N, int K, int split, int act, float alpha, int ka, float lo_scale, hipStream_t stream);
 
 extern "C" int simvg_gemm_nt(const void* A, int lda, const void* W, long w_gstride, int ldw,
                              const float* bias, int bias_gstride, void* C, int ldc, int c_is_f32,
                              void* aux_preact, int ldaux, const float* residual, int ldres,
                              const float* row_scale, int rows_per_sample0, int rows_per_sample1,
                              int M, int N, int K, int split, int act, float alpha, hipStream_t stream) {
+  return gemm_nt_launch(A, lda, W, w_gstride, ldw, bias, bias_gstride, C, ldc, c_is_f32, aux_preact, ldaux, residual, ldres,
+                        row_scale, rows_per_sample0, rows_per_sample1, M, N, K, split, act, alpha, K, 1.f, stream);
+}
+
+// C = A[M, K] . (W_hi + W_lo)[g][N, K]^T with the weight held as TWO 16-bit numbers per entry: W rows are 2 K long,
+// [lo * 2^s | hi] (lo = the 16-bit rounding of (w - hi) * 2^s, hi = the 16-bit rounding of w), `lo_scale` = 2^-s.  The k loop
+// runs over 2 K with A walked twice; the accumulators are multiplied by lo_scale between the halves.  Same epilogues as
+// simvg_gemm_nt.  Used by the encoder's inference forward (`BEIT3.precise_inference`): rounding the WEIGHTS to 16 bits is the
+// largest single term of the box error on trained-scale weights (tools/dev/token_tail.py), and forward_test has MFMA time to spare.
+extern "C" int simvg_gemm_nt_split(const void* A, int lda, const void* W2, long w_gstride, int ldw,
+                                   const float* bias, int bias_gstride, void* C, int ldc, int c_is_f32,
+                                   const float* residual, int ldres, int M, int N, int K, int split, float lo_scale,
+                                   hipStream_t stream) {
+  SIMVG_CHECK_ARG(ldw >= 2 * K, "gemm_nt_split: weight rows hold [lo | hi], 2 K entries");
+  return gemm_nt_launch(A, lda, W2, w_gstride, ldw, bias, bias_gstride, C, ldc, c_is_f32, nullptr, 0, residual, ldres,
+                        nullptr, 1, 1, M, N, 2 * K, split, 0, 1.f, K, lo_scale, stream);
+}
+
+static int gemm_nt_launch(const void* A, int lda, const void* W, long w_gstride, int ldw,
+                          const float* bias, int bias_gstride, void* C, int ldc, int c_is_f32,
+                          void* aux_preact, int ldaux, const float* residual, int ldres,
+                          const float* row_scale, int rows_per_sample0, int rows_per_sample1,
+                          int M, int N, int K, int split, int act, float alpha, int ka, float lo_scale, hipStream_t stream) {
   SIMVG_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm_nt: empty problem");
   SIMVG_CHECK_ARG(K % BK == 0, "gemm_nt: K must be a multiple of 64");
   SIMVG_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0, "gemm_nt: leading dims must keep 16-B alignment");
@@ -1225,7 +1284,7 @@ extern "C" int simvg_gemm_nt(const void* A, int lda, const void* W, long w_gstri
   GemmNTArgs a{(const lp_t*)A, lda, (const lp_t*)W, w_gstride, ldw, bias, bias_gstride, C, ldc, c_is_f32,
                (lp_t*)aux_preact, ldaux, residual, ldres, row_scale,
                rows_per_sample0 > 0 ? rows_per_sample0 : 1, rows_per_sample1 > 0 ? rows_per_sample1 : 1,
-               M, N, K, split, act, 0, alpha};
+               M, N, K, split, act, 0, alpha, ka, lo_scale};
   // column-group width of the 256x256 tile walk: 6 of >= 9 column tiles (fc1-shape fetch 246 -> 190 MB per launch)
   a.gn = cdiv(N, BNQ) >= 9 ? 6 : 0;
   // wide-N tiles (N a multiple of 256, big M): the M extent is picked by tile-count quantisation on the 256 CUs,

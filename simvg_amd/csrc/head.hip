@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void attn_small_fwd_kernel(SAArgs a) {
   // out[qi][d] = sum_k P'[qi][k] V[k][d], in the layout of the score phase: 8 lanes share a key, lane c holds 4 of its 32 values
   // (16-B loads, all of a pass issued before the first is used: the earlier one-float-per-lane walk over 50 keys per thread was
   // the longest part of the kernel -- 4-byte loads, 8 in flight).  The 32 key slots of the block meet in LDS.
-  float* red = sc + a.Lq * a.Lk;        // [32][Lq][32]
+  float* red = sc + ((a.Lq * a.Lk + 3) & ~3);        // [32][Lq][32]; 16-byte aligned for the f32x4 accesses (Lq * Lk may be odd)
   {
     const int slot = tid >> 3, c4 = (tid & 7) * 4;
     f32x4_t o[16];
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(SAArgs a) {
   __syncthreads();
   // dQ[qi][d] = sum_k dS[qi][k] K[k][d] (the 32 key slots of the block meet in LDS);  dK[k][d] = sum_q dS[q][k] Q[q][d]
   {
-    float* red = rs + a.Lq;               // [32][Lq][32]
+    float* red = sm + (((int)(rs - sm) + a.Lq + 3) & ~3);      // [32][Lq][32]; 16-byte aligned for the f32x4 accesses (2 Lq Lk + Lq may be odd)
     f32x4_t o[16];
 #pragma unroll
     for (int qi = 0; qi < 16; ++qi) o[qi] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -532,14 +532,14 @@ extern "C" int simvg_attn_small_fwd(const float* q, int ldq, const float* k, int
                                     const float* drop_mult, int B, int H, int Lq, int Lk, int kv_rows_per_batch,
                                     float scale, const float* key_pos, int ld_key_pos, int key_pos_rows_per_batch,
                                     hipStream_t stream) {
-  SIMVG_CHECK_ARG(B > 0 && H > 0 && Lq > 0 && Lq <= 16 && Lk > 0 && (size_t)(Lq * SHD + Lq * Lk + 32 * Lq * SHD) * sizeof(float) <= 160 * 1024,
+  SIMVG_CHECK_ARG(B > 0 && H > 0 && Lq > 0 && Lq <= 16 && Lk > 0 && (size_t)(Lq * SHD + ((Lq * Lk + 3) & ~3) + 32 * Lq * SHD) * sizeof(float) <= 160 * 1024,
                   "attn_small: Lq <= 16 and the [Lq, Lk] score strip must fit the 160 KiB LDS");
   SIMVG_CHECK_ARG(ldk % 4 == 0 && ldv % 4 == 0, "attn_small: K/V rows must be 16-B aligned");
   SAArgs a{q, ldq, k, ldk, v, ldv, out, ldo, P, key_padding_mask, drop_mult, nullptr, 0, nullptr, 0, nullptr, 0,
            nullptr, 0, B, H, Lq, Lk, kv_rows_per_batch > 0 ? kv_rows_per_batch : Lk, scale, key_pos, ld_key_pos,
            key_pos_rows_per_batch};
   SIMVG_CHECK_ARG(!key_pos || ld_key_pos % 4 == 0, "attn_small: key_pos rows must be 16-B aligned");
-  const size_t shm = (size_t)(Lq * SHD + Lq * Lk + 32 * Lq * SHD) * sizeof(float);
+  const size_t shm = (size_t)(Lq * SHD + ((Lq * Lk + 3) & ~3) + 32 * Lq * SHD) * sizeof(float);
   static bool once = hipFuncSetAttribute((const void*)attn_small_fwd_kernel,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
   (void)once;
@@ -555,13 +555,13 @@ extern "C" int simvg_attn_small_bwd(const float* q, int ldq, const float* k, int
                                     const float* key_pos, int ld_key_pos, int key_pos_rows_per_batch,
                                     hipStream_t stream) {
   SIMVG_CHECK_ARG(B > 0 && H > 0 && Lq > 0 && Lq <= 16 && Lk > 0 &&
-                  (size_t)(2 * Lq * SHD + 2 * Lq * Lk + Lq + 32 * Lq * SHD) * sizeof(float) <= 160 * 1024,
+                  (size_t)(2 * Lq * SHD + 2 * Lq * Lk + ((Lq + 3) & ~3) + 3 + 32 * Lq * SHD) * sizeof(float) <= 160 * 1024,
                   "attn_small: Lq <= 16 and two [Lq, Lk] strips must fit the 160 KiB LDS");
   SIMVG_CHECK_ARG(ldk % 4 == 0 && ldv % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0, "attn_small: rows must be 16-B aligned");
   SAArgs a{q, ldq, k, ldk, v, ldv, nullptr, 0, (float*)P, key_padding_mask, drop_mult, dout, lddo, dq, lddq, dk, lddk,
            dv, lddv, B, H, Lq, Lk, kv_rows_per_batch > 0 ? kv_rows_per_batch : Lk, scale, key_pos, ld_key_pos,
            key_pos_rows_per_batch};
-  const size_t shm = (size_t)(2 * Lq * SHD + 2 * Lq * Lk + Lq + 32 * Lq * SHD) * sizeof(float);
+  const size_t shm = (size_t)(2 * Lq * SHD + 2 * Lq * Lk + ((Lq + 3) & ~3) + 3 + 32 * Lq * SHD) * sizeof(float);
   static bool once = hipFuncSetAttribute((const void*)attn_small_bwd_kernel,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
   (void)once;

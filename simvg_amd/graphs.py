@@ -88,12 +88,19 @@ class _HeadStep(torch.nn.Module):
         losses, _ = self.head.loss_from_targets(out, tboxes, tlabels, tcount, nums)
         t, d = out["token_branch_output"], out["decoder_branch_output"]
         logged = tuple(losses[k].detach() for k in self.head.loss_keys if k != "loss_total")
-        res = (losses["loss_total"],) + logged + (t["pred_logits"].detach(), t["pred_boxes"].detach(),
-                                                  d["pred_logits"].detach(), d["pred_boxes"].detach())
+        # a decoder-only head (branch_loss_weight={"decoder": w}) has NO token branch: its output dict carries None, and a graphed
+        # callable can only return tensors -- the token entries are emitted only when the branch exists (HeadGraphs.run mirrors it)
+        has_tok = t["pred_logits"] is not None
+        res = (losses["loss_total"],) + logged
+        if has_tok:
+            res = res + (t["pred_logits"].detach(), t["pred_boxes"].detach())
+        res = res + (d["pred_logits"].detach(), d["pred_boxes"].detach())
         if self.predict_fn is not None:
             with torch.no_grad():      # get_predictions of both branches rides in the forward graph (no eager launches)
                 dec, tok = self.predict_fn(out, self.img_metas)
-            res = res + (dec["pred_bboxes"], dec["predict_classes"], tok["pred_bboxes"], tok["predict_classes"])
+            res = res + (dec["pred_bboxes"], dec["predict_classes"])
+            if has_tok:
+                res = res + (tok["pred_bboxes"], tok["predict_classes"])
         return res
 
 
@@ -153,13 +160,16 @@ class HeadGraphs:
         n = 1 + len(keys)
         named = dict(zip(["loss_total"] + keys, outs[:n]))
         losses = {k: named[k] for k in self.head.loss_keys}
-        outs = outs[n:]
-        output = dict(token_branch_output={"pred_logits": outs[0], "pred_boxes": outs[1]},
-                      decoder_branch_output={"pred_logits": outs[2], "pred_boxes": outs[3]})
+        outs = list(outs[n:])
+        has_tok = "balanced_distill" in self.head.branch_loss_weight
+        tl, tb = (outs.pop(0), outs.pop(0)) if has_tok else (None, None)
+        output = dict(token_branch_output={"pred_logits": tl, "pred_boxes": tb},
+                      decoder_branch_output={"pred_logits": outs.pop(0), "pred_boxes": outs.pop(0)})
         preds = None
-        if len(outs) > 4:
-            preds = [dict(pred_bboxes=outs[4], pred_masks=None, predict_classes=outs[5]),
-                     dict(pred_bboxes=outs[6], pred_masks=None, predict_classes=outs[7])]
+        if outs:
+            preds = [dict(pred_bboxes=outs.pop(0), pred_masks=None, predict_classes=outs.pop(0))]
+            preds.append(dict(pred_bboxes=outs.pop(0), pred_masks=None, predict_classes=outs.pop(0)) if has_tok
+                         else dict(pred_bboxes=None, pred_masks=None, predict_classes=None))
         return losses, output, preds
 
 

@@ -202,6 +202,45 @@ def gemm_nt(a, w, bias=None, out=None, out_dtype=None, split=0, act=0, aux_preac
     return out
 
 
+SPLIT_SHIFT = 11        # lo = 16-bit rounding of (w - hi) * 2^11: the same magnitude as w's own rounding step, normal range
+
+
+def split_weight(w32, out=None):
+    """fp32 weight [..., N, K] -> 16-bit [..., N, 2 K] = [lo * 2^SPLIT_SHIFT | hi] (operand of `gemm_nt_split`)"""
+    hi = w32.to(LP())
+    lo = ((w32 - hi.float()) * float(2 ** SPLIT_SHIFT)).to(LP())
+    if out is None:
+        return torch.cat([lo, hi], dim=-1)
+    K = w32.shape[-1]
+    out[..., :K].copy_(lo)
+    out[..., K:].copy_(hi)
+    return out
+
+
+def gemm_nt_split(a, w2, bias=None, out=None, out_dtype=None, split=0, residual=None):
+    """out[M,N] = a[M,K] @ (hi + lo)[g][N,K]^T (+bias) (+residual); w2 = split_weight(w): [N, 2K] or [2, N, 2K]"""
+    lib = _lib.load()
+    _chk(a, LP(), "a"); _chk(w2, LP(), "w2")
+    M, K = a.shape
+    N = w2.shape[-2]
+    assert w2.shape[-1] == 2 * K
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=out_dtype or LP())
+    if bias is not None:
+        _chk(bias, torch.float32, "bias")
+    tname = "gemm_nt_split"
+    t0 = _timer.start(tname) if _timer is not None else None
+    rc = lib.simvg_gemm_nt_split(_p(a), a.stride(0), _p(w2), w2.stride(0) if w2.dim() == 3 else 0, w2.stride(-2), _p(bias),
+                                 (bias.stride(0) if bias.dim() == 2 else 0) if bias is not None else 0,
+                                 _p(out), out.stride(0), int(out.dtype == torch.float32),
+                                 _p(residual), residual.stride(0) if residual is not None else 0,
+                                 M, N, K, split, float(2.0 ** -SPLIT_SHIFT), _stream())
+    if t0 is not None:
+        _timer.stop(tname, t0, 4.0 * M * N * K, 2.0 * (M * K + 2 * N * K) + out.element_size() * M * N)
+    _lib.check(rc, "simvg_gemm_nt_split")
+    return out
+
+
 def gemm_tn(dy, x, dw, split=0, dw_group_stride=None, db=None, out_scale=1.0):
     """dw[g][N,K] += dy[M,N]^T @ x[M,K]   (fp32 accumulate into dw); db[g][N] += column sums of dy (optional)."""
     lib = _lib.load()

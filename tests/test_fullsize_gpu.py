@@ -3,9 +3,12 @@ GRefCOCO multi-target, num_queries 10) -- where the CPU oracle is too slow to be
 step takes it minutes).  The oracle pins the kernels on the small fixtures (tests/test_model_gpu.py, batch 2-3); here the
 same model is held to size-independent properties at the real batch, on the harsh (trained-scale) weights:
 
-  P1  precision: the 16-bit engine's boxes against the exact-fp32 engine's (`precision="fp32"`, itself pinned to the
-      reference to 1e-3 on every fixture), L1 over normalised cxcywh, for ALL boxes of the batch (3 decoder layers x B x nq
-      + B x nq token boxes).  Decoder branch (cross-attention averages the rounding noise of 400 image tokens): every box
+  P0  (round 4) the REFERENCE at full size: fixtures `base_nq1_full` / `large_nq10_grec_full` were recorded once from the
+      executed reference (64 / 32 pairs, minutes of CPU and tens of GB of host memory in the dev container): the HIP path's
+      boxes, the five losses and every parameter's gradient (norm + 16 entries) are compared with THOSE, in both precision
+      modes; the exact-fp32 engine must sit on the reference (<= 5e-5 on boxes, 5e-5 on sampled gradient entries);
+  P1  precision: the 16-bit engine's boxes against the reference's, L1 over normalised cxcywh, for ALL boxes of the batch
+      (3 decoder layers x B x nq + B x nq token boxes).  Decoder branch (cross-attention averages the rounding noise of 400 image tokens): every box
       within the north_star bound of 1e-3 (measured max 6.1e-4).  Token branch (one object token's feature -> MLP -> box,
       no averaging): mean within 1e-3 (measured 4.7e-4 / 5.6e-4), maximum within 2e-3 (measured 1.25e-3: the maximum over
       hundreds of boxes of the deliberately harsh weights is a tail statistic -- the 2-3 pair fixtures measure <= 6.4e-4,
@@ -18,13 +21,20 @@ same model is held to size-independent properties at the real batch, on the hars
       gradient norm of the 16-bit step agrees with the exact-fp32 step's), and gradients that point the same way as the
       exact-fp32 engine's (cosine over the whole encoder arena and over the head).
 """
+import os
+import sys
+
 import pytest
 import torch
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 CASES = [("large", 32, 10, True), ("base", 64, 1, False)]
+# recorded ONCE from the executed reference at these sizes (oracle/make_golden.py cases *_full: same weights seed 31, batch seed
+# 77 as `_model` / `_batch` below): boxes, logits, the five losses, every parameter's gradient norm + 16 entries
+FULL_FIXTURE = {("large", 32, 10): "large_nq10_grec_full", ("base", 64, 1): "base_nq1_full"}
 
 
 def _model(vit, nq, seed=31):
@@ -62,7 +72,10 @@ def _l1_stats(a, b):
 
 
 @pytest.mark.parametrize("vit,B,nq,grec", CASES)
-def test_full_size_inference_properties(vit, B, nq, grec):
+def test_full_size_inference_properties(golden, vit, B, nq, grec):
+    fx = golden(FULL_FIXTURE[(vit, B, nq)])
+    assert (fx["B"], fx["wseed"], fx["iseed"], fx["num_queries"]) == (B, 31, 77, nq)
+    ref = {"outputs_coord_decoder_branch": fx["dec_boxes"].float(), "outputs_coord_token_branch": fx["tok_boxes"].float()}
     model, cfg = _model(vit, nq)
     model.eval()
     b = _batch(cfg, B, grec)
@@ -80,17 +93,20 @@ def test_full_size_inference_properties(vit, B, nq, grec):
     for k in full:
         assert torch.equal(full[k], junk[k]), ("padded ids reach the output", k)
         d2 = _l1(full[k][:, :4], alone[k])                                     # [layers, B, nq, 4]
-        mx, p99, mean, n = _l1_stats(full[k], exact[k])
-        print(f"[full size {vit} B={B} nq={nq}] {k}: vs exact fp32 over {n} boxes max {mx:.2e} p99 {p99:.2e} mean {mean:.2e}; "
-              f"batch of {B} vs batch of 4: {d2:.2e}")
+        # the checker is the REFERENCE's own output at this size; the exact-fp32 engine is shown beside it (it must sit on the
+        # reference: that is what makes it usable as the stand-in where no reference fixture exists)
+        ex_mx = _l1_stats(exact[k].cpu(), ref[k])[0]
+        assert ex_mx <= 5e-5, ("exact-fp32 engine vs the reference at full size", k, ex_mx)
+        mx, p99, mean, n = _l1_stats(full[k].cpu(), ref[k])
+        print(f"[full size {vit} B={B} nq={nq}] {k}: vs the REFERENCE over {n} boxes max {mx:.2e} p99 {p99:.2e} mean {mean:.2e} "
+              f"(exact-fp32 engine vs the reference: max {ex_mx:.2e}); batch of {B} vs batch of 4: {d2:.2e}")
         if "decoder" in k:
             assert mx <= 1e-3, (k, mx)
         else:
-            # the token branch at full batch on TRAINED-SCALE weights does NOT stay within the north_star's 1e-3 for every box:
-            # measured mean 4.7e-4 ... 5.5e-4, p99 1.0e-3 (ViT-B bs 64) / 1.13e-3 (ViT-L bs 32, nq 10), max 1.25e-3 / 1.30e-3
-            # -- stated in README / DESIGN in these words.  Reference-initialised weights (what bench.py runs) stay below 7e-5
-            # and every 2-3 pair fixture below 6.4e-4 (tests/test_model_gpu.py); precision="fp32" is the mode with a guarantee.
-            assert mean <= 1e-3 and p99 <= 1.5e-3 and mx <= 2e-3, (k, mx, p99, mean)
+            # round 4: forward_test carries hi + lo 16-bit weights (`precise_inference`, simvg_gemm_nt_split); every token box
+            # of the full batch stays within the north_star's 1e-3 (round 3, single 16-bit weights: max 1.11e-3 / 1.17e-3
+            # against the reference, mean 4.8e-4 / 5.2e-4)
+            assert mx <= 1e-3, (k, mx, p99, mean)
         assert d2 <= 1e-3, (k, d2)
 
 
@@ -103,7 +119,8 @@ def _grads(model):
 
 
 @pytest.mark.parametrize("vit,B,nq,grec", CASES)
-def test_full_size_training_step_properties(vit, B, nq, grec):
+def test_full_size_training_step_properties(golden, vit, B, nq, grec):
+    fx = golden(FULL_FIXTURE[(vit, B, nq)])
     model, cfg = _model(vit, nq)
     model.eval()                  # dropout / DropPath off: the exact-fp32 engine has none, and the two must see one function
     b = _batch(cfg, B, grec)
@@ -119,6 +136,19 @@ def test_full_size_training_step_properties(vit, B, nq, grec):
             missing = [n for n, p in model.named_parameters() if p.grad is None]
             assert missing == ["vis_enc.beit3.vision_embed.mask_token"], missing
         res[prec] = (float(losses["loss_total"]),) + _grads(model)
+        # against the reference's full-size step: the five losses, both whole-module gradient norms, every parameter's norm
+        # and 16 sampled entries
+        ltol, ntol, stol = (1e-4, 1e-3, 5e-5) if prec == "fp32" else (2e-3, 6e-2, 1.2e-1)
+        assert list(losses) == list(fx["losses"])
+        for k, v in fx["losses"].items():
+            assert abs(float(losses[k]) - v) <= ltol * max(1.0, abs(v)), (prec, k, float(losses[k]), v)
+        params = dict(model.named_parameters())
+        from gradcheck import check_all_grads
+        bad, worst_n, worst_s = check_all_grads(fx, params, ntol, stol, f"full size {vit} B={B} nq={nq} {prec}")
+        print(f"[full size {vit} B={B} nq={nq}] {prec} step vs the REFERENCE's: losses within {ltol:g}; all "
+              f"{len(fx['grads_all']['keys'])} parameter gradients: worst norm error {worst_n:.2e}, worst sampled entry "
+              f"{worst_s:.2e} of the tensor's largest")
+        assert not bad, (prec, bad[:12])
     (l16, e16, h16), (l32, e32, h32) = res["lowp"], res["fp32"]
     assert torch.isfinite(e16).all() and torch.isfinite(h16).all() and l16 == l16
     cos = lambda a, c: float(torch.dot(a.double(), c.double()) / (a.double().norm() * c.double().norm()))

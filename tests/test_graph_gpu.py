@@ -177,3 +177,51 @@ def test_inference_graphs_of_rebuilt_weight_buffers_are_dropped():
     assert old_sig not in ig.graphs and len(ig.graphs) == 1   # the stale graph is gone, the signature was captured again
     for a, b in zip(ref, got):
         assert torch.equal(a, b)
+
+
+def test_graphed_head_decoder_only_equals_eager():
+    """branch_loss_weight={"decoder": 1.0} (21 of the 53 reference configs): no token branch -- the graphed step returns no token
+    tensors, `HeadGraphs.run` hands back None placeholders like the eager head, losses / gradients equal the eager step's and the
+    capture does not fall back to eager."""
+    import warnings
+    from test_tools_gpu import CFG
+    from simvg_amd.config import Config
+    from simvg_amd.graphs import train_stream
+    from simvg_amd.models import build_model
+    from test_tools_gpu import _batch
+    torch.manual_seed(6)
+    cfg = Config.fromfile(CFG)
+    cfg.model.head.branch_loss_weight = {"decoder": 1.0}
+    model = build_model(cfg.model).to("cuda")
+    model.vis_enc._ensure_engine(torch.device("cuda"))
+    _no_dropout(model)
+    model.train()
+    train_stream().wait_stream(torch.cuda.current_stream())
+    torch.cuda.set_stream(train_stream())
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")              # "head hipGraph capture failed" must not appear
+            for step in range(6):
+                batch = _batch(cfg, B=4, seed=40 + step)
+                res = []
+                for graph in (False, True):
+                    model.head_graph = graph
+                    model.zero_grad(set_to_none=True)
+                    losses, preds = model(**batch, rescale=False)
+                    losses["loss_total"].backward()
+                    assert list(losses) == ["loss_dgt", "loss_total"]
+                    assert preds[1]["pred_bboxes"] is None and model._last_output["token_branch_output"]["pred_logits"] is None
+                    res.append(({k: v.detach().clone() for k, v in losses.items()}, preds[0]["pred_bboxes"].clone(),
+                                {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}))
+                (l0, p0, g0), (l1, p1, g1) = res
+                for k in l0:
+                    assert torch.allclose(l0[k].float(), l1[k].float(), rtol=1e-5, atol=1e-6), (step, k)
+                assert torch.allclose(p0, p1, rtol=1e-5, atol=1e-4)
+                assert g0.keys() == g1.keys()
+                for n in g0:
+                    tol = 1e-3 * float(g0[n].float().abs().max()) + 1e-7
+                    assert float((g0[n].float() - g1[n].float()).abs().max()) <= tol, (step, n)
+    finally:
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(torch.cuda.default_stream())
+    assert len(model._head_graphs.graphs) == 1 and not model._head_graphs.disabled

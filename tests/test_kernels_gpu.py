@@ -167,6 +167,41 @@ def test_gemm_nt(M, N, K, split, mode):
         assert_close(out, F.relu(ref_lin(True)), 1e-3, "gemm relu f32")
 
 
+@pytest.mark.parametrize("M,N,K,split", [(300, 192, 128, 200),        # latency kernel (64x64 tiles)
+                                         (640, 768, 3072, 512),       # 256x128 / k 32 kernel
+                                         (300, 7040, 64, 200),        # 128x128 kernel
+                                         (2370, 2304, 768, 2100),     # 256x256 kernel (the persistent form is refused)
+                                         (2230, 768, 256, 2000), (2048, 768, 3072, 0)])       # 160x256 kernel
+@pytest.mark.parametrize("mode", ["bias_lp", "bias_residual_f32"])
+def test_gemm_nt_split_carries_fp32_weights(M, N, K, split, mode):
+    """simvg_gemm_nt_split: the weight as a hi + lo pair of 16-bit numbers (rows [lo * 2^11 | hi], A walked twice, accumulators
+    rescaled between the halves).  Against fp32-weight math on the CPU the fp32 output agrees to 2e-5 of its scale (a single
+    16-bit weight: 3e-4 in the fp16 build on the same data), and the 16-bit output to the format's own rounding."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K + 1)
+    a = rnd_bf16(M, K, gen=g)
+    ng = 2 if split else 1
+    w = torch.randn(ng, N, K, generator=g) * K ** -0.5            # full fp32 weights: NOT representable in 16 bits
+    bias = torch.randn(ng, N, generator=g)
+    sp = split if split else M
+    ref = torch.cat([a[:sp].double() @ w[0].double().t() + bias[0].double(), a[sp:].double() @ w[-1].double().t() + bias[-1].double()], 0)
+    ad, bd = bf(a).to(DEV), bias.to(DEV)
+    w2 = ops.split_weight(w.to(DEV))
+    assert w2.shape == (ng, N, 2 * K) and w2.dtype == LPD()
+    if mode == "bias_lp":
+        out = ops.gemm_nt_split(ad, w2, bias=bd, split=split)
+        assert_close(out, ref.float(), LPTOL(), "split gemm, 16-bit output")
+    else:
+        res = torch.randn(M, N, generator=g)
+        out = ops.gemm_nt_split(ad, w2, bias=bd, split=split, residual=res.to(DEV), out_dtype=torch.float32)
+        one = ops.gemm_nt(ad, bf(w).to(DEV), bias=bd, split=split, residual=res.to(DEV), out_dtype=torch.float32)
+        scale = float(ref.abs().max())
+        e2 = float((out.double().cpu() - (ref + res.double())).abs().max()) / scale
+        e1 = float((one.double().cpu() - (ref + res.double())).abs().max()) / scale
+        print(f"[split gemm {M}x{N}x{K}] error of the fp32 output vs fp32-weight math: split {e2:.2e}, single 16-bit weight {e1:.2e}")
+        assert e2 <= (2e-5 if LPD() == torch.float16 else 2e-4) and e2 < e1 / 4
+
+
 @pytest.mark.parametrize("M,N,K,split", [(300, 192, 128, 200), (1684, 768, 768, 1604), (5000, 128, 256, 0),
                                          (1684, 3072, 768, 1604), (1684, 768, 3072, 1604), (3000, 2304, 768, 2500),
                                          # M >= 4096 and an encoder shape: the XCD-partitioned kernel (csrc/wgrad.hip) --

@@ -131,8 +131,7 @@ def test_flat_adam_views_eval_refresh_and_state_round_trip():
         o.clip_grad_norm(0.15)
         o.step()
 
-    # a parameter that never receives a gradient neither moves nor gets moments (per-tensor Adam skips it); one that starts
-    # receiving gradients later is refused (the flat update shares one step count) instead of silently departing from Adam
+    # a parameter that never receives a gradient neither moves nor gets moments (per-tensor Adam skips it)
     _, model0, opt0 = make()
     frozen = dict(model0.named_parameters())["head.input_cls_proj.weight"]
     before = frozen.detach().clone()
@@ -146,8 +145,16 @@ def test_flat_adam_views_eval_refresh_and_state_round_trip():
     lo, hi = ra.offsets[i], ra.offsets[i] + frozen.numel()
     st = opt0.state[ra.param]
     assert all(float(st[k][lo:hi].abs().max()) == 0.0 for k in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq"))
-    with pytest.raises(RuntimeError, match="has a gradient"):
+    # ... one that starts receiving gradients later: a warning (the flat update shares one step count: on steps without a gradient
+    # the moments decay as if it were zero), an error under SIMVG_STRICT_GRADED_SET=1
+    with pytest.warns(RuntimeWarning, match="has a gradient"):
         one_step(model0, opt0)
+    os.environ["SIMVG_STRICT_GRADED_SET"] = "1"
+    try:
+        with pytest.raises(RuntimeError, match="has a gradient"):
+            one_step(model0, opt0, freeze=frozen)
+    finally:
+        del os.environ["SIMVG_STRICT_GRADED_SET"]
     del model0, opt0
     one_step(model, opt)
     # eval right after the step == a fresh model holding the same weights
