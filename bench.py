@@ -81,11 +81,11 @@ def synthetic_batch(B, seed, device):
                 gt_bbox=[gt[b] for b in range(B)])
 
 
-def cpu_baseline(batch_size=8, max_threads=32):
+def cpu_baseline(batch_size=8, max_threads=32, steps=3):
     """The oracle's training step (forward_train + backward + clip + Adam amsgrad) and its forward_test on the host cores.
     Bounded sample: the thread count is capped (eager PyTorch on hundreds of threads is slower, not faster, for the
     ~1400 small ops of this model -- measured 678 s/step with 256 threads); one B=8 training step and a few forward_test
-    calls at B=1 / B=8 are timed (a few seconds each)."""
+    calls at B=1 / B=8 are timed (a few seconds each); three training steps, mean and spread reported."""
     from oracle import simvg_cpu as O, weights as W
     host_cores = os.cpu_count() or 1
     torch.set_num_threads(max(1, min(host_cores, max_threads)))
@@ -104,9 +104,12 @@ def cpu_baseline(batch_size=8, max_threads=32):
         opt.step()
 
     step(1, 0)                    # untimed warm-up (allocator, MKL threads, Adam state)
-    t0 = time.perf_counter()
-    step(batch_size, 1)
-    dt = time.perf_counter() - t0
+    times = []
+    for i in range(steps):        # bounded sample: `steps` training steps at B = batch_size on fresh batches (~4-5 s each)
+        t0 = time.perf_counter()
+        step(batch_size, 1 + i)
+        times.append(time.perf_counter() - t0)
+    dt = sum(times) / len(times)
 
     def infer(B, reps):           # tools/misc/inference_time.py:68-75: eval mode, warm-up, mean over repeated forward_test
         b = W.synthetic_batch(cfg, B, 7)
@@ -120,7 +123,9 @@ def cpu_baseline(batch_size=8, max_threads=32):
     t1, t8 = infer(1, 5), infer(8, 2)
     return dict(value=round(batch_size / dt, 4), unit="pairs/s", cores=torch.get_num_threads(), host_cores=host_cores,
                 kind="port",
-                sample=f"1 training step (fwd+bwd+clip+Adam amsgrad), ViT-B/32 @640, B={batch_size}, fp32, {dt:.1f} s",
+                sample=f"{steps} training steps (fwd+bwd+clip+Adam amsgrad) after one warm-up step, ViT-B/32 @640, B={batch_size}, fp32: "
+                       f"mean {dt:.2f} s, min {min(times):.2f} s, max {max(times):.2f} s per step; value = B / mean",
+                best=round(batch_size / min(times), 4), step_seconds=[round(t, 3) for t in times],
                 forward_test_b1=dict(value=round(1 / t1, 3), unit="pairs/s", ms_per_call=round(t1 * 1e3, 1),
                                      sample="mean of 5 forward_test calls after 1 warm-up, B=1, fp32"),
                 forward_test_b8=dict(value=round(8 / t8, 3), unit="pairs/s", ms_per_call=round(t8 * 1e3, 1),
@@ -162,10 +167,10 @@ def attention_roofline(B, H, Nv, T, hd, device, reps=50):
 
 
 def traffic_stamp(kernel="gemm_nt", source="gemm.hip"):
-    """profiles/gemm_nt_hbm_traffic.json -> (bytes per launch | None, provenance).  The PMC pass cannot run inside this
+    """profiles/gemm_nt_hbm_traffic.json -> (bytes per launch | None, provenance).  The PMC passes cannot run inside this
     process (rocprofv3 wraps it), so the committed figure is reported only while it describes the kernels that are
-    running: the JSON records the sha256 of the csrc file it was measured on (gemm.hip for the gemm_nt figure, wgrad.hip
-    for the wgrad_x one)."""
+    running: the JSON records the sha256 of the csrc file each kernel family was measured on (gemm.hip for gemm_nt, wgrad.hip
+    for wgrad_x, attention.hip for attn_fwd / attn_bwd, layernorm.hip for ln_fwd / ln_bwd, optim.hip for adam)."""
     import hashlib
     tfile = os.path.join(ROOT, "profiles", "gemm_nt_hbm_traffic.json")
     src = os.path.join(ROOT, "simvg_amd", "csrc", source)
@@ -279,6 +284,7 @@ def main():
                           model=model)
     assert type(opt).__name__ == "FlatAdam"
     reducer = GradReducer(model)
+    reducer.timing = reducer.active         # two events per step around finish()'s waits: the exposed part of the exchange
 
     def step():
         batch = batches[counter[0] % len(batches)]
@@ -317,6 +323,7 @@ def main():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
+        reducer._exposed = []               # set-up / warm-up steps are not part of the exposed-exchange statistic
         t0 = time.perf_counter()
         for i in range(a.steps):
             marks[i].record()
@@ -328,6 +335,7 @@ def main():
             dist.barrier()
         dt = time.perf_counter() - t0
         hip_ops.set_timer(None)
+        exposed = reducer.exposed_ms() if reducer.active else None
     if use_dist:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -410,6 +418,17 @@ def main():
                      "share_of_step": round(g["ms"] / (dt * 1e3 * sampled_steps / a.steps), 4)},
     }
     out["reducer"] = dict(reducer.last_stats, active=reducer.active) if reducer.active else {"active": False, "world": world}
+    if reducer.active:
+        sched = {}
+        for k, nbytes in reducer.last_schedule:
+            kk = "layer" if k.startswith("layer:") else k
+            sched.setdefault(kk, [0, 0])
+            sched[kk][0] += 1
+            sched[kk][1] += nbytes
+        out["reducer"]["schedule"] = {"order": [k for k, _ in reducer.last_schedule],
+                                      "messages_bytes": {k: {"messages": v[0], "bytes": v[1]} for k, v in sched.items()}}
+        out["reducer"]["exposed"] = dict(exposed or {}, what="time per step the training stream waits for RCCL in GradReducer.finish() "
+                                         "(HIP events around the waits): the part of the exchange NOT hidden under the backward")
     if "gemm_tn" in extra:
         d = extra["gemm_tn"]
         tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
@@ -427,8 +446,11 @@ def main():
         if k in extra:
             d = extra[k]
             gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+            tr, tsrc = traffic_stamp(k, "optim.hip" if k == "adam" else "layernorm.hip")
             hb[k] = {"what": label, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                     "launches_per_step": d["calls"] // 4, "ms_per_step": round(d["ms"] / 4, 3)}
+                     "launches_per_step": d["calls"] // 4, "ms_per_step": round(d["ms"] / 4, 3),
+                     "algorithmic_bytes_per_launch": round(d["bytes"] / d["calls"]), "traffic": tr,
+                     "traffic_over_algorithmic": None if not tr else round(tr / (d["bytes"] / d["calls"]), 3), "traffic_source": tsrc}
     if hb:
         out["hbm_kernels"] = dict(hb, bound="hbm", note="algorithmic bytes / HIP-event time of every launch in 4 extra steps; "
                                   "8 TB/s spec, ~6.3 TB/s achievable (MI355X_MICROARCH.md)")
@@ -445,6 +467,18 @@ def main():
           "in_situ": {k: {"avg_launch_us": round(d["ms"] / d["calls"] * 1e3, 2), "launches": d["calls"],
                           "tflops": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 2)} for k, d in situ.items()},
       }
+      # HBM bytes per launch by PMC (forward: one kernel; backward: per KERNEL launch, the dq and dkv kernels are two launches
+      # per call) beside the algorithmic bytes of a call: forward reads qkv and writes o (+ lse), backward reads qkv, o, dO and
+      # writes dqkv
+      Mrows, Dm = B * iso["N"], H * hd
+      alg = {"attn_fwd": 2.0 * Mrows * (3 * Dm + Dm), "attn_bwd": 2.0 * Mrows * (3 * Dm + Dm + Dm + 3 * Dm)}
+      for k in ("attn_fwd", "attn_bwd"):
+          tr, tsrc = traffic_stamp(k, "attention.hip")
+          per_call = None if tr is None else tr * (2 if k == "attn_bwd" else 1)
+          out["roofline_attn"]["traffic_" + k] = {"hbm_bytes_per_call": per_call, "algorithmic_bytes_per_call": round(alg[k]),
+                                                  "traffic_over_algorithmic": None if not per_call else round(per_call / alg[k], 3),
+                                                  "traffic_source": tsrc}
+      out["roofline_attn"]["traffic"] = out["roofline_attn"]["traffic_attn_fwd"]["hbm_bytes_per_call"]
     # forward_test latency / throughput on the GPU (same protocol as the CPU figures of cpu_baseline: warm-up, mean of repeated
     # calls with a synchronisation after each call -- tools/misc/inference_time.py:68-75 of the reference)
     model.eval()
@@ -462,10 +496,27 @@ def main():
                 torch.cuda.synchronize()
             ms = (time.perf_counter() - t1) / reps * 1e3
             infer[f"b{nb}"] = {"ms_per_call": round(ms, 3), "pairs_per_s": round(nb / ms * 1e3, 1)}
+        if infer and getattr(model.vis_enc, "precise_inference", False):
+            # the same calls with single 16-bit weights (round 3's forward_test): what `precise_inference` costs
+            model.vis_enc.precise_inference = False
+            bb = synthetic_batch(B, 4242, device)
+            kw = dict(return_loss=False, text_attention_mask=bb["text_attention_mask"], with_bbox=True, with_mask=False, rescale=False)
+            for _ in range(3):
+                model(bb["img"], bb["ref_expr_inds"], bb["img_metas"], **kw)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                model(bb["img"], bb["ref_expr_inds"], bb["img_metas"], **kw)
+                torch.cuda.synchronize()
+            ms = (time.perf_counter() - t1) / 5 * 1e3
+            infer[f"b{B}_single_16bit_weights"] = {"ms_per_call": round(ms, 3), "pairs_per_s": round(B / ms * 1e3, 1)}
+            model.vis_enc.precise_inference = True
     model.train()
     if infer:
         out["forward_test"] = dict(infer, note="MIXDETRMB.forward_test incl. post-processing, one synchronisation per call; batches <= 16 replay "
-                                   "encoder + head as one hipGraph per input signature (simvg_amd/graphs.py::InferenceGraphs)")
+                                   "encoder + head as one hipGraph per input signature (simvg_amd/graphs.py::InferenceGraphs); the encoder's "
+                                   "Linears carry hi + lo 16-bit weights in this forward (precise_inference, simvg_gemm_nt_split: every box of a "
+                                   "full batch within 1e-3 of the reference); `*_single_16bit_weights` = the same call without it")
     if a.breakdown:
         tot = dt * 1e3
         for k, d in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):

@@ -38,6 +38,12 @@ class GradReducer:
         # with all_gather_into_tensor, rows of the sparse text-table message
         self.last_stats = {}
         self._n_msgs = 0
+        # the step's message schedule, in issue order: (what, bytes) with what in {"head", "ids", "layer:<i>", "rest", "text_rows",
+        # "late"} -- the overlap design of DESIGN.md section 7 as data (tests assert it: head first, layers L-1 .. 0 from inside
+        # the backward, everything else after the last layer).  `timing` = True brackets finish()'s waits with two events on the
+        # training stream: the time that stream stalls on RCCL = the EXPOSED (non-overlapped) part of the exchange.
+        self.schedule, self.last_schedule, self._what = [], [], "rest"
+        self.timing, self._exposed = False, []
         # SIMVG_DIST_CHECK=1: verify every step (one host synchronisation) that all ranks hold the same gathered id list --
         # the sparse text-row exchange is correct only then (rows are matched by position in that list)
         self.check_ids = os.environ.get("SIMVG_DIST_CHECK") == "1"
@@ -62,7 +68,7 @@ class GradReducer:
         A = self.enc._arena
         if i >= 0:
             lo, hi = A.slice_of(self.enc.layer_param_names(i))
-            self._launch(A.flat_grad[lo:hi])
+            self._launch(A.flat_grad[lo:hi], f"layer:{i}")
             self._done_layers.add(i)
         else:
             # everything that is not a layer slice: embeddings, position tables, final LayerNorm.  The text table
@@ -87,7 +93,7 @@ class GradReducer:
                 ids = ids.reshape(-1)
                 table = A.grad(self.TEXT_TABLE)
                 rows = table.index_select(0, ids)          # duplicates carry the same row: harmless, no unique() / sync
-                self._launch(rows)
+                self._launch(rows, "text_rows")
                 self._text_rows = (table, ids, rows)
                 self.last_sparse_rows = int(ids.numel())
 
@@ -101,6 +107,7 @@ class GradReducer:
             return
         ids = ids.reshape(-1).contiguous()
         out = torch.empty(self.world * ids.numel(), dtype=ids.dtype, device=ids.device)
+        self.schedule.append(("ids", out.numel() * out.element_size()))
         if self._avg:      # RCCL
             work = dist.all_gather_into_tensor(out, ids, async_op=True)
         else:              # gloo (CPU tests)
@@ -109,8 +116,9 @@ class GradReducer:
             out, work = torch.cat(parts), None
         self._all_ids = (work, out)
 
-    def _launch(self, t):
+    def _launch(self, t, what="rest"):
         if t.numel():
+            self.schedule.append((what, t.numel() * (2 if self.message_dtype is not None else t.element_size())))
             op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
             if self.message_dtype is not None:
                 msg = t.to(self.message_dtype)
@@ -130,7 +138,7 @@ class GradReducer:
             return
         flat = torch.cat([g.reshape(-1) for g in grads])           # one batched copy kernel (torch.cat over a list)
         self._head = (grads, flat)
-        self._launch(flat)
+        self._launch(flat, "head")
 
     def _assert_same_ids(self, ids):
         """every rank must hold the SAME gathered id list, in the same order: row r of the compact message belongs to
@@ -152,6 +160,16 @@ class GradReducer:
         self.pending, self._scale, self._head, self._lowp = [], [], None, []
         self._all_ids, self._ids_done, self._text_rows = None, False, None
         self._n_msgs = 0
+        self.schedule = []
+
+    def exposed_ms(self):
+        """mean / max time per step the training stream waited for RCCL inside finish() (`timing` = True), or None"""
+        if not self._exposed:
+            return None
+        torch.cuda.synchronize()
+        t = [a.elapsed_time(b) for a, b in self._exposed]
+        self._exposed = []
+        return dict(mean_ms=sum(t) / len(t), max_ms=max(t), steps=len(t))
 
     def finish(self):
         """Call after loss.backward(): waits for every message, averages, scatters the head gradients back."""
@@ -168,9 +186,16 @@ class GradReducer:
         self.last_late = len(late)
         if late:
             late_flat = torch.cat([g.reshape(-1) for g in late])
-            self._launch(late_flat)
+            self._launch(late_flat, "late")
+        ev = None
+        if self.timing and torch.cuda.is_available() and self.pending:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for w in self.pending:
             w.wait()
+        if ev is not None:
+            ev[1].record()
+            self._exposed.append(ev)
         for t in self._scale:
             t.div_(self.world)
         for dst, msg in self._lowp:          # 16-bit messages: back into the fp32 master gradients
@@ -188,6 +213,8 @@ class GradReducer:
         self.last_stats = dict(messages=self._n_msgs, avg_in_collective=bool(self._avg),
                                ids_gathered=self._all_ids is not None, gather_into_tensor=bool(self._avg and self._all_ids is not None),
                                sparse_rows=int(self._text_rows[1].numel()) if self._text_rows is not None else 0,
-                               message_dtype="bf16" if self.message_dtype is not None else "fp32", world=self.world)
+                               message_dtype="bf16" if self.message_dtype is not None else "fp32", world=self.world,
+                               bytes=sum(b for _, b in self.schedule))
+        self.last_schedule = list(self.schedule)
         self.pending, self._scale, self._head, self._lowp = [], [], None, []
         self._all_ids, self._ids_done, self._text_rows = None, False, None

@@ -103,7 +103,26 @@ def _worker(rank, world, port, out, uneven=False, message=None):
     flats = [None] * world
     dist.all_gather_object(flats, A.flat_grad.clone())
     ok = ok and all(torch.equal(flats[0], f) for f in flats)       # replicas end bit-identical
-    out[rank] = bool(ok) and red.last_sparse_rows == world * 8     # the text table went as `world` x 8 token rows
+    # the message schedule: ids gathered and the packed head message first, then one message per layer
+    # in backward order, then everything that is not a layer slice, the compact text rows last, the late head gradient at
+    # finish(); every message's bytes = what it covers (fp32, or 2 bytes per entry for bf16 messages)
+    A_ = model.vis_enc._arena
+    esz = 4 if message is None else 2
+    kinds = [k for k, _ in red.last_schedule]
+    L = model.vis_enc.L
+    sched_ok = (kinds[:2] in (["head", "ids"], ["ids", "head"]) and kinds[2:2 + L] == [f"layer:{i}" for i in reversed(range(L))]
+                and kinds[-2:] == ["text_rows", "late"] and set(kinds[2 + L:-2]) == {"rest"})
+    by = dict()
+    for k, b in red.last_schedule:
+        by[k] = by.get(k, 0) + b
+    layer_bytes = [esz * (A_.slice_of(model.vis_enc.layer_param_names(i))[1] - A_.slice_of(model.vis_enc.layer_param_names(i))[0]) for i in range(L)]
+    sched_ok = sched_ok and all(by[f"layer:{i}"] == layer_bytes[i] for i in range(L))
+    sched_ok = sched_ok and by["head"] == esz * model.head.weight.numel() and by["late"] == esz * model.head.bias.numel()
+    sched_ok = sched_ok and by["text_rows"] == esz * world * 8 * 8 and by["ids"] == 8 * world * 8       # int64 ids, D = 8
+    # dense remainder = the arena minus the layer slices minus the (sparsely exchanged) text table
+    sched_ok = sched_ok and by["rest"] == esz * (A_.total - sum(layer_bytes) // esz - A_.params["beit3.text_embed.weight"].numel())
+    sched_ok = sched_ok and red.last_stats["bytes"] == sum(b for _, b in red.last_schedule)
+    out[rank] = bool(ok) and red.last_sparse_rows == world * 8 and bool(sched_ok)     # the text table went as `world` x 8 token rows
     dist.destroy_process_group()
 
 
