@@ -93,6 +93,23 @@ int simvg_ln_bwd(const void* dy, int dy_is_f32, int lddy, const void* x, int x_i
                  float param_scale /* multiplies what is added to dgamma / dbeta: 1 / gradient scale of dy */,
                  simvg_stream_t stream);
 long simvg_ln_bwd_ws_floats(int M, int D, int split);
+/* The same backward with the SECOND stage of the two-stage dgamma / dbeta reduction left out: its description is written to
+ * *desc_out (host memory), and simvg_ln_param_reduce_batched runs the second stages of up to SIMVG_LN_REDUCE_MAX such calls in
+ * ONE launch (each partial workspace has to stay untouched until then).  A training step's 49 LayerNorm backward calls
+ * otherwise end in 49 launches of ~7 us on 48 workgroups each.  The sums are formed in the same fixed order either way
+ * (bit-identical dgamma / dbeta).  desc_out->partial == NULL afterwards: the call took a kernel that reduces with atomics. */
+typedef struct simvg_ln_reduce_desc {
+  const float* partial; float* dgamma; float* dbeta;
+  int group_stride, D, blocks0, blocks1;
+} simvg_ln_reduce_desc;
+#define SIMVG_LN_REDUCE_MAX 64
+int simvg_ln_bwd_deferred(const void* dy, int dy_is_f32, int lddy, const void* x, int x_is_lp, int ldx, const float* mean,
+                          const float* rstd, const float* gamma, int group_stride, float* dgamma, float* dbeta,
+                          void* dx_lp, int lddxb, const void* gelu_u_lp, int ldu, const float* dres,
+                          float* dx_f32, int lddxf, void* dx_scaled_lp, int lddxs, const float* row_scale,
+                          int rows_per_sample0, int rows_per_sample1, int M, int D, int split, float* partial_ws,
+                          float dy_scale, float param_scale, simvg_ln_reduce_desc* desc_out, simvg_stream_t stream);
+int simvg_ln_param_reduce_batched(const simvg_ln_reduce_desc* descs, int n, simvg_stream_t stream);
 
 /* ---- fused encoder self-attention ----------------------------------------------------------------
  * softmax(scale * Q K^T + key_padding(-inf)) V per (sample, head), head_dim 64.  N = Nv+Nt <= 448: K and V of a

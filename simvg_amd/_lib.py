@@ -16,6 +16,11 @@ class WeightDesc(C.Structure):
                 ("tile_start", c_int), ("pad_", c_int)]
 
 
+class LnReduceDesc(C.Structure):        # simvg_ln_reduce_desc
+    _fields_ = [("partial", c_void_p), ("dgamma", c_void_p), ("dbeta", c_void_p), ("group_stride", c_int), ("D", c_int),
+                ("blocks0", c_int), ("blocks1", c_int)]
+
+
 class GemmF32Problem(C.Structure):      # simvg_gemm_f32_problem
     _fields_ = [("A", c_void_p), ("sam", c_long), ("sak", c_long), ("B", c_void_p), ("sbk", c_long), ("sbn", c_long),
                 ("C", c_void_p), ("ldc", c_long), ("bias", c_void_p), ("addend", c_void_p), ("ld_addend", c_long),
@@ -41,6 +46,10 @@ _SIGS = {
     "simvg_ln_bwd": [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                      c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
                      c_int, c_int, c_int, c_int, c_int, c_void_p, c_float, c_float, c_void_p],
+    "simvg_ln_bwd_deferred": [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                              c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                              c_int, c_int, c_int, c_int, c_int, c_void_p, c_float, c_float, c_void_p, c_void_p],
+    "simvg_ln_param_reduce_batched": [c_void_p, c_int, c_void_p],
     "simvg_attn_fwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                        c_float, c_void_p],
     "simvg_attn_bwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,

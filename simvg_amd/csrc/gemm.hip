@@ -11,6 +11,7 @@
 // HBM->LDS by global_load_lds (16 B/lane, LDS image lane-linear, XOR swizzle applied on the
 // SOURCE address and on the ds_read address), double-buffered, one barrier per K-tile.
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 
@@ -34,6 +35,7 @@ struct GemmNTArgs {
   // ka columns and is walked twice; after the lo half the accumulators are multiplied by lo_scale = 2^-s, so that
   // C = A . (hi + lo)^T with the weight carried to ~22 significand bits at twice the MFMA work.  ka == K: plain GEMM.
   int ka; float lo_scale;
+  int respf;   // fp32 + residual epilogue: residual rows requested one pass ahead (0: inside the read-out loop, round 3)
 };
 
 // k offset of the A operand for k-tile element offset k (A wraps around after ka columns)
@@ -172,6 +174,23 @@ template <int MI, int NJ = 4>
 __device__ __forceinline__ void gemm_nt_epilogue_lds(const GemmNTArgs& a, f32x4_t (&acc)[MI][NJ], int group, int row0,
                                                      int row_end, int n0, int wm, int wn, int wave, int lane,
                                                      char* smem) {
+  // fp32 + residual epilogue (out-proj, fc2: the residual stream): the residual rows of a 32-row pass are requested one pass
+  // AHEAD of their use -- pass 0's before the workgroup's rendezvous, pass p + 1's while pass p is staged and written -- instead
+  // of inside the read-out loop, where every pass waited a full memory latency for them (round 4)
+  constexpr int LPRF = NJ * 4, RPPF = 64 / LPRF, NITF = 32 / RPPF;
+  const bool pre_res = a.c_f32 && a.res && a.respf;
+  f32x4_t rnext[NITF];
+  auto load_res = [&](int p) {
+    const int mb = row0 + wm * (MI * 16) + p * 32, nb = n0 + wn * (NJ * 16);
+#pragma unroll
+    for (int it = 0; it < NITF; ++it) {
+      const int r = it * RPPF + lane / LPRF, c = (lane % LPRF) * 4;
+      const int m = mb + r, n = nb + c;
+      rnext[it] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      if (m < row_end && n < a.N && 2 * p + (r >> 4) < MI) rnext[it] = *(const f32x4_t*)(a.res + (long)m * a.ldres + n);
+    }
+  };
+  if (pre_res) load_res(0);
   __syncthreads();                                // every wave is done reading the ring
   constexpr int LD = NJ * 16 + 4;                 // floats per staged row (EPI_LD for NJ = 4)
   float* st = (float*)(smem + wave * (32 * LD * 4));   // wave-private slice (EPI_WAVE_BYTES for NJ = 4)
@@ -200,6 +219,12 @@ __device__ __forceinline__ void gemm_nt_epilogue_lds(const GemmNTArgs& a, f32x4_
             (f32x4_t){fmaf(v[0], a.alpha, bv[j][0]), fmaf(v[1], a.alpha, bv[j][1]), fmaf(v[2], a.alpha, bv[j][2]),
                       fmaf(v[3], a.alpha, bv[j][3])};
       }
+    }
+    f32x4_t rcur[NITF];
+    if (pre_res) {
+#pragma unroll
+      for (int it = 0; it < NITF; ++it) rcur[it] = rnext[it];
+      if (p + 1 < (MI + 1) / 2) load_res(p + 1);
     }
     // wave-private slice: only this wave's own LDS writes must have landed (no barrier)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -253,7 +278,7 @@ __device__ __forceinline__ void gemm_nt_epilogue_lds(const GemmNTArgs& a, f32x4_
         float rs = 1.f;
         if (a.row_scale) rs = a.row_scale[group ? (m - a.split) / a.rps1 : m / a.rps0];
         if (a.res) {
-          const f32x4_t rv = *(const f32x4_t*)(a.res + (long)m * a.ldres + n);
+          const f32x4_t rv = pre_res ? rcur[it] : *(const f32x4_t*)(a.res + (long)m * a.ldres + n);
 #pragma unroll
           for (int k = 0; k < 4; ++k) v[k] = rv[k] + rs * v[k];
         } else if (a.row_scale) {
@@ -806,6 +831,74 @@ __global__ __launch_bounds__(1024) void gemm_nt_kernel_160x256_r3(GemmNTArgs a) 
   gemm_nt_epilogue_lds<5, 2>(a, acc, group, row0, row_end, n0, wm, wn, wave, lane, smem);
 }
 
+// EXPERIMENT (round 4, SIMVG_GEMM_N768=w8): the same 160x256x64 tile and 3-stage ring with EIGHT waves, 2 (M) x 4 (N), each
+// 80x64 = acc[5][4]: 9 fragment reads per 20 MFMAs instead of 7 per 10 (the 16-wave layout reads 224 KiB of LDS per k-tile
+// against 52 KiB staged: 896 LDS cycles beside 1280 MFMA cycles per CU), two waves per SIMD with 256 registers each.
+__global__ __launch_bounds__(512) void gemm_nt_kernel_160x256_w8(GemmNTArgs a) {
+  constexpr int BMQ = 160;
+  constexpr int STAGEQ = (BMQ + BNQ) * BK * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int tiles_n = (a.N + BNQ - 1) / BNQ;
+  const int tm0 = (a.split + BMQ - 1) / BMQ;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+  const int group = tile_m >= tm0;
+  const int row0 = group ? a.split + (tile_m - tm0) * BMQ : tile_m * BMQ;
+  const int row_end = group ? a.M : a.split;
+  const int n0 = tile_n * BNQ;
+  const lp_t* W = a.W + (long)group * a.w_gstride;
+  f32x4_t acc[5][4];
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int nk = a.K / BK;
+  const bool seven = wave < 4;           // A: 20 pieces over 8 waves (waves 0-3 take three), B: 32 pieces (four each)
+#define STA(s_) (smem + (s_) * STAGEQ)
+#define STB(s_) (smem + (s_) * STAGEQ + BMQ * BK * 2)
+#define ISSUE(t_)                                                                                      \
+  do {                                                                                                 \
+    const int st__ = (t_) % 3;                                                                         \
+    stage_rows_k64(a.A, a.lda, row0, row_end - 1, a_koff(a, (t_) * BK), STA(st__), wave, lane, BMQ / 8, 8); \
+    stage_rows_k64(W, a.ldw, n0, a.N - 1, (t_) * BK, STB(st__), wave, lane, BNQ / 8, 8);               \
+  } while (0)
+  ISSUE(0);
+  if (nk > 1) ISSUE(1);
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) {
+      if (seven) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk) ISSUE(kt + 2);
+    const char* sA = STA(kt % 3);
+    const char* sB = STB(kt % 3);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      lpx8_t fa[5], fb[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = read_frag_k64(sB, wn * 64 + j * 16 + (lane & 15), s * 4 + (lane >> 4));
+#pragma unroll
+      for (int i = 0; i < 5; ++i) fa[i] = read_frag_k64(sA, wm * 80 + i * 16 + (lane & 15), s * 4 + (lane >> 4));
+#pragma unroll
+      for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = mfma_lp(fb[j], fa[i], acc[i][j]);
+    }
+    split_rescale(a, acc, (kt + 1) * BK);
+  }
+#undef STA
+#undef STB
+#undef ISSUE
+  gemm_nt_epilogue_lds<5, 4>(a, acc, group, row0, row_end, n0, wm, wn, wave, lane, smem);
+}
+
 // ------------------------------------------------------------------------------------------
 // Variant: same 256x128 tile / 8 waves / 3-stage ring, but K-tiles of 32 (24 KiB stages, 72 KiB LDS) so that TWO
 // workgroups are resident per CU (16 waves, 4 per SIMD): while one workgroup sits in its wait/barrier the other
@@ -1284,7 +1377,8 @@ static int gemm_nt_launch(const void* A, int lda, const void* W, long w_gstride,
   GemmNTArgs a{(const lp_t*)A, lda, (const lp_t*)W, w_gstride, ldw, bias, bias_gstride, C, ldc, c_is_f32,
                (lp_t*)aux_preact, ldaux, residual, ldres, row_scale,
                rows_per_sample0 > 0 ? rows_per_sample0 : 1, rows_per_sample1 > 0 ? rows_per_sample1 : 1,
-               M, N, K, split, act, 0, alpha, ka, lo_scale};
+               M, N, K, split, act, 0, alpha, ka, lo_scale, 1};
+  if (const char* e = getenv("SIMVG_GEMM_RESPF")) a.respf = atoi(e);
   // column-group width of the 256x256 tile walk: 6 of >= 9 column tiles (fc1-shape fetch 246 -> 190 MB per launch)
   a.gn = cdiv(N, BNQ) >= 9 ? 6 : 0;
   // wide-N tiles (N a multiple of 256, big M): the M extent is picked by tile-count quantisation on the 256 CUs,
@@ -1317,6 +1411,12 @@ static int gemm_nt_launch(const void* A, int lda, const void* W, long w_gstride,
     (void)oncew;
     const int tiles = (cdiv(split, 256) + cdiv(M - split, 256)) * cdiv(N, BNQ);
     hipLaunchKernelGGL(gemm_nt_kernel_256sq_w16, dim3(tiles), dim3(1024), SMW, stream, a);
+  } else if (wide_ok && getenv("SIMVG_GEMM_N768") && !strcmp(getenv("SIMVG_GEMM_N768"), "w8")) {
+    constexpr int SM3 = 3 * (160 + BNQ) * BK * 2;
+    static bool once3w = hipFuncSetAttribute((const void*)gemm_nt_kernel_160x256_w8, hipFuncAttributeMaxDynamicSharedMemorySize, SM3) == hipSuccess;
+    (void)once3w;
+    const int tiles = (cdiv(split, 160) + cdiv(M - split, 160)) * cdiv(N, BNQ);
+    hipLaunchKernelGGL(gemm_nt_kernel_160x256_w8, dim3(tiles), dim3(512), SM3, stream, a);
   } else if (wide_ok) {
     constexpr int SM3 = 3 * (160 + BNQ) * BK * 2;     // 156 KiB ring; 16 waves x 32 x 36 x 4 B = 72 KiB of epilogue staging fit
     static bool once3r = hipFuncSetAttribute((const void*)gemm_nt_kernel_160x256_r3, hipFuncAttributeMaxDynamicSharedMemorySize, SM3) == hipSuccess;

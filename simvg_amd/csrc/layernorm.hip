@@ -11,6 +11,13 @@
 
 #include "common.h"
 
+// include/simvg_hip.h: one deferred second stage of the two-stage dgamma / dbeta reduction
+struct simvg_ln_reduce_desc {
+  const float* partial; float* dgamma; float* dbeta;
+  int group_stride, D, blocks0, blocks1;
+};
+#define SIMVG_LN_REDUCE_MAX 64
+
 namespace {
 
 template <typename T> struct Ld4;
@@ -914,6 +921,42 @@ __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __re
   }
 }
 
+// the second stage of SEVERAL LayerNorm backward calls in one launch (blockIdx.z = call): a training step's 49 two-stage
+// reductions were 49 launches of ~7 us on 48 workgroups each (0.36 ms per step, r03_f_kernel_stats.csv)
+struct LnReduceTable { simvg_ln_reduce_desc d[SIMVG_LN_REDUCE_MAX]; };
+__global__ __launch_bounds__(1024) void ln_param_reduce_batched_kernel(LnReduceTable t) {
+  const simvg_ln_reduce_desc& e = t.d[blockIdx.z];
+  const int D = e.D;
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  if (blockIdx.x * 64 >= D) return;
+  const int which = blockIdx.y & 1, g = blockIdx.y >> 1;
+  const int b0 = g ? e.blocks0 : 0, b1 = g ? e.blocks0 + e.blocks1 : e.blocks0;
+  const float* partial = e.partial;
+  __shared__ float red[16][64];
+  float s = 0.f;
+  if (c < D) {
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = b0 + (threadIdx.x >> 6);
+    for (; b + 48 < b1; b += 64) {
+      s += partial[((long)b * 2 + which) * D + c];
+      s1 += partial[((long)(b + 16) * 2 + which) * D + c];
+      s2 += partial[((long)(b + 32) * 2 + which) * D + c];
+      s3 += partial[((long)(b + 48) * 2 + which) * D + c];
+    }
+    for (; b < b1; b += 16) s += partial[((long)b * 2 + which) * D + c];
+    s += (s1 + s2) + s3;
+  }
+  red[threadIdx.x >> 6][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (threadIdx.x < 64 && c < D && b1 > b0) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) v += red[w][threadIdx.x];
+    float* dst = (which ? e.dbeta : e.dgamma) + (long)g * e.group_stride + c;
+    *dst += v;
+  }
+}
+
 }  // namespace
 
 #define LN_DISPATCH_NIT(D, CALL)                                     \
@@ -1008,12 +1051,71 @@ extern "C" int simvg_ln_fwd(const void* x, int x_is_bf16, int ldx, const float* 
   return SIMVG_OK;
 }
 
+// `defer` (optional): the second stage of the two-stage dgamma / dbeta reduction is NOT launched; its description is written to
+// *defer for simvg_ln_param_reduce_batched (requires partial_ws; a call that takes the atomic path leaves defer->partial = 0)
+static int ln_bwd_impl(const void* dy_bf16, int dy_is_f32, int lddy, const void* x, int x_is_bf16, int ldx, const float* mean,
+                       const float* rstd, const float* gamma, int group_stride, float* dgamma, float* dbeta,
+                       void* dx_bf16, int lddxb, const void* gelu_u_bf16, int ldu, const float* dres,
+                       float* dx_f32, int lddxf, void* dx_scaled_bf16, int lddxs, const float* row_scale,
+                       int rows_per_sample0, int rows_per_sample1, int M, int D, int split,
+                       float* partial_ws, float dy_scale, float param_scale, simvg_ln_reduce_desc* defer, hipStream_t stream);
+
 extern "C" int simvg_ln_bwd(const void* dy_bf16, int dy_is_f32, int lddy, const void* x, int x_is_bf16, int ldx, const float* mean,
                             const float* rstd, const float* gamma, int group_stride, float* dgamma, float* dbeta,
                             void* dx_bf16, int lddxb, const void* gelu_u_bf16, int ldu, const float* dres,
                             float* dx_f32, int lddxf, void* dx_scaled_bf16, int lddxs, const float* row_scale,
                             int rows_per_sample0, int rows_per_sample1, int M, int D, int split,
                             float* partial_ws, float dy_scale, float param_scale, hipStream_t stream) {
+  return ln_bwd_impl(dy_bf16, dy_is_f32, lddy, x, x_is_bf16, ldx, mean, rstd, gamma, group_stride, dgamma, dbeta, dx_bf16, lddxb,
+                     gelu_u_bf16, ldu, dres, dx_f32, lddxf, dx_scaled_bf16, lddxs, row_scale, rows_per_sample0, rows_per_sample1,
+                     M, D, split, partial_ws, dy_scale, param_scale, nullptr, stream);
+}
+
+extern "C" int simvg_ln_bwd_deferred(const void* dy_bf16, int dy_is_f32, int lddy, const void* x, int x_is_bf16, int ldx,
+                                     const float* mean, const float* rstd, const float* gamma, int group_stride, float* dgamma,
+                                     float* dbeta, void* dx_bf16, int lddxb, const void* gelu_u_bf16, int ldu, const float* dres,
+                                     float* dx_f32, int lddxf, void* dx_scaled_bf16, int lddxs, const float* row_scale,
+                                     int rows_per_sample0, int rows_per_sample1, int M, int D, int split,
+                                     float* partial_ws, float dy_scale, float param_scale, simvg_ln_reduce_desc* desc_out,
+                                     hipStream_t stream) {
+  SIMVG_CHECK_ARG(desc_out && partial_ws, "ln_bwd_deferred: needs the descriptor to fill and the partial workspace");
+  desc_out->partial = nullptr;
+  return ln_bwd_impl(dy_bf16, dy_is_f32, lddy, x, x_is_bf16, ldx, mean, rstd, gamma, group_stride, dgamma, dbeta, dx_bf16, lddxb,
+                     gelu_u_bf16, ldu, dres, dx_f32, lddxf, dx_scaled_bf16, lddxs, row_scale, rows_per_sample0, rows_per_sample1,
+                     M, D, split, partial_ws, dy_scale, param_scale, desc_out, stream);
+}
+
+extern "C" int simvg_ln_param_reduce_batched(const simvg_ln_reduce_desc* descs, int n, hipStream_t stream) {
+  SIMVG_CHECK_ARG(descs && n > 0 && n <= SIMVG_LN_REDUCE_MAX, "ln_param_reduce_batched: 1 .. SIMVG_LN_REDUCE_MAX descriptors");
+  LnReduceTable t;
+  int m = 0, dmax = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!descs[i].partial) continue;          // that call reduced with atomics: nothing left to do
+    SIMVG_CHECK_ARG(descs[i].dgamma && descs[i].dbeta && descs[i].D > 0, "ln_param_reduce_batched: incomplete descriptor");
+    t.d[m++] = descs[i];
+    dmax = descs[i].D > dmax ? descs[i].D : dmax;
+  }
+  if (m == 0) return SIMVG_OK;
+  hipLaunchKernelGGL(ln_param_reduce_batched_kernel, dim3(cdiv(dmax, 64), 4, m), dim3(1024), 0, stream, t);
+  SIMVG_LAUNCH_CHECK();
+  return SIMVG_OK;
+}
+
+static int ln_bwd_impl(const void* dy_bf16, int dy_is_f32, int lddy, const void* x, int x_is_bf16, int ldx, const float* mean,
+                       const float* rstd, const float* gamma, int group_stride, float* dgamma, float* dbeta,
+                       void* dx_bf16, int lddxb, const void* gelu_u_bf16, int ldu, const float* dres,
+                       float* dx_f32, int lddxf, void* dx_scaled_bf16, int lddxs, const float* row_scale,
+                       int rows_per_sample0, int rows_per_sample1, int M, int D, int split,
+                       float* partial_ws, float dy_scale, float param_scale, simvg_ln_reduce_desc* defer, hipStream_t stream) {
+  // second stage of the two-stage reduction: launched here, or described for the batched launch
+  auto second_stage = [&](int b0, int b1) {
+    if (defer) {
+      *defer = simvg_ln_reduce_desc{partial_ws, dgamma, dbeta, group_stride, D, b0, b1};
+    } else {
+      hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(D, 64), 4), dim3(1024), 0, stream, partial_ws, dgamma, dbeta,
+                         group_stride, D, b0, b1);
+    }
+  };
   SIMVG_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 4096, "ln_bwd: D must be a multiple of 4 and <= 4096");
   SIMVG_CHECK_ARG(dy_is_f32 || dy_scale == 1.0f, "ln_bwd: dy_scale applies to an fp32 dy only (entry of a scaled backward)");
   SIMVG_CHECK_ARG(dx_bf16 || dx_f32, "ln_bwd: no output");
@@ -1037,9 +1139,7 @@ extern "C" int simvg_ln_bwd(const void* dy_bf16, int dy_is_f32, int lddy, const 
                        rps0, rps1, M, D, split, rpb, blocks0, partial_ws, dy_scale, param_scale)
     LN_DISPATCH_NIT(D, FCALL);
 #undef FCALL
-    if (partial_ws)
-      hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(D, 64), 4), dim3(1024), 0, stream, partial_ws, dgamma, dbeta,
-                         group_stride, D, blocks0, blocks1);
+    if (partial_ws) second_stage(blocks0, blocks1);
     SIMVG_LAUNCH_CHECK();
     return SIMVG_OK;
   }
@@ -1060,9 +1160,7 @@ extern "C" int simvg_ln_bwd(const void* dy_bf16, int dy_is_f32, int lddy, const 
     else { if (nitw <= 2) WCALL(float, 2); else if (nitw == 3) WCALL(float, 3); else WCALL(float, 4); }
 #undef WCALL
 #undef FCALL_FFN
-    if (partial_ws)
-      hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(D, 64), 4), dim3(1024), 0, stream, partial_ws, dgamma, dbeta,
-                         group_stride, D, blocks0, blocks1);
+    if (partial_ws) second_stage(blocks0, blocks1);
     SIMVG_LAUNCH_CHECK();
     return SIMVG_OK;
   }
@@ -1082,8 +1180,7 @@ extern "C" int simvg_ln_bwd(const void* dy_bf16, int dy_is_f32, int lddy, const 
       if (res) { if (D == 768) TCALL(float, true, 3, LN_TILE_R_RES); else TCALL(float, true, 4, LN_TILE_R_RES); }
       else { if (D == 768) TCALL(lp_t, false, 3, LN_TILE_R_SUB); else TCALL(lp_t, false, 4, LN_TILE_R_SUB); }
 #undef TCALL
-      hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(D, 64), 4), dim3(1024), 0, stream, partial_ws, dgamma, dbeta,
-                         group_stride, D, tb0, tb1);
+      second_stage(tb0, tb1);
       SIMVG_LAUNCH_CHECK();
       return SIMVG_OK;
     }
@@ -1121,9 +1218,7 @@ extern "C" int simvg_ln_bwd(const void* dy_bf16, int dy_is_f32, int lddy, const 
                        rps0, rps1, M, D, split, rpb, blocks0, partial_ws, 1.0f, param_scale)
   LN_DISPATCH_NIT(D, CALL);
 #undef CALL
-  if (partial_ws)
-    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(D, 64), 4), dim3(1024), 0, stream, partial_ws, dgamma, dbeta,
-                       group_stride, D, blocks0, blocks1);
+  if (partial_ws) second_stage(blocks0, blocks1);
   SIMVG_LAUNCH_CHECK();
   return SIMVG_OK;
 }

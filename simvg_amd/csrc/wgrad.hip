@@ -23,6 +23,7 @@
 // operands use the same one), so fragment addresses are one per-lane base plus compile-time immediates and the global
 // reads stay whole, unpermuted rows.
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 
@@ -71,7 +72,7 @@ struct WgradXArgs {
 // part of the DMA issue between the MFMAs (60-100 cycles per piece there) made the MFMA role the long one (680-740) and every shape
 // 5-6 % slower (fc1 165 -> 173-175 us); what this structure would need is the DMA issue spread evenly over the three roles
 // (a WAR hazard forbids it in group 0's LOADa) or dedicated producer waves (the accumulators of 8 consumer waves do not fit).
-template <int A, int B, int WI, int WJ>
+template <int A, int B, int WI, int WJ, bool ONEBAR = false>
 __global__ __launch_bounds__(A * B * 64) void wgrad_x_kernel(WgradXArgs a) {
   constexpr int NW = A * B, NST = 4;
   constexpr int TN = 16 * WI * A, TK = 16 * WJ * B;
@@ -172,6 +173,73 @@ __global__ __launch_bounds__(A * B * 64) void wgrad_x_kernel(WgradXArgs a) {
     if (nt > 2) issue(2);
     wait_oldest(min(nt - 1, 2));
     __builtin_amdgcn_s_barrier();
+    if constexpr (ONEBAR) {
+      // EXPERIMENT (round 4, SIMVG_WGRAD=x1): ONE barrier per stage.  The three role barriers of the rotation below cost every
+      // stage three rendezvous of all twelve waves (tools/dev/wgrad_profile.py: 2850 cycles per stage against ~1400 of issue
+      // work per wave; 280-460 cycles of waiting at each barrier).  Here a stage is one barrier-delimited iteration in which
+      // every wave does its three jobs -- R(t) fragment reads of stage t, M MFMAs, D(t + 3) LDS-DMA of stage t + 3 -- in an order
+      // that depends on its group, so that right after the barrier one wave per SIMD reads, one issues DMA and one multiplies,
+      // and from there on the waves run free:   group 0: R(t) M(t) D(t+3)    group 1: D(t+3) R(t) M(t)    group 2: M(t-1) D(t+3) R(t).
+      //   RAW: stage t is read only inside iteration t; every wave has waited for its pieces of stage t (counted vmcnt) before
+      //        the barrier that opens it.   WAR: D(t+3) overwrites the slot of stage t-1, whose reads were issued in iteration
+      //        t-1 and have returned before its closing barrier (group 2, which reads last, drains lgkmcnt before the barrier).
+      u32x2_t ry[WI][2], rx[WJ][2];
+      u32x4_t csv;
+      auto reads = [&](int t) {
+        const unsigned sb_ = lds0 + (unsigned)(t % NST) * STAGE;
+        const unsigned an = sb_ + fb_n, ak = sb_ + fb_k;
+#define RD_Y(i_) if constexpr ((i_) < WI) { ry[i_][0] = lds_tr16_asm<(i_) * 32>(an); ry[i_][1] = lds_tr16_asm<16 * SN + (i_) * 32>(an); }
+#define RD_X(j_) if constexpr ((j_) < WJ) { rx[j_][0] = lds_tr16_asm<(j_) * 32>(ak); rx[j_][1] = lds_tr16_asm<16 * SK + (j_) * 32>(ak); }
+        RD_Y(0) RD_Y(1) RD_Y(2) RD_Y(3) RD_Y(4) RD_Y(5) RD_Y(6) RD_Y(7) RD_Y(8)
+        RD_X(0) RD_X(1) RD_X(2) RD_X(3) RD_X(4) RD_X(5)
+#undef RD_Y
+#undef RD_X
+        if (cs_lane) csv = lds_b128_asm<0>(sb_ + cs_off);
+      };
+      auto mfmas = [&]() {
+        lds_wait_all();
+#pragma unroll
+        for (int i = 0; i < WI; ++i) lds_pin(ry[i][0], ry[i][1]);
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) lds_pin(rx[j][0], rx[j][1]);
+        lpx8_t fy[WI], fx[WJ];
+#pragma unroll
+        for (int i = 0; i < WI; ++i) fy[i] = frag8(ry[i][0], ry[i][1]);
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) fx[j] = frag8(rx[j][0], rx[j][1]);
+        if (cs_lane) {
+          asm volatile("" : "+v"(csv));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float lo, hi;
+            unpack_lp2(csv[e], lo, hi);
+            cs[2 * e] += lo;
+            cs[2 * e + 1] += hi;
+          }
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < WI; ++i)
+#pragma unroll
+          for (int j = 0; j < WJ; ++j) acc[i][j] = mfma_lp(fy[i], fx[j], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+      };
+      // one specialised loop per group (wave-uniform branch outside the loop: straight-line bodies, no role merges inside)
+      auto tail = [&](int t) {
+        if (t + 1 < nt) wait_oldest(min(nt - 2 - t, 2));
+        __builtin_amdgcn_s_barrier();
+      };
+      if (grp3 == 0) {
+#pragma clang loop unroll(disable)
+        for (int t = 0; t < nt; ++t) { reads(t); mfmas(); if (t + 3 < nt) issue(t + 3); tail(t); }
+      } else if (grp3 == 1) {
+#pragma clang loop unroll(disable)
+        for (int t = 0; t < nt; ++t) { if (t + 3 < nt) issue(t + 3); reads(t); mfmas(); tail(t); }
+      } else {
+#pragma clang loop unroll(disable)
+        for (int t = 0; t < nt; ++t) { reads(t); if (t + 3 < nt) issue(t + 3); mfmas(); tail(t); }
+      }
+    } else {
     for (int k = 0; k < grp3; ++k) __builtin_amdgcn_s_barrier();        // phase shift of this wave's group
     for (int t = 0; t < nt; ++t) {
       // ---------------- LOADa(t): fragment reads
@@ -231,6 +299,7 @@ __global__ __launch_bounds__(A * B * 64) void wgrad_x_kernel(WgradXArgs a) {
       WG_T(7);
     }
     for (int k = grp3; k < 2; ++k) __builtin_amdgcn_s_barrier();
+    }
     // ---- flush: fp32 atomics into dW[grp] (lanes 0-15 of a 16-lane group cover 64 contiguous bytes of one row)
     float* dW = a.dW + (long)grp * a.dw_gstride;
 #pragma unroll
@@ -265,11 +334,17 @@ template <int A, int B, int WI, int WJ>
 bool launch(const WgradXArgs& a, hipStream_t stream, int nsub = 1) {
   constexpr int TN = 16 * WI * A, TK = 16 * WJ * B;
   constexpr int LDS = 4 * 32 * (TN * 2 + 32 + TK * 2 + 32);
-  static bool once = hipFuncSetAttribute((const void*)wgrad_x_kernel<A, B, WI, WJ>,
+  static bool once = hipFuncSetAttribute((const void*)wgrad_x_kernel<A, B, WI, WJ, false>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess &&
+                     hipFuncSetAttribute((const void*)wgrad_x_kernel<A, B, WI, WJ, true>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
   (void)once;
   const int ntile = (a.N / TN) * (a.K / TK);
-  hipLaunchKernelGGL((wgrad_x_kernel<A, B, WI, WJ>), dim3(8 * ntile * nsub), dim3(A * B * 64), LDS, stream, a);
+  const char* v = getenv("SIMVG_WGRAD");
+  if (v && !strcmp(v, "x1"))
+    hipLaunchKernelGGL((wgrad_x_kernel<A, B, WI, WJ, true>), dim3(8 * ntile * nsub), dim3(A * B * 64), LDS, stream, a);
+  else
+    hipLaunchKernelGGL((wgrad_x_kernel<A, B, WI, WJ, false>), dim3(8 * ntile * nsub), dim3(A * B * 64), LDS, stream, a);
   return true;
 }
 

@@ -311,25 +311,73 @@ def _ln_workspace(M, D, split, device):
     return t
 
 
+class LnReduceBatch:
+    """The second stages of several `ln_bwd(..., defer=batch)` calls as ONE launch (`simvg_ln_param_reduce_batched`): each
+    deferred call gets a partial workspace of its own from a per-batch pool (it has to survive until `flush()`), its
+    description is kept on the host, `flush()` launches them all.  Same sums in the same order as the per-call second stage."""
+
+    def __init__(self):
+        import ctypes as C
+        self._C = C
+        self.descs = (_lib.LnReduceDesc * 64)()
+        self.n = 0
+        self._pool = {}          # (device, floats) -> [workspaces]; `_used` counts how many of each are taken this batch
+        self._used = {}
+
+    def workspace(self, M, D, split, device):
+        n = int(_lib.load().simvg_ln_bwd_ws_floats(M, D, split))
+        key = (str(device), n)
+        k = self._used.get(key, 0)
+        pool = self._pool.setdefault(key, [])
+        if k == len(pool):
+            pool.append(torch.empty(n, device=device, dtype=torch.float32))
+        self._used[key] = k + 1
+        return pool[k]
+
+    def next_desc(self):
+        if self.n == len(self.descs):
+            self.flush()
+        return self._C.byref(self.descs[self.n])
+
+    def commit(self):
+        self.n += 1
+
+    def flush(self):
+        if self.n:
+            rc = _lib.load().simvg_ln_param_reduce_batched(self._C.byref(self.descs), self.n, _stream())
+            _lib.check(rc, "simvg_ln_param_reduce_batched")
+        self.n = 0
+        self._used = {}
+
+
 def ln_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, split=0, dx_lp=None, gelu_u=None, dres=None, dx_f32=None,
-           dx_scaled=None, row_scale=None, rows_per_sample=(1, 1), dy_scale=1.0, param_scale=1.0):
+           dx_scaled=None, row_scale=None, rows_per_sample=(1, 1), dy_scale=1.0, param_scale=1.0, defer=None):
+    """defer: a `LnReduceBatch` -- the second stage of the two-stage dgamma / dbeta reduction joins the batch's single launch
+    (dgamma / dbeta are complete only after `defer.flush()`)"""
     lib = _lib.load()
     # two-stage dgamma/dbeta reduction pays for wide rows only (measured: profiles/r01_sweeps.md)
     # (and for the many-rows-in-flight kernel of the 768 / 1024-wide 16-bit-dy instances, csrc/layernorm.hip: ln_bwd_tile_kernel)
     ws = None
-    if dy.shape[0] >= 1024 and (dy.shape[1] >= 2048 or (dy.shape[1] in (768, 1024) and dy.dtype != torch.float32)):
-        ws = _ln_workspace(dy.shape[0], dy.shape[1], split, dy.device)
+    two_stage = dy.shape[0] >= 1024 and (dy.shape[1] >= 2048 or (dy.shape[1] in (768, 1024) and dy.dtype != torch.float32))
+    if two_stage:
+        ws = defer.workspace(dy.shape[0], dy.shape[1], split, dy.device) if defer is not None else \
+            _ln_workspace(dy.shape[0], dy.shape[1], split, dy.device)
     _chk(dy, None, "dy")
     M, D = dy.shape
     gs = gamma.stride(0) if gamma.dim() == 2 else 0
     t0 = _timer.start("ln_bwd") if _timer is not None else None
-    rc = lib.simvg_ln_bwd(_p(dy), int(dy.dtype == torch.float32), dy.stride(0), _p(x), int(x.dtype == LP()), x.stride(0), _p(mean), _p(rstd),
-                          _p(gamma), gs, _p(dgamma), _p(dbeta), _p(dx_lp),
-                          dx_lp.stride(0) if dx_lp is not None else 0, _p(gelu_u),
-                          gelu_u.stride(0) if gelu_u is not None else 0, _p(dres), _p(dx_f32),
-                          dx_f32.stride(0) if dx_f32 is not None else 0, _p(dx_scaled),
-                          dx_scaled.stride(0) if dx_scaled is not None else 0, _p(row_scale),
-                          rows_per_sample[0], rows_per_sample[1], M, D, split, _p(ws), dy_scale, param_scale, _stream())
+    args = (_p(dy), int(dy.dtype == torch.float32), dy.stride(0), _p(x), int(x.dtype == LP()), x.stride(0), _p(mean), _p(rstd),
+            _p(gamma), gs, _p(dgamma), _p(dbeta), _p(dx_lp),
+            dx_lp.stride(0) if dx_lp is not None else 0, _p(gelu_u),
+            gelu_u.stride(0) if gelu_u is not None else 0, _p(dres), _p(dx_f32),
+            dx_f32.stride(0) if dx_f32 is not None else 0, _p(dx_scaled),
+            dx_scaled.stride(0) if dx_scaled is not None else 0, _p(row_scale),
+            rows_per_sample[0], rows_per_sample[1], M, D, split, _p(ws), dy_scale, param_scale)
+    if defer is not None and two_stage:
+        rc = lib.simvg_ln_bwd_deferred(*args, defer.next_desc(), _stream())
+        defer.commit()
+    else:
+        rc = lib.simvg_ln_bwd(*args, _stream())
     if t0 is not None:
         nb = dy.element_size() + x.element_size() + (2 if dx_lp is not None else 0) + (2 if gelu_u is not None else 0) \
             + (4 if dres is not None else 0) + (4 if dx_f32 is not None else 0) + (2 if dx_scaled is not None else 0)

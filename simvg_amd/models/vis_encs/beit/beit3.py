@@ -471,6 +471,11 @@ class BEIT3(nn.Module):
         S = ops.grad_scale()
         inv = 1.0 / S
         self._scale_tracker.observe(dout)
+        # the second stages of the LayerNorm parameter-gradient reductions: one launch per LAYER when a gradient exchange reads
+        # the layer's slice right after its backward (`layer_done_cb`), one launch for the whole backward otherwise
+        red = getattr(self, "_ln_batch", None)
+        if red is None:
+            red = self._ln_batch = ops.LnReduceBatch()
         ops.ln_bwd(dout, xs[2 * L], mF, rF, V["lnog"], G["lnog"], G["lnob"], split=Mv, dx_f32=dx, dx_scaled=dyb,
                    row_scale=None if dp is None else dp[L - 1][1], rows_per_sample=rps, dy_scale=S, param_scale=inv)
         for i in reversed(range(L)):
@@ -480,25 +485,28 @@ class BEIT3(nn.Module):
             ops.gemm_nt(dyb, self.wb[f"w2T{i}"], out=dF, split=Mv)
             ops.gemm_tn(dyb, st["g2"], G[f"w2{i}"], split=Mv, db=G[f"b2{i}"], out_scale=inv)
             ops.ln_bwd(dF, st["u"], s["m4"], s["r4"], V[f"lnfg{i}"], G[f"lnfg{i}"], G[f"lnfb{i}"], split=Mv,
-                       dx_lp=dF2, gelu_u=st["u"], param_scale=inv)      # x == gelu_u: LN input gelu(u) and GELU'(u) recomputed from u
+                       dx_lp=dF2, gelu_u=st["u"], param_scale=inv, defer=red)      # x == gelu_u: LN input gelu(u) and GELU'(u) recomputed from u
             ops.gemm_nt(dF2, self.wb[f"w1T{i}"], out=dD, split=Mv)
             ops.gemm_tn(dF2, st["h2"], G[f"w1{i}"], split=Mv, db=G[f"b1{i}"], out_scale=inv)
             ops.ln_bwd(dD, xs[2 * i + 1], s["m3"], s["r3"], V[f"ln2g{i}"], G[f"ln2g{i}"], G[f"ln2b{i}"], split=Mv,
                        dres=dx, dx_f32=dx, dx_scaled=dyb, row_scale=None if dp is None else dp[i][0], rows_per_sample=rps,
-                       param_scale=inv)
+                       param_scale=inv, defer=red)
             # ---- attention branch: x_mid = x_in + dp0 * out_proj(LN(attn(qkv(LN(x_in)))))
             ops.gemm_nt(dyb, self.wb[f"woutT{i}"], out=dD, split=Mv)
             ops.gemm_tn(dyb, st["o2"], G[f"wout{i}"], split=Mv, db=G[f"bout{i}"], out_scale=inv)
             ops.ln_bwd(dD, st["o"], s["m2"], s["r2"], V[f"lnig{i}"], G[f"lnig{i}"], G[f"lnib{i}"], split=Mv, dx_lp=dO,
-                       param_scale=inv)
+                       param_scale=inv, defer=red)
             ops.attn_bwd(st["qkv"], st["o"], dO, st["lse"], B, H, Nv, T, pad=pad_u8, dqkv=dQKV)
             ops.gemm_nt(dQKV, self.wb[f"wqkvT{i}"], out=dD, split=Mv)
             ops.gemm_tn(dQKV, st["h"], G[f"wqkv{i}"], split=Mv, db=G[f"bqkv{i}"], out_scale=inv)
             ops.ln_bwd(dD, xs[2 * i], s["m1"], s["r1"], V[f"ln1g{i}"], G[f"ln1g{i}"], G[f"ln1b{i}"], split=Mv,
                        dres=dx, dx_f32=dx, dx_scaled=dyb,
-                       row_scale=None if (dp is None or i == 0) else dp[i - 1][1], rows_per_sample=rps, param_scale=inv)
+                       row_scale=None if (dp is None or i == 0) else dp[i - 1][1], rows_per_sample=rps, param_scale=inv,
+                       defer=red)
             if layer_done_cb is not None:
+                red.flush()              # this layer's dgamma / dbeta are complete before its gradient message leaves
                 layer_done_cb(i)
+        red.flush()
         ops.embed_bwd(dx, ws["dpatch"], A.grad("beit3.vision_embed.cls_token").view(-1),
                       A.grad("beit3.encoder.embed_positions.A.weight"), A.grad("beit3.encoder.embed_positions.B.weight"),
                       A.grad("beit3.text_embed.weight"), ids, pad_u8, B, self.np, T, param_scale=inv)

