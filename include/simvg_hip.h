@@ -67,6 +67,22 @@ int simvg_gemm_nt_split(const void* A_lp, int lda, const void* W2_lp, long w_gro
 int simvg_gemm_tn(const void* dY_lp, int lddy, const void* X_lp, int ldx, float* dW, long dw_group_stride,
                   int lddw, float* db, int db_group_stride, int M, int N, int K, int split, float out_scale,
                   simvg_stream_t stream);
+/* The same with a caller-owned workspace of simvg_gemm_tn_ws_floats(M, N, K) floats (0: the shape does not use one): the
+ * partial sums of the kernel's row partitions are written to slabs of the workspace (plain stores) and a second stage adds
+ * them into dW in a fixed order -- bit-reproducible, and without the 8 x N x K fp32 atomics of simvg_gemm_tn.  defer == NULL:
+ * the second stage is launched here.  Otherwise its description is written to *defer (host memory; defer->slabs == NULL
+ * afterwards: nothing to reduce) and simvg_wgrad_reduce_batched runs up to SIMVG_WGRAD_REDUCE_MAX second stages in ONE launch,
+ * on any stream ordered behind the first stage (the workspace has to stay untouched until then). */
+typedef struct simvg_wgrad_reduce_desc {
+  const float* slabs; float* dW; long dw_group_stride;
+  int lddw, N, K, Q, lo0, hi0, lo1, hi1;
+} simvg_wgrad_reduce_desc;
+#define SIMVG_WGRAD_REDUCE_MAX 16
+long simvg_gemm_tn_ws_floats(int M, int N, int K);
+int simvg_gemm_tn_ws(const void* dY_lp, int lddy, const void* X_lp, int ldx, float* dW, long dw_group_stride,
+                     int lddw, float* db, int db_group_stride, int M, int N, int K, int split, float out_scale,
+                     float* ws, simvg_wgrad_reduce_desc* defer, simvg_stream_t stream);
+int simvg_wgrad_reduce_batched(const simvg_wgrad_reduce_desc* descs, int n, simvg_stream_t stream);
 /* out[g][N] += column sums of Y over the rows of group g (bias gradients) */
 int simvg_colsum(const void* Y_lp, int ldy, float* out, int out_group_stride, int M, int N, int split,
                  simvg_stream_t stream);

@@ -21,6 +21,11 @@ class LnReduceDesc(C.Structure):        # simvg_ln_reduce_desc
                 ("blocks0", c_int), ("blocks1", c_int)]
 
 
+class WgradReduceDesc(C.Structure):     # simvg_wgrad_reduce_desc
+    _fields_ = [("slabs", c_void_p), ("dW", c_void_p), ("dw_group_stride", c_long), ("lddw", c_int), ("N", c_int), ("K", c_int),
+                ("Q", c_int), ("lo0", c_int), ("hi0", c_int), ("lo1", c_int), ("hi1", c_int)]
+
+
 class GemmF32Problem(C.Structure):      # simvg_gemm_f32_problem
     _fields_ = [("A", c_void_p), ("sam", c_long), ("sak", c_long), ("B", c_void_p), ("sbk", c_long), ("sbn", c_long),
                 ("C", c_void_p), ("ldc", c_long), ("bias", c_void_p), ("addend", c_void_p), ("ld_addend", c_long),
@@ -40,6 +45,9 @@ _SIGS = {
                             c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
     "simvg_gemm_tn": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_long, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                       c_float, c_void_p],
+    "simvg_gemm_tn_ws": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_long, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                         c_float, c_void_p, c_void_p, c_void_p],
+    "simvg_wgrad_reduce_batched": [c_void_p, c_int, c_void_p],
     "simvg_colsum": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "simvg_ln_fwd": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
                      c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p],
@@ -141,6 +149,8 @@ def load():
     lib.simvg_lowp_format.argtypes = []
     lib.simvg_ln_bwd_ws_floats.restype = c_long
     lib.simvg_ln_bwd_ws_floats.argtypes = [c_int, c_int, c_int]
+    lib.simvg_gemm_tn_ws_floats.restype = c_long
+    lib.simvg_gemm_tn_ws_floats.argtypes = [c_int, c_int, c_int]
     _lib = lib
     return lib
 
@@ -151,7 +161,7 @@ def lowp_format():
 
 
 def exported_symbols():
-    return sorted(_SIGS) + ["simvg_last_error", "simvg_version", "simvg_source_hash", "simvg_lowp_format", "simvg_ln_bwd_ws_floats"]
+    return sorted(_SIGS) + ["simvg_last_error", "simvg_version", "simvg_source_hash", "simvg_lowp_format", "simvg_ln_bwd_ws_floats", "simvg_gemm_tn_ws_floats"]
 
 
 def check(rc, what):

@@ -180,5 +180,14 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // wgrad.hip: XCD-partitioned weight gradient for the ViT-B encoder shapes; false = not handled (generic kernels run)
+// include/simvg_hip.h: the second stage of one slab-flushed wgrad (sum of the row partitions' slabs into dW)
+struct simvg_wgrad_reduce_desc {
+  const float* slabs; float* dW; long dw_group_stride;
+  int lddw, N, K, Q, lo0, hi0, lo1, hi1;
+};
+#define SIMVG_WGRAD_REDUCE_MAX 16
 bool simvg_wgrad_x(const void* dY, int lddy, const void* X, int ldx, float* dW, long dw_gstride, int lddw, float* db,
-                   int db_gstride, int M, int N, int K, int split, float out_scale, hipStream_t stream);
+                   int db_gstride, int M, int N, int K, int split, float out_scale, float* slabs,
+                   simvg_wgrad_reduce_desc* defer, hipStream_t stream);
+long simvg_wgrad_x_slab_floats(int M, int N, int K);
+int simvg_wgrad_reduce_launch(const simvg_wgrad_reduce_desc* descs, int n, hipStream_t stream);

@@ -1439,14 +1439,44 @@ static int gemm_nt_launch(const void* A, int lda, const void* W, long w_gstride,
   return SIMVG_OK;
 }
 
+static int gemm_tn_impl(const void* dY, int lddy, const void* X, int ldx, float* dW, long dw_gstride,
+                        int lddw, float* db, int db_gstride, int M, int N, int K, int split, float out_scale,
+                        float* slab_ws, simvg_wgrad_reduce_desc* defer, hipStream_t stream);
+
 extern "C" int simvg_gemm_tn(const void* dY, int lddy, const void* X, int ldx, float* dW, long dw_gstride,
                              int lddw, float* db, int db_gstride, int M, int N, int K, int split, float out_scale,
                              hipStream_t stream) {
+  return gemm_tn_impl(dY, lddy, X, ldx, dW, dw_gstride, lddw, db, db_gstride, M, N, K, split, out_scale, nullptr, nullptr, stream);
+}
+
+// the same with a caller-owned workspace of simvg_gemm_tn_ws_floats(M, N, K) floats: the XCD-partitioned kernel then leaves the
+// partial sums of its eight (sixteen) row partitions in slabs of that workspace (plain stores) and a second stage adds them
+// into dW in a fixed order, instead of 8 x N x K fp32 atomics (47 of the 166 us of the fc1 launch).  defer == NULL: the second
+// stage is launched here; otherwise its description is written to *defer (defer->slabs == NULL: nothing to do, the problem
+// took a kernel that needs no second stage) and simvg_wgrad_reduce_batched runs up to SIMVG_WGRAD_REDUCE_MAX of them in one
+// launch on ANY stream that is ordered behind this one -- the reduction is pure HBM streaming and can ride beside the next GEMMs.
+extern "C" long simvg_gemm_tn_ws_floats(int M, int N, int K) { return simvg_wgrad_x_slab_floats(M, N, K); }
+extern "C" int simvg_gemm_tn_ws(const void* dY, int lddy, const void* X, int ldx, float* dW, long dw_gstride,
+                                int lddw, float* db, int db_gstride, int M, int N, int K, int split, float out_scale,
+                                float* ws, simvg_wgrad_reduce_desc* defer, hipStream_t stream) {
+  return gemm_tn_impl(dY, lddy, X, ldx, dW, dw_gstride, lddw, db, db_gstride, M, N, K, split, out_scale, ws, defer, stream);
+}
+extern "C" int simvg_wgrad_reduce_batched(const simvg_wgrad_reduce_desc* descs, int n, hipStream_t stream) {
+  SIMVG_CHECK_ARG(descs && n > 0 && n <= SIMVG_WGRAD_REDUCE_MAX, "wgrad_reduce_batched: 1 .. SIMVG_WGRAD_REDUCE_MAX descriptors");
+  simvg_wgrad_reduce_launch(descs, n, stream);
+  SIMVG_LAUNCH_CHECK();
+  return SIMVG_OK;
+}
+
+static int gemm_tn_impl(const void* dY, int lddy, const void* X, int ldx, float* dW, long dw_gstride,
+                        int lddw, float* db, int db_gstride, int M, int N, int K, int split, float out_scale,
+                        float* slab_ws, simvg_wgrad_reduce_desc* defer, hipStream_t stream) {
   SIMVG_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm_tn: empty problem");
   SIMVG_CHECK_ARG(N % 8 == 0 && K % 8 == 0 && lddy % 8 == 0 && ldx % 8 == 0, "gemm_tn: N, K, ld must be multiples of 8");
   SIMVG_CHECK_ARG(split >= 0 && split <= M, "gemm_tn: split out of range");
   if (split == 0) split = M;
-  if (simvg_wgrad_x(dY, lddy, X, ldx, dW, dw_gstride, lddw, db, db_gstride, M, N, K, split, out_scale, stream)) {
+  if (defer) defer->slabs = nullptr;
+  if (simvg_wgrad_x(dY, lddy, X, ldx, dW, dw_gstride, lddw, db, db_gstride, M, N, K, split, out_scale, slab_ws, defer, stream)) {
     SIMVG_LAUNCH_CHECK();
     return SIMVG_OK;
   }

@@ -7,6 +7,8 @@ import ctypes as C
 
 import numpy
 
+import os
+
 import torch
 
 from . import _lib
@@ -241,8 +243,52 @@ def gemm_nt_split(a, w2, bias=None, out=None, out_dtype=None, split=0, residual=
     return out
 
 
-def gemm_tn(dy, x, dw, split=0, dw_group_stride=None, db=None, out_scale=1.0):
-    """dw[g][N,K] += dy[M,N]^T @ x[M,K]   (fp32 accumulate into dw); db[g][N] += column sums of dy (optional)."""
+_tn_ws = {}
+
+
+class WgradReduceBatch:
+    """Second stages of several `gemm_tn(..., defer=batch)` calls (the sum of the row partitions' slabs into dW) as ONE launch
+    (`simvg_wgrad_reduce_batched`): every deferred call gets a slab workspace of its own from the batch's pool (it has to
+    survive until `flush()`), `flush()` launches the batched reduction on the current stream and frees the pool for reuse.
+    (Measured in situ, profiles/r04_sweeps.md: one in-line launch per encoder layer 30.6 ms per step, the same launch on a side
+    stream beside the next layer's kernels 31.0 -- it competes with the HBM-bound LayerNorm kernels --, fp32 atomics 31.1.)"""
+
+    def __init__(self):
+        import ctypes as C
+        self._C = C
+        self.descs = (_lib.WgradReduceDesc * 16)()
+        self.n = 0
+        self._pool = {}
+        self._used = {}
+
+    def workspace(self, nfloats, device):
+        key = (str(device), nfloats)
+        k = self._used.get(key, 0)
+        pool = self._pool.setdefault(key, [])
+        if k == len(pool):
+            pool.append(torch.empty(nfloats, device=device, dtype=torch.float32))
+        self._used[key] = k + 1
+        return pool[k]
+
+    def next_desc(self):
+        if self.n == len(self.descs):
+            self.flush()
+        return self._C.byref(self.descs[self.n])
+
+    def commit(self):
+        self.n += 1
+
+    def flush(self):
+        if self.n:
+            rc = _lib.load().simvg_wgrad_reduce_batched(self._C.byref(self.descs), self.n, _stream())
+            _lib.check(rc, "simvg_wgrad_reduce_batched")
+        self.n = 0
+        self._used = {}
+
+
+def gemm_tn(dy, x, dw, split=0, dw_group_stride=None, db=None, out_scale=1.0, defer=None):
+    """dw[g][N,K] += dy[M,N]^T @ x[M,K]   (fp32 accumulate into dw); db[g][N] += column sums of dy (optional).
+    defer: a `WgradReduceBatch` -- dw is complete only after the batch's `flush()`."""
     lib = _lib.load()
     _chk(dy, LP(), "dy"); _chk(x, LP(), "x"); _chk(dw, torch.float32, "dw")
     M, N = dy.shape
@@ -251,9 +297,26 @@ def gemm_tn(dy, x, dw, split=0, dw_group_stride=None, db=None, out_scale=1.0):
         dw_group_stride = dw.stride(0) if dw.dim() == 3 else 0
     tname = f"gemm_tn[{M}x{N}x{K}]" if _timer is not None and _timer.only is None else "gemm_tn"
     t0 = _timer.start(tname) if _timer is not None else None
-    rc = lib.simvg_gemm_tn(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), dw_group_stride, dw.stride(-2),
-                           _p(db), (db.stride(0) if db.dim() == 2 else 0) if db is not None else 0,
-                           M, N, K, split, out_scale, _stream())
+    nws = int(lib.simvg_gemm_tn_ws_floats(M, N, K))
+    if nws:          # slabs for the partial sums of the XCD-partitioned kernel
+        if defer is not None:
+            ws = defer.workspace(nws, dy.device)
+            dptr = defer.next_desc()
+        else:
+            key = (str(dy.device), nws)
+            ws = _tn_ws.get(key)
+            if ws is None:
+                ws = _tn_ws[key] = torch.empty(nws, device=dy.device, dtype=torch.float32)
+            dptr = None
+        rc = lib.simvg_gemm_tn_ws(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), dw_group_stride, dw.stride(-2),
+                                  _p(db), (db.stride(0) if db.dim() == 2 else 0) if db is not None else 0,
+                                  M, N, K, split, out_scale, _p(ws), dptr, _stream())
+        if defer is not None:
+            defer.commit()
+    else:
+        rc = lib.simvg_gemm_tn(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), dw_group_stride, dw.stride(-2),
+                               _p(db), (db.stride(0) if db.dim() == 2 else 0) if db is not None else 0,
+                               M, N, K, split, out_scale, _stream())
     if t0 is not None:
         _timer.stop(tname, t0, 2.0 * M * N * K, 2.0 * M * (N + K) + 4.0 * N * K)
     _lib.check(rc, "simvg_gemm_tn")

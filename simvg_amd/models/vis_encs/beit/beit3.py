@@ -476,6 +476,11 @@ class BEIT3(nn.Module):
         red = getattr(self, "_ln_batch", None)
         if red is None:
             red = self._ln_batch = ops.LnReduceBatch()
+        # the second stages of the four weight gradients of a layer (sum of the row partitions' slabs, csrc/wgrad.hip): one batched
+        # launch per layer, right after the layer's backward
+        wred = getattr(self, "_wg_batch", None)
+        if wred is None:
+            wred = self._wg_batch = ops.WgradReduceBatch()
         ops.ln_bwd(dout, xs[2 * L], mF, rF, V["lnog"], G["lnog"], G["lnob"], split=Mv, dx_f32=dx, dx_scaled=dyb,
                    row_scale=None if dp is None else dp[L - 1][1], rows_per_sample=rps, dy_scale=S, param_scale=inv)
         for i in reversed(range(L)):
@@ -483,26 +488,27 @@ class BEIT3(nn.Module):
             s = st["stats"]
             # ---- FFN branch: x_out = x_mid + dp1 * fc2(LN(gelu(fc1(LN(x_mid)))))
             ops.gemm_nt(dyb, self.wb[f"w2T{i}"], out=dF, split=Mv)
-            ops.gemm_tn(dyb, st["g2"], G[f"w2{i}"], split=Mv, db=G[f"b2{i}"], out_scale=inv)
+            ops.gemm_tn(dyb, st["g2"], G[f"w2{i}"], split=Mv, db=G[f"b2{i}"], out_scale=inv, defer=wred)
             ops.ln_bwd(dF, st["u"], s["m4"], s["r4"], V[f"lnfg{i}"], G[f"lnfg{i}"], G[f"lnfb{i}"], split=Mv,
                        dx_lp=dF2, gelu_u=st["u"], param_scale=inv, defer=red)      # x == gelu_u: LN input gelu(u) and GELU'(u) recomputed from u
             ops.gemm_nt(dF2, self.wb[f"w1T{i}"], out=dD, split=Mv)
-            ops.gemm_tn(dF2, st["h2"], G[f"w1{i}"], split=Mv, db=G[f"b1{i}"], out_scale=inv)
+            ops.gemm_tn(dF2, st["h2"], G[f"w1{i}"], split=Mv, db=G[f"b1{i}"], out_scale=inv, defer=wred)
             ops.ln_bwd(dD, xs[2 * i + 1], s["m3"], s["r3"], V[f"ln2g{i}"], G[f"ln2g{i}"], G[f"ln2b{i}"], split=Mv,
                        dres=dx, dx_f32=dx, dx_scaled=dyb, row_scale=None if dp is None else dp[i][0], rows_per_sample=rps,
                        param_scale=inv, defer=red)
             # ---- attention branch: x_mid = x_in + dp0 * out_proj(LN(attn(qkv(LN(x_in)))))
             ops.gemm_nt(dyb, self.wb[f"woutT{i}"], out=dD, split=Mv)
-            ops.gemm_tn(dyb, st["o2"], G[f"wout{i}"], split=Mv, db=G[f"bout{i}"], out_scale=inv)
+            ops.gemm_tn(dyb, st["o2"], G[f"wout{i}"], split=Mv, db=G[f"bout{i}"], out_scale=inv, defer=wred)
             ops.ln_bwd(dD, st["o"], s["m2"], s["r2"], V[f"lnig{i}"], G[f"lnig{i}"], G[f"lnib{i}"], split=Mv, dx_lp=dO,
                        param_scale=inv, defer=red)
             ops.attn_bwd(st["qkv"], st["o"], dO, st["lse"], B, H, Nv, T, pad=pad_u8, dqkv=dQKV)
             ops.gemm_nt(dQKV, self.wb[f"wqkvT{i}"], out=dD, split=Mv)
-            ops.gemm_tn(dQKV, st["h"], G[f"wqkv{i}"], split=Mv, db=G[f"bqkv{i}"], out_scale=inv)
+            ops.gemm_tn(dQKV, st["h"], G[f"wqkv{i}"], split=Mv, db=G[f"bqkv{i}"], out_scale=inv, defer=wred)
             ops.ln_bwd(dD, xs[2 * i], s["m1"], s["r1"], V[f"ln1g{i}"], G[f"ln1g{i}"], G[f"ln1b{i}"], split=Mv,
                        dres=dx, dx_f32=dx, dx_scaled=dyb,
                        row_scale=None if (dp is None or i == 0) else dp[i - 1][1], rows_per_sample=rps, param_scale=inv,
                        defer=red)
+            wred.flush()
             if layer_done_cb is not None:
                 red.flush()              # this layer's dgamma / dbeta are complete before its gradient message leaves
                 layer_done_cb(i)

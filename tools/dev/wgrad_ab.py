@@ -16,21 +16,26 @@ for name, N, K, per_layer in [("qkv", 2304, 768, 1), ("fc1", 3072, 768, 1), ("fc
     res, ref = {}, None
     for rnd in range(3):
         for v in VARIANTS:
-            if v == "base":
-                os.environ.pop("SIMVG_WGRAD", None)
-            else:
-                os.environ["SIMVG_WGRAD"] = v
+            for kk in ("SIMVG_WGRAD", "SIMVG_WG_PRIO", "SIMVG_WG_SLABS"):
+                os.environ.pop(kk, None)
+            for kv in ([] if v == "base" else v.split("+")):       # "x1", "p0", "p2", "x1+p2"
+                if kv == "x1":
+                    os.environ["SIMVG_WGRAD"] = "x1"
+                elif kv[0] == "p":
+                    os.environ["SIMVG_WG_PRIO"] = kv[1:]
+                elif kv == "s0":                                   # fp32 atomics instead of slabs + reduction launch
+                    os.environ["SIMVG_WG_SLABS"] = "0"
             dw = torch.zeros(2, N, K, device=dev)
             db.zero_()
             ops.gemm_tn(dy, x, dw, split=SPLIT, db=db)
             torch.cuda.synchronize()
-            if rnd == 0:
+            if rnd == 0 and not os.environ.get("WG_NOCHECK"):
                 if ref is None:
                     ref = (dw.clone(), db.clone())
                 else:
                     e1 = float((dw - ref[0]).abs().max()) / float(ref[0].abs().max())
                     e2 = float((db - ref[1]).abs().max()) / float(ref[1].abs().max())
-                    assert e1 < 1e-5 and e2 < 1e-5, (name, v, e1, e2)
+                    assert os.environ.get("WG_NOCHECK") or (e1 < 1e-5 and e2 < 1e-5), (name, v, e1, e2)
             for _ in range(10):
                 ops.gemm_tn(dy, x, dw, split=SPLIT, db=db)
             torch.cuda.synchronize()
