@@ -5,11 +5,14 @@
 //                  replacing torchscale MultiwayNetwork's split -> A(x1), B(x2) -> cat
 //                  (reference call sites beit3_base.py:137-145,159; SURVEY.md §2.3 E6,E14,E16,E19).
 //                  Used for forward and (with the transposed weight copy) for dgrad.
-//  simvg_gemm_tn : dW[g][N,K] += dY[M,N]^T · X[M,K]   (wgrad; split over M, fp32 atomics)
+//  simvg_gemm_nt_split : the same with the weight carried as hi + lo 16-bit halves (precise inference forward)
+//  simvg_gemm_tn : dW[g][N,K] += dY[M,N]^T · X[M,K]   (wgrad; the encoder shapes go to wgrad.hip, the rest is split over M
+//                  here and meets through fp32 atomics)
 //
-// Tile 128x128x64, 256 threads = 2x2 waves of 64x64, v_mfma_f32_16x16x32_bf16.
-// HBM->LDS by global_load_lds (16 B/lane, LDS image lane-linear, XOR swizzle applied on the
-// SOURCE address and on the ds_read address), double-buffered, one barrier per K-tile.
+// Kernels by shape (dispatch in gemm_nt_launch): 16-wave 256x256x64 tiles, persistent with a 2-stage ring (N >= 2304, big M);
+// 16-wave 160x256x64 with a 3-stage ring (N = 768); 128x128x64 / latency variants for the small head shapes.  All of them:
+// v_mfma_f32_16x16x32, HBM->LDS by global_load_lds (16 B/lane, LDS image lane-linear, XOR swizzle applied on the SOURCE
+// address and on the ds_read address), counted vmcnt, LDS-staged coalesced epilogue.
 #include <stdlib.h>
 #include <string.h>
 
@@ -831,74 +834,6 @@ __global__ __launch_bounds__(1024) void gemm_nt_kernel_160x256_r3(GemmNTArgs a) 
   gemm_nt_epilogue_lds<5, 2>(a, acc, group, row0, row_end, n0, wm, wn, wave, lane, smem);
 }
 
-// EXPERIMENT (round 4, SIMVG_GEMM_N768=w8): the same 160x256x64 tile and 3-stage ring with EIGHT waves, 2 (M) x 4 (N), each
-// 80x64 = acc[5][4]: 9 fragment reads per 20 MFMAs instead of 7 per 10 (the 16-wave layout reads 224 KiB of LDS per k-tile
-// against 52 KiB staged: 896 LDS cycles beside 1280 MFMA cycles per CU), two waves per SIMD with 256 registers each.
-__global__ __launch_bounds__(512) void gemm_nt_kernel_160x256_w8(GemmNTArgs a) {
-  constexpr int BMQ = 160;
-  constexpr int STAGEQ = (BMQ + BNQ) * BK * 2;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  const int tiles_n = (a.N + BNQ - 1) / BNQ;
-  const int tm0 = (a.split + BMQ - 1) / BMQ;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
-  const int group = tile_m >= tm0;
-  const int row0 = group ? a.split + (tile_m - tm0) * BMQ : tile_m * BMQ;
-  const int row_end = group ? a.M : a.split;
-  const int n0 = tile_n * BNQ;
-  const lp_t* W = a.W + (long)group * a.w_gstride;
-  f32x4_t acc[5][4];
-#pragma unroll
-  for (int i = 0; i < 5; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  const int nk = a.K / BK;
-  const bool seven = wave < 4;           // A: 20 pieces over 8 waves (waves 0-3 take three), B: 32 pieces (four each)
-#define STA(s_) (smem + (s_) * STAGEQ)
-#define STB(s_) (smem + (s_) * STAGEQ + BMQ * BK * 2)
-#define ISSUE(t_)                                                                                      \
-  do {                                                                                                 \
-    const int st__ = (t_) % 3;                                                                         \
-    stage_rows_k64(a.A, a.lda, row0, row_end - 1, a_koff(a, (t_) * BK), STA(st__), wave, lane, BMQ / 8, 8); \
-    stage_rows_k64(W, a.ldw, n0, a.N - 1, (t_) * BK, STB(st__), wave, lane, BNQ / 8, 8);               \
-  } while (0)
-  ISSUE(0);
-  if (nk > 1) ISSUE(1);
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) {
-      if (seven) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    if (kt + 2 < nk) ISSUE(kt + 2);
-    const char* sA = STA(kt % 3);
-    const char* sB = STB(kt % 3);
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      lpx8_t fa[5], fb[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = read_frag_k64(sB, wn * 64 + j * 16 + (lane & 15), s * 4 + (lane >> 4));
-#pragma unroll
-      for (int i = 0; i < 5; ++i) fa[i] = read_frag_k64(sA, wm * 80 + i * 16 + (lane & 15), s * 4 + (lane >> 4));
-#pragma unroll
-      for (int i = 0; i < 5; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = mfma_lp(fb[j], fa[i], acc[i][j]);
-    }
-    split_rescale(a, acc, (kt + 1) * BK);
-  }
-#undef STA
-#undef STB
-#undef ISSUE
-  gemm_nt_epilogue_lds<5, 4>(a, acc, group, row0, row_end, n0, wm, wn, wave, lane, smem);
-}
-
 // ------------------------------------------------------------------------------------------
 // Variant: same 256x128 tile / 8 waves / 3-stage ring, but K-tiles of 32 (24 KiB stages, 72 KiB LDS) so that TWO
 // workgroups are resident per CU (16 waves, 4 per SIMD): while one workgroup sits in its wait/barrier the other
@@ -1411,12 +1346,6 @@ static int gemm_nt_launch(const void* A, int lda, const void* W, long w_gstride,
     (void)oncew;
     const int tiles = (cdiv(split, 256) + cdiv(M - split, 256)) * cdiv(N, BNQ);
     hipLaunchKernelGGL(gemm_nt_kernel_256sq_w16, dim3(tiles), dim3(1024), SMW, stream, a);
-  } else if (wide_ok && getenv("SIMVG_GEMM_N768") && !strcmp(getenv("SIMVG_GEMM_N768"), "w8")) {
-    constexpr int SM3 = 3 * (160 + BNQ) * BK * 2;
-    static bool once3w = hipFuncSetAttribute((const void*)gemm_nt_kernel_160x256_w8, hipFuncAttributeMaxDynamicSharedMemorySize, SM3) == hipSuccess;
-    (void)once3w;
-    const int tiles = (cdiv(split, 160) + cdiv(M - split, 160)) * cdiv(N, BNQ);
-    hipLaunchKernelGGL(gemm_nt_kernel_160x256_w8, dim3(tiles), dim3(512), SM3, stream, a);
   } else if (wide_ok) {
     constexpr int SM3 = 3 * (160 + BNQ) * BK * 2;     // 156 KiB ring; 16 waves x 32 x 36 x 4 B = 72 KiB of epilogue staging fit
     static bool once3r = hipFuncSetAttribute((const void*)gemm_nt_kernel_160x256_r3, hipFuncAttributeMaxDynamicSharedMemorySize, SM3) == hipSuccess;

@@ -13,9 +13,13 @@
 //     (3 per SIMD), each a 96 x 64 block (96 accumulator VGPRs): 20 transposed fragment reads feed 24 MFMAs per stage;
 //   * the three waves of a SIMD rotate through LOAD / LOAD / MFMA roles a third of a stage apart (see the kernel);
 //   * the bias gradient is taken from the dY stage that is in LDS anyway (each block sums 1/tiles_k of its columns);
-//   * the 8 partial results meet in dW / db through fp32 atomics (8 x N x K x 4 B = 75 MB per fc1 launch; measured 37 us of
-//     the 165: the device-scope atomics are memory-side read-modify-writes, their cost follows the byte count -- private
-//     slabs per XCD are no faster -- so it is the price of streaming every row from HBM once).
+//   * the 8 partial results (one per row partition and row group) leave through the LDS ring -- free after the last stage --
+//     as 16-B stores into private fp32 slabs, and wgrad_slab_reduce_kernel adds a weight's slabs to dW in a fixed order
+//     (batched: one launch for the four weights of an encoder layer, ops.WgradReduceBatch).  Round 3 added them to dW with
+//     fp32 atomics: device-scope atomics are memory-side read-modify-writes whose cost follows the count, not the
+//     coalescing (47 us of the 166 of the fc1 launch; plain stores of the same bytes 12 us + 16 us for the reduction,
+//     profiles/r04_sweeps.md section 3) and whose order made dW differ run to run.  SIMVG_WG_SLABS=0 keeps that path for
+//     A/B runs; db (N floats) still meets through atomics.
 // LDS image: a stage is 32 contraction rows, row-major, each row padded by 32 B so that the row stride is an ODD multiple
 // of 32 B.  A transposed fragment read (ds_read_b64_tr_b16) is served 32 lanes per LDS cycle = 8 rows x 32 B; with lane
 // group g reading rows 16h + 4g + (0..3) those are 8 CONSECUTIVE rows, which the odd stride spreads over all 64 banks:

@@ -280,7 +280,12 @@ class WgradReduceBatch:
 
     def flush(self):
         if self.n:
+            t0 = _timer.start("wgrad_reduce") if _timer is not None else None
             rc = _lib.load().simvg_wgrad_reduce_batched(self._C.byref(self.descs), self.n, _stream())
+            if t0 is not None:      # reads every partition's slab and dW, writes dW
+                nb = sum(4.0 * d.N * d.K * ((d.hi0 - d.lo0) + (d.hi1 - d.lo1) + 2 * ((d.hi0 > d.lo0) + (d.hi1 > d.lo1)))
+                         for d in self.descs[:self.n])
+                _timer.stop("wgrad_reduce", t0, 0.0, nb)
             _lib.check(rc, "simvg_wgrad_reduce_batched")
         self.n = 0
         self._used = {}

@@ -231,6 +231,42 @@ def test_gemm_tn_and_colsum(M, N, K, split):
     assert_close(db_fused, refb, 1e-4, "bias gradient fused into the wgrad")
 
 
+@pytest.mark.parametrize("M,N,K,split", [(6011, 3072, 768, 5614), (6011, 768, 768, 5614), (4500, 2304, 768, 0)])
+def test_wgrad_slabs_deferred_reduction_and_atomics_agree(M, N, K, split, monkeypatch):
+    """the XCD-partitioned kernel's partial sums go to per-partition slabs and a second launch adds them to dW in a fixed order:
+    (a) deferred into a WgradReduceBatch (several weights, one launch) == immediate, bit for bit; (b) the same call twice gives
+    the same bits (the fp32-atomic flush it replaces did not); (c) SIMVG_WG_SLABS=0 (atomics, the A/B switch) agrees to
+    rounding of the summation order."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    dy, x = bf(rnd_bf16(M, N, gen=g)).to(DEV), bf(rnd_bf16(M, K, gen=g)).to(DEV)
+    ng = 2 if split else 1
+    init = torch.randn(ng, N, K, generator=g).to(DEV)
+
+    def run(defer=None, nbatch=1):
+        outs = [(init.clone(), torch.zeros(ng, N, device=DEV)) for _ in range(nbatch)]
+        for dw, db in outs:
+            ops.gemm_tn(dy, x, dw, split=split, db=db, defer=defer)
+        if defer is not None:
+            defer.flush()
+        torch.cuda.synchronize()
+        return outs
+
+    (dw0, db0), = run()
+    (dw1, db1), = run()
+    assert torch.equal(dw0, dw1), "slab path is not reproducible run to run"      # (db still meets through fp32 atomics)
+    batch = ops.WgradReduceBatch()
+    for dwb, dbb in run(defer=batch, nbatch=3):
+        assert torch.equal(dwb, dw0), "deferred (batched) reduction differs from the immediate one"
+    for dwb, dbb in run(defer=batch, nbatch=2):           # the batch's workspace pool is reused after a flush
+        assert torch.equal(dwb, dw0)
+    monkeypatch.setenv("SIMVG_WG_SLABS", "0")
+    (dwa, dba), = run()
+    monkeypatch.delenv("SIMVG_WG_SLABS")
+    assert_close(dwa, dw0, 2e-5, "atomic flush vs slabs")
+    assert_close(dba, db0, 2e-5, "bias gradient, atomic flush vs slabs")
+
+
 # ------------------------------------------------------------------------------------------
 # LayerNorm
 # ------------------------------------------------------------------------------------------

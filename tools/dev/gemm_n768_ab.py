@@ -7,7 +7,7 @@ import torch
 from simvg_amd import hip_ops as ops
 
 M, SPLIT, N = 26944, 25664, 768
-VARIANTS = sys.argv[1].split(",") if len(sys.argv) > 1 else ["base", "w8"]
+VARIANTS = sys.argv[1].split(",") if len(sys.argv) > 1 else ["base", "respf0"]
 REPS, ROUNDS = 200, 3
 dev = "cuda"
 cases = [("out-proj fwd  K=768  f32+res", 768, True), ("fc2 fwd       K=3072 f32+res", 3072, True),
@@ -25,10 +25,8 @@ for name, K, res in cases:
         for v in VARIANTS:
             for kk in ("SIMVG_GEMM_N768", "SIMVG_GEMM_RESPF"):
                 os.environ.pop(kk, None)
-            for kv in ([] if v == "base" else v.split("+")):      # "w8", "respf0", "w8+respf0"
-                if kv == "w8":
-                    os.environ["SIMVG_GEMM_N768"] = "w8"
-                elif kv == "respf0":
+            for kv in ([] if v == "base" else v.split("+")):      # "respf0"  (the 8-wave variant "w8" of r04_sweeps.md section 2 is
+                if kv == "respf0":                                # no longer built: tools/dev/gemm_variants_r04.hip.txt)
                     os.environ["SIMVG_GEMM_RESPF"] = "0"
             for _ in range(10):
                 ops.gemm_nt(a, w, bias=bias, out=out, split=SPLIT, residual=r)

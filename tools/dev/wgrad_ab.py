@@ -7,7 +7,7 @@ dev = "cuda"
 LP = ops.LP()
 M, SPLIT = 64 * 421, 64 * 401
 REPS = 200
-VARIANTS = sys.argv[1].split(",") if len(sys.argv) > 1 else ["base", "x1"]
+VARIANTS = sys.argv[1].split(",") if len(sys.argv) > 1 else ["base", "s0"]
 tot = {v: 0.0 for v in VARIANTS}
 for name, N, K, per_layer in [("qkv", 2304, 768, 1), ("fc1", 3072, 768, 1), ("fc2", 768, 3072, 1), ("out", 768, 768, 1)]:
     dy = torch.randn(M, N, device=dev).to(LP)
@@ -18,12 +18,8 @@ for name, N, K, per_layer in [("qkv", 2304, 768, 1), ("fc1", 3072, 768, 1), ("fc
         for v in VARIANTS:
             for kk in ("SIMVG_WGRAD", "SIMVG_WG_PRIO", "SIMVG_WG_SLABS"):
                 os.environ.pop(kk, None)
-            for kv in ([] if v == "base" else v.split("+")):       # "x1", "p0", "p2", "x1+p2"
-                if kv == "x1":
-                    os.environ["SIMVG_WGRAD"] = "x1"
-                elif kv[0] == "p":
-                    os.environ["SIMVG_WG_PRIO"] = kv[1:]
-                elif kv == "s0":                                   # fp32 atomics instead of slabs + reduction launch
+            for kv in ([] if v == "base" else v.split("+")):       # (the one-barrier "x1" and s_setprio "p*" variants of
+                if kv == "s0":                                     #  r04_sweeps.md section 3: tools/dev/wgrad_variants_r04.hip.txt, not built)                                   # fp32 atomics instead of slabs + reduction launch
                     os.environ["SIMVG_WG_SLABS"] = "0"
             dw = torch.zeros(2, N, K, device=dev)
             db.zero_()
