@@ -1,5 +1,4 @@
-// Shared declarations of the encoder attention kernels (attention.hip: K / V resident per head; attention_stream.hip:
-// persistent workgroups, K / V streamed through an LDS-DMA ring).
+// Declarations of the encoder attention kernels (attention.hip: K / V resident per head).
 #pragma once
 #include "common.h"
 
@@ -35,6 +34,3 @@ __device__ __forceinline__ long tok_row(const AttnArgs& a, int b, int t) {
 
 }  // namespace
 
-// attention_stream.hip: persistent streamed forward / backward for training-size launches; false = geometry not handled
-// (the resident kernels of attention.hip run)
-bool simvg_attn_fwd_stream(const AttnArgs& a, hipStream_t stream);

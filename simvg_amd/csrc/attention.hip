@@ -965,10 +965,6 @@ extern "C" int simvg_attn_fwd(const void* qkv, int ldqkv, void* out, int ldo, fl
     SIMVG_LAUNCH_CHECK();
     return SIMVG_OK;
   }
-  if (simvg_attn_fwd_stream(a, stream)) {       // training-size launches of the path's geometry: attention_stream.hip
-    SIMVG_LAUNCH_CHECK();
-    return SIMVG_OK;
-  }
   const size_t shm = (size_t)2 * npad * ROWB + npad * sizeof(float);
   static bool once = set_lds_limit(attn_fwd_kernel, 160 * 1024) && set_lds_limit(attn_fwd_t_kernel<27, 25, 768>, 160 * 1024);
   (void)once;

@@ -207,7 +207,9 @@ def test_gemm_nt_split_carries_fp32_weights(M, N, K, split, mode):
                                          # M >= 4096 and an encoder shape: the XCD-partitioned kernel (csrc/wgrad.hip) --
                                          # ragged row counts, a row-group boundary inside a block's share, no text rows
                                          (4133, 3072, 768, 3850), (6011, 2304, 768, 5614), (4500, 768, 3072, 0),
-                                         (8421, 768, 3072, 8020), (4096, 3072, 768, 4090)])
+                                         (8421, 768, 3072, 8020), (4096, 3072, 768, 4090),
+                                         # ViT-L encoder shapes: the generic 256 x 128 kernel (gemm.hip), row chunks + fp32 atomics
+                                         (4700, 4096, 1024, 4400), (4517, 1024, 4096, 4100), (4500, 3072, 1024, 0)])
 def test_gemm_tn_and_colsum(M, N, K, split):
     ops = _ops()
     g = torch.Generator().manual_seed(7 * M + N)
@@ -458,46 +460,6 @@ def _mm_rows(B, Nv, Nt):
         idx[b, :Nv] = b * Nv + torch.arange(Nv)
         idx[b, Nv:] = B * Nv + b * Nt + torch.arange(Nt)
     return idx
-
-
-@pytest.mark.parametrize("B,H,use_pad", [(22, 12, True), (43, 12, True), (17, 16, False)])
-def test_attention_stream_forward(B, H, use_pad, monkeypatch):
-    """csrc/attention_stream.hip (opt-in, SIMVG_ATTN_STREAM=1): persistent workgroups, K / V through an LDS-DMA ring, deferred-
-    maximum online softmax.  Launches with at least one head per CU (1-2 and 2-3 heads per workgroup, ragged) against an fp32
-    PyTorch reference on the device and against the resident kernel."""
-    ops = _ops()
-    Nv, Nt, d = 401, 20, 64
-    N, D = Nv + Nt, H * d
-    g = torch.Generator().manual_seed(B * 131 + H)
-    qkv = bf(torch.randn(B * N, 3 * D, generator=g)).to(DEV)
-    pad = None
-    if use_pad:
-        pad = torch.zeros(B, Nt, dtype=torch.uint8)
-        for b in range(B):
-            pad[b, Nt - (3 + 5 * b) % Nt:] = 1
-        pad = pad.to(DEV)
-    x = qkv.float()
-    tok = torch.cat([x[:B * Nv].view(B, Nv, 3 * D), x[B * Nv:].view(B, Nt, 3 * D)], 1)
-    q, k, v = tok.split(D, -1)
-    q = q.view(B, N, H, d).transpose(1, 2) * d ** -0.5
-    k = k.view(B, N, H, d).transpose(1, 2)
-    v = v.view(B, N, H, d).transpose(1, 2)
-    w = q @ k.transpose(-1, -2)
-    if pad is not None:
-        kpm = torch.cat([torch.zeros(B, Nv, dtype=torch.bool, device=DEV), pad.bool()], 1)
-        w = w.masked_fill(kpm[:, None, None, :], float("-inf"))
-    o = (torch.softmax(w, -1) @ v).transpose(1, 2).reshape(B, N, D)
-    o_ref = torch.cat([o[:, :Nv].reshape(B * Nv, D), o[:, Nv:].reshape(B * Nt, D)], 0)
-    lse_ref = torch.logsumexp(w, -1).reshape(B * H, N)
-    monkeypatch.setenv("SIMVG_ATTN_STREAM", "1")
-    out_s, lse_s = ops.attn_fwd(qkv, B, H, Nv, Nt, pad=pad)
-    torch.cuda.synchronize()
-    monkeypatch.delenv("SIMVG_ATTN_STREAM")
-    out_r, lse_r = ops.attn_fwd(qkv, B, H, Nv, Nt, pad=pad)
-    assert_close(out_s.float(), o_ref, LPTOL(1.5), "streamed attention fwd")
-    assert_close(lse_s, lse_ref, 1e-3, "streamed attention lse")
-    assert_close(out_s.float(), out_r.float(), LPTOL(1.5), "streamed vs resident")
-    assert not torch.equal(out_s, torch.zeros_like(out_s))
 
 
 # N <= 448: K / V resident in LDS (421 = the path's compile-time geometry); N > 448: streamed blocks + online softmax

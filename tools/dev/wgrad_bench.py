@@ -8,7 +8,8 @@ LP = ops.LP()
 B = int(os.environ.get("B", 64))
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 M, SPLIT = B * 421, B * 401
-for name, N, K in [("qkv", 2304, 768), ("fc1", 3072, 768), ("fc2", 768, 3072), ("out", 768, 768)]:
+D = int(os.environ.get("D", 768))          # D=1024 B=32: the ViT-L shapes
+for name, N, K in [("qkv", 3 * D, D), ("fc1", 4 * D, D), ("fc2", D, 4 * D), ("out", D, D)]:
     dy = torch.randn(M, N, device=dev).to(LP)
     x = torch.randn(M, K, device=dev).to(LP)
     dw = torch.zeros(2, N, K, device=dev)
