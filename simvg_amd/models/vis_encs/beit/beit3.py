@@ -20,6 +20,7 @@ MI355X-first design (not a translation of the eager graph):
 state_dict keys are exactly the reference's.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -86,7 +87,13 @@ class BEIT3(nn.Module):
         # largest single term of the box error on trained-scale weights and the only one that every row shares
         # (tools/dev/token_tail.py); with it the boxes of a full batch stay within the path's 1e-3 bound (tests/test_fullsize_gpu.py).
         # The training forward keeps single 16-bit weights (its boxes only feed the loss).  False = the round-3 behaviour.
-        self.precise_inference = bool(precise_inference)
+        # precise_inference: True = every layer, False = none, an int k = the first k layers only (the early layers carry most of
+        # the weight-rounding error: profiles/r04_sweeps.md section 1); SIMVG_PRECISE_LAYERS overrides it (measurements)
+        if os.environ.get("SIMVG_PRECISE_LAYERS"):
+            precise_inference = int(os.environ["SIMVG_PRECISE_LAYERS"])
+        self.precise_layers = self.L if precise_inference is True else (0 if precise_inference is False else
+                                                                       max(0, min(int(precise_inference), self.L)))
+        self.precise_inference = self.precise_layers > 0
         self.wb2 = None
         self._build_parameters()
         self._arena = None
@@ -217,7 +224,7 @@ class BEIT3(nn.Module):
             self._prep_version = None
             return
         # (p.data views do not share the flat tensor's version counter, so the parameters' own counters are summed too)
-        v = (self._arena.flat._version, sum(p._version for p in self._arena.params.values()), self.precise_inference, self.precision)
+        v = (self._arena.flat._version, sum(p._version for p in self._arena.params.values()), self.precise_layers, self.precision)
         if v != self._prep_version:
             self._prep.run()
             if self.precise_inference and self.precision == "lowp":
@@ -231,12 +238,12 @@ class BEIT3(nn.Module):
         dev = A.flat.device
         if self.wb2 is None:
             self.wb2 = {"patch": torch.empty(D, 2 * 3 * P * P, device=dev, dtype=ops.LP())}
-            for i in range(L):
+            for i in range(self.precise_layers):
                 for tag, n, k in [("wqkv", 3 * D, D), ("wout", D, D), ("w1", F_, D), ("w2", D, F_)]:
                     self.wb2[f"{tag}{i}"] = torch.empty(2, n, 2 * k, device=dev, dtype=ops.LP())
         with torch.no_grad():
             ops.split_weight(A.params["beit3.vision_embed.proj.weight"].data.view(D, 3 * P * P), out=self.wb2["patch"])
-            for i in range(L):
+            for i in range(self.precise_layers):
                 for tag in ("wqkv", "wout", "w1", "w2"):
                     ops.split_weight(A.views[f"{tag}{i}"], out=self.wb2[f"{tag}{i}"])
 
@@ -295,7 +302,7 @@ class BEIT3(nn.Module):
         precise = (not save) and (not self.training) and self.precise_inference and self.wb2 is not None
 
         def lin(x, tag, bias, out, split=0, residual=None, row_scale=None):
-            if precise and row_scale is None:
+            if precise and row_scale is None and tag in self.wb2:
                 return ops.gemm_nt_split(x, self.wb2[tag], bias=bias, out=out, split=split, residual=residual)
             return ops.gemm_nt(x, self.wb[tag], bias=bias, out=out, split=split, residual=residual, row_scale=row_scale,
                                rows_per_sample=rps)
