@@ -64,6 +64,9 @@ def build(force=False, verbose=True, lowp=None):
         o = os.path.join(LIBDIR, os.path.basename(s)[:-4] + suffix + ".o")
         objs.append(o)
         f = list(flags)
+        head = open(s).readline()                                   # "// simvg-build-flags: ..." on a source's first line: this file only
+        if head.startswith("// simvg-build-flags:"):
+            f += head.split(":", 1)[1].split()
         if os.path.basename(s) == "api.hip":                        # the one object that carries the whole-source hash
             f.append(f'-DSIMVG_SOURCE_HASH="{whole}"')
         want = _sha([s] + hdrs, " ".join(f))

@@ -32,5 +32,53 @@ __device__ __forceinline__ long tok_row(const AttnArgs& a, int b, int t) {
   return t < a.Nv ? (long)b * a.Nv + t : (long)a.B * a.Nv + (long)b * a.Nt + (t - a.Nv);
 }
 
+// copy rows [0,nrows_pad) x 64 bf16 of one head into LDS (zero beyond N)
+__device__ __forceinline__ void load_head_to_lds(const AttnArgs& a, const lp_t* base, int ld, int col0, int b, int N,
+                                                 int nrows_pad, char* lds) {
+  for (int c = threadIdx.x; c < nrows_pad * 8; c += blockDim.x) {
+    const int row = c >> 3, slot = c & 7;
+    u32x4_t v = (u32x4_t){0u, 0u, 0u, 0u};
+    if (row < N) v = *(const u32x4_t*)(base + tok_row(a, b, row) * ld + col0 + slot * 8);
+    *(u32x4_t*)(lds + row * ROWB + lds_slot(row, slot) * 16) = v;
+  }
+}
+
+__device__ __forceinline__ lpx8_t lds_frag(const char* lds, int row, int slot) {
+  return *(const lpx8_t*)(lds + row * ROWB + lds_slot(row, slot) * 16);
+}
+
+// transposed fragment for contraction over LDS rows: lane (i = lane&15 -> column c0 + i,
+// g = lane>>4); rows rowA+4g..+3 (elements 0..3) and rowB+4g..+3 (elements 4..7)
+__device__ __forceinline__ lpx8_t lds_frag_tr(const char* lds, int rowA, int rowB, int c0, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  const int col = c0 + 4 * (i & 3), slot = col >> 3, within = (col & 7) * 2;
+  const int ra = rowA + 4 * g + (i >> 2), rb = rowB + 4 * g + (i >> 2);
+  const lpx4_t lo = lds_read_tr16(lds + ra * ROWB + lds_slot(ra, slot) * 16 + within);
+  const lpx4_t hi = lds_read_tr16(lds + rb * ROWB + lds_slot(rb, slot) * 16 + within);
+  return (lpx8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+__device__ __forceinline__ lpx8_t pack8(const float* lo, const float* hi) {
+  union { lpx8_t v; unsigned int u[4]; } r;
+  r.u[0] = pack_lp2(lo[0], lo[1]); r.u[1] = pack_lp2(lo[2], lo[3]);
+  r.u[2] = pack_lp2(hi[0], hi[1]); r.u[3] = pack_lp2(hi[2], hi[3]);
+  return r.v;
+}
+
+// The backward kernels are VALU-issue-bound (a wave64 VALU instruction holds its SIMD's issue port for 4 cycles: 930 VALU against
+// 164 MFMAs per 16-query strip of dQ, profiles/r03_sweeps.md): the per-score arithmetic  ds = exp2(s c - lse) (dp - delta)  is
+// written on pairs so that hipcc emits v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 (same IEEE operations, half the instructions)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void ds_pair(float s0, float s1, f32x2_t c, f32x2_t nl, float dp0, float dp1, f32x2_t dl, float& p0,
+                                        float& p1, float& ds0, float& ds1) {
+  const f32x2_t t = __builtin_elementwise_fma((f32x2_t){s0, s1}, c, nl);
+  const f32x2_t p = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+  const f32x2_t d = p * ((f32x2_t){dp0, dp1} - dl);
+  p0 = p[0]; p1 = p[1]; ds0 = d[0]; ds1 = d[1];
+}
+
 }  // namespace
+
+// attention_bwd1.hip: backward in one pass for the path's geometry; false = geometry not handled (the two kernels of attention.hip run)
+bool simvg_attn_bwd_onepass(const AttnArgs& a, hipStream_t stream);
 
