@@ -223,6 +223,9 @@ __global__ __launch_bounds__(256) void attn_bwd_one_kernel(AttnArgs a) {
       pf.u[2] = pack_lp2_raw(pr[1][0], pr[1][1]); pf.u[3] = pack_lp2_raw(pr[1][2], pr[1][3]);                            \
       dsf.v = pack8(ds[0], ds[1]);                                                                                       \
     }
+// (no scheduling fences between the three parts of a strip: left to itself hipcc's order measures 179 us, fenced 182; a three-stage
+// form -- S / dP of strip s + 2, softmax of s + 1, dV / dK of s as one region, with or without sched_group_barrier hints -- 186-188)
+#define B1_FENCE
 #define B1_STRIP(s)                                                                                                      \
     {                                                                                                                    \
       const lpx8_t pfc = pf.v, dsfc = dsf.v;                                                                             \
@@ -232,14 +235,14 @@ __global__ __launch_bounds__(256) void attn_bwd_one_kernel(AttnArgs a) {
         if ((s) + 2 < SPW) { kn0 = b1_rd<((s) + 2 < SPW ? (s) + 2 : 0) * 8192>(kA); kn1 = b1_rd<((s) + 2 < SPW ? (s) + 2 : 0) * 8192>(kB); } \
         B1_SDP((s) + 1 < SPW ? (s) + 1 : 0)                                                                              \
       }                                                                                                                  \
-      __builtin_amdgcn_sched_barrier(0);                                                                                 \
+      B1_FENCE                                                                                                           \
       _Pragma("unroll") for (int dt = 0; dt < 4; ++dt) {                                                                 \
         dv[s][dt] = mfma_lp(dof[dt], pfc, FIRST ? (f32x4_t){0.f, 0.f, 0.f, 0.f} : dv[s][dt]);                            \
         dk[s][dt] = mfma_lp(qf[dt], dsfc, FIRST ? (f32x4_t){0.f, 0.f, 0.f, 0.f} : dk[s][dt]);                            \
       }                                                                                                                  \
       *(u32x2_t*)(stw + (s) * 16 * B1_SROW) = (u32x2_t){dsu0, dsu1};                                                     \
       *(u32x2_t*)(stw + (s) * 16 * B1_SROW + 32) = (u32x2_t){dsu2, dsu3};                                                \
-      __builtin_amdgcn_sched_barrier(0);                                                                                 \
+      B1_FENCE                                                                                                           \
       if ((s) + 1 < SPW) B1_SOFTMAX((s) + 1)                                                                             \
       /* the K fragments requested at the top of this strip have landed once at most the (younger) tile store is pending */  \
       asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory"); __builtin_amdgcn_sched_barrier(0);                              \

@@ -1,6 +1,6 @@
-"""Phase timeline of the one-pass attention backward (development build: SIMVG_EXTRA_FLAGS="-DSIMVG_ATTN_ONEPASS -DB1_PROFILE"
-SIMVG_LIB_SUFFIX=_onepassprof python -m simvg_amd.build; run with SIMVG_HIP_LIB=simvg_amd/lib/libsimvg_hip_onepassprof.so
-SIMVG_ATTN_BWD1=1).  Workgroup 0 stamps s_memtime at 8 points of every query pair into the (otherwise unused) delta workspace."""
+"""Phase timeline of the one-pass attention backward (development build: SIMVG_EXTRA_FLAGS="-DB1_PROFILE"
+SIMVG_LIB_SUFFIX=_b1prof python -m simvg_amd.build; run with SIMVG_HIP_LIB=simvg_amd/lib/libsimvg_hip_b1prof.so
+).  Workgroup 0 stamps s_memtime at 8 points of every query pair into the (otherwise unused) delta workspace."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
