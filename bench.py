@@ -477,14 +477,16 @@ def main():
           "in_situ": {k: {"avg_launch_us": round(d["ms"] / d["calls"] * 1e3, 2), "launches": d["calls"],
                           "tflops": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 2)} for k, d in situ.items()},
       }
-      # HBM bytes per launch by PMC (forward: one kernel; backward: per KERNEL launch, the dq and dkv kernels are two launches
-      # per call) beside the algorithmic bytes of a call: forward reads qkv and writes o (+ lse), backward reads qkv, o, dO and
-      # writes dqkv
+      # HBM bytes per launch by PMC beside the algorithmic bytes of a call: forward reads qkv and writes o (+ lse), backward reads
+      # qkv, o, dO and writes dqkv.  The backward is ONE kernel per call for the path's geometry (csrc/attention_bwd1.hip) unless
+      # SIMVG_ATTN_BWD1=0 selects the dq + dkv pair (two launches per call)
       Mrows, Dm = B * iso["N"], H * hd
       alg = {"attn_fwd": 2.0 * Mrows * (3 * Dm + Dm), "attn_bwd": 2.0 * Mrows * (3 * Dm + Dm + Dm + 3 * Dm)}
+      one_pass = os.environ.get("SIMVG_ATTN_BWD1", "1") != "0" and (iso["N"] + 15) // 16 == 27
+      out["roofline_attn"]["backward_kernels_per_call"] = 1 if one_pass else 2
       for k in ("attn_fwd", "attn_bwd"):
-          tr, tsrc = traffic_stamp(k, "attention.hip")
-          per_call = None if tr is None else tr * (2 if k == "attn_bwd" else 1)
+          tr, tsrc = traffic_stamp(k, "attention_bwd1.hip" if (k == "attn_bwd" and one_pass) else "attention.hip")
+          per_call = None if tr is None else tr * (2 if (k == "attn_bwd" and not one_pass) else 1)
           out["roofline_attn"]["traffic_" + k] = {"hbm_bytes_per_call": per_call, "algorithmic_bytes_per_call": round(alg[k]),
                                                   "traffic_over_algorithmic": None if not per_call else round(per_call / alg[k], 3),
                                                   "traffic_source": tsrc}
