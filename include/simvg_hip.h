@@ -132,7 +132,10 @@ int simvg_ln_param_reduce_batched(const simvg_ln_reduce_desc* descs, int n, simv
  * head resident in LDS (the path's 421 tokens have compile-time-geometry kernels); larger N (patch 16, images above 640):
  * K / V streamed through LDS in 256-row blocks with an online softmax.
  * torchscale MultiheadAttention.forward as called at beit3_base.py:137-145 (bmm, masked_fill, fp32
- * softmax, bmm, head merge).  qkv: [M, 3D] = q | k | v columns.  pad: [B,Nt] bytes, 1 = padded key. */
+ * softmax, bmm, head merge).  qkv: [M, 3D] = q | k | v columns.  pad: [B,Nt] bytes, 1 = padded key.
+ * Backward (autograd of the same call): dqkv = d(q | k | v) from dout, the saved out and lse.  delta_ws: [B*H, N] floats of
+ * scratch the CALLER owns -- rowsum(dO * O) for the two-kernel form; the one-pass form of the path's geometry (27 key tiles,
+ * csrc/attention_bwd1.hip, default; SIMVG_ATTN_BWD1=0 selects the two kernels) only parks the stores of rows beyond N in it. */
 int simvg_attn_fwd(const void* qkv_lp, int ldqkv, void* out_lp, int ldo, float* lse, const unsigned char* pad,
                    int B, int H, int Nv, int Nt, int D, float scale, simvg_stream_t stream);
 int simvg_attn_bwd(const void* qkv_lp, int ldqkv, const void* out_lp, int ldo, const void* dout_lp, int lddo,
