@@ -438,8 +438,9 @@ def main():
         r = extra.get("wgrad_reduce", dict(calls=0, ms=0.0, bytes=0.0))
         tf_all = d["flops"] / ((d["ms"] + r["ms"]) * 1e-3) / 1e12
         out["roofline_wgrad"] = {
-            "kernel": "weight + bias gradients of the encoder / head-memory Linears: wgrad_x_kernel (XCD-partitioned, ViT-B shapes; partial "
-                      "sums of the row partitions to slabs) + wgrad_slab_reduce_kernel (one launch per encoder layer) and the generic "
+            "kernel": "weight + bias gradients of the encoder / head-memory Linears: wgrad_sq_kernel (256x256 tiles, 8 waves in ping-pong phases: fc1, fc2) / "
+                      "wgrad_x_kernel (XCD-partitioned 12-wave tiles: qkv, out-proj), partial sums of the row partitions to slabs + "
+                      "wgrad_slab_reduce_kernel (one launch per encoder layer), and the generic "
                       "gemm_tn kernels, every launch of a step", "bound": "mfma", "achieved": round(tf_all, 2),
             "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf_all / MFMA_BF16_PEAK_TFLOPS, 4),
             "first_stage_only": {"achieved": round(tf, 2), "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4)},

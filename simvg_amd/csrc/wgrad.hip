@@ -318,6 +318,336 @@ __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(WgradReduceTable
   *(f32x4_t*)dst = s;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Round 4, second form: 256 x 256 output tiles, EIGHT waves (2 x 4, each 128 x 64 = 128 accumulator registers, two waves per
+// SIMD), 32-row stages in a 4-deep ring, the two waves of a SIMD in PING-PONG phases (one barrier per phase): while one runs its
+// 32 MFMAs back-to-back the other issues its DMA and reads its fragments (the loop's comment has the schedule and its hazards).
+//   * work items = (row partition q, output tile), Q = 256 / tiles partitions: item x runs on XCD x / 32 (blockIdx % 8 -> XCD is
+//     a speed assumption only), so the workgroups that stream the same rows share an L2 and no XCD touches more than two
+//     partitions' rows; one workgroup per CU, one round;
+//   * same LDS image as above (rows padded to an odd multiple of 32 B: transposed reads conflict-free without a swizzle),
+//     same buffer-descriptor zero fill of the rows past a row group's end;
+//   * any N, K that are multiples of 256 with K >= 512 (the ViT-L shapes 4096 / 3072 / 1024 included, which the 12-wave tiles do
+//     not divide);
+//   * bias gradient from the staged dY: the workgroups of one tile row split its 32 16-B column chunks among them;
+//   * flush into per-partition slabs through the free ring (wave-private 32 x 68 floats), second stage as above.
+// What was measured on the way (kernel + second stage, fc1 shape, us; the 12-wave kernel: 170-174; profiles/r04_sweeps.md section 6):
+//   16 waves of 64 x 64, 64-row double buffer, one barrier per stage, everything in phase               177
+//   8 waves, every wave software-pipelined on its own (reads of stage t + 1 between the MFMA groups of t)   170
+//     ... + L2 prefetch of the stage 4 / 8 / 16 ahead (the loop is not HBM-latency-bound)                   170-173
+//     ... + the DMA pieces issued one at a time between the MFMA groups                                      166
+//     ablations of that form: MFMAs -50, DMA issue -30, fragment reads -20, bias -7: every component's time ADDS -- nothing
+//     a wave issues between its own MFMAs is hidden, and two waves of a SIMD in the same phase do not hide each other's
+//   ping-pong phases, all 24 reads + DMA in LOAD                                                             161.5
+//   ping-pong, all 24 reads between the MFMA groups, LOAD = DMA only                                         166
+//   ping-pong, dY reads in LOAD, X reads behind the MFMAs, bias sums in the MFMAs' shadow (this file)        159
+// ------------------------------------------------------------------------------------------
+constexpr int SQ_ROWS = 32, SQ_S = 256 * 2 + 32;            // stage rows; padded row stride (bytes) = 17 x 32
+constexpr int SQ_PART = SQ_ROWS * SQ_S;                     // one operand's part of a stage: 17 KiB = 17 pieces
+constexpr int SQ_STAGE = 2 * SQ_PART, SQ_NST = 4, SQ_LDS = SQ_NST * SQ_STAGE;  // 136 KiB (+ 8 KiB dump area of the out-of-range slots)
+constexpr int SQ_NPY = SQ_PART / 1024;
+static_assert((SQ_S / 32) % 2 == 1 && SQ_PART % 1024 == 0 && SQ_NPY == 17, "sq stage geometry");
+
+struct WgradSqArgs {
+  const lp_t* dY; int lddy;
+  const lp_t* X; int ldx;
+  float* dW; long dw_gstride; int lddw;
+  float* db; int db_gstride;
+  int M, N, K, split;
+  float out_scale;
+  float* slabs;
+  int Q, tiles_k, ntile;
+  int dbg;                        // development ablations (SIMVG_WG_DBG): 1 no MFMAs, 2 no DMA after the prologue, 4 no fragment reads, 8 no flush, 16 no bias sums
+};
+
+template <int N_> __device__ __forceinline__ void sq_lgkm() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N_) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int DBG>
+__global__ __launch_bounds__(512) void wgrad_sq_kernel(WgradSqArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave >> 2, wk = wave & 3;
+  const int item = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+  if (item >= a.Q * a.ntile) return;
+  const int q = item / a.ntile, tile = item - q * a.ntile;
+  const int tn = tile / a.tiles_k, tk = tile - tn * a.tiles_k;
+  const int n0 = tn * 256, k0 = tk * 256;
+  const int st0 = (a.split + SQ_ROWS - 1) / SQ_ROWS, st1 = (a.M - a.split + SQ_ROWS - 1) / SQ_ROWS, ST = st0 + st1;
+  const int s_begin = (int)((long)q * ST / a.Q), s_end = (int)((long)(q + 1) * ST / a.Q);
+
+  // this wave's pieces of a stage (piece p = bytes [1024 p, +1024) of the stage image; pieces < 17: dY rows, the others: X rows):
+  // two of dY, two of X; waves 0 / 1 also take the dY / X piece left over, the other waves issue that slot out of range into a
+  // dump area behind the ring -- every wave issues the same five operations per stage: no branches in the loop, one wait count
+  constexpr int SQ_DUMP = SQ_LDS;                           // 8 x 1 KiB (left-over slot)
+  const int pidx[4] = {2 * wave, 2 * wave + 1, SQ_NPY + 2 * wave, SQ_NPY + 2 * wave + 1};
+  const bool extra = wave < 2, extra_x = wave == 1;
+  const int xdst = extra ? (wave == 0 ? 16 : 2 * SQ_NPY - 1) * 1024 : -1;       // stage-relative; -1: the dump area
+  unsigned poff[5];
+#pragma unroll
+  for (int ii = 0; ii < 5; ++ii) {
+    const int p = ii < 4 ? pidx[ii] : (wave == 0 ? 16 : 2 * SQ_NPY - 1);
+    const bool x = p >= SQ_NPY;
+    const int o = (x ? p - SQ_NPY : p) * 1024 + lane * 16;
+    const int row = o / SQ_S, byte = o - row * SQ_S;
+    poff[ii] = byte < 512 && (ii < 4 || extra) ? (unsigned)(row * (x ? a.ldx : a.lddy) * 2 + (x ? k0 : n0) * 2 + byte) : 0xffffffffu;
+  }
+  // per-lane fragment bases: lane (i = lane & 15, g = lane >> 4) reads rows 16 h + 4 g + (i >> 2) of the stage
+  const int i16 = lane & 15, g4 = lane >> 4;
+  const unsigned lds0 = lds_addr(smem);
+  const unsigned fb_n = lds0 + (4 * g4 + (i16 >> 2)) * SQ_S + (wn * 128 + 4 * (i16 & 3)) * 2;
+  const unsigned fb_k = lds0 + SQ_PART + (4 * g4 + (i16 >> 2)) * SQ_S + (wk * 64 + 4 * (i16 & 3)) * 2;
+  // bias gradient: this workgroup sums the 16-B column chunks [c_lo, c_hi) of its dY tile; thread -> (row, chunk) of every stage
+  // (tiles_k >= 2: at most 16 chunks x 32 rows = 512 threads); the others read the same way and drop the value (uniform counts)
+  const int c_lo = tk * 32 / a.tiles_k, c_hi = (tk + 1) * 32 / a.tiles_k, nch = c_hi - c_lo;
+  const bool cs_on = a.db != nullptr && tid < 32 * nch;
+  const int cs_c = cs_on ? tid % nch : 0, cs_r0 = cs_on ? tid / nch : 0;
+  const unsigned cs_addr = lds0 + cs_r0 * SQ_S + (c_lo + cs_c) * 16;
+
+  char* x_dump = smem + SQ_DUMP + wave * 1024;
+
+  for (int grp = 0; grp < 2; ++grp) {
+    const int sb = grp ? max(s_begin, st0) : s_begin, se = grp ? s_end : min(s_end, st0);
+    if (sb >= se) continue;
+    const int r_first = grp ? a.split + (sb - st0) * SQ_ROWS : sb * SQ_ROWS;
+    const int m_end = grp ? a.M : a.split;
+    const int nt = se - sb;
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    // DMA of a stage: the descriptors (SGPRs), then this wave's six operations (4 pieces, the left-over slot, the prefetch slot).
+    // In the loop they go out ONE AT A TIME between the MFMA groups: the CU's address unit takes a 1-KiB piece per ~17 cycles, and
+    // with all 34 pieces of a stage issued behind the barrier every wave sat in that queue (~550 cycles per stage) while the
+    // matrix pipe idled (ablations: the DMA issue and the MFMAs each added their full time to the loop).  Past the segment's
+    // last stage the descriptors are empty: the operations are still issued (one wait count), as zero fill of a dead buffer.
+    auto desc_y = [&](int t, bool real) {                 // !real: a zero-sized descriptor (every lane out of range: zeros into a dead buffer)
+      const int row0 = r_first + t * SQ_ROWS;
+      return __builtin_amdgcn_make_buffer_rsrc((void*)(a.dY + (long)row0 * a.lddy), 0, real ? (int)((long)(m_end - row0) * a.lddy * 2) : 0, 0x00020000);
+    };
+    auto desc_x = [&](int t, bool real) {
+      const int row0 = r_first + t * SQ_ROWS;
+      return __builtin_amdgcn_make_buffer_rsrc((void*)(a.X + (long)row0 * a.ldx), 0, real ? (int)((long)(m_end - row0) * a.ldx * 2) : 0, 0x00020000);
+    };
+    // this wave's five DMA operations of stage t (past the segment's last stage: empty descriptors, the operations are still
+    // issued -- one wait count -- as zero fill of a dead buffer)
+    auto issue = [&](int t, bool real) {
+      const __amdgpu_buffer_rsrc_t dy = desc_y(t, real), dx = desc_x(t, real);
+      char* st = smem + (t & (SQ_NST - 1)) * SQ_STAGE;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(dy, LDS_PTR(st + pidx[0] * 1024), 16, (int)poff[0], 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(dy, LDS_PTR(st + pidx[1] * 1024), 16, (int)poff[1], 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(dx, LDS_PTR(st + pidx[2] * 1024), 16, (int)poff[2], 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(dx, LDS_PTR(st + pidx[3] * 1024), 16, (int)poff[3], 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(extra_x ? dx : dy, LDS_PTR(xdst >= 0 ? st + xdst : x_dump), 16, (int)poff[4], 0, 0, 0);
+    };
+    u32x2_t rx[4][2], nx[4][2], ry[8][2];
+    u32x4_t csv;
+    // Phases (one barrier each; `ph` = this wave's group, 0: waves 0-3, 1: waves 4-7 -- one wave of each group per SIMD).  Group 0
+    // runs LOAD(s) in phase 2 s - 1 and MFMA(s) in phase 2 s, group 1 LOAD(s) in phase 2 s and MFMA(s) in phase 2 s + 1: in every
+    // phase one wave of a SIMD owns the matrix pipe while its partner issues its DMA (MI355X_MICROARCH.md, "Two waves per SIMD":
+    // an in-order wave cannot slip MFMAs into the gaps of its own loads, and co-issued MFMAs of the partner come straight out of
+    // its stream -- a single-phase software-pipelined form of this loop measured every component's time ADDED: fc1 168 us =
+    // 50 MFMA + 30 DMA issue + 20 reads + 68 rest).
+    //   MFMA(s): 32 back-to-back MFMAs at priority 1 (the bias sums of stage s in their shadow), then the 8 transposed reads of
+    //            stage s + 1's X fragments (into nx), which return under the last MFMAs' execution and the barrier;
+    //   LOAD(s): this wave's five DMA operations of stage s + 3, the 16 reads of stage s's dY fragments, its bias chunk, nx -> rx,
+    //            lgkmcnt(0) -- MFMA(s) waits for nothing.  (All 24 reads in LOAD: fc1 161.5 us with a ~950-cycle LOAD against
+    //            ~550 of MFMA; all of them between the MFMA groups: 166 -- reads in the MFMA stream are not free.)
+    //   RAW: stage s + 1 is first read in group 0's MFMA(s): every wave waits for its own pieces of it before the barrier in front
+    //        of that phase -- group 0 at the end of LOAD(s) (stages s + 2, s + 3 issued since: vmcnt(10)), group 1 at the end of
+    //        MFMA(s - 1) (stage s + 2 issued since: vmcnt(5));
+    //   WAR: stage s + 3 is issued in LOAD(s) into the buffer of stage s - 1, last read in LOAD(s - 1) (bias) / MFMA(s - 2).
+    const int ph = wave >> 2;
+#define SQ_RXA(j_) nx[j_][0] = lds_tr16_asm<(j_) * 32>(ak);
+#define SQ_RXB(j_) nx[j_][1] = lds_tr16_asm<16 * SQ_S + (j_) * 32>(ak);
+#define SQ_RYA(i_) ry[i_][0] = lds_tr16_asm<(i_) * 32>(an);
+#define SQ_RYB(i_) ry[i_][1] = lds_tr16_asm<16 * SQ_S + (i_) * 32>(an);
+#define SQ_MMA(i_)                                                                                            \
+  if constexpr (!(DBG & 1)) {                                                                                 \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                \
+      acc[i_][j] = mfma_lp(frag8(ry[i_][0], ry[i_][1]), frag8(rx[j][0], rx[j][1]), acc[i_][j]);              \
+  }                                                                                                           \
+  __builtin_amdgcn_sched_barrier(0);
+#define SQ_RD(...) if constexpr (!(DBG & 4)) { __VA_ARGS__ } __builtin_amdgcn_sched_barrier(0);
+    issue(0, true);
+    issue(1, nt > 1);
+    issue(2, nt > 2);
+    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");      // stages 0 and 1
+    __builtin_amdgcn_s_barrier();
+    {                                                     // the fragments of stage 0
+      const unsigned an = fb_n, ak = fb_k;
+      SQ_RXA(0) SQ_RXB(0) SQ_RXA(1) SQ_RXB(1) SQ_RXA(2) SQ_RXB(2) SQ_RXA(3) SQ_RXB(3)
+      SQ_RYA(0) SQ_RYB(0) SQ_RYA(1) SQ_RYB(1) SQ_RYA(2) SQ_RYB(2) SQ_RYA(3) SQ_RYB(3)
+      SQ_RYA(4) SQ_RYB(4) SQ_RYA(5) SQ_RYB(5) SQ_RYA(6) SQ_RYB(6) SQ_RYA(7) SQ_RYB(7)
+    }
+    if (ph) __builtin_amdgcn_s_barrier();                 // group 1 starts one phase later
+    for (int t = 0; t < nt; ++t) {
+      // ---------------- LOAD(t)
+      issue(t + 3, t + 3 < nt && !(DBG & 2));
+      {
+        const unsigned so = (unsigned)(t & (SQ_NST - 1)) * SQ_STAGE;
+        const unsigned an = fb_n + so;
+        csv = lds_b128_asm<0>(cs_addr + so);
+        if (t > 0) { SQ_RD(SQ_RYA(0) SQ_RYB(0) SQ_RYA(1) SQ_RYB(1) SQ_RYA(2) SQ_RYB(2) SQ_RYA(3) SQ_RYB(3)
+                           SQ_RYA(4) SQ_RYB(4) SQ_RYA(5) SQ_RYB(5) SQ_RYA(6) SQ_RYB(6) SQ_RYA(7) SQ_RYB(7)) }
+      }
+      sq_lgkm<0>();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { lds_pin(nx[j][0], nx[j][1]); rx[j][0] = nx[j][0]; rx[j][1] = nx[j][1]; }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) lds_pin(ry[i][0], ry[i][1]);
+      asm volatile("" : "+v"(csv));
+      if (!ph) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");    // group 0: its pieces of stage t + 1
+      __builtin_amdgcn_s_barrier();
+      // ---------------- MFMA(t)
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+      SQ_MMA(0) SQ_MMA(1) SQ_MMA(2) SQ_MMA(3)
+      if (cs_on && !(DBG & 16)) {                         // bias sums of stage t, in the matrix pipe's shadow
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float lo, hi;
+          unpack_lp2(csv[e], lo, hi);
+          cs[2 * e] += lo;
+          cs[2 * e + 1] += hi;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      SQ_MMA(4) SQ_MMA(5) SQ_MMA(6) SQ_MMA(7)
+      __builtin_amdgcn_s_setprio(0);
+      {                                                   // the X fragments of stage t + 1, under the last MFMAs' execution
+        const unsigned ak = fb_k + (unsigned)((t + 1) & (SQ_NST - 1)) * SQ_STAGE;   // (past the last stage: zero fill or stale, unused)
+        SQ_RD(SQ_RXA(0) SQ_RXB(0) SQ_RXA(1) SQ_RXB(1) SQ_RXA(2) SQ_RXB(2) SQ_RXA(3) SQ_RXB(3))
+      }
+      if (ph) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");      // group 1: its pieces of stage t + 2 (read from group 0's MFMA(t + 1) on)
+      __builtin_amdgcn_s_barrier();
+    }
+    if (!ph) __builtin_amdgcn_s_barrier();                // group 0 meets group 1's last phase
+#undef SQ_RXA
+#undef SQ_RXB
+#undef SQ_RYA
+#undef SQ_RYB
+#undef SQ_MMA
+#undef SQ_RD
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the trailing zero fills too: the flush re-uses the ring)
+    __syncthreads();                                      // every wave has left the ring
+    if constexpr (DBG & 8) {
+    } else if (a.slabs) {
+      float* sl = a.slabs + ((long)grp * a.Q + q) * a.N * a.K;
+      constexpr int LD = 68;                              // floats per staged row (64 + 4: the 4 row groups of a store land in different banks)
+      float* st = (float*)(smem + wave * (32 * LD * 4));  // wave-private, 8.5 KiB each
+      static_assert(8 * 32 * LD * 4 <= SQ_LDS, "flush staging must fit the ring");
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st[(ii * 16 + 4 * g4 + r) * LD + j * 16 + i16] = acc[2 * p + ii][j][r] * a.out_scale;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int nb = n0 + wn * 128 + p * 32, kb = k0 + wk * 64;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {                  // 32 rows x 16 chunks of 16 B = 64 lanes x 8
+          const int e = it * 64 + lane, row = e >> 4, c = (e & 15) * 4;
+          *(f32x4_t*)(sl + (long)(nb + row) * a.K + kb + c) = *(const f32x4_t*)(st + row * LD + c);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    } else {
+      float* dW = a.dW + (long)grp * a.dw_gstride;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = k0 + wk * 64 + j * 16 + i16;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) atomicAdd(dW + (long)(n0 + wn * 128 + i * 16 + 4 * g4 + r) * a.lddw + k, acc[i][j][r] * a.out_scale);
+        }
+    }
+    if (a.db) {
+      __syncthreads();
+      float* red = (float*)smem;
+      if (tid < 256) red[tid] = 0.f;
+      __syncthreads();
+      if (cs_on) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(&red[cs_c * 8 + e], cs[e]);
+      }
+      __syncthreads();
+      if (tid < nch * 8) atomicAdd(a.db + (long)grp * a.db_gstride + n0 + c_lo * 8 + tid, red[tid] * a.out_scale);
+    }
+    __syncthreads();                                      // before the next segment's loads land in the ring
+  }
+}
+
+// which kernel takes (M, N, K): 0 = none of this file's, 12 = the 12-wave XCD kernel, 16 = the 256 x 256 kernel;
+// Q = row partitions (= slabs per row group), rows = rows per stage of the partition arithmetic
+struct WgradPlan { int kind, Q, rows; };
+static WgradPlan wgrad_plan(int M, int N, int K) {
+  WgradPlan p{0, 0, 32};
+  if (M < 4096) return p;
+  const char* e = getenv("SIMVG_WGRAD_SQ");                 // read per call (tools/dev/wgrad_ab.py switches it between launches)
+  const int sq = e ? atoi(e) : -1;                          // 0: never, 1: wherever it fits, default: by shape
+  auto fits = [&](int tn, int tk) { return N % tn == 0 && K % tk == 0 && (N / tn) * (K / tk) == 32 && ((tn / (K / tk)) % 8) == 0; };
+  const bool x8 = fits(384, 192) || fits(288, 192) || fits(192, 384);
+  const bool x16 = N % 192 == 0 && K % 192 == 0 && (N / 192) * (K / 192) == 16 && ((192 / (K / 192)) % 8) == 0;
+  const int tiles = (N % 256 == 0 && K % 256 == 0) ? (N / 256) * (K / 256) : 0;
+  const bool sq_ok = tiles > 0 && tiles <= 128 && K / 256 >= 2 && K / 256 <= 32;   // (K = 256: 32 bias chunks x 32 rows > 512 threads)
+  // default: the shapes the 12-wave tiles do not divide (ViT-L's) and, of those they do, fc1 / fc2 (36 tiles x 7 partitions:
+  // 159 / 155 us against 172 / 165 with the second stage; qkv -- 27 tiles x 9 -- measures equal, out-proj slower: 12-wave)
+  const bool want_sq = sq_ok && (sq == 1 || (sq != 0 && ((!x8 && !x16) || tiles >= 36)));
+  if (want_sq) {                                            // every partition must own at least one 64-row stage
+    p.kind = 16; p.Q = 256 / tiles < M / SQ_ROWS ? 256 / tiles : M / SQ_ROWS; p.rows = SQ_ROWS;
+    return p;
+  }
+  if (x8) { p.kind = 12; p.Q = 8; }
+  else if (x16) { p.kind = 12; p.Q = 16; }
+  return p;
+}
+
+static bool launch_sq(const WgradXArgs& x, const WgradPlan& pl, hipStream_t stream) {
+  const int tiles_k = x.K / 256, ntile = (x.N / 256) * tiles_k, Q = pl.Q;
+  float* slabs = x.slabs;
+  if (x.K % 4 != 0 || x.lddw % 4 != 0 || (x.dw_gstride & 3)) slabs = nullptr;
+  WgradSqArgs a{x.dY, x.lddy, x.X, x.ldx, x.dW, x.dw_gstride, x.lddw, x.db, x.db_gstride, x.M, x.N, x.K, x.split, x.out_scale,
+                slabs, Q, tiles_k, ntile, getenv("SIMVG_WG_DBG") ? atoi(getenv("SIMVG_WG_DBG")) : 0};
+#define SQ_LAUNCH(D_) case D_: { static bool once = hipFuncSetAttribute((const void*)wgrad_sq_kernel<D_>, hipFuncAttributeMaxDynamicSharedMemorySize, SQ_LDS + 8192) == hipSuccess; (void)once; \
+    hipLaunchKernelGGL(wgrad_sq_kernel<D_>, dim3(256), dim3(512), SQ_LDS + 8192, stream, a); break; }
+  switch (a.dbg) {
+#ifdef SIMVG_WG_ABLATE
+    SQ_LAUNCH(1) SQ_LAUNCH(2) SQ_LAUNCH(4) SQ_LAUNCH(8) SQ_LAUNCH(16) SQ_LAUNCH(7) SQ_LAUNCH(15) SQ_LAUNCH(31) SQ_LAUNCH(6) SQ_LAUNCH(9)
+#endif
+    default: SQ_LAUNCH(0)
+  }
+#undef SQ_LAUNCH
+  if (slabs) {
+    const int st0 = (x.split + SQ_ROWS - 1) / SQ_ROWS, st1 = (x.M - x.split + SQ_ROWS - 1) / SQ_ROWS, ST = st0 + st1;
+    int lo0 = Q, hi0 = 0, lo1 = Q, hi1 = 0;
+    for (int q = 0; q < Q; ++q) {
+      const int sb = (int)((long)q * ST / Q), se = (int)((long)(q + 1) * ST / Q);
+      if (sb < (se < st0 ? se : st0)) { lo0 = q < lo0 ? q : lo0; hi0 = q + 1; }
+      if ((sb > st0 ? sb : st0) < se) { lo1 = q < lo1 ? q : lo1; hi1 = q + 1; }
+    }
+    const simvg_wgrad_reduce_desc d{slabs, x.dW, x.dw_gstride, x.lddw, x.N, x.K, Q, lo0, hi0, lo1, hi1};
+    if (x.defer) {
+      *x.defer = d;
+    } else {
+      WgradReduceTable t;
+      t.d[0] = d;
+      hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((x.N * x.K / 4 + 255) / 256, 2, 1), dim3(256), 0, stream, t);
+    }
+  }
+  return true;
+}
+
 template <int A, int B, int WI, int WJ>
 bool launch(const WgradXArgs& a0, hipStream_t stream, int nsub = 1) {
   constexpr int TN = 16 * WI * A, TK = 16 * WJ * B;
@@ -360,11 +690,8 @@ bool launch(const WgradXArgs& a0, hipStream_t stream, int nsub = 1) {
 // generic kernels of gemm.hip
 // floats of slab workspace the XCD-partitioned kernel wants for this problem (0: the problem is not its)
 long simvg_wgrad_x_slab_floats(int M, int N, int K) {
-  if (M < 4096) return 0;
-  auto fits = [&](int tn, int tk) { return N % tn == 0 && K % tk == 0 && (N / tn) * (K / tk) == 32 && ((tn / (K / tk)) % 8) == 0; };
-  if (fits(384, 192) || fits(288, 192) || fits(192, 384)) return 2 * 8L * N * K;
-  if (N % 192 == 0 && K % 192 == 0 && (N / 192) * (K / 192) == 16 && ((192 / (K / 192)) % 8) == 0) return 2 * 16L * N * K;
-  return 0;
+  const WgradPlan p = wgrad_plan(M, N, K);
+  return p.kind ? 2L * p.Q * N * K : 0;
 }
 
 int simvg_wgrad_reduce_launch(const simvg_wgrad_reduce_desc* descs, int n, hipStream_t stream) {
@@ -389,6 +716,9 @@ bool simvg_wgrad_x(const void* dY, int lddy, const void* X, int ldx, float* dW, 
   if (const char* e = getenv("SIMVG_WG_SLABS")) { if (atoi(e) == 0) slabs = nullptr; }      // A/B switch (tools/dev/wgrad_ab.py)
   static unsigned long long* prof = getenv("SIMVG_WG_PROF_PTR") ? (unsigned long long*)strtoull(getenv("SIMVG_WG_PROF_PTR"), nullptr, 0) : nullptr;
   WgradXArgs a{(const lp_t*)dY, lddy, (const lp_t*)X, ldx, dW, dw_gstride, lddw, db, db_gstride, M, N, K, split, out_scale, slabs, defer, prof};
+  const WgradPlan pl = wgrad_plan(M, N, K);
+  if (pl.kind == 16) return launch_sq(a, pl, stream);
+  if (pl.kind != 12) return false;
   auto fits = [&](int tn, int tk) {
     return N % tn == 0 && K % tk == 0 && (N / tn) * (K / tk) == 32 && ((tn / (K / tk)) % 8) == 0;
   };
@@ -396,8 +726,7 @@ bool simvg_wgrad_x(const void* dY, int lddy, const void* X, int ldx, float* dW, 
   if (fits(288, 192)) return launch<3, 4, 6, 3>(a, stream);      // qkv: 2304 x 768, waves 3 x 4 of 96 x 48
   if (fits(192, 384)) return launch<3, 4, 4, 6>(a, stream);      // fc2 / patch embed: 768 x 3072, waves 3 x 4 of 64 x 96
   // out-proj: 768 x 768 = 16 tiles of 192 x 192 (waves 3 x 4 of 64 x 48); every XCD's row range is halved once more so that
-  // 32 workgroups per XCD exist (16 row partitions, 38 MB of fp32 atomics)
-  if (N % 192 == 0 && K % 192 == 0 && (N / 192) * (K / 192) == 16 && ((192 / (K / 192)) % 8) == 0)
-    return launch<3, 4, 4, 3>(a, stream, 2);
+  // 32 workgroups per XCD exist (16 row partitions)
+  if (pl.Q == 16) return launch<3, 4, 4, 3>(a, stream, 2);
   return false;
 }

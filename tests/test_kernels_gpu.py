@@ -233,6 +233,41 @@ def test_gemm_tn_and_colsum(M, N, K, split):
     assert_close(db_fused, refb, 1e-4, "bias gradient fused into the wgrad")
 
 
+@pytest.mark.parametrize("M,N,K,split", [(4133, 3072, 768, 3850), (6011, 2304, 768, 5614), (4500, 768, 3072, 0), (8421, 768, 768, 8020),
+                                         (4096, 512, 512, 4090), (26944, 768, 768, 25664), (5000, 512, 1024, 4999),
+                                         (4700, 4096, 1024, 4400)])
+@pytest.mark.parametrize("slabs", [True, False])
+def test_wgrad_square_tile_kernel(M, N, K, split, slabs, monkeypatch):
+    """the 16-wave 256 x 256 kernel (csrc/wgrad.hip, wgrad_sq_kernel) forced onto every shape it divides (SIMVG_WGRAD_SQ=1; by
+    default it takes the shapes the 12-wave tiles do not divide, e.g. ViT-L's): ragged last stages, a row-group boundary inside a
+    partition, one tile (as many partitions as stages), slabs and the atomic flush, the fused bias gradient; run twice: same bits."""
+    ops = _ops()
+    monkeypatch.setenv("SIMVG_WGRAD_SQ", "1")
+    if not slabs:
+        monkeypatch.setenv("SIMVG_WG_SLABS", "0")
+    g = torch.Generator().manual_seed(11 * M + N + K)
+    dy = rnd_bf16(M, N, gen=g)
+    x = rnd_bf16(M, K, gen=g)
+    sp = split if split else M
+    ng = 2 if split else 1
+    init = torch.randn(ng, N, K, generator=g)
+    ref = init.clone().double()
+    ref[0] += dy[:sp].double().t() @ x[:sp].double()
+    if split:
+        ref[1] += dy[sp:].double().t() @ x[sp:].double()
+    refb = torch.stack([dy[:sp].double().sum(0)] + ([dy[sp:].double().sum(0)] if split else [])).float()
+    outs = []
+    for _ in range(2):
+        dw = init.clone().to(DEV)
+        db = torch.zeros(ng, N, device=DEV)
+        ops.gemm_tn(bf(dy).to(DEV), bf(x).to(DEV), dw, split=split, db=db)
+        assert_close(dw, ref.float(), 1e-4, "wgrad, 256 x 256 tiles")
+        assert_close(db, refb, 1e-4, "bias gradient, 256 x 256 tiles")
+        outs.append(dw)
+    if slabs:
+        assert torch.equal(outs[0], outs[1]), "slab path is not reproducible run to run"
+
+
 @pytest.mark.parametrize("M,N,K,split", [(6011, 3072, 768, 5614), (6011, 768, 768, 5614), (4500, 2304, 768, 0)])
 def test_wgrad_slabs_deferred_reduction_and_atomics_agree(M, N, K, split, monkeypatch):
     """the XCD-partitioned kernel's partial sums go to per-partition slabs and a second launch adds them to dW in a fixed order:

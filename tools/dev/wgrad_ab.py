@@ -5,22 +5,31 @@ import torch
 from simvg_amd import hip_ops as ops
 dev = "cuda"
 LP = ops.LP()
-M, SPLIT = 64 * 421, 64 * 401
+B = int(os.environ.get("B", 64))
+D = int(os.environ.get("D", 768))          # D=1024 B=32: the ViT-L shapes
+M, SPLIT = B * 421, B * 401
 REPS = 200
 VARIANTS = sys.argv[1].split(",") if len(sys.argv) > 1 else ["base", "s0"]
 tot = {v: 0.0 for v in VARIANTS}
-for name, N, K, per_layer in [("qkv", 2304, 768, 1), ("fc1", 3072, 768, 1), ("fc2", 768, 3072, 1), ("out", 768, 768, 1)]:
+for name, N, K, per_layer in [("qkv", 3 * D, D, 1), ("fc1", 4 * D, D, 1), ("fc2", D, 4 * D, 1), ("out", D, D, 1)]:
     dy = torch.randn(M, N, device=dev).to(LP)
     x = torch.randn(M, K, device=dev).to(LP)
     db = torch.zeros(2, N, device=dev)
     res, ref = {}, None
     for rnd in range(3):
         for v in VARIANTS:
-            for kk in ("SIMVG_WGRAD", "SIMVG_WG_PRIO", "SIMVG_WG_SLABS"):
+            for kk in ("SIMVG_WGRAD", "SIMVG_WG_PRIO", "SIMVG_WG_SLABS", "SIMVG_WGRAD_SQ", "SIMVG_WG_DBG"):
                 os.environ.pop(kk, None)
             for kv in ([] if v == "base" else v.split("+")):       # (the one-barrier "x1" and s_setprio "p*" variants of
                 if kv == "s0":                                     #  r04_sweeps.md section 3: tools/dev/wgrad_variants_r04.hip.txt, not built)                                   # fp32 atomics instead of slabs + reduction launch
                     os.environ["SIMVG_WG_SLABS"] = "0"
+                if kv == "sq":                                     # the 16-wave 256 x 256 kernel on every shape it divides
+                    os.environ["SIMVG_WGRAD_SQ"] = "1"
+                if kv.startswith("dbg"):                           # ablations of the 256 x 256 kernel: a build with -DSIMVG_WG_ABLATE
+                                                                   # (SIMVG_EXTRA_FLAGS, SIMVG_HIP_LIB); wrong results: WG_NOCHECK=1
+                    os.environ["SIMVG_WG_DBG"] = kv[3:]
+                if kv == "sq0":                                    # never (ViT-L shapes: the generic kernel of gemm.hip)
+                    os.environ["SIMVG_WGRAD_SQ"] = "0"
             dw = torch.zeros(2, N, K, device=dev)
             db.zero_()
             ops.gemm_tn(dy, x, dw, split=SPLIT, db=db)
