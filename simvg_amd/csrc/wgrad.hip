@@ -42,7 +42,24 @@ struct WgradXArgs {
   float* slabs;                   // SLABS kernels: fp32 slabs [2 row groups][Q partitions][N][K] of the partial sums
   simvg_wgrad_reduce_desc* defer; // host pointer: where to leave the description of the second stage instead of launching it
   unsigned long long* prof;       // development builds (-DSIMVG_WG_PROFILE): s_memtime at the role boundaries of stages 8..23
+  int fv;                         // virtual stages of the second flush (wg_bound)
 };
+// Row partition q of Q: stages [wg_bound(q), wg_bound(q + 1)) of the launch's stage list (row group 0 first, st0 = its stages).  The
+// partition that holds the boundary between the row groups flushes TWICE (one partial sum per group): `fv` virtual stages stand
+// at the boundary for that second flush, so that its share of real stages is shorter by what the flush costs (the launch ends
+// with its slowest workgroup: without it the straddling partition's workgroups finish a flush -- 12-17 us -- after all others;
+// measured, kernel + second stage: 12-wave kernel qkv 128 -> 114 us, fc1 170 -> 160, out-proj 54.6 -> 51.5 at fv = 14; the 256 x 256
+// kernel fc1 158 -> 149, fc2 152 -> 147.5 at fv = 12; profiles/r04_sweeps.md section 6).
+__host__ __device__ inline int wg_bound(int q, int Q, int ST, int st0, int fv) {
+  if (st0 <= 0 || st0 >= ST) fv = 0;
+  if (fv > ST / Q / 2) fv = ST / Q / 2;                     // (every partition keeps at least one real stage)
+  const int v = (int)((long)q * (ST + fv) / Q);
+  return v <= st0 ? v : (v < st0 + fv ? st0 : v - fv);
+}
+static int wg_fv(int dflt) {                                 // SIMVG_WG_FV: A/B switch for the virtual flush stages (0: even split)
+  const char* e = getenv("SIMVG_WG_FV");
+  return e ? atoi(e) : dflt;
+}
 #ifdef SIMVG_WG_PROFILE
 #define WG_T(k_) do { if (a.prof && blockIdx.x == 8 && lane == 0 && (wave & 3) == 0 && t >= 8 && t < 24)                 \
     a.prof[((wave >> 2) * 16 + (t - 8)) * 8 + (k_)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -101,7 +118,7 @@ __global__ __launch_bounds__(A * B * 64) void wgrad_x_kernel(WgradXArgs a) {
   // the launch's rows as a list of 32-row stages, group 0 (rows [0, split)) first; this block takes a contiguous share
   const int st0 = (a.split + 31) >> 5, st1 = (a.M - a.split + 31) >> 5, ST = st0 + st1;
   const int q = xcd * nsub + sub, Q = 8 * nsub;
-  const int s_begin = q * ST / Q, s_end = (q + 1) * ST / Q;
+  const int s_begin = wg_bound(q, Q, ST, st0, a.fv), s_end = wg_bound(q + 1, Q, ST, st0, a.fv);
 
   // ---- this wave's pieces of a stage: LDS piece p holds bytes [p * 1024, +1024) of the stage image.  The loads are
   // buffer loads (`buffer_load_dwordx4 ... offen lds`): the descriptor is rebuilt per stage with its base at the stage's
@@ -357,7 +374,7 @@ struct WgradSqArgs {
   int M, N, K, split;
   float out_scale;
   float* slabs;
-  int Q, tiles_k, ntile;
+  int Q, tiles_k, ntile, fv;
   int dbg;                        // development ablations (SIMVG_WG_DBG): 1 no MFMAs, 2 no DMA after the prologue, 4 no fragment reads, 8 no flush, 16 no bias sums
 };
 
@@ -378,7 +395,7 @@ __global__ __launch_bounds__(512) void wgrad_sq_kernel(WgradSqArgs a) {
   const int tn = tile / a.tiles_k, tk = tile - tn * a.tiles_k;
   const int n0 = tn * 256, k0 = tk * 256;
   const int st0 = (a.split + SQ_ROWS - 1) / SQ_ROWS, st1 = (a.M - a.split + SQ_ROWS - 1) / SQ_ROWS, ST = st0 + st1;
-  const int s_begin = (int)((long)q * ST / a.Q), s_end = (int)((long)(q + 1) * ST / a.Q);
+  const int s_begin = wg_bound(q, a.Q, ST, st0, a.fv), s_end = wg_bound(q + 1, a.Q, ST, st0, a.fv);
 
   // this wave's pieces of a stage (piece p = bytes [1024 p, +1024) of the stage image; pieces < 17: dY rows, the others: X rows):
   // two of dY, two of X; waves 0 / 1 also take the dY / X piece left over, the other waves issue that slot out of range into a
@@ -618,7 +635,7 @@ static bool launch_sq(const WgradXArgs& x, const WgradPlan& pl, hipStream_t stre
   float* slabs = x.slabs;
   if (x.K % 4 != 0 || x.lddw % 4 != 0 || (x.dw_gstride & 3)) slabs = nullptr;
   WgradSqArgs a{x.dY, x.lddy, x.X, x.ldx, x.dW, x.dw_gstride, x.lddw, x.db, x.db_gstride, x.M, x.N, x.K, x.split, x.out_scale,
-                slabs, Q, tiles_k, ntile, getenv("SIMVG_WG_DBG") ? atoi(getenv("SIMVG_WG_DBG")) : 0};
+                slabs, Q, tiles_k, ntile, wg_fv(12), getenv("SIMVG_WG_DBG") ? atoi(getenv("SIMVG_WG_DBG")) : 0};
 #define SQ_LAUNCH(D_) case D_: { static bool once = hipFuncSetAttribute((const void*)wgrad_sq_kernel<D_>, hipFuncAttributeMaxDynamicSharedMemorySize, SQ_LDS + 8192) == hipSuccess; (void)once; \
     hipLaunchKernelGGL(wgrad_sq_kernel<D_>, dim3(256), dim3(512), SQ_LDS + 8192, stream, a); break; }
   switch (a.dbg) {
@@ -632,7 +649,7 @@ static bool launch_sq(const WgradXArgs& x, const WgradPlan& pl, hipStream_t stre
     const int st0 = (x.split + SQ_ROWS - 1) / SQ_ROWS, st1 = (x.M - x.split + SQ_ROWS - 1) / SQ_ROWS, ST = st0 + st1;
     int lo0 = Q, hi0 = 0, lo1 = Q, hi1 = 0;
     for (int q = 0; q < Q; ++q) {
-      const int sb = (int)((long)q * ST / Q), se = (int)((long)(q + 1) * ST / Q);
+      const int sb = wg_bound(q, Q, ST, st0, a.fv), se = wg_bound(q + 1, Q, ST, st0, a.fv);
       if (sb < (se < st0 ? se : st0)) { lo0 = q < lo0 ? q : lo0; hi0 = q + 1; }
       if ((sb > st0 ? sb : st0) < se) { lo1 = q < lo1 ? q : lo1; hi1 = q + 1; }
     }
@@ -658,11 +675,11 @@ bool launch(const WgradXArgs& a0, hipStream_t stream, int nsub = 1) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
   (void)once;
   WgradXArgs a = a0;
-  // which partitions own rows of which group (the kernel's row partition: stages [q ST / Q, (q + 1) ST / Q) of 32 rows, group 0 first)
+  // which partitions own rows of which group (the kernel's row partition: wg_bound)
   const int st0 = (a.split + 31) >> 5, st1 = (a.M - a.split + 31) >> 5, ST = st0 + st1, Q = 8 * nsub;
   int lo0 = Q, hi0 = 0, lo1 = Q, hi1 = 0;
   for (int q = 0; q < Q; ++q) {
-    const int sb = (int)((long)q * ST / Q), se = (int)((long)(q + 1) * ST / Q);
+    const int sb = wg_bound(q, Q, ST, st0, a.fv), se = wg_bound(q + 1, Q, ST, st0, a.fv);
     if (sb < (se < st0 ? se : st0)) { lo0 = q < lo0 ? q : lo0; hi0 = q + 1; }
     if ((sb > st0 ? sb : st0) < se) { lo1 = q < lo1 ? q : lo1; hi1 = q + 1; }
   }
@@ -715,7 +732,7 @@ bool simvg_wgrad_x(const void* dY, int lddy, const void* X, int ldx, float* dW, 
   if (M < 4096 || (lddy & 7) || (ldx & 7)) return false;
   if (const char* e = getenv("SIMVG_WG_SLABS")) { if (atoi(e) == 0) slabs = nullptr; }      // A/B switch (tools/dev/wgrad_ab.py)
   static unsigned long long* prof = getenv("SIMVG_WG_PROF_PTR") ? (unsigned long long*)strtoull(getenv("SIMVG_WG_PROF_PTR"), nullptr, 0) : nullptr;
-  WgradXArgs a{(const lp_t*)dY, lddy, (const lp_t*)X, ldx, dW, dw_gstride, lddw, db, db_gstride, M, N, K, split, out_scale, slabs, defer, prof};
+  WgradXArgs a{(const lp_t*)dY, lddy, (const lp_t*)X, ldx, dW, dw_gstride, lddw, db, db_gstride, M, N, K, split, out_scale, slabs, defer, prof, wg_fv(14)};
   const WgradPlan pl = wgrad_plan(M, N, K);
   if (pl.kind == 16) return launch_sq(a, pl, stream);
   if (pl.kind != 12) return false;

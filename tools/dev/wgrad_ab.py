@@ -18,7 +18,7 @@ for name, N, K, per_layer in [("qkv", 3 * D, D, 1), ("fc1", 4 * D, D, 1), ("fc2"
     res, ref = {}, None
     for rnd in range(3):
         for v in VARIANTS:
-            for kk in ("SIMVG_WGRAD", "SIMVG_WG_PRIO", "SIMVG_WG_SLABS", "SIMVG_WGRAD_SQ", "SIMVG_WG_DBG"):
+            for kk in ("SIMVG_WGRAD", "SIMVG_WG_PRIO", "SIMVG_WG_SLABS", "SIMVG_WGRAD_SQ", "SIMVG_WG_DBG", "SIMVG_WG_FV"):
                 os.environ.pop(kk, None)
             for kv in ([] if v == "base" else v.split("+")):       # (the one-barrier "x1" and s_setprio "p*" variants of
                 if kv == "s0":                                     #  r04_sweeps.md section 3: tools/dev/wgrad_variants_r04.hip.txt, not built)                                   # fp32 atomics instead of slabs + reduction launch
@@ -28,6 +28,8 @@ for name, N, K, per_layer in [("qkv", 3 * D, D, 1), ("fc1", 4 * D, D, 1), ("fc2"
                 if kv.startswith("dbg"):                           # ablations of the 256 x 256 kernel: a build with -DSIMVG_WG_ABLATE
                                                                    # (SIMVG_EXTRA_FLAGS, SIMVG_HIP_LIB); wrong results: WG_NOCHECK=1
                     os.environ["SIMVG_WG_DBG"] = kv[3:]
+                if kv.startswith("fv"):                            # virtual stages of the straddling partition's second flush
+                    os.environ["SIMVG_WG_FV"] = kv[2:]
                 if kv == "sq0":                                    # never (ViT-L shapes: the generic kernel of gemm.hip)
                     os.environ["SIMVG_WGRAD_SQ"] = "0"
             dw = torch.zeros(2, N, K, device=dev)
