@@ -12,7 +12,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE"; do
 done
 python - <<'PY'
 import csv, glob, json, collections, hashlib, os, subprocess, time
-FAMILIES = [("gemm_nt", "gemm_nt_kernel", "gemm.hip"), ("wgrad_x", "wgrad_x_kernel", "wgrad.hip"), ("wgrad_reduce", "wgrad_slab_reduce", "wgrad.hip"), ("gemm_tn", "gemm_tn_kernel", "gemm.hip"),
+FAMILIES = [("gemm_nt", "gemm_nt_kernel", "gemm.hip"), ("wgrad_x", "wgrad_x_kernel", "wgrad.hip"), ("wgrad_x", "wgrad_sq_kernel", "wgrad.hip"), ("wgrad_reduce", "wgrad_slab_reduce", "wgrad.hip"), ("gemm_tn", "gemm_tn_kernel", "gemm.hip"),
             ("attn_fwd", "attn_fwd", "attention.hip"), ("attn_bwd", "attn_bwd", "attention_bwd1.hip"),
             ("ln_fwd", "ln_fwd", "layernorm.hip"), ("ln_bwd", "ln_bwd", "layernorm.hip"), ("ln_bwd", "ln_param_reduce", "layernorm.hip"),
             ("adam", "adam_kernel", "optim.hip"), ("adam", "sumsq_kernel", "optim.hip")]
