@@ -23,7 +23,7 @@ class LnReduceDesc(C.Structure):        # simvg_ln_reduce_desc
 
 class WgradReduceDesc(C.Structure):     # simvg_wgrad_reduce_desc
     _fields_ = [("slabs", c_void_p), ("dW", c_void_p), ("dw_group_stride", c_long), ("lddw", c_int), ("N", c_int), ("K", c_int),
-                ("Q", c_int), ("lo0", c_int), ("hi0", c_int), ("lo1", c_int), ("hi1", c_int)]
+                ("Q", c_int), ("lo0", c_int), ("hi0", c_int), ("lo1", c_int), ("hi1", c_int), ("assign", c_int)]
 
 
 class GemmF32Problem(C.Structure):      # simvg_gemm_f32_problem

@@ -82,9 +82,25 @@ class ParamArena:
         hi = max(self.offsets[n] + self.params[n].numel() for n in names)
         return lo, hi
 
-    def begin_backward(self):
+    def complement_views(self, key, ranges):
+        """views of the gradient arena OUTSIDE the given (offset, numel) ranges, cached under `key`"""
+        cache = self.__dict__.setdefault("_complement", {})
+        if key not in cache:
+            views, pos = [], 0
+            for off, n in sorted(ranges):
+                if off > pos:
+                    views.append(self.flat_grad[pos:off])
+                pos = max(pos, off + n)
+            if pos < self.total:
+                views.append(self.flat_grad[pos:self.total])
+            cache[key] = views
+        return cache[key]
+
+    def begin_backward(self, assigned=None):
         """Attach .grad views.  If any grad was dropped (zero_grad(set_to_none=True)) the arena is
-        zeroed first; otherwise kernels keep accumulating (PyTorch's += semantics)."""
+        zeroed first; otherwise kernels keep accumulating (PyTorch's += semantics).
+        assigned = (key, [(offset, numel), ...]): ranges this backward WRITES (first accumulation: `gemm_tn(assign=True)`) -- a fresh
+        arena then zeroes only the rest, in one multi-tensor launch.  -> fresh"""
         fresh = False
         for n, p in self.params.items():
             if not p.requires_grad or n in self.no_grad:
@@ -94,7 +110,10 @@ class ParamArena:
                 fresh = True
                 break
         if fresh:
-            self.flat_grad.zero_()
+            if assigned is None:
+                self.flat_grad.zero_()
+            else:
+                torch._foreach_zero_(self.complement_views(*assigned))
             for n, p in self.params.items():
                 if p.requires_grad and n not in self.no_grad:
                     p.grad = self._grad_of[n]

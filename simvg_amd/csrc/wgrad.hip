@@ -327,10 +327,10 @@ __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(WgradReduceTable
   if (e >= (long)d.N * d.K) return;
   const int g = blockIdx.y;
   const int lo = g ? d.lo1 : d.lo0, hi = g ? d.hi1 : d.hi0;
-  if (lo >= hi) return;
+  if (lo >= hi && !d.assign) return;                        // (assign: a row group without rows leaves zeros)
   const int n = (int)(e / d.K), k = (int)(e - (long)n * d.K);
   float* dst = d.dW + (long)g * d.dw_group_stride + (long)n * d.lddw + k;
-  f32x4_t s = *(const f32x4_t*)dst;
+  f32x4_t s = d.assign ? (f32x4_t){0.f, 0.f, 0.f, 0.f} : *(const f32x4_t*)dst;
   for (int x = lo; x < hi; ++x) s += *(const f32x4_t*)(d.slabs + ((long)g * d.Q + x) * d.N * d.K + e);
   *(f32x4_t*)dst = s;
 }
@@ -653,7 +653,7 @@ static bool launch_sq(const WgradXArgs& x, const WgradPlan& pl, hipStream_t stre
       if (sb < (se < st0 ? se : st0)) { lo0 = q < lo0 ? q : lo0; hi0 = q + 1; }
       if ((sb > st0 ? sb : st0) < se) { lo1 = q < lo1 ? q : lo1; hi1 = q + 1; }
     }
-    const simvg_wgrad_reduce_desc d{slabs, x.dW, x.dw_gstride, x.lddw, x.N, x.K, Q, lo0, hi0, lo1, hi1};
+    const simvg_wgrad_reduce_desc d{slabs, x.dW, x.dw_gstride, x.lddw, x.N, x.K, Q, lo0, hi0, lo1, hi1, 0};
     if (x.defer) {
       *x.defer = d;
     } else {
@@ -687,7 +687,7 @@ bool launch(const WgradXArgs& a0, hipStream_t stream, int nsub = 1) {
   const int ntile = (a.N / TN) * (a.K / TK);
   if (a.slabs) {
     hipLaunchKernelGGL((wgrad_x_kernel<A, B, WI, WJ, true>), dim3(8 * ntile * nsub), dim3(A * B * 64), LDS, stream, a);
-    const simvg_wgrad_reduce_desc d{a.slabs, a.dW, a.dw_gstride, a.lddw, a.N, a.K, Q, lo0, hi0, lo1, hi1};
+    const simvg_wgrad_reduce_desc d{a.slabs, a.dW, a.dw_gstride, a.lddw, a.N, a.K, Q, lo0, hi0, lo1, hi1, 0};
     if (a.defer) {
       *a.defer = d;                   // the caller batches the second stage (simvg_wgrad_reduce_batched), possibly on another stream
     } else {
@@ -707,6 +707,7 @@ bool launch(const WgradXArgs& a0, hipStream_t stream, int nsub = 1) {
 // generic kernels of gemm.hip
 // floats of slab workspace the XCD-partitioned kernel wants for this problem (0: the problem is not its)
 long simvg_wgrad_x_slab_floats(int M, int N, int K) {
+  if (const char* e = getenv("SIMVG_WG_SLABS")) { if (atoi(e) == 0) return 0; }     // the A/B switch: no slabs, no second stage
   const WgradPlan p = wgrad_plan(M, N, K);
   return p.kind ? 2L * p.Q * N * K : 0;
 }

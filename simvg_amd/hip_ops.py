@@ -283,7 +283,7 @@ class WgradReduceBatch:
             t0 = _timer.start("wgrad_reduce") if _timer is not None else None
             rc = _lib.load().simvg_wgrad_reduce_batched(self._C.byref(self.descs), self.n, _stream())
             if t0 is not None:      # reads every partition's slab and dW, writes dW
-                nb = sum(4.0 * d.N * d.K * ((d.hi0 - d.lo0) + (d.hi1 - d.lo1) + 2 * ((d.hi0 > d.lo0) + (d.hi1 > d.lo1)))
+                nb = sum(4.0 * d.N * d.K * ((d.hi0 - d.lo0) + (d.hi1 - d.lo1) + (1 if d.assign else 2) * ((d.hi0 > d.lo0) + (d.hi1 > d.lo1)))
                          for d in self.descs[:self.n])
                 _timer.stop("wgrad_reduce", t0, 0.0, nb)
             _lib.check(rc, "simvg_wgrad_reduce_batched")
@@ -291,9 +291,17 @@ class WgradReduceBatch:
         self._used = {}
 
 
-def gemm_tn(dy, x, dw, split=0, dw_group_stride=None, db=None, out_scale=1.0, defer=None):
+def gemm_tn_can_assign(M, N, K):
+    """True if `gemm_tn(..., defer=batch, assign=True)` is available for this problem: it runs on a kernel that leaves its partial
+    sums in slabs (csrc/wgrad.hip), so the batched second stage can WRITE dw instead of adding to it."""
+    return int(_lib.load().simvg_gemm_tn_ws_floats(M, N, K)) > 0
+
+
+def gemm_tn(dy, x, dw, split=0, dw_group_stride=None, db=None, out_scale=1.0, defer=None, assign=False):
     """dw[g][N,K] += dy[M,N]^T @ x[M,K]   (fp32 accumulate into dw); db[g][N] += column sums of dy (optional).
-    defer: a `WgradReduceBatch` -- dw is complete only after the batch's `flush()`."""
+    defer: a `WgradReduceBatch` -- dw is complete only after the batch's `flush()`.
+    assign (with defer, where `gemm_tn_can_assign`): dw = ... instead of dw += ...: dw need not be zeroed and is not read (db still
+    accumulates)."""
     lib = _lib.load()
     _chk(dy, LP(), "dy"); _chk(x, LP(), "x"); _chk(dw, torch.float32, "dw")
     M, N = dy.shape
@@ -317,8 +325,16 @@ def gemm_tn(dy, x, dw, split=0, dw_group_stride=None, db=None, out_scale=1.0, de
                                   _p(db), (db.stride(0) if db.dim() == 2 else 0) if db is not None else 0,
                                   M, N, K, split, out_scale, _p(ws), dptr, _stream())
         if defer is not None:
+            if assign:
+                if not defer.descs[defer.n].slabs:
+                    raise RuntimeError("gemm_tn(assign=True): this problem has no second stage (check gemm_tn_can_assign)")
+                defer.descs[defer.n].assign = 1
             defer.commit()
+        elif assign:
+            raise ValueError("gemm_tn(assign=True) needs defer=")
     else:
+        if assign:
+            raise RuntimeError("gemm_tn(assign=True): this problem has no second stage (check gemm_tn_can_assign)")
         rc = lib.simvg_gemm_tn(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), dw_group_stride, dw.stride(-2),
                                _p(db), (db.stride(0) if db.dim() == 2 else 0) if db is not None else 0,
                                M, N, K, split, out_scale, _stream())

@@ -462,7 +462,30 @@ class BEIT3(nn.Module):
                      1, D, dpatch.shape[0], accumulate=True)
 
     # ------------------------------------------------------------------ engine: backward
-    def _engine_backward(self, ws, dout, layer_done_cb=None):
+    def _assigned_ranges(self, ws):
+        """(key, ranges) of the gradient arena that this backward WRITES instead of accumulating into -- the four Linear weights of
+        every layer, when their weight-gradient kernels leave slabs for a second stage at this row count (`ops.gemm_tn_can_assign`):
+        a fresh arena then skips their zero fill (76 % of its bytes) and the second stage skips reading them.  None: accumulate as
+        before (SIMVG_WGRAD_ASSIGN=0, small batches, shapes without a slab kernel)."""
+        import os
+        if os.environ.get("SIMVG_WGRAD_ASSIGN", "1") == "0":
+            return None
+        B, T = ws["ctx"][0], ws["ctx"][1]
+        M = B * (self.np + 1 + T)
+        cache = self.__dict__.setdefault("_assign_cache", {})
+        if M not in cache:
+            D, F_, A = self.D, self.F, self._arena
+            ok = all(ops.gemm_tn_can_assign(M, n, k) for n, k in ((3 * D, D), (D, D), (F_, D), (D, F_)))
+            rng = None
+            if ok:
+                rng = []
+                for vname, names, shape in A._group_spec:
+                    if vname.startswith(("wqkv", "wout", "w1", "w2")) and vname[-1].isdigit():
+                        rng.append((A.offsets[names[0]], sum(A.params[k].numel() for k in names)))
+            cache[M] = None if rng is None else (("enc_linear", M), rng)
+        return cache[M]
+
+    def _engine_backward(self, ws, dout, layer_done_cb=None, assign=False):
         A = self._arena
         V, G = A.views, A.grad_views
         B, T, ids, pad_u8, dp = ws["ctx"]
@@ -495,22 +518,22 @@ class BEIT3(nn.Module):
             s = st["stats"]
             # ---- FFN branch: x_out = x_mid + dp1 * fc2(LN(gelu(fc1(LN(x_mid)))))
             ops.gemm_nt(dyb, self.wb[f"w2T{i}"], out=dF, split=Mv)
-            ops.gemm_tn(dyb, st["g2"], G[f"w2{i}"], split=Mv, db=G[f"b2{i}"], out_scale=inv, defer=wred)
+            ops.gemm_tn(dyb, st["g2"], G[f"w2{i}"], split=Mv, db=G[f"b2{i}"], out_scale=inv, defer=wred, assign=assign)
             ops.ln_bwd(dF, st["u"], s["m4"], s["r4"], V[f"lnfg{i}"], G[f"lnfg{i}"], G[f"lnfb{i}"], split=Mv,
                        dx_lp=dF2, gelu_u=st["u"], param_scale=inv, defer=red)      # x == gelu_u: LN input gelu(u) and GELU'(u) recomputed from u
             ops.gemm_nt(dF2, self.wb[f"w1T{i}"], out=dD, split=Mv)
-            ops.gemm_tn(dF2, st["h2"], G[f"w1{i}"], split=Mv, db=G[f"b1{i}"], out_scale=inv, defer=wred)
+            ops.gemm_tn(dF2, st["h2"], G[f"w1{i}"], split=Mv, db=G[f"b1{i}"], out_scale=inv, defer=wred, assign=assign)
             ops.ln_bwd(dD, xs[2 * i + 1], s["m3"], s["r3"], V[f"ln2g{i}"], G[f"ln2g{i}"], G[f"ln2b{i}"], split=Mv,
                        dres=dx, dx_f32=dx, dx_scaled=dyb, row_scale=None if dp is None else dp[i][0], rows_per_sample=rps,
                        param_scale=inv, defer=red)
             # ---- attention branch: x_mid = x_in + dp0 * out_proj(LN(attn(qkv(LN(x_in)))))
             ops.gemm_nt(dyb, self.wb[f"woutT{i}"], out=dD, split=Mv)
-            ops.gemm_tn(dyb, st["o2"], G[f"wout{i}"], split=Mv, db=G[f"bout{i}"], out_scale=inv, defer=wred)
+            ops.gemm_tn(dyb, st["o2"], G[f"wout{i}"], split=Mv, db=G[f"bout{i}"], out_scale=inv, defer=wred, assign=assign)
             ops.ln_bwd(dD, st["o"], s["m2"], s["r2"], V[f"lnig{i}"], G[f"lnig{i}"], G[f"lnib{i}"], split=Mv, dx_lp=dO,
                        param_scale=inv, defer=red)
             ops.attn_bwd(st["qkv"], st["o"], dO, st["lse"], B, H, Nv, T, pad=pad_u8, dqkv=dQKV)
             ops.gemm_nt(dQKV, self.wb[f"wqkvT{i}"], out=dD, split=Mv)
-            ops.gemm_tn(dQKV, st["h"], G[f"wqkv{i}"], split=Mv, db=G[f"bqkv{i}"], out_scale=inv, defer=wred)
+            ops.gemm_tn(dQKV, st["h"], G[f"wqkv{i}"], split=Mv, db=G[f"bqkv{i}"], out_scale=inv, defer=wred, assign=assign)
             ops.ln_bwd(dD, xs[2 * i], s["m1"], s["r1"], V[f"ln1g{i}"], G[f"ln1g{i}"], G[f"ln1b{i}"], split=Mv,
                        dres=dx, dx_f32=dx, dx_scaled=dyb,
                        row_scale=None if (dp is None or i == 0) else dp[i - 1][1], rows_per_sample=rps, param_scale=inv,
@@ -613,7 +636,8 @@ class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         enc = ctx.enc
-        enc._arena.begin_backward()
+        assigned = enc._assigned_ranges(ctx.ws)
+        fresh = enc._arena.begin_backward(assigned)
         hook = getattr(enc, "_grad_ready_hook", None)
-        enc._engine_backward(ctx.ws, dout.contiguous(), hook)
+        enc._engine_backward(ctx.ws, dout.contiguous(), hook, assign=bool(fresh and assigned is not None))
         return (None,) * 7

@@ -304,6 +304,30 @@ def test_wgrad_slabs_deferred_reduction_and_atomics_agree(M, N, K, split, monkey
     assert_close(dba, db0, 2e-5, "bias gradient, atomic flush vs slabs")
 
 
+@pytest.mark.parametrize("M,N,K,split", [(6011, 3072, 768, 5614), (6011, 768, 768, 5614), (4500, 2304, 768, 0), (4700, 1024, 4096, 4700)])
+def test_wgrad_second_stage_assign_mode(M, N, K, split):
+    """`gemm_tn(defer=batch, assign=True)`: the second stage WRITES dW (the arena skips its zero fill, simvg_amd/arena.py): on a
+    buffer full of garbage it gives, bit for bit, what the accumulating form gives on zeros; a row group without rows gets zeros."""
+    ops = _ops()
+    assert ops.gemm_tn_can_assign(M, N, K)
+    g = torch.Generator().manual_seed(3 * M + N + K)
+    dy, x = bf(rnd_bf16(M, N, gen=g)).to(DEV), bf(rnd_bf16(M, K, gen=g)).to(DEV)
+    ng = 2 if split else 1
+    batch = ops.WgradReduceBatch()
+    dw0, db0 = torch.zeros(ng, N, K, device=DEV), torch.zeros(ng, N, device=DEV)
+    ops.gemm_tn(dy, x, dw0, split=split, db=db0, defer=batch)
+    batch.flush()
+    dw1, db1 = torch.full((ng, N, K), float("nan"), device=DEV), torch.zeros(ng, N, device=DEV)
+    ops.gemm_tn(dy, x, dw1, split=split, db=db1, defer=batch, assign=True)
+    batch.flush()
+    torch.cuda.synchronize()
+    assert torch.equal(dw0, dw1)
+    if split == M:                       # every row in group 0: group 1's gradient is exactly zero
+        assert float(dw1[1].abs().max()) == 0.0
+    with pytest.raises((RuntimeError, ValueError)):
+        ops.gemm_tn(dy, x, dw1, split=split, db=db1, assign=True)          # no defer
+
+
 # ------------------------------------------------------------------------------------------
 # LayerNorm
 # ------------------------------------------------------------------------------------------
