@@ -76,9 +76,10 @@ int simvg_gemm_tn(const void* dY_lp, int lddy, const void* X_lp, int ldx, float*
 typedef struct simvg_wgrad_reduce_desc {
   const float* slabs; float* dW; long dw_group_stride;
   int lddw, N, K, Q, lo0, hi0, lo1, hi1;
-  int assign;   /* written 0 by simvg_gemm_tn_ws; a caller that has NOT zeroed dW sets it to 1 before simvg_wgrad_reduce_batched:
-                 * dW = sum of the slabs (a row group without rows: zeros) instead of dW += sum -- the first accumulation of a
-                 * step then needs neither the zero fill of dW nor its read */
+  int assign;   /* written 0 by simvg_gemm_tn_ws; a caller that has NOT zeroed dW sets it to 1 or 2 before simvg_wgrad_reduce_batched:
+                 * dW = sum of the slabs instead of dW += sum -- the first accumulation of a step then needs neither the zero
+                 * fill of dW nor its read.  1: only row groups that have rows are written (dW may hold one group only); 2: dW
+                 * holds both groups, and one without rows (split == M) is zeroed */
 } simvg_wgrad_reduce_desc;
 #define SIMVG_WGRAD_REDUCE_MAX 16
 long simvg_gemm_tn_ws_floats(int M, int N, int K);

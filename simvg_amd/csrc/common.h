@@ -184,7 +184,8 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 struct simvg_wgrad_reduce_desc {
   const float* slabs; float* dW; long dw_group_stride;
   int lddw, N, K, Q, lo0, hi0, lo1, hi1;
-  int assign;     // 1: dW = sum of the slabs (dW need not be zeroed, is not read); 0: dW += sum.  Set by the caller on a deferred description
+  int assign;     // 0: dW += sum of the slabs; 1: dW = sum (dW need not be zeroed, is not read); 2: the same, and dW holds BOTH row
+                  // groups: a group without rows is zeroed.  Set by the caller on a deferred description
 };
 #define SIMVG_WGRAD_REDUCE_MAX 16
 bool simvg_wgrad_x(const void* dY, int lddy, const void* X, int ldx, float* dW, long dw_gstride, int lddw, float* db,

@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(WgradReduceTable
   if (e >= (long)d.N * d.K) return;
   const int g = blockIdx.y;
   const int lo = g ? d.lo1 : d.lo0, hi = g ? d.hi1 : d.hi0;
-  if (lo >= hi && !d.assign) return;                        // (assign: a row group without rows leaves zeros)
+  if (lo >= hi && d.assign < 2) return;                     // (assign == 2: dW holds both groups, one without rows gets zeros)
   const int n = (int)(e / d.K), k = (int)(e - (long)n * d.K);
   float* dst = d.dW + (long)g * d.dw_group_stride + (long)n * d.lddw + k;
   f32x4_t s = d.assign ? (f32x4_t){0.f, 0.f, 0.f, 0.f} : *(const f32x4_t*)dst;

@@ -328,7 +328,7 @@ def gemm_tn(dy, x, dw, split=0, dw_group_stride=None, db=None, out_scale=1.0, de
             if assign:
                 if not defer.descs[defer.n].slabs:
                     raise RuntimeError("gemm_tn(assign=True): this problem has no second stage (check gemm_tn_can_assign)")
-                defer.descs[defer.n].assign = 1
+                defer.descs[defer.n].assign = 2 if (dw.dim() == 3 and dw.shape[0] == 2) else 1     # 2: a group without rows is zeroed
             defer.commit()
         elif assign:
             raise ValueError("gemm_tn(assign=True) needs defer=")
