@@ -88,6 +88,43 @@ def test_full_size_backward_is_linear_in_the_loss_scale(full):
     assert worst <= 2e-3, worst
 
 
+def test_full_size_gradients_assign_mode_equals_accumulate_mode_and_accumulates(full, monkeypatch):
+    """the first backward after zero_grad() WRITES the encoder Linears' weight gradients (second stage in assign mode, the arena
+    skips their zero fill: simvg_amd/arena.py); (a) the same bits as with SIMVG_WGRAD_ASSIGN=0 (zero fill + accumulate) for the
+    weights, the rest to the order of its atomics; (b) a second backward WITHOUT zero_grad() accumulates: gradients double."""
+    model, batch = full
+    model.eval()                     # no dropout / DropPath: every pass sees the same function
+
+    def backward(zero=True):
+        if zero:
+            model.zero_grad(set_to_none=True)
+        losses, _ = model(img=batch["img"], ref_expr_inds=batch["ref_expr_inds"], img_metas=batch["img_metas"],
+                          text_attention_mask=batch["text_attention_mask"], gt_bbox=batch["gt_bbox"], rescale=False)
+        losses["loss_total"].backward()
+        return {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    g_assign = backward()
+    g_twice = backward(zero=False)
+    monkeypatch.setenv("SIMVG_WGRAD_ASSIGN", "0")
+    g_acc = backward()
+    assert g_assign.keys() == g_acc.keys() == g_twice.keys() and len(g_assign) > 300
+    lin = ("q_proj", "k_proj", "v_proj", "out_proj", "fc1", "fc2")
+    n_lin = 0
+    for n in g_assign:
+        a, b, c = g_assign[n].float(), g_acc[n].float(), g_twice[n].float()
+        den = float(b.abs().max())
+        if den == 0.0:
+            assert float(a.abs().max()) == 0.0 and float(c.abs().max()) == 0.0, n
+            continue
+        if "vis_enc" in n and n.endswith(".weight") and any(k in n for k in lin) and "encoder.layers" in n:
+            assert torch.equal(a, b), n                  # slabs summed in a fixed order: bit-identical
+            n_lin += 1
+        else:
+            assert float((a - b).abs().max()) / den <= 2e-3, n
+        assert float((c - 2.0 * a).abs().max()) / den <= 4e-3, n
+    assert n_lin >= 12 * 12
+
+
 def test_other_geometry_512px_15_tokens_batch_independence_and_training_step():
     """the reference's 512x512 / max_token 15 dataset bases (configs/_base_/datasets/detection/*.py): 257 + 15 tokens"""
     import bench
