@@ -364,9 +364,6 @@ constexpr int SQ_ROWS = 32, SQ_S = 256 * 2 + 32;            // stage rows; padde
 constexpr int SQ_PART = SQ_ROWS * SQ_S;                     // one operand's part of a stage: 17 KiB = 17 pieces
 constexpr int SQ_STAGE = 2 * SQ_PART, SQ_NST = 4, SQ_LDS = SQ_NST * SQ_STAGE;  // 136 KiB (+ 8 KiB dump area of the out-of-range slots)
 constexpr int SQ_NPY = SQ_PART / 1024;
-#ifndef SQ_NYM
-#define SQ_NYM 0                 // dY fragments of the next stage requested behind their MFMA groups instead of in LOAD (sweep: profiles/r04_sweeps.md)
-#endif
 static_assert((SQ_S / 32) % 2 == 1 && SQ_PART % 1024 == 0 && SQ_NPY == 17, "sq stage geometry");
 
 struct WgradSqArgs {
@@ -515,11 +512,8 @@ __global__ __launch_bounds__(512) void wgrad_sq_kernel(WgradSqArgs a) {
         const unsigned so = (unsigned)(t & (SQ_NST - 1)) * SQ_STAGE;
         const unsigned an = fb_n + so;
         csv = lds_b128_asm<0>(cs_addr + so);
-        if (t > 0) {                                      // (the first SQ_NYM dY fragments were requested behind their MFMA groups)
-#define SQ_RYL(i_) if constexpr ((i_) >= SQ_NYM) { SQ_RYA(i_) SQ_RYB(i_) }
-          SQ_RD(SQ_RYL(0) SQ_RYL(1) SQ_RYL(2) SQ_RYL(3) SQ_RYL(4) SQ_RYL(5) SQ_RYL(6) SQ_RYL(7))
-#undef SQ_RYL
-        }
+        if (t > 0) { SQ_RD(SQ_RYA(0) SQ_RYB(0) SQ_RYA(1) SQ_RYB(1) SQ_RYA(2) SQ_RYB(2) SQ_RYA(3) SQ_RYB(3)
+                           SQ_RYA(4) SQ_RYB(4) SQ_RYA(5) SQ_RYB(5) SQ_RYA(6) SQ_RYB(6) SQ_RYA(7) SQ_RYB(7)) }
       }
       sq_lgkm<0>();
 #pragma unroll
@@ -532,9 +526,7 @@ __global__ __launch_bounds__(512) void wgrad_sq_kernel(WgradSqArgs a) {
       // ---------------- MFMA(t)
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
-#define SQ_RYM(i_) if constexpr ((i_) < SQ_NYM) { SQ_RD(SQ_RYA(i_) SQ_RYB(i_)) }
-      const unsigned an = fb_n + (unsigned)((t + 1) & (SQ_NST - 1)) * SQ_STAGE;
-      SQ_MMA(0) SQ_RYM(0) SQ_MMA(1) SQ_RYM(1) SQ_MMA(2) SQ_RYM(2) SQ_MMA(3) SQ_RYM(3)
+      SQ_MMA(0) SQ_MMA(1) SQ_MMA(2) SQ_MMA(3)
       if (cs_on && !(DBG & 16)) {                         // bias sums of stage t, in the matrix pipe's shadow
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -545,8 +537,7 @@ __global__ __launch_bounds__(512) void wgrad_sq_kernel(WgradSqArgs a) {
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      SQ_MMA(4) SQ_RYM(4) SQ_MMA(5) SQ_RYM(5) SQ_MMA(6) SQ_RYM(6) SQ_MMA(7) SQ_RYM(7)
-#undef SQ_RYM
+      SQ_MMA(4) SQ_MMA(5) SQ_MMA(6) SQ_MMA(7)
       __builtin_amdgcn_s_setprio(0);
       {                                                   // the X fragments of stage t + 1, under the last MFMAs' execution
         const unsigned ak = fb_k + (unsigned)((t + 1) & (SQ_NST - 1)) * SQ_STAGE;   // (past the last stage: zero fill or stale, unused)
