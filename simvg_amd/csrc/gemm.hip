@@ -834,6 +834,70 @@ __global__ __launch_bounds__(1024) void gemm_nt_kernel_160x256_r3(GemmNTArgs a) 
   gemm_nt_epilogue_lds<5, 2>(a, acc, group, row0, row_end, n0, wm, wn, wave, lane, smem);
 }
 
+// 224x256x64 tile with sixteen waves: 2 (M) x 8 (N), each 112x32 = acc[7][2] (round 4).  For row counts where 256-row tiles
+// leave CUs idle: ViT-L at 32 pairs per step has M = 13 472 = 52.6 x 256 -- 53 x 4 = 212 tiles of 256 x 256 for the N = 1024
+// launches (out-proj, fc2, three dgrads per layer) on 256 CUs, 61 x 4 = 244 tiles of 224 rows fill 95 % of them in one round of
+// 7/8 the length.  Two 60 KiB LDS buffers (three do not fit), one rendezvous per k-tile like the 256x256 kernel; 9 fragment
+// reads per 14 MFMAs.
+__global__ __launch_bounds__(1024) void gemm_nt_kernel_224x256_w16(GemmNTArgs a) {
+  constexpr int BMQ = 224;
+  constexpr int STAGEQ = (BMQ + BNQ) * BK * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 3, wn = wave & 7;
+  const int tiles_n = (a.N + BNQ - 1) / BNQ;
+  const int tm0 = (a.split + BMQ - 1) / BMQ;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  int tile_m, tile_n;
+  tile_order(bid, (int)gridDim.x / tiles_n, tiles_n, a.gn, tile_m, tile_n);
+  const int group = tile_m >= tm0;
+  const int row0 = group ? a.split + (tile_m - tm0) * BMQ : tile_m * BMQ;
+  const int row_end = group ? a.M : a.split;
+  const int n0 = tile_n * BNQ;
+  const lp_t* W = a.W + (long)group * a.w_gstride;
+  f32x4_t acc[7][2];
+#pragma unroll
+  for (int i = 0; i < 7; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int nk = a.K / BK;
+#define STA(s_) (smem + (s_) * STAGEQ)
+#define STB(s_) (smem + (s_) * STAGEQ + BMQ * BK * 2)
+#define ISSUE(t_)                                                                                      \
+  do {                                                                                                 \
+    const int st__ = (t_) & 1;                                                                         \
+    stage_rows_k64(a.A, a.lda, row0, row_end - 1, a_koff(a, (t_) * BK), STA(st__), wave, lane, BMQ / 8, 16); \
+    stage_rows_k64(W, a.ldw, n0, a.N - 1, (t_) * BK, STB(st__), wave, lane, BNQ / 8, 16);              \
+  } while (0)
+  ISSUE(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's share of tile kt has landed
+    __builtin_amdgcn_s_barrier();                        // everyone's has, and everyone is past compute(kt-1)
+    if (kt + 1 < nk) ISSUE(kt + 1);
+    const char* sA = STA(kt & 1);
+    const char* sB = STB(kt & 1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      lpx8_t fa[7], fb[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = read_frag_k64(sB, wn * 32 + j * 16 + (lane & 15), s * 4 + (lane >> 4));
+#pragma unroll
+      for (int i = 0; i < 7; ++i) fa[i] = read_frag_k64(sA, wm * 112 + i * 16 + (lane & 15), s * 4 + (lane >> 4));
+#pragma unroll
+      for (int i = 0; i < 7; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = mfma_lp(fb[j], fa[i], acc[i][j]);
+    }
+    split_rescale(a, acc, (kt + 1) * BK);
+  }
+#undef STA
+#undef STB
+#undef ISSUE
+  gemm_nt_epilogue_lds<7, 2>(a, acc, group, row0, row_end, n0, wm, wn, wave, lane, smem);
+}
+
 // ------------------------------------------------------------------------------------------
 // Variant: same 256x128 tile / 8 waves / 3-stage ring, but K-tiles of 32 (24 KiB stages, 72 KiB LDS) so that TWO
 // workgroups are resident per CU (16 waves, 4 per SIMD): while one workgroup sits in its wait/barrier the other
@@ -1324,6 +1388,20 @@ static int gemm_nt_launch(const void* A, int lda, const void* W, long w_gstride,
     // 160-row tiles stage 23 % more bytes per FLOP: they have to win the quantisation estimate by 20 % to be chosen
     return (double)cdiv((int)tiles, 256) * bm * (bm == 160 ? 1.20 : 1.0);
   };
+  // 224-row tiles: where they need fewer rows x rounds than both other extents by 10 % (ViT-L's N = 1024 launches at 32 pairs per
+  // step: one round of 244 tiles instead of one of 212 longer ones); SIMVG_GEMM_224 = 0 / 1: never / wherever they divide (A/B)
+  auto use224 = [&]() {
+    const char* e = getenv("SIMVG_GEMM_224");
+    if (e && atoi(e) == 0) return false;
+    const long t224 = (long)(cdiv(split, 224) + cdiv(M - split, 224)) * cdiv(N, BNQ);
+    if (e && atoi(e) == 1) return true;
+    const double c224 = (double)cdiv((int)t224, 256) * 224;
+    const double best = tile_cost(256) < tile_cost(160) ? tile_cost(256) : tile_cost(160);
+    // one round only, and only epilogues the persistent 256-row kernel does not take (fp32 / residual / activation / copy: measured,
+    // tools/dev/gemm_vitl_ab.py, out-proj fwd 53.7 -> 41.9 us, fc2 fwd 127.9 -> 112.2; the 16-bit dgrads 29.5 / 74.3 / 98.0 us on the
+    // persistent kernel against 31.6 / 80.4 / 104.6 on this one)
+    return c224 * 1.10 <= best && t224 <= 256 && !(tile_cost(256) <= tile_cost(160) && persist_ok(a));
+  };
   // problems that cannot fill the chip with the big tiles (forward_test at B <= 8): the latency kernel while its 64x64 tiles
   // fit about one residency round of 3 workgroups per CU (tools/dev/gemm_small_bench.py, us for qkv / out / fc1 / fc2:
   // B = 1: 21.7 19.6 20.6 45.5 -> 10.1 8.6 10.5 19.4;  B = 2: 18.8 17.1 19.1 53.1 -> 11.1 9.6 13.2 20.2;
@@ -1333,6 +1411,12 @@ static int gemm_nt_launch(const void* A, int lda, const void* W, long w_gstride,
     static bool oncel = hipFuncSetAttribute((const void*)gemm_nt_kernel_lat<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * LAT_STAGE) == hipSuccess;
     (void)oncel;
     hipLaunchKernelGGL(gemm_nt_kernel_lat<3>, dim3((int)tiles64), dim3(256), 3 * LAT_STAGE, stream, a);
+  } else if (wide_ok && use224()) {
+    constexpr int SM224 = 2 * (224 + BNQ) * BK * 2;   // 120 KiB ring; the epilogue staging (16 waves x 32 x 36 x 4 B = 72 KiB) fits
+    static bool once224 = hipFuncSetAttribute((const void*)gemm_nt_kernel_224x256_w16, hipFuncAttributeMaxDynamicSharedMemorySize, SM224) == hipSuccess;
+    (void)once224;
+    const int tiles = (cdiv(split, 224) + cdiv(M - split, 224)) * cdiv(N, BNQ);
+    hipLaunchKernelGGL(gemm_nt_kernel_224x256_w16, dim3(tiles), dim3(1024), SM224, stream, a);
   } else if (wide_ok && tile_cost(256) <= tile_cost(160) && persist_ok(a)) {
     static bool oncep = hipFuncSetAttribute((const void*)gemm_nt_kernel_256sq_p, hipFuncAttributeMaxDynamicSharedMemorySize, PQ_SMEM) == hipSuccess;
     (void)oncep;

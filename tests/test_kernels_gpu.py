@@ -122,7 +122,8 @@ def test_probe_glds_lane_linear():
                                          (2306, 4096, 64, 2100),      # 16 column tiles walked in groups of 6 / 6 / 4
                                          (7000, 3072, 128, 6500),     # 336 tiles: persistent workgroups take two tiles, ragged row groups
                                          (300, 7040, 64, 200),        # few rows, many columns: the 128x128 kernel
-                                         (2230, 768, 256, 2000), (2048, 768, 3072, 0)])       # 160x256 tile path
+                                         (2230, 768, 256, 2000), (2048, 768, 3072, 0),        # 160x256 tile path
+                                         (10300, 1024, 256, 9800), (9900, 1024, 128, 0)])     # 224x256 tile path (one round of 224-row tiles)
 @pytest.mark.parametrize("mode", ["plain", "bias", "bias_gelu_aux", "residual_scale_f32", "relu_f32"])
 def test_gemm_nt(M, N, K, split, mode):
     ops = _ops()

@@ -23,11 +23,13 @@ for name, K, res in cases:
     t = {v: [] for v in VARIANTS}
     for rnd in range(ROUNDS):
         for v in VARIANTS:
-            for kk in ("SIMVG_GEMM_N768", "SIMVG_GEMM_RESPF", "SIMVG_GEMM_PP"):
+            for kk in ("SIMVG_GEMM_N768", "SIMVG_GEMM_RESPF", "SIMVG_GEMM_PP", "SIMVG_GEMM_320"):
                 os.environ.pop(kk, None)
             for kv in ([] if v == "base" else v.split("+")):      # "respf0"  (the 8-wave variant "w8" of r04_sweeps.md section 2 is
                 if kv == "respf0":                                # no longer built: tools/dev/gemm_variants_r04.hip.txt)
                     os.environ["SIMVG_GEMM_RESPF"] = "0"
+                if kv == "t320":                                  # one round of 320 x 256 tiles (round 4; not built: tools/dev/gemm_320x256_r04.hip.txt)
+                    os.environ["SIMVG_GEMM_320"] = "1"
                 if kv == "pp":                                    # the ping-pong form of the 160 x 256 kernel (round 4; not built any
                     os.environ["SIMVG_GEMM_PP"] = "1"             # more: tools/dev/gemm_pingpong_r04.hip.txt)
             for _ in range(10):
