@@ -1,5 +1,6 @@
 """Sustained training run on the bench configuration (ViT-B/32, B = 64, 8 rotating synthetic batches): loss trajectory, step
-time drift and the gradient scale -- `python tools/dev/soak.py [steps]`."""
+time drift and the gradient scale -- `python tools/dev/soak.py [steps]`; `SOAK_VIT=large SOAK_BATCH=32 SOAK_QUERIES=10` for the other
+BASELINE configurations."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -11,13 +12,14 @@ from simvg_amd.graphs import training_stream
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 dev = torch.device("cuda", 0)
 torch.manual_seed(1234)
-model = build_model(bench.model_cfg()).to(dev).train()
+VIT, BATCH, NQ = os.environ.get("SOAK_VIT", "base"), int(os.environ.get("SOAK_BATCH", 64)), int(os.environ.get("SOAK_QUERIES", 1))
+model = build_model(bench.model_cfg(NQ, VIT)).to(dev).train()
 model.vis_enc._ensure_engine(dev)
 named = list(model.named_parameters())
 groups = [{"params": [p for n, p in named if "vis_enc" in n], "lr": 5e-5}, {"params": [], "lr": 5e-4},
           {"params": [p for n, p in named if "vis_enc" not in n], "lr": 5e-4}]
 opt = build_optimizer(dict(type="Adam", lr=5e-4, betas=(0.9, 0.98), eps=1e-9, weight_decay=0, amsgrad=True), groups, model=model)
-batches = [bench.synthetic_batch(64, 1000 + i, dev) for i in range(8)]
+batches = [bench.synthetic_batch(BATCH, 1000 + i, dev) for i in range(8)]
 hist, t_hist = [], []
 with training_stream(dev):
     torch.cuda.synchronize()
