@@ -2,7 +2,10 @@
 """bench.py -- SimVG hot-path throughput on MI355X (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1: the script starts its N ranks itself (one process per GPU under torch.distributed.run on 127.0.0.1, as the
+    reference's tools/dist_train.sh <cfg> N does) and refuses -- exit code 2 -- on a node with fewer than N GPUs; launched
+    under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (the driver's form) it joins that job,
+    and refuses a WORLD_SIZE that is not N.
 
 One "step" = one full training step of MIXDETRMB (ViT-B/32 BEiT-3, 640x640 image + 20-token expression,
 num_queries=1, B = 64 per GPU, train mode: DropPath + decoder dropout) on synthetic RefCOCO-shape data already
@@ -217,6 +220,44 @@ def bf16_line(a):
         return {"error": repr(e)}
 
 
+def self_launch(n, share=False):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks here -- one process per GPU under
+    torch.distributed.run on 127.0.0.1 (the counterpart of the reference's launcher, tools/dist_train.sh:8-10, which takes the GPU
+    count as its argument) -- and hand rank 0's one JSON line through.  Fails before anything is started when the node has
+    fewer than N GPUs: a job that printed `n_gpus: 1` for `--gpus 8` would void the scaling record."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if not share and have < n:
+        print(f"bench.py: --gpus {n} but torch.cuda.device_count() = {have}: refusing to run a smaller job under that name",
+              file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n))))
+    for k in ("RANK", "LOCAL_RANK", "SIMVG_FORCE_REDUCE"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)      # stderr passes through
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    rest = [l for l in r.stdout.splitlines() if not l.startswith("{")]
+    if rest:                                                                  # keep stdout to the one line
+        print("\n".join(rest), file=sys.stderr)
+    if r.returncode != 0 or len(lines) != 1:
+        print(f"bench.py: the {n}-rank job failed (exit code {r.returncode}, {len(lines)} result lines)", file=sys.stderr)
+        return r.returncode or 1
+    j = json.loads(lines[0])
+    if j.get("n_gpus") != n or j.get("reducer", {}).get("world") != n:
+        print(f"bench.py: asked for {n} ranks, the job reports n_gpus={j.get('n_gpus')} / reducer.world={j.get('reducer', {}).get('world')}",
+              file=sys.stderr)
+        return 1
+    print(lines[0], flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -241,13 +282,23 @@ def main():
                          "(torch.save; tests compare a reduced run with an unreduced one)")
     a = ap.parse_args()
 
+    # SIMVG_BENCH_SHARE_DEVICE=1 (tests only): every rank on cuda:0 over gloo -- the control flow of a world > 1 run (barriers,
+    # who leaves when, which side measurements are skipped) on a one-GPU box; RCCL refuses two ranks per device
+    share = os.environ.get("SIMVG_BENCH_SHARE_DEVICE") == "1"
+    if a.gpus < 1:
+        sys.exit(f"bench.py: --gpus {a.gpus}: need at least one GPU")
+    if "WORLD_SIZE" not in os.environ:
+        if a.gpus > 1:
+            sys.exit(self_launch(a.gpus, share))       # `python bench.py --gpus N` = the reference's `dist_train.sh <cfg> N`
+    elif int(os.environ["WORLD_SIZE"]) != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks: the line would "
+                 "report a job that did not run (pass --gpus equal to --nproc-per-node)")
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     import torch.distributed as dist
-    # SIMVG_BENCH_SHARE_DEVICE=1 (tests only): every rank on cuda:0 over gloo -- the control flow of a world > 1 run (barriers,
-    # who leaves when, which side measurements are skipped) on a one-GPU box; RCCL refuses two ranks per device
-    share = os.environ.get("SIMVG_BENCH_SHARE_DEVICE") == "1"
+    if not share and torch.cuda.device_count() <= local:
+        sys.exit(f"bench.py: rank {rank} (LOCAL_RANK {local}) has no GPU: {torch.cuda.device_count()} visible, world {world}")
     if share:
         local = 0
     torch.cuda.set_device(local)
@@ -260,6 +311,8 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
+        if dist.get_world_size() != a.gpus:
+            sys.exit(f"bench.py: the {dist.get_backend()} world has {dist.get_world_size()} ranks, --gpus says {a.gpus}")
     from simvg_amd.models import build_model
     from simvg_amd.dist import GradReducer
     from simvg_amd.core import build_optimizer

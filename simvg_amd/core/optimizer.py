@@ -81,9 +81,9 @@ class _RestArena:
         written) -- i.e. for a parameter that NEVER receives a gradient (the token branch under branch_loss_weight=
         {"decoder": w}, `mask_token`).  A parameter graded on SOME steps only departs from torch.optim.Adam on the steps
         without a gradient (its moments decay with a zero gradient and its bias correction uses the flat tensor's step
-        count): the update stays finite and well defined, so a changed set WARNS (once per change) and the run continues;
-        SIMVG_STRICT_GRADED_SET=1 turns the warning into an error for runs that must stay step-for-step equal to per-tensor
-        Adam (`optimizer_config.flat=False` is the exact alternative)."""
+        count).  That is not the reference optimizer's arithmetic, so a changed set RAISES (round 5; no reference config
+        produces one: every head node is in the graph on every step).  SIMVG_ALLOW_GRADED_SET_CHANGE=1 opts into
+        warn-and-continue (the update stays finite and well defined); `optimizer_config.flat=False` is the exact alternative."""
         mask = tuple(p.grad is not None for p in self.params)
         if getattr(self, "_graded", None) is None:
             self._graded = mask
@@ -92,8 +92,9 @@ class _RestArena:
             msg = (f"FlatAdam: {len(changed)} parameter(s) changed between 'has a gradient' and 'has none' "
                    "(first: index %d, shape %s); on steps without a gradient their moments decay as if it were zero, "
                    "unlike per-tensor torch Adam which skips them" % (changed[0], tuple(self.params[changed[0]].shape)))
-            if os.environ.get("SIMVG_STRICT_GRADED_SET") == "1":
-                raise RuntimeError(msg + " (SIMVG_STRICT_GRADED_SET=1)")
+            if os.environ.get("SIMVG_ALLOW_GRADED_SET_CHANGE") != "1":
+                raise RuntimeError(msg + "; use optimizer_config.flat=False (per-tensor Adam) for such a model, or "
+                                   "SIMVG_ALLOW_GRADED_SET_CHANGE=1 to continue with the flat update")
             warnings.warn(msg, RuntimeWarning, stacklevel=2)
             self._graded = mask
         have = [(v, p.grad) for v, p in zip(self.grad_views, self.params) if p.grad is not None]

@@ -1358,6 +1358,9 @@ extern "C" int simvg_gemm_nt_split(const void* A, int lda, const void* W2, long 
                                    const float* residual, int ldres, int M, int N, int K, int split, float lo_scale,
                                    hipStream_t stream) {
   SIMVG_CHECK_ARG(ldw >= 2 * K, "gemm_nt_split: weight rows hold [lo | hi], 2 K entries");
+  // the lo half must end on a k-tile boundary of EVERY kernel the dispatcher may pick (BK = 64; the 256k32 variant's 32 divides it):
+  // with K % 64 == 32 the rescale between the halves never fires and A wraps in the middle of a k-tile
+  SIMVG_CHECK_ARG(K % BK == 0, "gemm_nt_split: K must be a multiple of 64");
   return gemm_nt_launch(A, lda, W2, w_gstride, ldw, bias, bias_gstride, C, ldc, c_is_f32, nullptr, 0, residual, ldres,
                         nullptr, 1, 1, M, N, 2 * K, split, 0, 1.f, K, lo_scale, stream);
 }

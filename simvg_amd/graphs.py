@@ -201,7 +201,10 @@ class InferenceGraphs:
         enc, head = self.model.vis_enc, self.model.head
         return (tuple(img.shape), img.dtype, tuple(ids.shape), None if mask is None else (tuple(mask.shape), mask.dtype),
                 tuple(tuple(m["img_shape"][:2]) for m in img_metas),
-                tuple(img_metas[0].get("batch_input_shape", ())), getattr(enc, "precision", None)) + self._generation()
+                tuple(img_metas[0].get("batch_input_shape", ())), getattr(enc, "precision", None),
+                # which kernels the captured forward launches: hi + lo weights or single ones, and for how many layers / Linears
+                (bool(getattr(enc, "precise_inference", False)), getattr(enc, "precise_layers", 0),
+                 getattr(enc, "precise_which", ()), getattr(enc, "wb2", None) is not None)) + self._generation()
 
     def _generation(self):
         """(serial number of the encoder's, of the head's 16-bit weight buffers): a captured graph's launches point into exactly

@@ -278,6 +278,11 @@ class WgradReduceBatch:
     def commit(self):
         self.n += 1
 
+    def reset(self):
+        """drop whatever an aborted backward left behind (descriptors of slabs that were never reduced)"""
+        self.n = 0
+        self._used = {}
+
     def flush(self):
         if self.n:
             t0 = _timer.start("wgrad_reduce") if _timer is not None else None
@@ -313,8 +318,9 @@ def gemm_tn(dy, x, dw, split=0, dw_group_stride=None, db=None, out_scale=1.0, de
     nws = int(lib.simvg_gemm_tn_ws_floats(M, N, K))
     if nws:          # slabs for the partial sums of the XCD-partitioned kernel
         if defer is not None:
-            ws = defer.workspace(nws, dy.device)
+            # the descriptor first: a full table flushes here and frees the pool, BEFORE this call's slabs are taken from it
             dptr = defer.next_desc()
+            ws = defer.workspace(nws, dy.device)
         else:
             key = (str(dy.device), nws)
             ws = _tn_ws.get(key)
@@ -325,6 +331,7 @@ def gemm_tn(dy, x, dw, split=0, dw_group_stride=None, db=None, out_scale=1.0, de
                                   _p(db), (db.stride(0) if db.dim() == 2 else 0) if db is not None else 0,
                                   M, N, K, split, out_scale, _p(ws), dptr, _stream())
         if defer is not None:
+            _lib.check(rc, "simvg_gemm_tn_ws")          # a refused call wrote no descriptor: never commit a stale one
             if assign:
                 if not defer.descs[defer.n].slabs:
                     raise RuntimeError("gemm_tn(assign=True): this problem has no second stage (check gemm_tn_can_assign)")
@@ -426,6 +433,11 @@ class LnReduceBatch:
     def commit(self):
         self.n += 1
 
+    def reset(self):
+        """drop whatever an aborted backward left behind"""
+        self.n = 0
+        self._used = {}
+
     def flush(self):
         if self.n:
             rc = _lib.load().simvg_ln_param_reduce_batched(self._C.byref(self.descs), self.n, _stream())
@@ -441,11 +453,15 @@ def ln_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, split=0, dx_lp=None, gelu_u=
     lib = _lib.load()
     # two-stage dgamma/dbeta reduction pays for wide rows only (measured: profiles/r01_sweeps.md)
     # (and for the many-rows-in-flight kernel of the 768 / 1024-wide 16-bit-dy instances, csrc/layernorm.hip: ln_bwd_tile_kernel)
-    ws = None
+    ws = dptr = None
     two_stage = dy.shape[0] >= 1024 and (dy.shape[1] >= 2048 or (dy.shape[1] in (768, 1024) and dy.dtype != torch.float32))
     if two_stage:
-        ws = defer.workspace(dy.shape[0], dy.shape[1], split, dy.device) if defer is not None else \
-            _ln_workspace(dy.shape[0], dy.shape[1], split, dy.device)
+        if defer is not None:
+            # the descriptor first: a full table flushes here and frees the pool, BEFORE this call's workspace is taken from it
+            dptr = defer.next_desc()
+            ws = defer.workspace(dy.shape[0], dy.shape[1], split, dy.device)
+        else:
+            ws = _ln_workspace(dy.shape[0], dy.shape[1], split, dy.device)
     _chk(dy, None, "dy")
     M, D = dy.shape
     gs = gamma.stride(0) if gamma.dim() == 2 else 0
@@ -458,7 +474,8 @@ def ln_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, split=0, dx_lp=None, gelu_u=
             dx_scaled.stride(0) if dx_scaled is not None else 0, _p(row_scale),
             rows_per_sample[0], rows_per_sample[1], M, D, split, _p(ws), dy_scale, param_scale)
     if defer is not None and two_stage:
-        rc = lib.simvg_ln_bwd_deferred(*args, defer.next_desc(), _stream())
+        rc = lib.simvg_ln_bwd_deferred(*args, dptr, _stream())
+        _lib.check(rc, "simvg_ln_bwd_deferred")
         defer.commit()
     else:
         rc = lib.simvg_ln_bwd(*args, _stream())

@@ -94,6 +94,9 @@ class BEIT3(nn.Module):
         self.precise_layers = self.L if precise_inference is True else (0 if precise_inference is False else
                                                                        max(0, min(int(precise_inference), self.L)))
         self.precise_inference = self.precise_layers > 0
+        # which of a layer's four Linears carry the pair (measurements: SIMVG_PRECISE_WHICH=wqkv,wout,w1,w2 -- default all four)
+        self.precise_which = tuple(t for t in os.environ.get("SIMVG_PRECISE_WHICH", "wqkv,wout,w1,w2").split(",") if t)
+        assert set(self.precise_which) <= {"wqkv", "wout", "w1", "w2"}, self.precise_which
         self.wb2 = None
         self._build_parameters()
         self._arena = None
@@ -224,7 +227,8 @@ class BEIT3(nn.Module):
             self._prep_version = None
             return
         # (p.data views do not share the flat tensor's version counter, so the parameters' own counters are summed too)
-        v = (self._arena.flat._version, sum(p._version for p in self._arena.params.values()), self.precise_layers, self.precision)
+        v = (self._arena.flat._version, sum(p._version for p in self._arena.params.values()), self.precise_layers, self.precise_which,
+             self.precision)
         if v != self._prep_version:
             self._prep.run()
             if self.precise_inference and self.precision == "lowp":
@@ -236,15 +240,22 @@ class BEIT3(nn.Module):
         moved (eval mode only; captured inference graphs keep pointing at the same buffers)"""
         A, D, F_, L, P = self._arena, self.D, self.F, self.L, self.patch_size
         dev = A.flat.device
-        if self.wb2 is None:
-            self.wb2 = {"patch": torch.empty(D, 2 * 3 * P * P, device=dev, dtype=ops.LP())}
+        shapes = {"wqkv": (3 * D, D), "wout": (D, D), "w1": (F_, D), "w2": (D, F_)}
+        want = {"patch"} | {f"{tag}{i}" for i in range(self.precise_layers) for tag in self.precise_which}
+        if self.wb2 is None or set(self.wb2) != want:
+            old = self.wb2 or {}           # buffers that stay keep their address (captured inference graphs point at them)
+            self.wb2 = {"patch": old.get("patch", None)}
+            if self.wb2["patch"] is None:
+                self.wb2["patch"] = torch.empty(D, 2 * 3 * P * P, device=dev, dtype=ops.LP())
             for i in range(self.precise_layers):
-                for tag, n, k in [("wqkv", 3 * D, D), ("wout", D, D), ("w1", F_, D), ("w2", D, F_)]:
-                    self.wb2[f"{tag}{i}"] = torch.empty(2, n, 2 * k, device=dev, dtype=ops.LP())
+                for tag in self.precise_which:
+                    n, k = shapes[tag]
+                    t = old.get(f"{tag}{i}")
+                    self.wb2[f"{tag}{i}"] = t if t is not None else torch.empty(2, n, 2 * k, device=dev, dtype=ops.LP())
         with torch.no_grad():
             ops.split_weight(A.params["beit3.vision_embed.proj.weight"].data.view(D, 3 * P * P), out=self.wb2["patch"])
             for i in range(self.precise_layers):
-                for tag in ("wqkv", "wout", "w1", "w2"):
+                for tag in self.precise_which:
                     ops.split_weight(A.views[f"{tag}{i}"], out=self.wb2[f"{tag}{i}"])
 
     def mark_weights_dirty(self):
@@ -473,7 +484,9 @@ class BEIT3(nn.Module):
         B, T = ws["ctx"][0], ws["ctx"][1]
         M = B * (self.np + 1 + T)
         cache = self.__dict__.setdefault("_assign_cache", {})
-        if M not in cache:
+        # `gemm_tn_can_assign` also depends on switches the kernels read at every call: they are part of the key
+        ckey = (M, os.environ.get("SIMVG_WG_SLABS"), os.environ.get("SIMVG_WGRAD_SQ"))
+        if ckey not in cache:
             D, F_, A = self.D, self.F, self._arena
             ok = all(ops.gemm_tn_can_assign(M, n, k) for n, k in ((3 * D, D), (D, D), (F_, D), (D, F_)))
             rng = None
@@ -482,8 +495,8 @@ class BEIT3(nn.Module):
                 for vname, names, shape in A._group_spec:
                     if vname.startswith(("wqkv", "wout", "w1", "w2")) and vname[-1].isdigit():
                         rng.append((A.offsets[names[0]], sum(A.params[k].numel() for k in names)))
-            cache[M] = None if rng is None else (("enc_linear", M), rng)
-        return cache[M]
+            cache[ckey] = None if rng is None else (("enc_linear", M), rng)
+        return cache[ckey]
 
     def _engine_backward(self, ws, dout, layer_done_cb=None, assign=False):
         A = self._arena
@@ -511,6 +524,8 @@ class BEIT3(nn.Module):
         wred = getattr(self, "_wg_batch", None)
         if wred is None:
             wred = self._wg_batch = ops.WgradReduceBatch()
+        red.reset()         # a backward that raised half-way must not leave its descriptors to this one's flush
+        wred.reset()
         ops.ln_bwd(dout, xs[2 * L], mF, rF, V["lnog"], G["lnog"], G["lnob"], split=Mv, dx_f32=dx, dx_scaled=dyb,
                    row_scale=None if dp is None else dp[L - 1][1], rows_per_sample=rps, dy_scale=S, param_scale=inv)
         for i in reversed(range(L)):

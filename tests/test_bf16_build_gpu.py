@@ -33,6 +33,15 @@ def _run(args, timeout=1500):
     return r.stdout
 
 
+def _counts(out):
+    """(passed, skipped, [skip reasons]) of a `pytest -rs` run: an inner skip must be visible in THIS test's result -- the driver
+    sees only the outer test"""
+    import re
+    last = [l for l in out.splitlines() if re.search(r"\b(passed|failed|skipped)\b", l) and " in " in l][-1]
+    n = lambda w: int((re.search(r"(\d+) " + w, last) or [0, 0])[1])
+    return n("passed"), n("skipped"), [l for l in out.splitlines() if l.startswith("SKIPPED")]
+
+
 def test_bf16_build_is_what_the_subprocess_loads():
     env = dict(os.environ, SIMVG_HIP_LIB=BF16_LIB)
     r = subprocess.run([sys.executable, "-c", "from simvg_amd import _lib; print(_lib.lowp_format(), _lib.LIB_PATH)"],
@@ -44,12 +53,38 @@ def test_bf16_build_is_what_the_subprocess_loads():
 def test_bf16_build_whole_model_vs_reference_fixtures():
     out = _run(["tests/test_model_gpu.py::test_forward_train_matches_reference", "tests/test_model_gpu.py::test_forward_test_boxes",
                 "-k", MODEL_K, "-s", "-rs"])
-    assert " passed" in out
+    passed, skipped, reasons = _counts(out)
     for line in out.splitlines():          # measured bf16 deviations and any Hungarian-assignment skip, into this test's own output
         if line.startswith("[gradients") or "SKIPPED" in line:
             print("[bf16 build]", line)
+    # the ONLY skip this run may contain is the named one: on trained-scale weights the bf16 build's ~1e-2 box deviations flip a
+    # near-tied Hungarian assignment (seen on base_nq10_grec_deconly), after which the loss terms belong to other pairs.
+    # Anything else that skipped -- or more than two such cases -- fails HERE, and the count is printed
+    print(f"[bf16 build] fixture cases compared: {passed} passed, {skipped} skipped ({len(reasons)} reasons listed)")
+    assert passed >= 12, (passed, skipped)
+    assert skipped == len(reasons) <= 2, (skipped, reasons)
+    for r_ in reasons:
+        assert "Hungarian assignment" in r_ and "bf16 build" in r_, r_
 
 
 def test_bf16_build_encoder_vs_oracle():
-    out = _run(["tests/test_encoder_gpu.py", "tests/test_kernels_gpu.py"])
-    assert " passed" in out
+    out = _run(["tests/test_encoder_gpu.py", "tests/test_kernels_gpu.py", "-rs"])
+    passed, skipped, reasons = _counts(out)
+    print(f"[bf16 build] kernel / encoder cases: {passed} passed, {skipped} skipped")
+    # the only skips of these two modules: the one-pass attention backward's switch on geometries it does not serve (a
+    # parametrisation artefact: attn_bwd_one_kernel exists for 27 key tiles, on either build) and the gradient-scale test (bf16 has
+    # fp32's exponent range: the build carries no gradient scale)
+    assert passed >= 100 and skipped == len(reasons), (passed, skipped, reasons)
+    assert all("27-tile geometry" in r_ or "no gradient scale" in r_ for r_ in reasons), reasons
+
+
+def test_bf16_build_at_baseline_full_sizes():
+    """BASELINE config 2's literal dtype at its literal size: tests/test_fullsize_gpu.py (ViT-B bs 64, ViT-L bs 32 x 10 queries,
+    against the full-size fixtures recorded from the executed reference) on the bf16 library, with the bf16 build's stated
+    bounds (`tests/test_fullsize_gpu.py::_tol`)."""
+    out = _run(["tests/test_fullsize_gpu.py", "-s", "-rs"], timeout=2400)
+    passed, skipped, reasons = _counts(out)
+    for line in out.splitlines():
+        if line.startswith("[full size"):
+            print("[bf16 build]", line)
+    assert passed == 4 and skipped == 0, (passed, skipped, reasons)

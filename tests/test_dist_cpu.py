@@ -237,3 +237,22 @@ def test_loss_normalisers_are_averaged_over_ranks_before_the_head():
     mp.spawn(_nums_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     assert out[0][0] == out[1][0] == [2.5, 2.0]            # (3 + 2) / 2 GT boxes, (2 + 2) / 2 matched pseudo targets
     assert out[0][1] == [3, 0] and out[1][1] == [1, 1]
+
+
+def test_bench_gpus_n_refuses_a_node_with_fewer_gpus_and_a_mismatched_world():
+    """`python bench.py --gpus N` starts its own ranks (bench.py::self_launch, the counterpart of the reference's
+    tools/dist_train.sh:8-10).  On a box with fewer than N GPUs (this container: none) it must exit non-zero with a message
+    instead of printing an `n_gpus: 1` line under the name of an N-GPU job; under a launcher whose WORLD_SIZE is not N it must
+    refuse as well."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    have = torch.cuda.device_count()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SIMVG_BENCH_SHARE_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(have + 1 if have else 2), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, cwd=root, timeout=300)
+    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    assert "refusing" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), cwd=root, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and not r.stdout.strip(), (r.returncode, r.stderr[-500:])

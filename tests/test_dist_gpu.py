@@ -139,7 +139,7 @@ def test_bench_under_torchrun_takes_the_rccl_branches_and_matches_the_unreduced_
 
 
 def test_bench_with_two_ranks_finishes_and_reports_the_whole_job(tmp_path):
-    """The driver's N > 1 launch line with two ranks on the one GPU of the test box (gloo, SIMVG_BENCH_SHARE_DEVICE=1): rank 0
+    """`python bench.py --gpus 2` (self-launched ranks) on the one GPU of the test box (gloo, SIMVG_BENCH_SHARE_DEVICE=1): rank 0
     prints ONE line for the whole job (n_gpus 2, global batch 2 x B, value = pairs of both ranks / max time), the other rank
     leaves without printing, nothing after the timed region waits for a rank that has left (the side measurements of a
     single-process run are skipped), and the reducer reports one message per layer + head + embeddings."""
@@ -147,8 +147,9 @@ def test_bench_with_two_ranks_finishes_and_reports_the_whole_job(tmp_path):
     import subprocess
     root = os.path.dirname(HERE)
     env = dict(os.environ, SIMVG_BENCH_SHARE_DEVICE="1", MASTER_ADDR="127.0.0.1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+    # round 5: no launcher around it -- `python bench.py --gpus 2` starts its two ranks itself (bench.py::self_launch)
+    env = {k: v for k, v in env.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
                         "--batch", "4", "--batches", "2"],
                        capture_output=True, text=True, env=env, cwd=root, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]

@@ -62,6 +62,21 @@ def _boxes(model, b, sl=slice(None), ids=None):
     return {k: out[k].detach().float().clone() for k in ("outputs_coord_decoder_branch", "outputs_coord_token_branch")}
 
 
+def _fp16():
+    from simvg_amd import _lib
+    return _lib.lowp_format() == "fp16"
+
+
+def _tol():
+    """Bounds of the 16-bit engine at full size.  fp16 build (shipped): the north_star's 1e-3 on every box of `forward_test`.
+    bf16 build (BASELINE config 2's literal dtype; run by tests/test_bf16_build_gpu.py in a subprocess on libsimvg_hip_bf16.so):
+    8 significand bits on trained-scale weights -- the bound test_model_gpu.py::_box_tol states for it (1.5e-2), losses 2e-2,
+    gradient norms / entries as in test_model_gpu.py::_check_all_grads, direction cosine 0.97."""
+    if _fp16():
+        return dict(box=1e-3, train_tok=1.25e-3, alone=1e-3, loss=2e-3, gnorm=6e-2, gent=1.2e-1, cos=0.99, nratio=0.03)
+    return dict(box=1.5e-2, train_tok=1.5e-2, alone=1.5e-2, loss=2e-2, gnorm=0.3, gent=0.6, cos=0.97, nratio=0.06)
+
+
 def _l1(a, b):
     return float((a - b).abs().sum(-1).max())
 
@@ -79,6 +94,7 @@ def test_full_size_inference_properties(golden, vit, B, nq, grec):
     model, cfg = _model(vit, nq)
     model.eval()
     b = _batch(cfg, B, grec)
+    T = _tol()
     with torch.no_grad():
         full = _boxes(model, b)
         # P3: garbage ids under the padding mask
@@ -100,14 +116,11 @@ def test_full_size_inference_properties(golden, vit, B, nq, grec):
         mx, p99, mean, n = _l1_stats(full[k].cpu(), ref[k])
         print(f"[full size {vit} B={B} nq={nq}] {k}: vs the REFERENCE over {n} boxes max {mx:.2e} p99 {p99:.2e} mean {mean:.2e} "
               f"(exact-fp32 engine vs the reference: max {ex_mx:.2e}); batch of {B} vs batch of 4: {d2:.2e}")
-        if "decoder" in k:
-            assert mx <= 1e-3, (k, mx)
-        else:
-            # round 4: forward_test carries hi + lo 16-bit weights (`precise_inference`, simvg_gemm_nt_split); every token box
-            # of the full batch stays within the north_star's 1e-3 (round 3, single 16-bit weights: max 1.11e-3 / 1.17e-3
-            # against the reference, mean 4.8e-4 / 5.2e-4)
-            assert mx <= 1e-3, (k, mx, p99, mean)
-        assert d2 <= 1e-3, (k, d2)
+        # round 4: forward_test carries hi + lo 16-bit weights (`precise_inference`, simvg_gemm_nt_split); every box of both
+        # branches of the full batch stays within the north_star's 1e-3 (round 3, single 16-bit weights: token max 1.11e-3 /
+        # 1.17e-3 against the reference, mean 4.8e-4 / 5.2e-4).  bf16 build: `_tol`
+        assert mx <= T["box"], (k, mx, p99, mean)
+        assert d2 <= T["alone"], (k, d2)
 
 
 def _grads(model):
@@ -125,6 +138,8 @@ def test_full_size_training_step_properties(golden, vit, B, nq, grec):
     model.eval()                  # dropout / DropPath off: the exact-fp32 engine has none, and the two must see one function
     b = _batch(cfg, B, grec)
     res = {}
+    T = _tol()
+    ref_boxes = {"outputs_coord_decoder_branch": fx["dec_boxes"].float(), "outputs_coord_token_branch": fx["tok_boxes"].float()}
     for prec in ("lowp", "fp32"):
         model.vis_enc.set_precision(prec)
         model.zero_grad(set_to_none=True)
@@ -138,8 +153,19 @@ def test_full_size_training_step_properties(golden, vit, B, nq, grec):
         res[prec] = (float(losses["loss_total"]),) + _grads(model)
         # against the reference's full-size step: the five losses, both whole-module gradient norms, every parameter's norm
         # and 16 sampled entries
-        ltol, ntol, stol = (1e-4, 1e-3, 5e-5) if prec == "fp32" else (2e-3, 6e-2, 1.2e-1)
+        ltol, ntol, stol = (1e-4, 1e-3, 5e-5) if prec == "fp32" else (T["loss"], T["gnorm"], T["gent"])
         assert list(losses) == list(fx["losses"])
+        # round 5: the boxes of the TRAINING forward at the full batch (single 16-bit weights: the hi + lo pairs are forward_test's).
+        # Decoder branch within the north_star's 1e-3; token branch: the stated bound is 1.25e-3 -- measured max 1.11e-3 (ViT-B,
+        # 64 pairs) / 1.17e-3 (ViT-L, 32 x 10) on the harsh weights, mean 4.8e-4 / 5.2e-4 (profiles/r04_sweeps.md section 1): these
+        # boxes feed the losses (asserted right below), the boxes a user receives come from forward_test (<= 1e-3, test above)
+        out = model._last_output
+        for k, rb in ref_boxes.items():
+            mx, p99, mean, n = _l1_stats(out[k].detach().float().cpu(), rb)
+            bound = 5e-5 if prec == "fp32" else (T["box"] if "decoder" in k else T["train_tok"])
+            print(f"[full size {vit} B={B} nq={nq}] {prec} TRAINING forward {k}: vs the REFERENCE over {n} boxes max {mx:.2e} p99 {p99:.2e} "
+                  f"mean {mean:.2e} (bound {bound:g})")
+            assert mx <= bound, (prec, k, mx, p99, mean)
         for k, v in fx["losses"].items():
             assert abs(float(losses[k]) - v) <= ltol * max(1.0, abs(v)), (prec, k, float(losses[k]), v)
         params = dict(model.named_parameters())
@@ -156,6 +182,6 @@ def test_full_size_training_step_properties(golden, vit, B, nq, grec):
     ne, nh = float(e16.norm() / e32.norm()), float(h16.norm() / h32.norm())
     print(f"[full size {vit} B={B} nq={nq}] loss 16-bit {l16:.5f} / fp32 {l32:.5f}; encoder gradient cosine {ce:.5f} "
           f"norm ratio {ne:.4f}; head gradient cosine {ch:.5f} norm ratio {nh:.4f}")
-    assert abs(l16 - l32) <= 2e-3 * max(1.0, abs(l32))
-    assert ce >= 0.99 and ch >= 0.99, (ce, ch)
-    assert abs(ne - 1) <= 0.03 and abs(nh - 1) <= 0.03, (ne, nh)
+    assert abs(l16 - l32) <= T["loss"] * max(1.0, abs(l32))
+    assert ce >= T["cos"] and ch >= T["cos"], (ce, ch)
+    assert abs(ne - 1) <= T["nratio"] and abs(nh - 1) <= T["nratio"], (ne, nh)

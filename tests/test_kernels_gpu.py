@@ -329,6 +329,67 @@ def test_wgrad_second_stage_assign_mode(M, N, K, split):
         ops.gemm_tn(dy, x, dw1, split=split, db=db1, assign=True)          # no defer
 
 
+def test_deferred_second_stages_survive_an_overflow_flush_of_the_descriptor_table():
+    """More deferred calls than the batch's descriptor table holds (16 weight-gradient / 64 LayerNorm descriptors), of MIXED
+    sizes: the table flushes in the middle of a batch and frees the workspace pool.  The workspace of the call that triggers the
+    flush must be taken AFTER it (round 5, advisor: it used to be taken before and was then no longer counted as in use, so a
+    later call of the same size could be handed the same slabs while their second stage was still pending).  Every result must
+    equal the immediate (undeferred) call's, bit for bit, and no two descriptors between two flushes may share a workspace."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(77)
+    shapes = [(4500, 768, 768, 0), (4600, 2304, 768, 4200), (4500, 768, 768, 0)]      # two problems share a slab size
+    data = []
+    for M, N, K, split in shapes:
+        dy, x = bf(rnd_bf16(M, N, gen=g)).to(DEV), bf(rnd_bf16(M, K, gen=g)).to(DEV)
+        ng = 2 if split else 1
+        ref = torch.zeros(ng, N, K, device=DEV)
+        ops.gemm_tn(dy, x, ref, split=split)
+        data.append((dy, x, split, ref))
+    batch = ops.WgradReduceBatch()
+    seen = []
+    orig = batch.flush
+
+    def flush():                          # every flush: the slabs of its descriptors are pairwise distinct
+        ptrs = [batch.descs[i].slabs for i in range(batch.n)]
+        assert len(set(ptrs)) == len(ptrs), "two pending second stages share their slabs"
+        seen.append(batch.n)
+        orig()
+    batch.flush = flush
+    outs = []
+    for r in range(37):                   # 37 calls against a table of 16: two overflow flushes + the final one
+        dy, x, split, ref = data[(r * r + r // 3) % 3]
+        dw = torch.zeros_like(ref)
+        ops.gemm_tn(dy, x, dw, split=split, defer=batch)
+        outs.append((dw, ref))
+    batch.flush()
+    torch.cuda.synchronize()
+    assert seen == [16, 16, 5], seen
+    for dw, ref in outs:
+        assert torch.equal(dw, ref)
+    # the LayerNorm parameter reductions: 70 deferred calls (table of 64), two row counts
+    lb = ops.LnReduceBatch()
+    cases = []
+    for M, D, split in [(2048, 768, 1500), (3000, 768, 0)]:
+        x = bf(rnd_bf16(M, D, gen=g)).to(DEV)
+        dy = bf(rnd_bf16(M, D, gen=g)).to(DEV)
+        ng = 2 if split else 1
+        gamma, beta = (1 + 0.1 * torch.randn(ng, D, generator=g)).to(DEV), torch.zeros(ng, D, device=DEV)
+        _, _, mean, rstd = ops.ln_fwd(x, gamma, beta, split=split)
+        dgr, dbr, dxr = torch.zeros(ng, D, device=DEV), torch.zeros(ng, D, device=DEV), torch.empty(M, D, device=DEV, dtype=LPD())
+        ops.ln_bwd(dy, x, mean, rstd, gamma, dgr, dbr, split=split, dx_lp=dxr)
+        cases.append((dy, x, mean, rstd, gamma, split, dgr, dbr))
+    res = []
+    for r in range(70):
+        dy, x, mean, rstd, gamma, split, dgr, dbr = cases[(r // 5) % 2]
+        dg, db_ = torch.zeros_like(dgr), torch.zeros_like(dbr)
+        ops.ln_bwd(dy, x, mean, rstd, gamma, dg, db_, split=split, dx_lp=torch.empty_like(x), defer=lb)
+        res.append((dg, db_, dgr, dbr))
+    lb.flush()
+    torch.cuda.synchronize()
+    for dg, db_, dgr, dbr in res:
+        assert torch.equal(dg, dgr) and torch.equal(db_, dbr)
+
+
 # ------------------------------------------------------------------------------------------
 # LayerNorm
 # ------------------------------------------------------------------------------------------
