@@ -188,6 +188,65 @@ int simvg_attn_small_bwd(const float* q, int ldq, const float* k, int ldk, const
                          int kv_rows_per_batch, float scale, const float* key_pos, int ld_key_pos,
                          int key_pos_rows_per_batch, simvg_stream_t stream);
 
+/* ---- a decoder layer's attention block as ONE launch (round 5) ---------------------------------------------------------
+ * detrex BaseTransformerLayer as the reference configures it (simvg/models/heads/tgqs_kd_detr_head/transformer.py:93-131;
+ * called from the decoder loop :134-186 and for the TGQG layers at tgqs_kd_detr_head.py:391-399, decoder :425-428), operation
+ * order (self_attn, norm, cross_attn, norm): one workgroup per sample owns its R = num_queries rows and computes
+ *   q|k = (tgt + qpos) Ws[0:2E]^T, v = tgt Ws[2E:]^T; self-attention (8 heads x 32, dropout multipliers dm0);
+ *   r1 = tgt + o Wso^T + bso; t1 = LayerNorm(r1; g0, b0);
+ *   qc = ((t1 + qpos) Wc[0:E]^T + bc[0:E]) / sqrt(32); cross-attention over the sample's Lk SOURCE rows s_k (16-bit or fp32
+ *   rows; key = s_k + kpos_k, value = s_k) WITHOUT materialising K = s Wk^T, V = s Wv^T:
+ *       qk[r][h] = Wk_h^T qc_h[r];  P = softmax_k(qk[r][h] . (s_k + kpos_k)) (key_padding_mask -> -inf);  P' = P * dm1
+ *       ctx[r][h] = sum_k P'[k] s_k;  o2[r][h] = Wv_h ctx[r][h] + bv_h * sum_k P'[k]
+ *   (identical to nn.MultiheadAttention: the key bias adds a per-row constant to the scores, which the softmax removes);
+ *   r2 = t1 + o2 Wco^T + bco; t2 = LayerNorm(r2; g1, b1).
+ * Every intermediate the backward needs is written to the caller's buffers (rows of [B*R, .] matrices; P0 [B,H,R,R],
+ * P1 [B,H,R,Lk], qk / ctx [B*R, H, E], sp [B*R, H]).  E = 256, H = 8, R <= 16, Lk <= 1024. */
+typedef struct simvg_dec_attn_args {
+  int B, R, Lk, kv_rows, kv_off;       /* source rows of sample b: rows b*kv_rows + kv_off + [0, Lk) */
+  const float* tgt; const float* qpos; /* [B*R, E] */
+  const float *Ws, *bs, *Wso, *bso, *g0, *b0, *Wc, *bc, *Wco, *bco, *g1, *b1;
+  const void* src16; const float* src32; long ldsrc;   /* exactly one of the two; row stride in elements */
+  const float* kpos; long ldkp; int kpos_rows;         /* key_pos rows (or NULL); kpos_rows = rows per sample, 0 = one set */
+  const unsigned char* kpm;                            /* [B, Lk], 1 = masked key, or NULL */
+  const float* dm0; const float* dm1;                  /* dropout multipliers [B,H,R,R] / [B,H,R,Lk], or NULL */
+  float *qkv, *P0, *o, *r1, *mean1, *rstd1, *t1, *qc, *qk, *P1, *ctx, *sp, *o2, *r2, *mean2, *rstd2, *t2;
+  float eps;
+} simvg_dec_attn_args;
+int simvg_dec_attn_fwd(const simvg_dec_attn_args* args, simvg_stream_t stream);
+
+/* Backward of simvg_dec_attn_fwd (autograd of the same reference modules), two launches:
+ *  simvg_dec_attn_bwd  : workgroup per sample, the forward's walk in reverse.  d(t2) = dt2 (may be NULL) + the sum of `nslab`
+ *                        slabs [nslab][B*R][E] (the FFN backward's partial sums, simvg_dec_ffn_bwd).  Writes d_tgt, d_qpos [B*R, E];
+ *                        the gradient of the cross-attention's source rows into dsrc [B*kv_rows, lddsrc] (fp32; written, or added to
+ *                        when dsrc_accumulate: the image memory is shared by the decoder's layers) -- rows of a sample that are no
+ *                        keys are zeroed when writing; and, per row, the operands of the parameter gradients (dt2sum .. dqkv:
+ *                        [B*R, E] each, dctx / dqk [B*R, H, E], dqkv [B*R, 3E]).
+ *  simvg_dec_attn_wgrad: all 12 parameter gradients of the block (dWs, dbs, dWso, dbso, dg0, db0, dWc, dbc, dWco, dbco, dg1,
+ *                        db1: WRITTEN, reference layout) as contractions of those operands over the B*R rows, fixed summation order. */
+typedef struct simvg_dec_attn_bwd_args {
+  int B, R, Lk, kv_rows, kv_off;
+  const float *Ws, *Wso, *g0, *Wc, *bc, *Wco, *g1;
+  const void* src16; const float* src32; long ldsrc;
+  const float* kpos; long ldkp; int kpos_rows;
+  const float* dm0; const float* dm1;
+  const float *qkv, *P0, *r1, *mean1, *rstd1, *qk, *P1, *r2, *mean2, *rstd2;      /* saved by simvg_dec_attn_fwd */
+  const float* dt2; const float* dt2_slabs; int nslab; long slab_stride;
+  float* d_tgt; float* d_qpos;
+  float* dsrc; long lddsrc; int dsrc_accumulate;
+  float *dt2sum, *gx2, *d_r2, *d_o2, *dctx, *dqk, *dqpre, *d_t1, *gx1, *d_r1, *dqkv;
+} simvg_dec_attn_bwd_args;
+int simvg_dec_attn_bwd(const simvg_dec_attn_bwd_args* args, simvg_stream_t stream);
+typedef struct simvg_dec_attn_wgrad_args {
+  int MR;                                                                          /* B * R rows */
+  const float *tgt, *qpos, *t1, *o, *o2, *ctx, *sp, *qc;                           /* forward (inputs + saved) */
+  const float *dqkv, *d_r1, *gx1, *d_t1, *dqpre, *dqk, *d_o2, *d_r2, *gx2, *dt2sum; /* left by simvg_dec_attn_bwd */
+  float *dWs, *dbs, *dWso, *dbso, *dg0, *db0, *dWc, *dbc, *dWco, *dbco, *dg1, *db1;
+} simvg_dec_attn_wgrad_args;
+int simvg_dec_attn_wgrad(const simvg_dec_attn_wgrad_args* args, simvg_stream_t stream);
+/* the largest number of keys per sample the two kernels above hold in LDS */
+int simvg_dec_attn_max_keys(void);
+
 /* exact-fp32 forward pieces (precision="fp32" inference mode: the reference computes in fp32, use_fp16=False in all
  * 53 configs): fp32 im2col and an fp32 encoder attention with the same modality-major row layout as simvg_attn_fwd. */
 int simvg_im2col_f32(const float* img_nchw, float* cols, int B, int S, int P, simvg_stream_t stream);

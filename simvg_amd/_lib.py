@@ -34,7 +34,38 @@ class GemmF32Problem(C.Structure):      # simvg_gemm_f32_problem
                 ("ld_gate", c_long)]
 
 
+class DecAttnArgs(C.Structure):         # simvg_dec_attn_args
+    _fields_ = ([(n, c_int) for n in ("B", "R", "Lk", "kv_rows", "kv_off")] +
+                [(n, c_void_p) for n in ("tgt", "qpos", "Ws", "bs", "Wso", "bso", "g0", "b0", "Wc", "bc", "Wco", "bco", "g1", "b1",
+                                         "src16", "src32")] +
+                [("ldsrc", c_long), ("kpos", c_void_p), ("ldkp", c_long), ("kpos_rows", c_int), ("kpm", c_void_p), ("dm0", c_void_p),
+                 ("dm1", c_void_p)] +
+                [(n, c_void_p) for n in ("qkv", "P0", "o", "r1", "mean1", "rstd1", "t1", "qc", "qk", "P1", "ctx", "sp", "o2", "r2",
+                                         "mean2", "rstd2", "t2")] +
+                [("eps", c_float)])
+
+
+class DecAttnBwdArgs(C.Structure):      # simvg_dec_attn_bwd_args
+    _fields_ = ([(n, c_int) for n in ("B", "R", "Lk", "kv_rows", "kv_off")] +
+                [(n, c_void_p) for n in ("Ws", "Wso", "g0", "Wc", "bc", "Wco", "g1", "src16", "src32")] +
+                [("ldsrc", c_long), ("kpos", c_void_p), ("ldkp", c_long), ("kpos_rows", c_int), ("dm0", c_void_p), ("dm1", c_void_p)] +
+                [(n, c_void_p) for n in ("qkv", "P0", "r1", "mean1", "rstd1", "qk", "P1", "r2", "mean2", "rstd2", "dt2", "dt2_slabs")] +
+                [("nslab", c_int), ("slab_stride", c_long), ("d_tgt", c_void_p), ("d_qpos", c_void_p), ("dsrc", c_void_p),
+                 ("lddsrc", c_long), ("dsrc_accumulate", c_int)] +
+                [(n, c_void_p) for n in ("dt2sum", "gx2", "d_r2", "d_o2", "dctx", "dqk", "dqpre", "d_t1", "gx1", "d_r1", "dqkv")])
+
+
+class DecAttnWgradArgs(C.Structure):    # simvg_dec_attn_wgrad_args
+    _fields_ = ([("MR", c_int)] +
+                [(n, c_void_p) for n in ("tgt", "qpos", "t1", "o", "o2", "ctx", "sp", "qc", "dqkv", "d_r1", "gx1", "d_t1", "dqpre",
+                                         "dqk", "d_o2", "d_r2", "gx2", "dt2sum", "dWs", "dbs", "dWso", "dbso", "dg0", "db0", "dWc",
+                                         "dbc", "dWco", "dbco", "dg1", "db1")])
+
+
 _SIGS = {
+    "simvg_dec_attn_fwd": [c_void_p, c_void_p],
+    "simvg_dec_attn_bwd": [c_void_p, c_void_p],
+    "simvg_dec_attn_wgrad": [c_void_p, c_void_p],
     "simvg_gemm_f32_grouped": [c_void_p, c_int, c_void_p],
     "simvg_postprocess": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                           c_int, c_int, c_int, c_void_p],
@@ -151,6 +182,8 @@ def load():
     lib.simvg_ln_bwd_ws_floats.argtypes = [c_int, c_int, c_int]
     lib.simvg_gemm_tn_ws_floats.restype = c_long
     lib.simvg_gemm_tn_ws_floats.argtypes = [c_int, c_int, c_int]
+    lib.simvg_dec_attn_max_keys.restype = c_int
+    lib.simvg_dec_attn_max_keys.argtypes = []
     _lib = lib
     return lib
 
@@ -161,7 +194,8 @@ def lowp_format():
 
 
 def exported_symbols():
-    return sorted(_SIGS) + ["simvg_last_error", "simvg_version", "simvg_source_hash", "simvg_lowp_format", "simvg_ln_bwd_ws_floats", "simvg_gemm_tn_ws_floats"]
+    return sorted(_SIGS) + ["simvg_last_error", "simvg_version", "simvg_source_hash", "simvg_lowp_format", "simvg_ln_bwd_ws_floats", "simvg_gemm_tn_ws_floats",
+                            "simvg_dec_attn_max_keys"]
 
 
 def check(rc, what):

@@ -708,6 +708,145 @@ def attn_small_bwd(q, k, v, P, dout, dq, dk, dv, B, H, Lq, Lk, kpm=None, drop=No
     _lib.check(rc, "simvg_attn_small_bwd")
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# decoder layers as few launches (csrc/decoder.hip)
+DEC_E, DEC_H = 256, 8
+_DEC_SAVED = ("qkv", "P0", "o", "r1", "mean1", "rstd1", "t1", "qc", "qk", "P1", "ctx", "sp", "o2", "r2", "mean2", "rstd2", "t2")
+
+
+def _carve(sizes, device):
+    """one allocation, 16-byte aligned fp32 views of the given element counts"""
+    offs, total = [], 0
+    for n in sizes:
+        offs.append(total)
+        total += (n + 3) // 4 * 4
+    flat = torch.empty(total, device=device, dtype=torch.float32)
+    return [flat[o:o + n] for o, n in zip(offs, sizes)]
+
+
+def dec_attn_fwd(tgt, qpos, W, src, B, R, Lk, kv_rows=0, kv_off=0, kpos=None, kpm=None, dm0=None, dm1=None, eps=1e-5):
+    """The attention block of one decoder layer (self-attention, norm, cross-attention, norm) in one launch.
+    tgt, qpos [B*R, E] fp32; W = (Ws, bs, Wso, bso, g0, b0, Wc, bc, Wco, bco, g1, b1) (the layer's parameters, reference layout);
+    src: the cross-attention's source rows [B*kv_rows, E], 16-bit (LP()) or fp32 -- keys are src + kpos, values are src; sample
+    b uses rows b*kv_rows + kv_off + [0, Lk).  kpos [Lk, E] (shared) or [B*Lk, E]; kpm [B, Lk] uint8; dm0 / dm1 dropout
+    multipliers [B,H,R,R] / [B,H,R,Lk].  Returns the dict of saved tensors; ["t2"] is the block's output [B*R, E]."""
+    lib = _lib.load()
+    E, H, M = DEC_E, DEC_H, B * R
+    dev = tgt.device
+    for t, n in ((tgt, "tgt"), (qpos, "qpos")):
+        _chk(t, torch.float32, n)
+        assert tuple(t.shape) == (M, E) and t.is_contiguous(), n
+    for w in W:
+        _chk(w, torch.float32, "decoder parameter")
+        assert w.is_contiguous()
+    kv_rows = kv_rows or Lk
+    assert src.dim() == 2 and src.shape[1] == E and src.stride(1) == 1 and src.shape[0] >= B * kv_rows
+    sizes = dict(qkv=M * 3 * E, P0=B * H * R * R, o=M * E, r1=M * E, mean1=M, rstd1=M, t1=M * E, qc=M * E, qk=M * H * E,
+                 P1=B * H * R * Lk, ctx=M * H * E, sp=M * H, o2=M * E, r2=M * E, mean2=M, rstd2=M, t2=M * E)
+    bufs = dict(zip(_DEC_SAVED, _carve([sizes[k] for k in _DEC_SAVED], dev)))
+    a = _lib.DecAttnArgs()
+    a.B, a.R, a.Lk, a.kv_rows, a.kv_off = B, R, Lk, kv_rows, kv_off
+    a.tgt, a.qpos = tgt.data_ptr(), qpos.data_ptr()
+    for name, w in zip(("Ws", "bs", "Wso", "bso", "g0", "b0", "Wc", "bc", "Wco", "bco", "g1", "b1"), W):
+        setattr(a, name, w.data_ptr())
+    if src.dtype == LP():
+        a.src16, a.src32 = src.data_ptr(), None
+    else:
+        _chk(src, torch.float32, "src")
+        a.src16, a.src32 = None, src.data_ptr()
+    a.ldsrc = src.stride(0)
+    if kpos is not None:
+        _chk(kpos, torch.float32, "kpos")
+        assert kpos.dim() == 2 and kpos.stride(1) == 1 and kpos.shape[0] in (Lk, B * Lk)
+        a.kpos, a.ldkp, a.kpos_rows = kpos.data_ptr(), kpos.stride(0), (Lk if kpos.shape[0] > Lk else 0)
+    a.kpm = kpm.data_ptr() if kpm is not None else None
+    a.dm0 = dm0.data_ptr() if dm0 is not None else None
+    a.dm1 = dm1.data_ptr() if dm1 is not None else None
+    for k in _DEC_SAVED:
+        setattr(a, k, bufs[k].data_ptr())
+    a.eps = eps
+    t0 = _timer.start("dec_attn_fwd") if _timer is not None else None
+    rc = lib.simvg_dec_attn_fwd(C.byref(a), _stream())
+    if t0 is not None:
+        _timer.stop("dec_attn_fwd", t0, 0.0, 0.0)
+    _lib.check(rc, "simvg_dec_attn_fwd")
+    shapes = dict(qkv=(M, 3 * E), P0=(B, H, R, R), P1=(B, H, R, Lk), qk=(M, H, E), ctx=(M, H, E), sp=(M, H), mean1=(M,), rstd1=(M,),
+                  mean2=(M,), rstd2=(M,))
+    return {k: v.view(shapes.get(k, (M, E))) for k, v in bufs.items()}
+
+
+_DEC_BWD_ROWS = ("dt2sum", "gx2", "d_r2", "d_o2", "dqpre", "d_t1", "gx1", "d_r1")     # [M, E] each
+_DEC_PARAM_GRADS = ("dWs", "dbs", "dWso", "dbso", "dg0", "db0", "dWc", "dbc", "dWco", "dbco", "dg1", "db1")
+
+
+def dec_attn_bwd(saved, tgt, qpos, W, src, B, R, Lk, dt2=None, dt2_slabs=None, kv_rows=0, kv_off=0, kpos=None, dm0=None, dm1=None,
+                 dsrc=None, dsrc_accumulate=False):
+    """Backward of `dec_attn_fwd` (two launches).  saved: the forward's dict; dt2 [B*R, E] and / or dt2_slabs [n, B*R, E] (summed):
+    the gradient of the block's output t2.  dsrc: fp32 [B*kv_rows, E] buffer for the gradient of the source rows (None: not
+    computed); written, or added to with dsrc_accumulate.  Returns (d_tgt, d_qpos, {parameter gradients in W's order})."""
+    lib = _lib.load()
+    E, H, M = DEC_E, DEC_H, B * R
+    dev = tgt.device
+    kv_rows = kv_rows or Lk
+    Ws, bs, Wso, bso, g0, b0, Wc, bc, Wco, bco, g1, b1 = W
+    names = ("d_tgt", "d_qpos") + _DEC_BWD_ROWS + ("dctx", "dqk", "dqkv") + _DEC_PARAM_GRADS
+    psize = dict(dWs=3 * E * E, dbs=3 * E, dWso=E * E, dbso=E, dg0=E, db0=E, dWc=3 * E * E, dbc=3 * E, dWco=E * E, dbco=E, dg1=E, db1=E)
+    sizes = {n: M * E for n in ("d_tgt", "d_qpos") + _DEC_BWD_ROWS}
+    sizes.update(dctx=M * H * E, dqk=M * H * E, dqkv=M * 3 * E, **psize)
+    buf = dict(zip(names, _carve([sizes[n] for n in names], dev)))
+    a = _lib.DecAttnBwdArgs()
+    a.B, a.R, a.Lk, a.kv_rows, a.kv_off = B, R, Lk, kv_rows, kv_off
+    for n, w in (("Ws", Ws), ("Wso", Wso), ("g0", g0), ("Wc", Wc), ("bc", bc), ("Wco", Wco), ("g1", g1)):
+        setattr(a, n, w.data_ptr())
+    if src.dtype == LP():
+        a.src16, a.src32 = src.data_ptr(), None
+    else:
+        a.src16, a.src32 = None, src.data_ptr()
+    a.ldsrc = src.stride(0)
+    if kpos is not None:
+        a.kpos, a.ldkp, a.kpos_rows = kpos.data_ptr(), kpos.stride(0), (Lk if kpos.shape[0] > Lk else 0)
+    a.dm0 = dm0.data_ptr() if dm0 is not None else None
+    a.dm1 = dm1.data_ptr() if dm1 is not None else None
+    for n in ("qkv", "P0", "r1", "mean1", "rstd1", "qk", "P1", "r2", "mean2", "rstd2"):
+        setattr(a, n, saved[n].data_ptr())
+    if dt2 is not None:
+        _chk(dt2, torch.float32, "dt2")
+        assert dt2.is_contiguous() and dt2.numel() == M * E
+        a.dt2 = dt2.data_ptr()
+    if dt2_slabs is not None:
+        _chk(dt2_slabs, torch.float32, "dt2_slabs")
+        assert dt2_slabs.dim() == 3 and dt2_slabs.shape[1:] == (M, E) and dt2_slabs[0].is_contiguous()
+        a.dt2_slabs, a.nslab, a.slab_stride = dt2_slabs.data_ptr(), dt2_slabs.shape[0], dt2_slabs.stride(0)
+    a.d_tgt, a.d_qpos = buf["d_tgt"].data_ptr(), buf["d_qpos"].data_ptr()
+    if dsrc is not None:
+        _chk(dsrc, torch.float32, "dsrc")
+        assert dsrc.dim() == 2 and dsrc.stride(1) == 1 and dsrc.shape[0] >= B * kv_rows and dsrc.shape[1] == E
+        a.dsrc, a.lddsrc, a.dsrc_accumulate = dsrc.data_ptr(), dsrc.stride(0), int(bool(dsrc_accumulate))
+    for n in _DEC_BWD_ROWS + ("dctx", "dqk", "dqkv"):
+        setattr(a, n, buf[n].data_ptr())
+    t0 = _timer.start("dec_attn_bwd") if _timer is not None else None
+    rc = lib.simvg_dec_attn_bwd(C.byref(a), _stream())
+    _lib.check(rc, "simvg_dec_attn_bwd")
+    w = _lib.DecAttnWgradArgs()
+    w.MR = M
+    w.tgt, w.qpos = tgt.data_ptr(), qpos.data_ptr()
+    for n in ("t1", "o", "o2", "ctx", "sp", "qc"):
+        setattr(w, n, saved[n].data_ptr())
+    for n in ("dqkv", "d_r1", "gx1", "d_t1", "dqpre", "dqk", "d_o2", "d_r2", "gx2", "dt2sum") + _DEC_PARAM_GRADS:
+        setattr(w, n, buf[n].data_ptr())
+    rc = lib.simvg_dec_attn_wgrad(C.byref(w), _stream())
+    if t0 is not None:
+        _timer.stop("dec_attn_bwd", t0, 0.0, 0.0)
+    _lib.check(rc, "simvg_dec_attn_wgrad")
+    pshape = dict(dWs=(3 * E, E), dWso=(E, E), dWc=(3 * E, E), dWco=(E, E))
+    grads = [buf[n].view(pshape[n]) if n in pshape else buf[n] for n in _DEC_PARAM_GRADS]
+    return buf["d_tgt"].view(M, E), buf["d_qpos"].view(M, E), grads
+
+
+def dec_attn_max_keys():
+    return int(_lib.load().simvg_dec_attn_max_keys())
+
+
 class _PackRing:
     """pinned staging buffers for the one host->device copy of `pack_targets`: a slot is rewritten only after the copy that read it
     has completed (the host may run steps ahead of the device)"""

@@ -87,15 +87,24 @@ class BEIT3(nn.Module):
         # largest single term of the box error on trained-scale weights and the only one that every row shares
         # (tools/dev/token_tail.py); with it the boxes of a full batch stay within the path's 1e-3 bound (tests/test_fullsize_gpu.py).
         # The training forward keeps single 16-bit weights (its boxes only feed the loss).  False = the round-3 behaviour.
-        # precise_inference: True = every layer, False = none, an int k = the first k layers only (the early layers carry most of
-        # the weight-rounding error: profiles/r04_sweeps.md section 1); SIMVG_PRECISE_LAYERS overrides it (measurements)
+        # precise_inference: True (default) = the ATTENTION projections (qkv, out-proj) of every layer; "full" = all four Linears of
+        # every layer (round 4's default); an int k = all four Linears of the first k layers; False = none.  Measured on the
+        # full-size fixtures (tools/dev/precise_sweep.py, profiles/r05_sweeps.md: token-branch max over the batch, ViT-B 64 pairs /
+        # ViT-L 32 x 10): none 1.11e-3 / 1.17e-3; attention projections 7.2e-4 / 9.2e-4 at +12 % / +16 % of the forward's time;
+        # all four 5.8e-4 / 8.0e-4 at +45 % / +53 %; first half of the layers 8.3e-4 / 8.7e-4 at +20 % / +24 %: the q / k weights'
+        # rounding moves every row's attention logits coherently, the FFN weights' rounding is averaged by the LayerNorm behind it.
+        # SIMVG_PRECISE_LAYERS / SIMVG_PRECISE_WHICH (= wqkv,wout,w1,w2) override it (measurements)
+        which = ("wqkv", "wout") if precise_inference is True else ("wqkv", "wout", "w1", "w2")
+        if precise_inference == "full":
+            precise_inference = True
         if os.environ.get("SIMVG_PRECISE_LAYERS"):
             precise_inference = int(os.environ["SIMVG_PRECISE_LAYERS"])
         self.precise_layers = self.L if precise_inference is True else (0 if precise_inference is False else
                                                                        max(0, min(int(precise_inference), self.L)))
         self.precise_inference = self.precise_layers > 0
-        # which of a layer's four Linears carry the pair (measurements: SIMVG_PRECISE_WHICH=wqkv,wout,w1,w2 -- default all four)
-        self.precise_which = tuple(t for t in os.environ.get("SIMVG_PRECISE_WHICH", "wqkv,wout,w1,w2").split(",") if t)
+        if os.environ.get("SIMVG_PRECISE_WHICH"):
+            which = tuple(t for t in os.environ["SIMVG_PRECISE_WHICH"].split(",") if t)
+        self.precise_which = which
         assert set(self.precise_which) <= {"wqkv", "wout", "w1", "w2"}, self.precise_which
         self.wb2 = None
         self._build_parameters()

@@ -39,7 +39,10 @@ def _counts(out):
     import re
     last = [l for l in out.splitlines() if re.search(r"\b(passed|failed|skipped)\b", l) and " in " in l][-1]
     n = lambda w: int((re.search(r"(\d+) " + w, last) or [0, 0])[1])
-    return n("passed"), n("skipped"), [l for l in out.splitlines() if l.startswith("SKIPPED")]
+    reasons = [l for l in out.splitlines() if l.startswith("SKIPPED")]
+    listed = sum(int((re.match(r"SKIPPED \[(\d+)\]", l) or [0, 1])[1]) for l in reasons)       # "SKIPPED [6] file:line: reason"
+    assert listed == n("skipped"), (last, reasons)
+    return n("passed"), n("skipped"), reasons
 
 
 def test_bf16_build_is_what_the_subprocess_loads():
@@ -62,7 +65,7 @@ def test_bf16_build_whole_model_vs_reference_fixtures():
     # Anything else that skipped -- or more than two such cases -- fails HERE, and the count is printed
     print(f"[bf16 build] fixture cases compared: {passed} passed, {skipped} skipped ({len(reasons)} reasons listed)")
     assert passed >= 12, (passed, skipped)
-    assert skipped == len(reasons) <= 2, (skipped, reasons)
+    assert skipped <= 2, (skipped, reasons)
     for r_ in reasons:
         assert "Hungarian assignment" in r_ and "bf16 build" in r_, r_
 
@@ -74,7 +77,7 @@ def test_bf16_build_encoder_vs_oracle():
     # the only skips of these two modules: the one-pass attention backward's switch on geometries it does not serve (a
     # parametrisation artefact: attn_bwd_one_kernel exists for 27 key tiles, on either build) and the gradient-scale test (bf16 has
     # fp32's exponent range: the build carries no gradient scale)
-    assert passed >= 100 and skipped == len(reasons), (passed, skipped, reasons)
+    assert passed >= 100, (passed, skipped, reasons)
     assert all("27-tile geometry" in r_ or "no gradient scale" in r_ for r_ in reasons), reasons
 
 
