@@ -247,6 +247,37 @@ int simvg_dec_attn_wgrad(const simvg_dec_attn_wgrad_args* args, simvg_stream_t s
 /* the largest number of keys per sample the two kernels above hold in LDS */
 int simvg_dec_attn_max_keys(void);
 
+/* ---- a decoder layer's FFN split over its hidden units (round 5) ---------------------------------------------------------
+ * detrex FFN + norm as configured at transformer.py:118-131: r3 = t2 + dropout(relu(t2 W1^T + b1) dropout W2^T + b2),
+ * t3 = LayerNorm(r3), and the decoder's shared post-norm hs = LayerNorm(t3) (transformer.py:176-183).  Workgroup s owns hidden
+ * units [64 s, 64 s + 64) for all M rows:
+ *   simvg_dec_ffn_fwd    : h1d[:, slice] = relu(.) * m1 (saved), slabs[s] = h_s W2[:, slice]^T      (Fd / 64 workgroups)
+ *   simvg_dec_ffn_finish : r3 = t2 + m2 * (sum_s slabs[s] + b2), t3, mean3, rstd3 (+ hs, meanP, rstdP when gP != NULL)
+ *   simvg_dec_ffn_bwd    : from d_t3 and / or d_hs: d_r3 (+ the row operands gx3, dy3, gxP, dr3m), slabs[s] = d(h_s) W1_s --
+ *                          d(t2) = d_r3 + sum_s slabs[s], which simvg_dec_attn_bwd forms --, dW1, db1, dW2 (written whole, fixed
+ *                          summation order) and, in a second small launch, db2, dg2, db2n, dgP, dbP (column sums over the rows).
+ * m1 [M, Fd], m2 [M, E]: dropout multipliers or NULL.  E = 256, Fd a multiple of 64. */
+typedef struct simvg_dec_ffn_args { int M, Fd; const float *t2, *W1, *b1, *W2, *m1; float* h1d; float* slabs; } simvg_dec_ffn_args;
+int simvg_dec_ffn_fwd(const simvg_dec_ffn_args* args, simvg_stream_t stream);
+typedef struct simvg_dec_ffn_finish_args {
+  int M, NS;
+  const float *t2, *slabs, *b2, *m2, *g2, *b2n, *gP, *bP;
+  float *r3, *mean3, *rstd3, *t3, *hs, *meanP, *rstdP;
+  float eps;
+} simvg_dec_ffn_finish_args;
+int simvg_dec_ffn_finish(const simvg_dec_ffn_finish_args* args, simvg_stream_t stream);
+typedef struct simvg_dec_ffn_bwd_args {
+  int M, Fd;
+  const float *d_t3, *d_hs;                                            /* either may be NULL */
+  const float *r3, *mean3, *rstd3, *g2, *t3, *meanP, *rstdP, *gP, *m2;
+  const float *W1, *W2, *h1d, *m1, *t2;
+  float *d_r3, *gx3, *dy3, *gxP, *dr3m;                                /* [M, E] each */
+  float* slabs;                                                        /* [Fd / 64][M][E] */
+  float *dW1, *db1, *dW2;
+  float *db2, *dg2, *db2n, *dgP, *dbP;
+} simvg_dec_ffn_bwd_args;
+int simvg_dec_ffn_bwd(const simvg_dec_ffn_bwd_args* args, simvg_stream_t stream);
+
 /* exact-fp32 forward pieces (precision="fp32" inference mode: the reference computes in fp32, use_fp16=False in all
  * 53 configs): fp32 im2col and an fp32 encoder attention with the same modality-major row layout as simvg_attn_fwd. */
 int simvg_im2col_f32(const float* img_nchw, float* cols, int B, int S, int P, simvg_stream_t stream);

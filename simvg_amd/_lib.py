@@ -62,7 +62,27 @@ class DecAttnWgradArgs(C.Structure):    # simvg_dec_attn_wgrad_args
                                          "dbc", "dWco", "dbco", "dg1", "db1")])
 
 
+class DecFfnArgs(C.Structure):          # simvg_dec_ffn_args
+    _fields_ = [("M", c_int), ("Fd", c_int)] + [(n, c_void_p) for n in ("t2", "W1", "b1", "W2", "m1", "h1d", "slabs")]
+
+
+class DecFfnFinishArgs(C.Structure):    # simvg_dec_ffn_finish_args
+    _fields_ = ([("M", c_int), ("NS", c_int)] +
+                [(n, c_void_p) for n in ("t2", "slabs", "b2", "m2", "g2", "b2n", "gP", "bP", "r3", "mean3", "rstd3", "t3", "hs", "meanP",
+                                         "rstdP")] + [("eps", c_float)])
+
+
+class DecFfnBwdArgs(C.Structure):       # simvg_dec_ffn_bwd_args
+    _fields_ = ([("M", c_int), ("Fd", c_int)] +
+                [(n, c_void_p) for n in ("d_t3", "d_hs", "r3", "mean3", "rstd3", "g2", "t3", "meanP", "rstdP", "gP", "m2", "W1", "W2", "h1d",
+                                         "m1", "t2", "d_r3", "gx3", "dy3", "gxP", "dr3m", "slabs", "dW1", "db1", "dW2", "db2", "dg2",
+                                         "db2n", "dgP", "dbP")])
+
+
 _SIGS = {
+    "simvg_dec_ffn_fwd": [c_void_p, c_void_p],
+    "simvg_dec_ffn_finish": [c_void_p, c_void_p],
+    "simvg_dec_ffn_bwd": [c_void_p, c_void_p],
     "simvg_dec_attn_fwd": [c_void_p, c_void_p],
     "simvg_dec_attn_bwd": [c_void_p, c_void_p],
     "simvg_dec_attn_wgrad": [c_void_p, c_void_p],

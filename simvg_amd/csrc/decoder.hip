@@ -22,6 +22,14 @@
 
 #include "common.h"
 
+#ifdef DEC_TIMELINE      // development builds only (SIMVG_EXTRA_FLAGS=-DDEC_TIMELINE): workgroup 0's phase boundaries on the 100 MHz clock
+__device__ unsigned long long dec_tl[64];
+#define TL(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) dec_tl[i] = wall_clock64(); } while (0)
+extern "C" int simvg_dec_timeline(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dec_tl), sizeof(dec_tl)); }
+#else
+#define TL(i)
+#endif
+
 namespace {
 
 constexpr int DE = 256;        // embed_dim of the head (tgqs_kd_detr_head.py: embed_dim=256 in every config)
@@ -51,47 +59,82 @@ __device__ __forceinline__ f32x4_t ld4_lp(const lp_t* p) {
 
 // The source rows of a cross-attention (keys AND values): 16-bit rows (the image memory) or fp32 rows (text rows; the image
 // memory of the exact-fp32 mode); the keys get `kpos` rows added (sine positions), the values do not.
+template <bool S16>       // (compile-time source format: a run-time branch around a load would blur the compiler's count of loads in flight)
 struct SrcRows {
   const lp_t* s16; const float* s32; long ld;      // row r of this sample at (s16 | s32) + r * ld
-  const float* kpos; long ldkp;                     // key_pos rows of this sample (or null)
-  __device__ __forceinline__ f32x4_t val(int r, int c) const { return s16 ? ld4_lp(s16 + r * ld + c) : ld4(s32 + r * ld + c); }
-  __device__ __forceinline__ f32x4_t key(int r, int c) const {
-    f32x4_t v = val(r, c);
-    if (kpos) v += ld4(kpos + r * ldkp + c);
-    return v;
+  const float* kpos; long ldkp;                     // key_pos rows of this sample
+  __device__ __forceinline__ f32x4_t val(int r, int c) const {
+    if constexpr (S16) return ld4_lp(s16 + r * ld + c);
+    else return ld4(s32 + r * ld + c);
   }
+  __device__ __forceinline__ f32x4_t key(int r, int c) const { return val(r, c) + ld4(kpos + r * ldkp + c); }
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
 // P1: Y[r][n] = sum_k A(r, k) * W(n, k)  -- the contraction index is contiguous in W's rows.  One call = the n-tiles of ONE
 // wave (16 output columns each), streamed as a flat sequence of (tile, 16-k step) pairs with U steps of W in flight.
-//   bload(t, k)  -> the wave's B fragment of its t-th tile at contraction offset k: lane (j = lane & 15, g = lane >> 4) supplies
-//                   W(n0(t) + j, k + 4g .. +3)
-//   aload(t, k, rt) -> A fragment of row tile rt: A(16 rt + j, k + 4g .. +3)
-//   epi(t, rt, acc) -> acc[v] = Y[16 rt + 4g + v][n0(t) + j]
-template <int KS, int NRT, int U, class BLoad, class ALoad, class Epi>
-__device__ __forceinline__ void stream_nt(int ntiles, BLoad bload, ALoad aload, Epi epi) {
-  static_assert(KS % U == 0, "a tile's steps are a whole number of prefetch groups");
+//   bload(t, k)       -> the wave's B fragment of its t-th tile at contraction offset k: lane (j = lane & 15, g = lane >> 4)
+//                        supplies W(n0(t) + j, k + 4g .. +3)
+//   aload(t, k, row)  -> A(row, k + 4g .. +3)
+//   epi(t, rt, acc)   -> acc[v] = Y[16 rt + 4g + v][n0(t) + j]
+// RR = 0: v_mfma_f32_16x16x4_f32 on 16-row tiles (NRT of them).  RR = 1 (NRT = 1): only row 0 exists (num_queries
+// = 1: a 16-row MFMA tile would spend 15/16 of its 32 cycles on padding, and the fp32 MFMA rate -- 256 FLOP per cycle and
+// CU -- made the whole kernel MFMA-bound): each lane keeps the partial dot products of its quarter of k, the four quarters meet
+// through two cross-lane adds at the end of the tile, and the result is handed to `epi` in the MFMA layout (rows >= RR zero).
+// (the first U loads of a phase may be issued EARLY -- `stream_nt_prefetch` before the previous phase's barrier: W does not depend
+// on the data, and a phase that starts with its loads already in flight does not pay a memory round trip before its first FMA;
+// at 14 phases per kernel those round trips were most of the kernel's time)
+template <int KS, int U, class BLoad>
+__device__ __forceinline__ void stream_nt_prefetch(int ntiles, BLoad bload, f32x4_t (&bq)[U]) {
   const int total = ntiles * KS;
-  f32x4_t bq[U], bn[U];
+  if (total <= 0) return;
 #pragma unroll
-  for (int u = 0; u < U; ++u) bq[u] = u < total ? bload(u / KS, (u % KS) * 16) : f4zero();
+  for (int u = 0; u < U; ++u) { const int su = min(u, total - 1); bq[u] = bload(su / KS, (su % KS) * 16); }     // (unconditional: see gemv256)
+}
+template <int KS, int NRT, int U, int RR, class BLoad, class ALoad, class Epi>
+__device__ __forceinline__ void stream_nt(int ntiles, BLoad bload, ALoad aload, Epi epi, f32x4_t (&bq)[U]) {
+  static_assert(KS % U == 0, "a tile's steps are a whole number of prefetch groups");
+  static_assert(RR == 0 || NRT == 1, "the small-row form has one row tile");
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+  const int total = ntiles * KS;
+  f32x4_t bn[U];
   f32x4_t acc[NRT];
+  float part[RR > 0 ? RR : 1];
 #pragma unroll
   for (int rt = 0; rt < NRT; ++rt) acc[rt] = f4zero();
+#pragma unroll
+  for (int r = 0; r < (RR > 0 ? RR : 1); ++r) part[r] = 0.f;
   for (int s0 = 0; s0 < total; s0 += U) {
     const int t = s0 / KS, kb = (s0 % KS) * 16;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int sn = s0 + U + u;
-      bn[u] = sn < total ? bload(sn / KS, (sn % KS) * 16) : f4zero();
+      const int sn = min(s0 + U + u, total - 1);
+      bn[u] = bload(sn / KS, (sn % KS) * 16);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
+      if constexpr (RR == 0) {
 #pragma unroll
-      for (int rt = 0; rt < NRT; ++rt) acc[rt] = mfma4(aload(t, kb + 16 * u, rt), bq[u], acc[rt]);
+        for (int rt = 0; rt < NRT; ++rt) acc[rt] = mfma4(aload(t, kb + 16 * u, 16 * rt + j), bq[u], acc[rt]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < RR; ++r) {
+          const f32x4_t av = aload(t, kb + 16 * u, r);
+          part[r] = fmaf(av[0], bq[u][0], fmaf(av[1], bq[u][1], fmaf(av[2], bq[u][2], fmaf(av[3], bq[u][3], part[r]))));
+        }
+      }
     }
     if (kb + 16 * U == KS * 16) {
+      if constexpr (RR > 0) {
+#pragma unroll
+        for (int r = 0; r < RR; ++r) {
+          float v = part[r];
+          v += __shfl_xor(v, 16, 64);
+          v += __shfl_xor(v, 32, 64);
+          acc[0][r] = g == 0 ? v : 0.f;
+          part[r] = 0.f;
+        }
+      }
 #pragma unroll
       for (int rt = 0; rt < NRT; ++rt) { epi(t, rt, acc[rt]); acc[rt] = f4zero(); }
     }
@@ -100,37 +143,67 @@ __device__ __forceinline__ void stream_nt(int ntiles, BLoad bload, ALoad aload, 
   }
 }
 
+template <int KS, int NRT, int U, int RR, class BLoad, class ALoad, class Epi>
+__device__ __forceinline__ void stream_nt(int ntiles, BLoad bload, ALoad aload, Epi epi) {
+  f32x4_t bq[U];
+  stream_nt_prefetch<KS, U>(ntiles, bload, bq);
+  stream_nt<KS, NRT, U, RR>(ntiles, bload, aload, epi, bq);
+}
+
 // P2: Y[r][c] = sum_n D(r, n) * W(n, c)  -- the OUTPUT index is contiguous in W's rows (dgrad of a Linear; P' V; dS K).  A wave
 // owns NCG groups of 64 output columns; lane (j, g) holds columns cb + 4j .. +3 of its group as FOUR accumulators (one MFMA per
 // column offset), so one 16-byte load of W(n0 + g, cb + 4j ..) feeds four MFMAs and a wave instruction reads 4 rows x 256 B.
-//   bload(n, cg) -> W(n, cb(cg) + 4j .. +3) for the lane's n = n0 + g        (n may be out of range: return zeros)
-//   aload(n, rt) -> D(16 rt + j, n)                                            (the same)
+//   bload(n, cg)   -> W(n, cb(cg) + 4j .. +3) for the lane's n = n0 + g        (n may be out of range: return zeros)
+//   aload(n, row)  -> D(row, n)                                                  (the same)
 //   acc[rt][cg][c][v] = Y[16 rt + 4g + v][cb(cg) + 4j + c]
-template <int NRT, int NCG, int U, class BLoad, class ALoad>
-__device__ __forceinline__ void stream_nn(int n_begin, int n_end, BLoad bload, ALoad aload, f32x4_t (&acc)[NRT][NCG][4]) {
+// RR as above (rows 0 .. RR-1 on the VALU: lane (j, g) sums its n = n0 + g, n0 + 4 + g, ...; the four g meet at the end).
+template <int NCG, int U, class BLoad>
+__device__ __forceinline__ void stream_nn_prefetch(int n_begin, int n_end, BLoad bload, f32x4_t (&bq)[U][NCG]) {
   const int g = (threadIdx.x & 63) >> 4;
   const int steps = (n_end - n_begin + 3) >> 2;
-  f32x4_t bq[U][NCG], bn[U][NCG];
+  if (steps <= 0) return;
 #pragma unroll
   for (int u = 0; u < U; ++u)
 #pragma unroll
-    for (int cg = 0; cg < NCG; ++cg) bq[u][cg] = u < steps ? bload(n_begin + 4 * u + g, cg) : f4zero();
+    for (int cg = 0; cg < NCG; ++cg) bq[u][cg] = bload(n_begin + 4 * min(u, steps - 1) + g, cg);
+}
+template <int NRT, int NCG, int U, int RR, class BLoad, class ALoad>
+__device__ __forceinline__ void stream_nn(int n_begin, int n_end, BLoad bload, ALoad aload, f32x4_t (&acc)[NRT][NCG][4],
+                                          f32x4_t (&bq)[U][NCG]) {
+  static_assert(RR == 0 || NRT == 1, "the small-row form has one row tile");
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+  const int steps = (n_end - n_begin + 3) >> 2;
+  f32x4_t bn[U][NCG];
+  f32x4_t part[RR > 0 ? RR : 1][NCG];
+#pragma unroll
+  for (int r = 0; r < (RR > 0 ? RR : 1); ++r)
+#pragma unroll
+    for (int cg = 0; cg < NCG; ++cg) part[r][cg] = f4zero();
   for (int s0 = 0; s0 < steps; s0 += U) {
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int cg = 0; cg < NCG; ++cg) bn[u][cg] = s0 + U + u < steps ? bload(n_begin + 4 * (s0 + U + u) + g, cg) : f4zero();
+      for (int cg = 0; cg < NCG; ++cg) bn[u][cg] = bload(n_begin + 4 * min(s0 + U + u, steps - 1) + g, cg);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (s0 + u < steps) {
         const int n = n_begin + 4 * (s0 + u) + g;
+        if constexpr (RR == 0) {
 #pragma unroll
-        for (int rt = 0; rt < NRT; ++rt) {
-          const float a = aload(n, rt);
+          for (int rt = 0; rt < NRT; ++rt) {
+            const float a = aload(n, 16 * rt + j);
 #pragma unroll
-          for (int cg = 0; cg < NCG; ++cg)
+            for (int cg = 0; cg < NCG; ++cg)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[rt][cg][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq[u][cg][c], acc[rt][cg][c], 0, 0, 0);
+              for (int c = 0; c < 4; ++c) acc[rt][cg][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq[u][cg][c], acc[rt][cg][c], 0, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < RR; ++r) {
+            const float a = aload(n, r);
+#pragma unroll
+            for (int cg = 0; cg < NCG; ++cg) part[r][cg] += a * bq[u][cg];
+          }
         }
       }
     }
@@ -138,6 +211,206 @@ __device__ __forceinline__ void stream_nn(int n_begin, int n_end, BLoad bload, A
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int cg = 0; cg < NCG; ++cg) bq[u][cg] = bn[u][cg];
+  }
+  if constexpr (RR > 0) {
+#pragma unroll
+    for (int cg = 0; cg < NCG; ++cg)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < RR; ++r) {
+          float v = part[r][cg][c];
+          v += __shfl_xor(v, 16, 64);
+          v += __shfl_xor(v, 32, 64);
+          acc[0][cg][c][r] += g == 0 ? v : 0.f;
+        }
+  }
+}
+
+template <int NRT, int NCG, int U, int RR, class BLoad, class ALoad>
+__device__ __forceinline__ void stream_nn(int n_begin, int n_end, BLoad bload, ALoad aload, f32x4_t (&acc)[NRT][NCG][4]) {
+  f32x4_t bq[U][NCG];
+  stream_nn_prefetch<NCG, U>(n_begin, n_end, bload, bq);
+  stream_nn<NRT, NCG, U, RR>(n_begin, n_end, bload, aload, acc, bq);
+}
+
+// One query row (num_queries = 1): y[n] = sum_k x(n)[k] W(n, k) for n in [0, N), K = 256, as a matrix-vector product with every wave
+// instruction reading 4 whole 256-byte row segments (lane (c = lane & 15, rr = lane >> 4): W(n0 + rr, 64 kc + 4c .. +3)); the 16 lanes
+// of a row meet through 4 cross-lane adds.  Row groups n0 = 4 (wave + NW i); U row groups (4 loads of 16 B each per lane) in flight,
+// kept in a ring (a group's registers are reloaded the moment it is consumed).  xsel(n0) -> the LDS vector (256 floats) the rows of
+// group n0 contract with; out(n, y) is called by ONE lane per n.
+template <int NW, int U, class XSel, class Out>
+__device__ __forceinline__ void gemv256(const float* W, long ldw, int N, XSel xsel, Out out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, rr = lane >> 4;
+  const int groups = N >> 2;
+  const int mine = (groups - wave + NW - 1) / NW;
+  f32x4_t w[U][4];
+  if (mine <= 0) return;
+  // (loads past the wave's last group re-read that group: an UNCONDITIONAL load keeps the compiler's vmcnt bookkeeping exact -- with
+  // predicated loads it assumed the fewest in flight and its waits drained the queue once per pass)
+  auto lw = [&](int i, f32x4_t (&wg)[4]) {
+    const float* p = W + (long)(4 * (wave + NW * min(i, mine - 1)) + rr) * ldw + 4 * c;
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) wg[kc] = ld4(p + 64 * kc);
+  };
+#pragma unroll
+  for (int u = 0; u < U; ++u) lw(u, w[u]);
+  for (int i0 = 0; i0 < mine; i0 += U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (i0 + u < mine) {
+        const int n0 = 4 * (wave + NW * (i0 + u));
+        const float* x = xsel(n0);
+        f32x4_t t = w[u][0] * ld4(x + 4 * c);
+#pragma unroll
+        for (int kc = 1; kc < 4; ++kc) t += w[u][kc] * ld4(x + 64 * kc + 4 * c);
+        lw(i0 + U + u, w[u]);
+        float v = (t[0] + t[1]) + (t[2] + t[3]);
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 8, 64);
+        if (c == 0) out(n0 + rr, v);
+      }
+    }
+  }
+}
+
+// ---- one query per sample: the cross-attention's passes over the source rows on the VALU, every load a whole row -----------------
+// (The MFMA forms above fetch 32- / 64-byte pieces of 16 rows per instruction; with 8 (query, head) rows per sample the pieces of a
+// row were requested by different instructions far apart, the 32 KB L1 did not hold them in between, and every 128-byte line came
+// from L2 two to four times: 15 GB/s.)
+// 8 row values per lane at columns 8 c32 .. +7 of source row r: value form (S16: one 16-byte load) or key form (+ the position row)
+template <bool S16, bool KEY>
+struct Row8 {
+  u32x4_t raw; f32x4_t lo, hi, p0, p1;
+  __device__ __forceinline__ void load(const SrcRows<S16>& s, int r, int c) {
+    if constexpr (S16) raw = *(const u32x4_t*)(s.s16 + r * s.ld + c);
+    else { lo = ld4(s.s32 + r * s.ld + c); hi = ld4(s.s32 + r * s.ld + c + 4); }
+    if constexpr (KEY) { p0 = ld4(s.kpos + r * s.ldkp + c); p1 = ld4(s.kpos + r * s.ldkp + c + 4); }
+  }
+  __device__ __forceinline__ void get(f32x4_t& a, f32x4_t& b) const {
+    if constexpr (S16) {
+      float x0, x1, x2, x3, x4, x5, x6, x7;
+      unpack_lp2(raw[0], x0, x1); unpack_lp2(raw[1], x2, x3); unpack_lp2(raw[2], x4, x5); unpack_lp2(raw[3], x6, x7);
+      a = (f32x4_t){x0, x1, x2, x3}; b = (f32x4_t){x4, x5, x6, x7};
+    } else { a = lo; b = hi; }
+    if constexpr (KEY) { a += p0; b += p1; }
+  }
+};
+
+// out[h][kk] = Q[h] . row(kk) (+ add[h]) for the 8 heads: 32 lanes per row (8 columns each), two rows per wave instruction; the
+// 32 partial sums of the 8 heads meet in a butterfly (4 + 2 + 1 + 1 + 1 cross-lane adds: afterwards lane l of the half-wave holds
+// head (l >> 2) & 7).  Rows round-robin over the waves in pairs, U pairs in flight.  Q: LDS [8][DLD]; out: LDS [8][LKP].
+template <bool S16, bool KEY, int U, class Fin>
+__device__ __forceinline__ void rowdot8(const SrcRows<S16>& src, const float* Q, int Lk, Fin fin) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c32 = lane & 31, par = lane >> 5;
+  f32x4_t qa[8], qb[8];
+#pragma unroll
+  for (int h = 0; h < 8; ++h) { qa[h] = ld4(Q + h * DLD + 8 * c32); qb[h] = ld4(Q + h * DLD + 8 * c32 + 4); }
+  const int pairs = (Lk + 1) >> 1;
+  const int mine = (pairs - wave + DNW - 1) / DNW;
+  if (mine <= 0) return;
+  Row8<S16, KEY> ring[U];
+  auto row_of = [&](int i) { return min(2 * (wave + DNW * min(i, mine - 1)) + par, Lk - 1); };
+#pragma unroll
+  for (int u = 0; u < U; ++u) ring[u].load(src, row_of(u), 8 * c32);
+  for (int i0 = 0; i0 < mine; i0 += U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (i0 + u < mine) {
+        f32x4_t ka, kb;
+        ring[u].get(ka, kb);
+        ring[u].load(src, row_of(i0 + U + u), 8 * c32);
+        float v[8];
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+          const f32x4_t t = qa[h] * ka + qb[h] * kb;
+          v[h] = (t[0] + t[1]) + (t[2] + t[3]);
+        }
+        // butterfly over the 32 lanes of the row: halve the number of live heads at each of the first three steps
+        float w4[4], w2[2], w1;
+        const bool b4 = c32 & 16, b3 = c32 & 8, b2 = c32 & 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float keep = b4 ? v[4 + k] : v[k], send = b4 ? v[k] : v[4 + k];
+          w4[k] = keep + __shfl_xor(send, 16, 64);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const float keep = b3 ? w4[2 + k] : w4[k], send = b3 ? w4[k] : w4[2 + k];
+          w2[k] = keep + __shfl_xor(send, 8, 64);
+        }
+        {
+          const float keep = b2 ? w2[1] : w2[0], send = b2 ? w2[0] : w2[1];
+          w1 = keep + __shfl_xor(send, 4, 64);
+        }
+        w1 += __shfl_xor(w1, 2, 64);
+        w1 += __shfl_xor(w1, 1, 64);
+        const int kk = 2 * (wave + DNW * (i0 + u)) + par;
+        if ((c32 & 3) == 0 && kk < Lk) fin((c32 >> 2) & 7, kk, w1);       // head = b4 b3 b2
+      }
+    }
+  }
+}
+
+// acc[h][4 columns] += PT[kk][h] * row(kk)[columns 4 lane .. +3] over the wave's rows (kk = wave, wave + 8, ...): one whole row per
+// wave instruction, U rows in flight.  PT: LDS [Lk][8] (row kk's 8 head factors).  The waves' partial sums are combined by the caller.
+template <bool S16, bool KEY, int U>
+__device__ __forceinline__ void rowacc8(const SrcRows<S16>& src, const float* PT, int Lk, f32x4_t (&acc)[8]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int mine = (Lk - wave + DNW - 1) / DNW;
+  if (mine <= 0) return;
+  f32x4_t ring[U], pring[U];
+  u32x2_t ring16[U];
+  auto row_of = [&](int i) { return wave + DNW * min(i, mine - 1); };
+  auto ld = [&](int u, int i) {
+    const int r = row_of(i);
+    if constexpr (S16) ring16[u] = *(const u32x2_t*)(src.s16 + r * src.ld + 4 * lane);
+    else ring[u] = ld4(src.s32 + r * src.ld + 4 * lane);
+    if constexpr (KEY) pring[u] = ld4(src.kpos + r * src.ldkp + 4 * lane);
+  };
+#pragma unroll
+  for (int u = 0; u < U; ++u) ld(u, u);
+  for (int i0 = 0; i0 < mine; i0 += U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (i0 + u < mine) {
+        f32x4_t x;
+        if constexpr (S16) { float a0, a1, a2, a3; unpack_lp2(ring16[u][0], a0, a1); unpack_lp2(ring16[u][1], a2, a3); x = (f32x4_t){a0, a1, a2, a3}; }
+        else x = ring[u];
+        if constexpr (KEY) x += pring[u];
+        ld(u, i0 + U + u);
+        const int kk = wave + DNW * (i0 + u);
+        const f32x4_t f0 = ld4(PT + kk * 8), f1 = ld4(PT + kk * 8 + 4);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) { acc[h] += f0[h] * x; acc[4 + h] += f1[h] * x; }
+      }
+    }
+  }
+}
+// the 8 waves' partial [8][256] sums -> their sum in `out` (LDS [8][DLD]) and at out_g (global rows of E floats): waves 4 .. 7 park
+// theirs in PART ([4][8][256]), waves 0 .. 3 add their own on top, then every thread sums 4 of the 2048 entries (fixed order)
+__device__ __forceinline__ void rowacc8_combine(f32x4_t (&acc)[8], float* PART, float* out, float* out_g) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (wave >= 4) {
+#pragma unroll
+    for (int h = 0; h < 8; ++h) *(f32x4_t*)(PART + ((wave - 4) * 8 + h) * DE + 4 * lane) = acc[h];
+  }
+  __syncthreads();
+  if (wave < 4) {
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+      float* p = PART + (wave * 8 + h) * DE + 4 * lane;
+      *(f32x4_t*)p = acc[h] + ld4(p);
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < 8 * (DE / 4); e += DNT) {
+    const int h = e / (DE / 4), c = 4 * (e % (DE / 4));
+    const f32x4_t v = (ld4(PART + h * DE + c) + ld4(PART + (8 + h) * DE + c)) + (ld4(PART + (16 + h) * DE + c) + ld4(PART + (24 + h) * DE + c));
+    *(f32x4_t*)(out + h * DLD + c) = v;
+    if (out_g) *(f32x4_t*)(out_g + (long)h * DE + c) = v;
   }
 }
 
@@ -173,7 +446,11 @@ struct DecAttnArgs {
 };
 
 // LDS map (floats): T, QP, X1 [16][DLD] each, then BIG: { qkv [16][3E+4] + self-attention scores } | { chunk buffers }
-constexpr int L_T = 0, L_QP = 16 * DLD, L_X1 = 2 * 16 * DLD, L_BIG = 3 * 16 * DLD;
+// PAR: the layer's biases and LayerNorm parameters + the sample's key mask and sum(P') -- staged ONCE: a global load inside a
+// streaming loop (a bias in a tile's epilogue) makes the in-order vmcnt wait drain every weight load in flight behind it
+constexpr int P_BS = 0, P_BSO = 3 * DE, P_BC = 4 * DE, P_BCO = 7 * DE, P_G0 = 8 * DE, P_B0 = 9 * DE, P_G1 = 10 * DE, P_B1 = 11 * DE,
+              P_SP = 12 * DE, P_KPM = 12 * DE + 16 * DH, P_END = P_KPM + 1024 / 4;
+constexpr int L_T = 0, L_QP = 16 * DLD, L_X1 = 2 * 16 * DLD, L_PAR = 3 * 16 * DLD, L_BIG = L_PAR + P_END;
 constexpr int QKV_LD = 3 * DE + 4;
 constexpr int CR = 32;                // (query, head) rows per cross-attention chunk: 4 queries x 8 heads
 __host__ __device__ constexpr int lkp_of(int Lk) { return ((Lk + 15) & ~15) + 4; }
@@ -183,15 +460,46 @@ __host__ __device__ constexpr int dec_attn_fwd_lds_floats(int Lk) {
   return L_BIG + (a > b ? a : b);
 }
 
+template <int RR, bool S16>
 __global__ __launch_bounds__(DNT) void dec_attn_fwd_kernel(DecAttnArgs a) {
+  constexpr int UW = RR ? 16 : 8;     // 16-byte loads of W in flight per lane in the weight phases
   extern __shared__ float sm[];
   float* T = sm + L_T;
   float* QP = sm + L_QP;
   float* X1 = sm + L_X1;
+  float* PAR = sm + L_PAR;
+  float* SPL = PAR + P_SP;                        // [16][H] sum_k P'
+  unsigned char* KPM = (unsigned char*)(PAR + P_KPM);
   float* BIG = sm + L_BIG;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
   const int R = a.R;
   const long row0 = (long)b * R;
+  const int Lk = a.Lk, LKP = lkp_of(Lk);
+  const int ktiles = (Lk + 15) >> 4;
+  SrcRows<S16> src;
+  src.s16 = a.src16 ? a.src16 + ((long)b * a.kv_rows + a.kv_off) * a.ldsrc : nullptr;
+  src.s32 = a.src32 ? a.src32 + ((long)b * a.kv_rows + a.kv_off) * a.ldsrc : nullptr;
+  src.ld = a.ldsrc;
+  src.kpos = a.kpos + (long)b * a.kpos_rows * a.ldkp;
+  src.ldkp = a.ldkp;
+  // the B-fragment loaders of every phase (each phase's first loads are issued before the previous phase's barrier)
+  auto tile_row = [&](int t) { return 16 * (wave + DNW * t) + j; };
+  auto bl_s = [&](int t, int k) { return ld4(a.Ws + (long)tile_row(t) * DE + k + 4 * g); };
+  auto bl_so = [&](int t, int k) { return ld4(a.Wso + (long)tile_row(t) * DE + k + 4 * g); };
+  auto bl_q = [&](int t, int k) { return ld4(a.Wc + (long)tile_row(t) * DE + k + 4 * g); };
+  const float* Wk_h = a.Wc + (long)(DE + wave * DHD) * DE;         // phase 5: wave = head
+  auto bl_k = [&](int n, int cg) { return ld4(Wk_h + (long)n * DE + 64 * cg + 4 * j); };
+  auto bl_v = [&](int t, int k) { return ld4(a.Wc + (long)(2 * DE + tile_row(t)) * DE + k + 4 * g); };
+  auto bl_co = [&](int t, int k) { return ld4(a.Wco + (long)tile_row(t) * DE + k + 4 * g); };
+  const int key_mine = (ktiles - wave + DNW - 1) / DNW;
+  auto bl_key = [&](int t, int k) { return src.key(min(tile_row(t), Lk - 1), k + 4 * g); };
+  const int ccg = wave & 3, chalf = wave >> 2;
+  const int kmid = ((ktiles + 1) >> 1) << 4;
+  const int cb = chalf ? kmid : 0, ce = chalf ? (ktiles << 4) : kmid;
+  auto bl_val = [&](int n, int) { return src.val(min(n, Lk - 1), 64 * ccg + 4 * j); };     // (rows past Lk meet zero probabilities)
+  f32x4_t pf_s[UW];
+  TL(0);
+  stream_nt_prefetch<16, UW>(6, bl_s, pf_s);
   // ---- 0: the sample's rows (rows >= R of the 16-row tiles are zero and stay zero)
   for (int e = tid; e < 16 * (DE / 4); e += DNT) {
     const int r = e / (DE / 4), c = 4 * (e % (DE / 4));
@@ -201,15 +509,20 @@ __global__ __launch_bounds__(DNT) void dec_attn_fwd_kernel(DecAttnArgs a) {
     *(f32x4_t*)(QP + r * DLD + c) = q;
     *(f32x4_t*)(X1 + r * DLD + c) = t + q;
   }
-  __syncthreads();
+  for (int e = tid; e < 3 * DE; e += DNT) { PAR[P_BS + e] = a.bs[e]; PAR[P_BC + e] = a.bc[e]; }
+  for (int e = tid; e < DE; e += DNT) {
+    PAR[P_BSO + e] = a.bso[e]; PAR[P_BCO + e] = a.bco[e];
+    PAR[P_G0 + e] = a.g0[e]; PAR[P_B0 + e] = a.b0[e]; PAR[P_G1 + e] = a.g1[e]; PAR[P_B1 + e] = a.b1[e];
+  }
+  for (int e = tid; e < Lk; e += DNT) KPM[e] = a.kpm ? a.kpm[(long)b * Lk + e] : 0;
+  __syncthreads(); TL(1);
   // ---- 1: self-attention in-projection: q | k from tgt + qpos, v from tgt (48 column tiles, 6 per wave)
   float* QKV = BIG;
   {
-    auto bload = [&](int t, int k) { return ld4(a.Ws + (long)(16 * (wave + DNW * t) + j) * DE + k + 4 * g); };
-    auto aload = [&](int t, int k, int) { return ld4(((wave + DNW * t) < 32 ? X1 : T) + j * DLD + k + 4 * g); };
+    auto aload = [&](int t, int k, int row) { return ld4(((wave + DNW * t) < 32 ? X1 : T) + row * DLD + k + 4 * g); };
     auto epi = [&](int t, int, f32x4_t acc) {
-      const int n = 16 * (wave + DNW * t) + j;
-      const float bias = a.bs[n];
+      const int n = tile_row(t);
+      const float bias = PAR[P_BS + n];
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int r = 4 * g + v;
@@ -218,9 +531,20 @@ __global__ __launch_bounds__(DNT) void dec_attn_fwd_kernel(DecAttnArgs a) {
         if (r < R) a.qkv[(row0 + r) * (3 * DE) + n] = y;
       }
     };
-    stream_nt<16, 1, 8>(6, bload, aload, epi);
+    if constexpr (RR == 1) {
+      // one query: the softmax over its single key is 1 whatever q and k are -- only v = tgt Wv^T + bv reaches the output, and
+      // q, k get no gradient (dS = 0): their projections (2/3 of this weight) are not computed; the saved q | k are zeros
+      (void)pf_s;
+      for (int e = tid; e < 2 * DE; e += DNT) { QKV[e] = 0.f; a.qkv[row0 * (3 * DE) + e] = 0.f; }
+      gemv256<DNW, 8>(a.Ws + (long)2 * DE * DE, DE, DE, [&](int) { return T; },
+                      [&](int n, float y) { y += PAR[P_BS + 2 * DE + n]; QKV[2 * DE + n] = y; a.qkv[row0 * (3 * DE) + 2 * DE + n] = y; });
+    } else {
+      stream_nt<16, 1, UW, RR>(6, bl_s, aload, epi, pf_s);
+    }
   }
-  __syncthreads();
+  f32x4_t pf_so[UW];
+  stream_nt_prefetch<16, UW>(2, bl_so, pf_so);
+  __syncthreads(); TL(2);
   // ---- 2: self-attention over the sample's R queries (8 heads x 32): scores, softmax, dropout, P V
   float* S0 = BIG + 16 * QKV_LD;                  // [H][16][16]
   {
@@ -234,7 +558,7 @@ __global__ __launch_bounds__(DNT) void dec_attn_fwd_kernel(DecAttnArgs a) {
       for (int d = 0; d < DHD; ++d) s = fmaf(q[d], k[d], s);
       S0[(h * 16 + r) * 16 + r2] = s * scale;
     }
-    __syncthreads();
+    __syncthreads(); TL(3);
     for (int e = tid; e < DH * R; e += DNT) {
       const int h = e / R, r = e % R;
       float* s = S0 + (h * 16 + r) * 16;
@@ -250,7 +574,7 @@ __global__ __launch_bounds__(DNT) void dec_attn_fwd_kernel(DecAttnArgs a) {
         s[i] = a.dm0 ? p * a.dm0[pg + i] : p;
       }
     }
-    __syncthreads();
+    __syncthreads(); TL(4);
     for (int e = tid; e < R * DE; e += DNT) {
       const int r = e / DE, n = e % DE, h = n / DHD;
       const float* p = S0 + (h * 16 + r) * 16;
@@ -260,15 +584,14 @@ __global__ __launch_bounds__(DNT) void dec_attn_fwd_kernel(DecAttnArgs a) {
       a.o[(row0 + r) * DE + n] = o;
     }
   }
-  __syncthreads();
+  __syncthreads(); TL(5);
   // ---- 3: r1 = tgt + o Wso^T + bso ; t1 = LayerNorm(r1)
   float* R1 = BIG;                                // qkv is dead
   {
-    auto bload = [&](int t, int k) { return ld4(a.Wso + (long)(16 * (wave + DNW * t) + j) * DE + k + 4 * g); };
-    auto aload = [&](int, int k, int) { return ld4(X1 + j * DLD + k + 4 * g); };
+    auto aload = [&](int, int k, int row) { return ld4(X1 + row * DLD + k + 4 * g); };
     auto epi = [&](int t, int, f32x4_t acc) {
-      const int n = 16 * (wave + DNW * t) + j;
-      const float bias = a.bso[n];
+      const int n = tile_row(t);
+      const float bias = PAR[P_BSO + n];
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int r = 4 * g + v;
@@ -277,11 +600,13 @@ __global__ __launch_bounds__(DNT) void dec_attn_fwd_kernel(DecAttnArgs a) {
         if (r < R) a.r1[(row0 + r) * DE + n] = y;
       }
     };
-    stream_nt<16, 1, 8>(2, bload, aload, epi);
+    stream_nt<16, 1, UW, RR>(2, bl_so, aload, epi, pf_so);
   }
-  __syncthreads();
-  ln_rows(R1, X1, R, a.g0, a.b0, a.eps, a.t1 + row0 * DE, a.mean1 + row0, a.rstd1 + row0);      // X1 = t1
-  __syncthreads();
+  f32x4_t pf_q[UW];
+  stream_nt_prefetch<16, UW>(2, bl_q, pf_q);
+  __syncthreads(); TL(6);
+  ln_rows(R1, X1, R, PAR + P_G0, PAR + P_B0, a.eps, a.t1 + row0 * DE, a.mean1 + row0, a.rstd1 + row0);      // X1 = t1
+  __syncthreads(); TL(7);
   // ---- 4: cross-attention query: qc = ((t1 + qpos) Wq^T + bq) * 32^-1/2
   float* XQ = BIG;                                 // [16][DLD]
   float* QC = BIG + 16 * DLD;                      // [16][DLD]
@@ -289,13 +614,12 @@ __global__ __launch_bounds__(DNT) void dec_attn_fwd_kernel(DecAttnArgs a) {
     const int r = e / (DE / 4), c = 4 * (e % (DE / 4));
     *(f32x4_t*)(XQ + r * DLD + c) = ld4(X1 + r * DLD + c) + ld4(QP + r * DLD + c);
   }
-  __syncthreads();
+  __syncthreads(); TL(8);
   {
-    auto bload = [&](int t, int k) { return ld4(a.Wc + (long)(16 * (wave + DNW * t) + j) * DE + k + 4 * g); };
-    auto aload = [&](int, int k, int) { return ld4(XQ + j * DLD + k + 4 * g); };
+    auto aload = [&](int, int k, int row) { return ld4(XQ + row * DLD + k + 4 * g); };
     auto epi = [&](int t, int, f32x4_t acc) {
-      const int n = 16 * (wave + DNW * t) + j;
-      const float bias = a.bc[n];
+      const int n = tile_row(t);
+      const float bias = PAR[P_BC + n];
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int r = 4 * g + v;
@@ -304,9 +628,11 @@ __global__ __launch_bounds__(DNT) void dec_attn_fwd_kernel(DecAttnArgs a) {
         if (r < R) a.qc[(row0 + r) * DE + n] = y;
       }
     };
-    stream_nt<16, 1, 8>(2, bload, aload, epi);
+    stream_nt<16, 1, UW, RR>(2, bl_q, aload, epi, pf_q);
   }
-  __syncthreads();
+  f32x4_t pf_k[4][4];
+  stream_nn_prefetch<4, 4>(0, DHD, bl_k, pf_k);
+  __syncthreads(); TL(9);
   // ---- 5: qk[r][h][:] = Wk_h^T qc_h[r]  (wave = head: 32 rows of Wk, all 256 columns) -> global [B*R, H, E]
   {
     const int h = wave;
@@ -315,55 +641,87 @@ __global__ __launch_bounds__(DNT) void dec_attn_fwd_kernel(DecAttnArgs a) {
     for (int cg = 0; cg < 4; ++cg)
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc[0][cg][c] = f4zero();
-    const float* Wk = a.Wc + (long)(DE + h * DHD) * DE;
-    auto bload = [&](int n, int cg) { return ld4(Wk + (long)n * DE + 64 * cg + 4 * j); };
-    auto aload = [&](int n, int) { return QC[j * DLD + h * DHD + n]; };
-    stream_nn<1, 4, 4>(0, DHD, bload, aload, acc);
+    auto aload = [&](int n, int row) { return QC[row * DLD + h * DHD + n]; };
+    stream_nn<1, 4, 4, RR>(0, DHD, bl_k, aload, acc, pf_k);
 #pragma unroll
     for (int cg = 0; cg < 4; ++cg)
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int r = 4 * g + v;
-        if (r < R)
-          *(f32x4_t*)(a.qk + ((row0 + r) * DH + h) * DE + 64 * cg + 4 * j) =
-              (f32x4_t){acc[0][cg][0][v], acc[0][cg][1][v], acc[0][cg][2][v], acc[0][cg][3][v]};
+        if (r < R) {
+          const f32x4_t o = (f32x4_t){acc[0][cg][0][v], acc[0][cg][1][v], acc[0][cg][2][v], acc[0][cg][3][v]};
+          *(f32x4_t*)(a.qk + ((row0 + r) * DH + h) * DE + 64 * cg + 4 * j) = o;
+          if constexpr (RR == 1) *(f32x4_t*)(BIG + h * DLD + 64 * cg + 4 * j) = o;      // one query: its 8 (query, head) rows straight into the chunk tile
+        }
       }
   }
-  __syncthreads();            // (also orders the qk stores before the chunk loop's loads: same workgroup, write-through L1)
-  // ---- 6: cross-attention over the source rows, 4 queries (32 (query, head) rows) at a time
-  const int Lk = a.Lk, LKP = lkp_of(Lk);
-  float* QKC = BIG;                                // [CR][DLD]
-  float* SC = BIG + CR * DLD;                      // [CR][LKP]
-  SrcRows src;
-  src.s16 = a.src16 ? a.src16 + ((long)b * a.kv_rows + a.kv_off) * a.ldsrc : nullptr;
-  src.s32 = a.src32 ? a.src32 + ((long)b * a.kv_rows + a.kv_off) * a.ldsrc : nullptr;
-  src.ld = a.ldsrc;
-  src.kpos = a.kpos ? a.kpos + (long)b * a.kpos_rows * a.ldkp : nullptr;
-  src.ldkp = a.ldkp;
-  const int ktiles = (Lk + 15) >> 4;
-  for (int q0 = 0; q0 < R; q0 += 4) {
-    const int nrho = min(4, R - q0) * DH;          // valid (query, head) rows of this chunk: rho = (r - q0) * H + h
-    for (int e = tid; e < CR * (DE / 4); e += DNT) {
-      const int rho = e / (DE / 4), c = 4 * (e % (DE / 4));
-      *(f32x4_t*)(QKC + rho * DLD + c) = rho < nrho ? ld4(a.qk + ((row0 + q0) * DH + rho) * DE + c) : f4zero();
+  f32x4_t pf_key[8];
+  if constexpr (RR == 0) stream_nt_prefetch<16, 8>(key_mine, bl_key, pf_key);
+  __syncthreads(); TL(10);            // (also orders the qk stores before the chunk loop's loads: same workgroup, write-through L1)
+  // ---- 6 (one query): scores, softmax, context on the VALU with whole-row loads
+  f32x4_t pf_v[UW];
+  float* QKC = BIG;                                // [CR][DLD]   (one query: rows 0 .. 7 = the heads' qk, written by phase 5)
+  float* SC = BIG + (RR == 1 ? 8 : CR) * DLD;      // [CR][LKP]   (one query: [8][LKP], then P' transposed and the waves' partial sums)
+  if constexpr (RR == 1) {
+    float* PT = SC + 8 * LKP;                      // [Lk][8]  P' transposed
+    float* PARTS = PT + 8 * LKP;                   // [4][8][256]
+    rowdot8<S16, true, 6>(src, QKC, Lk, [&](int h, int kk, float v) { SC[h * LKP + kk] = KPM[kk] ? -INFINITY : v; });
+    stream_nt_prefetch<16, UW>(2, bl_v, pf_v);
+    __syncthreads();
+    {
+      const int h = wave;                          // 8 waves = 8 heads
+      float* sr = SC + h * LKP;
+      float mx = -INFINITY;
+      for (int kk = lane; kk < Lk; kk += 64) mx = fmaxf(mx, sr[kk]);
+      mx = wave_max(mx);
+      float sum = 0.f;
+      for (int kk = lane; kk < Lk; kk += 64) { const float p = expf(sr[kk] - mx); sr[kk] = p; sum += p; }
+      sum = wave_sum(sum);
+      const float inv = 1.f / sum;
+      const long pg = ((long)b * DH + h) * Lk;
+      float sp = 0.f;
+      for (int kk = lane; kk < Lk; kk += 64) {
+        const float p = sr[kk] * inv;
+        a.P1[pg + kk] = p;
+        const float pd = a.dm1 ? p * a.dm1[pg + kk] : p;
+        PT[kk * 8 + h] = pd;
+        sp += pd;
+      }
+      sp = wave_sum(sp);
+      if (lane == 0) { a.sp[row0 * DH + h] = sp; SPL[h] = sp; }
     }
     __syncthreads();
+    f32x4_t cacc[8];
+#pragma unroll
+    for (int h = 0; h < 8; ++h) cacc[h] = f4zero();
+    rowacc8<S16, false, 16>(src, PT, Lk, cacc);
+    rowacc8_combine(cacc, PARTS, SC, a.ctx + row0 * DH * DE);          // ctx rows: LDS (SC rows 0 .. 7, stride DLD) + global
+    __syncthreads();
+  } else {
+  for (int q0 = 0; q0 < R; q0 += 4) {
+    const int nrho = min(4, R - q0) * DH;          // valid (query, head) rows of this chunk: rho = (r - q0) * H + h
+    if constexpr (RR == 0) {
+      for (int e = tid; e < CR * (DE / 4); e += DNT) {
+        const int rho = e / (DE / 4), c = 4 * (e % (DE / 4));
+        *(f32x4_t*)(QKC + rho * DLD + c) = rho < nrho ? ld4(a.qk + ((row0 + q0) * DH + rho) * DE + c) : f4zero();
+      }
+      __syncthreads();
+    } TL(11);
     // scores[rho][kk] = qk[rho] . key[kk]: key tiles round-robin over the waves
     {
-      const int mine = (ktiles - wave + DNW - 1) / DNW;
-      auto krow = [&](int t) { return min(16 * (wave + DNW * t) + j, Lk - 1); };
-      auto bload = [&](int t, int k) { return src.key(krow(t), k + 4 * g); };
-      auto aload = [&](int, int k, int rt) { return ld4(QKC + (16 * rt + j) * DLD + k + 4 * g); };
+      auto aload = [&](int, int k, int row) { return ld4(QKC + row * DLD + k + 4 * g); };
       auto epi = [&](int t, int rt, f32x4_t acc) {
-        const int kk = 16 * (wave + DNW * t) + j;
-        const bool dead = kk >= Lk || (a.kpm && a.kpm[(long)b * Lk + kk]);
+        const int kk = tile_row(t);
+        const bool dead = kk >= Lk || KPM[kk];
 #pragma unroll
         for (int v = 0; v < 4; ++v) SC[(16 * rt + 4 * g + v) * LKP + kk] = dead ? -INFINITY : acc[v];
       };
-      if (nrho > 16) stream_nt<16, 2, 8>(mine, bload, aload, epi);
-      else stream_nt<16, 1, 8>(mine, bload, aload, epi);
+      if (nrho > 16) stream_nt<16, 2, 8, 0>(key_mine, bl_key, aload, epi, pf_key);
+      else stream_nt<16, 1, 8, 0>(key_mine, bl_key, aload, epi, pf_key);
     }
-    __syncthreads();
+    f32x4_t pf_val[8][1];
+    stream_nn_prefetch<1, 8>(cb, ce, bl_val, pf_val);
+    __syncthreads(); TL(12);
     // softmax per (query, head) row; P1 to global, P' = P * dropout in place, sp = sum P'
     for (int rho = wave; rho < nrho; rho += DNW) {
       float* s = SC + rho * LKP;
@@ -386,35 +744,34 @@ __global__ __launch_bounds__(DNT) void dec_attn_fwd_kernel(DecAttnArgs a) {
       }
       for (int kk = Lk + lane; kk < LKP - 4; kk += 64) s[kk] = 0.f;        // the padding keys of the last tile
       sp = wave_sum(sp);
-      if (lane == 0) a.sp[(row0 + r) * DH + h] = sp;
+      if (lane == 0) { a.sp[(row0 + r) * DH + h] = sp; SPL[r * DH + h] = sp; }
     }
     for (int rho = nrho + wave; rho < CR; rho += DNW)                       // rows without a query: zero probabilities
       for (int kk = lane; kk < LKP - 4; kk += 64) SC[rho * LKP + kk] = 0.f;
-    __syncthreads();
+    __syncthreads(); TL(13);
     // ctx[rho][c] = sum_kk P'[rho][kk] val[kk][c]: wave = (64-column group, key half); the halves meet in LDS
     {
-      const int cg = wave & 3, half = wave >> 2;
-      const int kmid = ((ktiles + 1) >> 1) << 4;
-      const int kb = half ? kmid : 0, ke = half ? (ktiles << 4) : kmid;
       f32x4_t acc[2][1][4];
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[rt][0][c] = f4zero();
-      auto bload = [&](int n, int) { return n < Lk ? src.val(n, 64 * cg + 4 * j) : f4zero(); };
-      auto aload = [&](int n, int rt) { return SC[(16 * rt + j) * LKP + n]; };
-      stream_nn<2, 1, 8>(kb, ke, bload, aload, acc);
+      auto aload = [&](int n, int row) { return SC[row * LKP + n]; };
+      if (nrho > 16) stream_nn<2, 1, 8, 0>(cb, ce, bl_val, aload, acc, pf_val);
+      else stream_nn<1, 1, 8, 0>(cb, ce, bl_val, aload, reinterpret_cast<f32x4_t (&)[1][1][4]>(acc), pf_val);
+      if (q0 + 4 < R) stream_nt_prefetch<16, 8>(key_mine, bl_key, pf_key);       // the next chunk's first keys
+      else stream_nt_prefetch<16, UW>(2, bl_v, pf_v);                            // or the first rows of Wv
       float* PART = QKC;                            // the qk chunk is dead: the second half's partial sums go here
-      if (half) {
+      if (chalf) {
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
           for (int v = 0; v < 4; ++v)
-            *(f32x4_t*)(PART + (16 * rt + 4 * g + v) * DLD + 64 * cg + 4 * j) =
+            *(f32x4_t*)(PART + (16 * rt + 4 * g + v) * DLD + 64 * ccg + 4 * j) =
                 (f32x4_t){acc[rt][0][0][v], acc[rt][0][1][v], acc[rt][0][2][v], acc[rt][0][3][v]};
       }
-      __syncthreads();
-      if (!half) {
+      __syncthreads(); TL(14);
+      if (!chalf) {
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -422,45 +779,47 @@ __global__ __launch_bounds__(DNT) void dec_attn_fwd_kernel(DecAttnArgs a) {
             const int rho = 16 * rt + 4 * g + v;
             if (rho < nrho) {
               const f32x4_t o = (f32x4_t){acc[rt][0][0][v], acc[rt][0][1][v], acc[rt][0][2][v], acc[rt][0][3][v]} +
-                                ld4(PART + rho * DLD + 64 * cg + 4 * j);
-              *(f32x4_t*)(a.ctx + ((row0 + q0) * DH + rho) * DE + 64 * cg + 4 * j) = o;
+                                ld4(PART + rho * DLD + 64 * ccg + 4 * j);
+              *(f32x4_t*)(a.ctx + ((row0 + q0) * DH + rho) * DE + 64 * ccg + 4 * j) = o;
+              if constexpr (RR == 1) *(f32x4_t*)(SC + rho * DLD + 64 * ccg + 4 * j) = o;     // (the score strip is dead: ctx rows for phase 7)
             }
           }
       }
     }
-    __syncthreads();
+    __syncthreads(); TL(15);
+  }
   }
   // ---- 7: o2[r][h*32+d] = Wv_h ctx[r][h] + bv * sp[r][h]   (A fragments straight from the ctx rows this workgroup just wrote)
-  float* O2 = BIG;                                  // [16][DLD]
+  float* O2 = T;                                    // [16][DLD]  (tgt is dead since phase 3; BIG still holds the ctx rows of a single query)
+  f32x4_t pf_co[UW];
   {
-    const float* Wv = a.Wc + (long)2 * DE * DE;
-    auto bload = [&](int t, int k) { return ld4(Wv + (long)(16 * (wave + DNW * t) + j) * DE + k + 4 * g); };
-    auto aload = [&](int t, int k, int) {
+    auto aload = [&](int t, int k, int row) {
       const int h = (wave + DNW * t) >> 1;          // two 16-column tiles per head
-      return j < R ? ld4(a.ctx + ((row0 + j) * DH + h) * DE + k + 4 * g) : f4zero();
+      if constexpr (RR == 1) return ld4(SC + h * DLD + k + 4 * g);
+      else return row < R ? ld4(a.ctx + ((row0 + row) * DH + h) * DE + k + 4 * g) : f4zero();
     };
     auto epi = [&](int t, int, f32x4_t acc) {
-      const int n = 16 * (wave + DNW * t) + j, h = n / DHD;
-      const float bias = a.bc[2 * DE + n];
+      const int n = tile_row(t), h = n / DHD;
+      const float bias = PAR[P_BC + 2 * DE + n];
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int r = 4 * g + v;
-        const float y = r < R ? acc[v] + bias * a.sp[(row0 + r) * DH + h] : 0.f;
+        const float y = r < R ? acc[v] + bias * SPL[r * DH + h] : 0.f;
         O2[r * DLD + n] = y;
         if (r < R) a.o2[(row0 + r) * DE + n] = y;
       }
     };
-    stream_nt<16, 1, 8>(2, bload, aload, epi);
+    stream_nt<16, 1, UW, RR>(2, bl_v, aload, epi, pf_v);
+    stream_nt_prefetch<16, UW>(2, bl_co, pf_co);
   }
-  __syncthreads();
+  __syncthreads(); TL(16);
   // ---- 8: r2 = t1 + o2 Wco^T + bco ; t2 = LayerNorm(r2)
   float* R2 = BIG + 16 * DLD;
   {
-    auto bload = [&](int t, int k) { return ld4(a.Wco + (long)(16 * (wave + DNW * t) + j) * DE + k + 4 * g); };
-    auto aload = [&](int, int k, int) { return ld4(O2 + j * DLD + k + 4 * g); };
+    auto aload = [&](int, int k, int row) { return ld4(O2 + row * DLD + k + 4 * g); };
     auto epi = [&](int t, int, f32x4_t acc) {
-      const int n = 16 * (wave + DNW * t) + j;
-      const float bias = a.bco[n];
+      const int n = tile_row(t);
+      const float bias = PAR[P_BCO + n];
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int r = 4 * g + v;
@@ -469,12 +828,12 @@ __global__ __launch_bounds__(DNT) void dec_attn_fwd_kernel(DecAttnArgs a) {
         if (r < R) a.r2[(row0 + r) * DE + n] = y;
       }
     };
-    stream_nt<16, 1, 8>(2, bload, aload, epi);
+    stream_nt<16, 1, UW, RR>(2, bl_co, aload, epi, pf_co);
   }
-  __syncthreads();
-  ln_rows(R2, T, R, a.g1, a.b1, a.eps, a.t2 + row0 * DE, a.mean2 + row0, a.rstd2 + row0);
+  __syncthreads(); TL(17);
+  ln_rows(R2, T, R, PAR + P_G1, PAR + P_B1, a.eps, a.t2 + row0 * DE, a.mean2 + row0, a.rstd2 + row0);
+  TL(40);
 }
-
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Backward of the attention block: the same workgroup-per-sample walk in reverse.  It produces the gradients that stay
@@ -507,7 +866,7 @@ __host__ __device__ constexpr int dec_attn_bwd_lds_floats(int Lk) {
 
 // out[r][c] = sum_{n < N} D(r, n) W[n][c] for the 256 output columns: wave = (64-column group, half of the contraction range);
 // the second half's partial sums meet the first's through TMP ([16][DLD]); epi(r, c, f32x4 of columns c .. c+3) for rows < 16
-template <class ALoad, class Epi>
+template <int RR, class ALoad, class Epi>
 __device__ __forceinline__ void dgrad256(const float* W, long ldw, int N, ALoad aload, float* TMP, Epi epi) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
   const int cg = wave & 3, half = wave >> 2;
@@ -515,9 +874,9 @@ __device__ __forceinline__ void dgrad256(const float* W, long ldw, int N, ALoad 
   f32x4_t acc[1][1][4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) acc[0][0][c] = f4zero();
-  auto bload = [&](int n, int) { return n < N ? ld4(W + (long)n * ldw + 64 * cg + 4 * j) : f4zero(); };
-  auto al = [&](int n, int) { return n < N ? aload(j, n) : 0.f; };
-  stream_nn<1, 1, 8>(half ? mid : 0, half ? N : mid, bload, al, acc);
+  auto bload = [&](int n, int) { return ld4(W + (long)min(n, N - 1) * ldw + 64 * cg + 4 * j); };
+  auto al = [&](int n, int row) { return n < N ? aload(row, n) : 0.f; };
+  stream_nn<1, 1, RR ? 16 : 8, RR>(half ? mid : 0, half ? N : mid, bload, al, acc);
   if (half) {
 #pragma unroll
     for (int v = 0; v < 4; ++v)
@@ -553,7 +912,9 @@ __device__ __forceinline__ void ln_bwd_rows(float* DY, int R, const float* x_g, 
   }
 }
 
+template <int RR, bool S16>
 __global__ __launch_bounds__(DNT) void dec_attn_bwd_kernel(DecAttnBwdArgs a) {
+  constexpr int UW = RR ? 16 : 8;
   extern __shared__ float sm[];
   float* A0 = sm + LB_A0;
   float* A1 = sm + LB_A1;
@@ -582,7 +943,7 @@ __global__ __launch_bounds__(DNT) void dec_attn_bwd_kernel(DecAttnBwdArgs a) {
   ln_bwd_rows(A1, R, a.r2 + row0 * DE, a.mean2 + row0, a.rstd2 + row0, a.g1, a.d_r2 + row0 * DE, a.gx2 + row0 * DE, a.dt2sum + row0 * DE);
   __syncthreads();                                 // A1 = d(r2)
   // ---- B2: d(o2) = d(r2) Wco
-  dgrad256(a.Wco, DE, DE, [&](int r, int n) { return A1[r * DLD + n]; }, BIG, [&](int r, int c, f32x4_t v) {
+  dgrad256<RR>(a.Wco, DE, DE, [&](int r, int n) { return A1[r * DLD + n]; }, BIG, [&](int r, int c, f32x4_t v) {
     *(f32x4_t*)(A3 + r * DLD + c) = v;
     if (r < R) *(f32x4_t*)(a.d_o2 + (row0 + r) * DE + c) = v;
   });
@@ -597,16 +958,18 @@ __global__ __launch_bounds__(DNT) void dec_attn_bwd_kernel(DecAttnBwdArgs a) {
       for (int c = 0; c < 4; ++c) acc[0][cg][c] = f4zero();
     const float* Wv = a.Wc + (long)(2 * DE + h * DHD) * DE;
     auto bload = [&](int n, int cg) { return ld4(Wv + (long)n * DE + 64 * cg + 4 * j); };
-    auto aload = [&](int n, int) { return A3[j * DLD + h * DHD + n]; };
-    stream_nn<1, 4, 4>(0, DHD, bload, aload, acc);
+    auto aload = [&](int n, int row) { return A3[row * DLD + h * DHD + n]; };
+    stream_nn<1, 4, 4, RR>(0, DHD, bload, aload, acc);
 #pragma unroll
     for (int cg = 0; cg < 4; ++cg)
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int r = 4 * g + v;
-        if (r < R)
-          *(f32x4_t*)(a.dctx + ((row0 + r) * DH + h) * DE + 64 * cg + 4 * j) =
-              (f32x4_t){acc[0][cg][0][v], acc[0][cg][1][v], acc[0][cg][2][v], acc[0][cg][3][v]};
+        if (r < R) {
+          const f32x4_t o = (f32x4_t){acc[0][cg][0][v], acc[0][cg][1][v], acc[0][cg][2][v], acc[0][cg][3][v]};
+          *(f32x4_t*)(a.dctx + ((row0 + r) * DH + h) * DE + 64 * cg + 4 * j) = o;
+          if constexpr (RR == 1) *(f32x4_t*)(BIG + h * DLD + 64 * cg + 4 * j) = o;      // one query: straight into the chunk tile (DCX)
+        }
       }
     if (tid < 16 * DH) {
       const int r = tid / DH, hh = tid % DH;
@@ -622,11 +985,11 @@ __global__ __launch_bounds__(DNT) void dec_attn_bwd_kernel(DecAttnBwdArgs a) {
   float* QKC = BIG + CRB * DLD;                    // [CRB][DLD]  qk chunk
   float* DS = BIG + 2 * CRB * DLD;                 // [CRB][LKP]  d(P') then dS
   float* PP = DS + CRB * LKP;                      // [CRB][LKP]  P'
-  SrcRows src;
+  SrcRows<S16> src;
   src.s16 = a.src16 ? a.src16 + ((long)b * a.kv_rows + a.kv_off) * a.ldsrc : nullptr;
   src.s32 = a.src32 ? a.src32 + ((long)b * a.kv_rows + a.kv_off) * a.ldsrc : nullptr;
   src.ld = a.ldsrc;
-  src.kpos = a.kpos ? a.kpos + (long)b * a.kpos_rows * a.ldkp : nullptr;
+  src.kpos = a.kpos + (long)b * a.kpos_rows * a.ldkp;
   src.ldkp = a.ldkp;
   const int ktiles = (Lk + 15) >> 4;
   float* dsrc_b = a.dsrc ? a.dsrc + ((long)b * a.kv_rows + a.kv_off) * a.lddsrc : nullptr;
@@ -643,7 +1006,7 @@ __global__ __launch_bounds__(DNT) void dec_attn_bwd_kernel(DecAttnBwdArgs a) {
     for (int e = tid; e < CRB * (DE / 4); e += DNT) {
       const int rho = e / (DE / 4), c = 4 * (e % (DE / 4));
       const bool ok = rho < nrho;
-      *(f32x4_t*)(DCX + rho * DLD + c) = ok ? ld4(a.dctx + ((row0 + q0) * DH + rho) * DE + c) : f4zero();
+      if (RR == 0 || !ok) *(f32x4_t*)(DCX + rho * DLD + c) = ok ? ld4(a.dctx + ((row0 + q0) * DH + rho) * DE + c) : f4zero();
       *(f32x4_t*)(QKC + rho * DLD + c) = ok ? ld4(a.qk + ((row0 + q0) * DH + rho) * DE + c) : f4zero();
     }
     __syncthreads();
@@ -652,7 +1015,7 @@ __global__ __launch_bounds__(DNT) void dec_attn_bwd_kernel(DecAttnBwdArgs a) {
       const int mine = (ktiles - wave + DNW - 1) / DNW;
       auto krow = [&](int t) { return min(16 * (wave + DNW * t) + j, Lk - 1); };
       auto bload = [&](int t, int k) { return src.val(krow(t), k + 4 * g); };
-      auto aload = [&](int, int k, int) { return ld4(DCX + j * DLD + k + 4 * g); };
+      auto aload = [&](int, int k, int row) { return ld4(DCX + row * DLD + k + 4 * g); };
       auto epi = [&](int t, int, f32x4_t acc) {
         const int kk = 16 * (wave + DNW * t) + j;
 #pragma unroll
@@ -661,7 +1024,7 @@ __global__ __launch_bounds__(DNT) void dec_attn_bwd_kernel(DecAttnBwdArgs a) {
           DS[rho * LKP + kk] = acc[v] + DSP[(q0 + rho / DH) * DH + rho % DH];      // (rows without a query are zeroed below)
         }
       };
-      stream_nt<16, 1, 8>(mine, bload, aload, epi);
+      stream_nt<16, 1, 8, 0>(mine, bload, aload, epi);
     }
     __syncthreads();
     for (int rho = wave; rho < CRB; rho += DNW) {
@@ -697,9 +1060,9 @@ __global__ __launch_bounds__(DNT) void dec_attn_bwd_kernel(DecAttnBwdArgs a) {
       f32x4_t acc[1][1][4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc[0][0][c] = f4zero();
-      auto bload = [&](int n, int) { return n < Lk ? src.key(n, 64 * cg + 4 * j) : f4zero(); };
-      auto aload = [&](int n, int) { return DS[j * LKP + n]; };
-      stream_nn<1, 1, 8>(half ? kmid : 0, half ? (ktiles << 4) : kmid, bload, aload, acc);
+      auto bload = [&](int n, int) { return src.key(min(n, Lk - 1), 64 * cg + 4 * j); };
+      auto aload = [&](int n, int row) { return DS[row * LKP + n]; };
+      stream_nn<1, 1, 8, 0>(half ? kmid : 0, half ? (ktiles << 4) : kmid, bload, aload, acc);
       if (half) {
 #pragma unroll
         for (int v = 0; v < 4; ++v)
@@ -710,9 +1073,11 @@ __global__ __launch_bounds__(DNT) void dec_attn_bwd_kernel(DecAttnBwdArgs a) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const int rho = 4 * g + v;
-          if (rho < nrho)
-            *(f32x4_t*)(a.dqk + ((row0 + q0) * DH + rho) * DE + 64 * cg + 4 * j) =
-                (f32x4_t){acc[0][0][0][v], acc[0][0][1][v], acc[0][0][2][v], acc[0][0][3][v]} + ld4(A2 + rho * DLD + 64 * cg + 4 * j);
+          if (rho < nrho) {
+            const f32x4_t o = (f32x4_t){acc[0][0][0][v], acc[0][0][1][v], acc[0][0][2][v], acc[0][0][3][v]} + ld4(A2 + rho * DLD + 64 * cg + 4 * j);
+            *(f32x4_t*)(a.dqk + ((row0 + q0) * DH + rho) * DE + 64 * cg + 4 * j) = o;
+            if constexpr (RR == 1) *(f32x4_t*)(A0 + rho * DLD + 64 * cg + 4 * j) = o;       // one query: d(qk) rows for B5 (A0 is free here)
+          }
         }
       }
     }
@@ -751,9 +1116,10 @@ __global__ __launch_bounds__(DNT) void dec_attn_bwd_kernel(DecAttnBwdArgs a) {
   {
     const float* Wk = a.Wc + (long)DE * DE;
     auto bload = [&](int t, int k) { return ld4(Wk + (long)(16 * (wave + DNW * t) + j) * DE + k + 4 * g); };
-    auto aload = [&](int t, int k, int) {
+    auto aload = [&](int t, int k, int row) {
       const int h = (wave + DNW * t) >> 1;
-      return j < R ? ld4(a.dqk + ((row0 + j) * DH + h) * DE + k + 4 * g) : f4zero();
+      if constexpr (RR == 1) return ld4(A0 + h * DLD + k + 4 * g);
+      else return row < R ? ld4(a.dqk + ((row0 + row) * DH + h) * DE + k + 4 * g) : f4zero();
     };
     auto epi = [&](int t, int, f32x4_t acc) {
       const int n = 16 * (wave + DNW * t) + j;
@@ -765,11 +1131,11 @@ __global__ __launch_bounds__(DNT) void dec_attn_bwd_kernel(DecAttnBwdArgs a) {
         if (r < R) a.dqpre[(row0 + r) * DE + n] = y;
       }
     };
-    stream_nt<16, 1, 8>(2, bload, aload, epi);
+    stream_nt<16, 1, UW, RR>(2, bload, aload, epi);
   }
   __syncthreads();                                 // A2 = d(q pre-scale)
   // ---- B6: d(t1 + qpos) = d(q) Wq ; d(t1) = that + d(r2)
-  dgrad256(a.Wc, DE, DE, [&](int r, int n) { return A2[r * DLD + n]; }, BIG, [&](int r, int c, f32x4_t v) {
+  dgrad256<RR>(a.Wc, DE, DE, [&](int r, int n) { return A2[r * DLD + n]; }, BIG, [&](int r, int c, f32x4_t v) {
     *(f32x4_t*)(A3 + r * DLD + c) = v;
     *(f32x4_t*)(A0 + r * DLD + c) = v + ld4(A1 + r * DLD + c);
   });
@@ -778,7 +1144,7 @@ __global__ __launch_bounds__(DNT) void dec_attn_bwd_kernel(DecAttnBwdArgs a) {
   ln_bwd_rows(A0, R, a.r1 + row0 * DE, a.mean1 + row0, a.rstd1 + row0, a.g0, a.d_r1 + row0 * DE, a.gx1 + row0 * DE, a.d_t1 + row0 * DE);
   __syncthreads();                                 // A0 = d(r1)
   // ---- B8: d(o) = d(r1) Wso
-  dgrad256(a.Wso, DE, DE, [&](int r, int n) { return A0[r * DLD + n]; }, BIG, [&](int r, int c, f32x4_t v) {
+  dgrad256<RR>(a.Wso, DE, DE, [&](int r, int n) { return A0[r * DLD + n]; }, BIG, [&](int r, int c, f32x4_t v) {
     *(f32x4_t*)(A2 + r * DLD + c) = v;
   });
   __syncthreads();                                 // A2 = d(o)
@@ -842,10 +1208,10 @@ __global__ __launch_bounds__(DNT) void dec_attn_bwd_kernel(DecAttnBwdArgs a) {
     for (int c = 0; c < 4; ++c) { axq[0][0][c] = f4zero(); av[0][0][c] = f4zero(); }
     auto bload = [&](int n, int) { return ld4(a.Ws + (long)n * DE + 64 * cg + 4 * j); };
     // half 0: d(q) rows of Ws (n in [0, 256)) and the first half of d(v)'s; half 1: d(k) rows and the second half of d(v)'s
-    auto aqk = [&](int n, int) { return n < DE ? A0[j * DLD + n] : A1[j * DLD + n - DE]; };
-    auto avl = [&](int n, int) { return DV[j * DLD + n - 2 * DE]; };
-    stream_nn<1, 1, 8>(half ? DE : 0, half ? 2 * DE : DE, bload, aqk, axq);
-    stream_nn<1, 1, 8>(2 * DE + (half ? DE / 2 : 0), 2 * DE + (half ? DE : DE / 2), bload, avl, av);
+    auto aqk = [&](int n, int row) { return n < DE ? A0[row * DLD + n] : A1[row * DLD + n - DE]; };
+    auto avl = [&](int n, int row) { return DV[row * DLD + n - 2 * DE]; };
+    if constexpr (RR == 0) stream_nn<1, 1, 8, 0>(half ? DE : 0, half ? 2 * DE : DE, bload, aqk, axq);      // (one query: d(q) = d(k) = 0)
+    stream_nn<1, 1, RR ? 16 : 8, RR>(2 * DE + (half ? DE / 2 : 0), 2 * DE + (half ? DE : DE / 2), bload, avl, av);
     float* TQ = QKV;                               // the qkv tile is dead (every wave is past the loop above): [16][DLD] x 2
     float* TV = QKV + 16 * DLD;
     __syncthreads();
@@ -1004,7 +1370,7 @@ __global__ __launch_bounds__(256) void dec_ffn_fwd_kernel(DecFfnArgs a) {
     __syncthreads();
     {   // h_s: one 16-column tile per wave, 4 row tiles
       auto bload = [&](int, int k) { return ld4(a.W1 + (long)(f0 + 16 * wave + j) * DE + k + 4 * g); };
-      auto aload = [&](int, int k, int rt) { return ld4(X + (16 * rt + j) * DLD + k + 4 * g); };
+      auto aload = [&](int, int k, int row) { return ld4(X + row * DLD + k + 4 * g); };
       auto epi = [&](int, int rt, f32x4_t acc) {
         const int f = 16 * wave + j;
         const float bias = a.b1[f0 + f];
@@ -1020,12 +1386,12 @@ __global__ __launch_bounds__(256) void dec_ffn_fwd_kernel(DecFfnArgs a) {
           HS[r * FLD + f] = y;
         }
       };
-      stream_nt<16, 4, 8>(1, bload, aload, epi);
+      stream_nt<16, 4, 8, 0>(1, bload, aload, epi);
     }
     __syncthreads();
     {   // slab[s][r][n] = sum_f h_s[r][f] W2[n][f0 + f]: 16 column tiles, 4 per wave
       auto bload = [&](int t, int k) { return ld4(a.W2 + (long)(16 * (wave + 4 * t) + j) * a.Fd + f0 + k + 4 * g); };
-      auto aload = [&](int, int k, int rt) { return ld4(HS + (16 * rt + j) * FLD + k + 4 * g); };
+      auto aload = [&](int, int k, int row) { return ld4(HS + row * FLD + k + 4 * g); };
       auto epi = [&](int t, int rt, f32x4_t acc) {
         const int n = 16 * (wave + 4 * t) + j;
 #pragma unroll
@@ -1034,7 +1400,7 @@ __global__ __launch_bounds__(256) void dec_ffn_fwd_kernel(DecFfnArgs a) {
           if (r < rows) a.slabs[((long)s * a.M + m0 + r) * DE + n] = acc[v];
         }
       };
-      stream_nt<4, 4, 4>(4, bload, aload, epi);
+      stream_nt<4, 4, 4, 0>(4, bload, aload, epi);
     }
     __syncthreads();
   }
@@ -1144,8 +1510,8 @@ __global__ __launch_bounds__(256) void dec_ffn_bwd_kernel(DecFfnBwdArgs a) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc[0][0][c] = f4zero();
       auto bload = [&](int n, int) { return ld4(a.W2 + (long)n * a.Fd + f0 + 4 * j); };
-      auto aload = [&](int n, int) { return DRM[(16 * rt + j) * DLD + n]; };
-      stream_nn<1, 1, 8>(half ? DE / 2 : 0, half ? DE : DE / 2, bload, aload, acc);
+      auto aload = [&](int n, int row) { return DRM[(16 * rt + row) * DLD + n]; };
+      stream_nn<1, 1, 8, 0>(half ? DE / 2 : 0, half ? DE : DE / 2, bload, aload, acc);
       if (half) {
 #pragma unroll
         for (int v = 0; v < 4; ++v)
@@ -1174,8 +1540,8 @@ __global__ __launch_bounds__(256) void dec_ffn_bwd_kernel(DecFfnBwdArgs a) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[rt][0][c] = f4zero();
       auto bload = [&](int f, int) { return ld4(a.W1 + (long)(f0 + f) * DE + 64 * wave + 4 * j); };
-      auto aload = [&](int f, int rt) { return DH[(16 * rt + j) * FLD + f]; };
-      stream_nn<2, 1, 8>(0, FS, bload, aload, acc);
+      auto aload = [&](int f, int row) { return DH[row * FLD + f]; };
+      stream_nn<2, 1, 8, 0>(0, FS, bload, aload, acc);
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -1261,15 +1627,24 @@ extern "C" int simvg_dec_attn_fwd(const simvg_dec_attn_args* p, hipStream_t stre
   SIMVG_CHECK_ARG(p->B > 0 && p->R > 0 && p->R <= 16, "dec_attn_fwd: 1..16 queries per sample");
   SIMVG_CHECK_ARG(p->Lk > 0 && p->Lk <= 1024 && p->kv_rows >= p->kv_off + p->Lk, "dec_attn_fwd: 1..1024 keys inside the sample's source rows");
   SIMVG_CHECK_ARG((p->src16 != nullptr) != (p->src32 != nullptr), "dec_attn_fwd: exactly one of src16 / src32");
-  SIMVG_CHECK_ARG(p->ldsrc % 4 == 0 && (!p->kpos || p->ldkp % 4 == 0), "dec_attn_fwd: source / key_pos rows must be 16-byte aligned");
+  SIMVG_CHECK_ARG(p->kpos != nullptr, "dec_attn_fwd: key_pos rows are required (pass zeros for none)");
+  SIMVG_CHECK_ARG(p->ldsrc % 4 == 0 && p->ldkp % 4 == 0, "dec_attn_fwd: source / key_pos rows must be 16-byte aligned");
   static_assert(sizeof(simvg_dec_attn_args) == sizeof(DecAttnArgs), "C mirror of DecAttnArgs");
   DecAttnArgs a;
   memcpy(&a, p, sizeof(a));
   const size_t shm = (size_t)dec_attn_fwd_lds_floats(p->Lk) * sizeof(float);
   SIMVG_CHECK_ARG(shm <= 160 * 1024, "dec_attn_fwd: the score strip does not fit the 160 KiB LDS");
-  static bool once = hipFuncSetAttribute((const void*)dec_attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+  // instantiations: one query per sample (num_queries = 1, the RefCOCO configs: the weight phases on the VALU -- a 16-row MFMA tile
+  // would be 15/16 padding) or MFMA (GRefCOCO: 10 queries) x 16-bit or fp32 source rows
+  typedef void (*kern_t)(DecAttnArgs);
+  static const kern_t kerns[4] = {dec_attn_fwd_kernel<0, false>, dec_attn_fwd_kernel<0, true>, dec_attn_fwd_kernel<1, false>, dec_attn_fwd_kernel<1, true>};
+  static bool once = [] {
+    bool ok = true;
+    for (kern_t k : kerns) ok = ok && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    return ok;
+  }();
   (void)once;
-  hipLaunchKernelGGL(dec_attn_fwd_kernel, dim3(p->B), dim3(DNT), shm, stream, a);
+  hipLaunchKernelGGL(kerns[(p->R == 1 ? 2 : 0) + (p->src16 ? 1 : 0)], dim3(p->B), dim3(DNT), shm, stream, a);
   SIMVG_LAUNCH_CHECK();
   return SIMVG_OK;
 }
@@ -1292,7 +1667,8 @@ extern "C" int simvg_dec_attn_bwd(const simvg_dec_attn_bwd_args* p, hipStream_t 
   SIMVG_CHECK_ARG(p->B > 0 && p->R > 0 && p->R <= 16, "dec_attn_bwd: 1..16 queries per sample");
   SIMVG_CHECK_ARG(p->Lk > 0 && p->kv_rows >= p->kv_off + p->Lk, "dec_attn_bwd: the keys must lie inside the sample's source rows");
   SIMVG_CHECK_ARG((p->src16 != nullptr) != (p->src32 != nullptr), "dec_attn_bwd: exactly one of src16 / src32");
-  SIMVG_CHECK_ARG(p->ldsrc % 4 == 0 && (!p->kpos || p->ldkp % 4 == 0) && (!p->dsrc || p->lddsrc % 4 == 0),
+  SIMVG_CHECK_ARG(p->kpos != nullptr, "dec_attn_bwd: key_pos rows are required (pass zeros for none)");
+  SIMVG_CHECK_ARG(p->ldsrc % 4 == 0 && p->ldkp % 4 == 0 && (!p->dsrc || p->lddsrc % 4 == 0),
                   "dec_attn_bwd: source / key_pos / d(source) rows must be 16-byte aligned");
   SIMVG_CHECK_ARG(p->nslab >= 0 && (p->nslab == 0 || p->dt2_slabs != nullptr), "dec_attn_bwd: nslab slabs need a pointer");
   static_assert(sizeof(simvg_dec_attn_bwd_args) == sizeof(DecAttnBwdArgs), "C mirror of DecAttnBwdArgs");
@@ -1300,9 +1676,17 @@ extern "C" int simvg_dec_attn_bwd(const simvg_dec_attn_bwd_args* p, hipStream_t 
   memcpy(&a, p, sizeof(a));
   const size_t shm = (size_t)dec_attn_bwd_lds_floats(p->Lk) * sizeof(float);
   SIMVG_CHECK_ARG(shm <= 160 * 1024, "dec_attn_bwd: the score strips do not fit the 160 KiB LDS (Lk <= 448)");
-  static bool once = hipFuncSetAttribute((const void*)dec_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+  // instantiations: one query per sample (num_queries = 1, the RefCOCO configs: the weight phases on the VALU -- a 16-row MFMA tile
+  // would be 15/16 padding) or MFMA (GRefCOCO: 10 queries) x 16-bit or fp32 source rows
+  typedef void (*kern_t)(DecAttnBwdArgs);
+  static const kern_t kerns[4] = {dec_attn_bwd_kernel<0, false>, dec_attn_bwd_kernel<0, true>, dec_attn_bwd_kernel<1, false>, dec_attn_bwd_kernel<1, true>};
+  static bool once = [] {
+    bool ok = true;
+    for (kern_t k : kerns) ok = ok && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    return ok;
+  }();
   (void)once;
-  hipLaunchKernelGGL(dec_attn_bwd_kernel, dim3(p->B), dim3(DNT), shm, stream, a);
+  hipLaunchKernelGGL(kerns[(p->R == 1 ? 2 : 0) + (p->src16 ? 1 : 0)], dim3(p->B), dim3(DNT), shm, stream, a);
   SIMVG_LAUNCH_CHECK();
   return SIMVG_OK;
 }

@@ -847,6 +847,83 @@ def dec_attn_max_keys():
     return int(_lib.load().simvg_dec_attn_max_keys())
 
 
+def dec_ffn_fwd(t2, W1, b1, W2, b2, g2, b2n, gP=None, bP=None, m1=None, m2=None, eps=1e-5):
+    """The FFN + norm (+ the decoder's post-norm) of one decoder layer in two launches; returns the dict of saved tensors
+    (["t3"] the layer output, ["hs"] its post-norm or None)."""
+    lib = _lib.load()
+    M, E = t2.shape
+    Fd = W1.shape[0]
+    NS = Fd // 64
+    dev = t2.device
+    names = ("h1d", "slabs", "r3", "mean3", "rstd3", "t3") + (("hs", "meanP", "rstdP") if gP is not None else ())
+    sizes = dict(h1d=M * Fd, slabs=NS * M * E, r3=M * E, mean3=M, rstd3=M, t3=M * E, hs=M * E, meanP=M, rstdP=M)
+    buf = dict(zip(names, _carve([sizes[n] for n in names], dev)))
+    a = _lib.DecFfnArgs()
+    a.M, a.Fd = M, Fd
+    a.t2, a.W1, a.b1, a.W2 = t2.data_ptr(), W1.data_ptr(), b1.data_ptr(), W2.data_ptr()
+    a.m1 = m1.data_ptr() if m1 is not None else None
+    a.h1d, a.slabs = buf["h1d"].data_ptr(), buf["slabs"].data_ptr()
+    t0 = _timer.start("dec_ffn_fwd") if _timer is not None else None
+    _lib.check(lib.simvg_dec_ffn_fwd(C.byref(a), _stream()), "simvg_dec_ffn_fwd")
+    f = _lib.DecFfnFinishArgs()
+    f.M, f.NS = M, NS
+    f.t2, f.slabs, f.b2 = t2.data_ptr(), buf["slabs"].data_ptr(), b2.data_ptr()
+    f.m2 = m2.data_ptr() if m2 is not None else None
+    f.g2, f.b2n = g2.data_ptr(), b2n.data_ptr()
+    f.gP, f.bP = (gP.data_ptr(), bP.data_ptr()) if gP is not None else (None, None)
+    for n in ("r3", "mean3", "rstd3", "t3"):
+        setattr(f, n, buf[n].data_ptr())
+    if gP is not None:
+        f.hs, f.meanP, f.rstdP = buf["hs"].data_ptr(), buf["meanP"].data_ptr(), buf["rstdP"].data_ptr()
+    f.eps = eps
+    _lib.check(lib.simvg_dec_ffn_finish(C.byref(f), _stream()), "simvg_dec_ffn_finish")
+    if t0 is not None:
+        _timer.stop("dec_ffn_fwd", t0, 0.0, 0.0)
+    out = {n: (buf[n].view(M, Fd) if n == "h1d" else buf[n].view(NS, M, E) if n == "slabs" else
+               buf[n] if n in ("mean3", "rstd3", "meanP", "rstdP") else buf[n].view(M, E)) for n in names}
+    out.setdefault("hs", None)
+    return out
+
+
+def dec_ffn_bwd(saved, t2, W1, W2, g2, gP=None, d_t3=None, d_hs=None, m1=None, m2=None):
+    """Backward of `dec_ffn_fwd`: returns (d_r3 [M, E], slabs [Fd/64, M, E] -- d(t2) = d_r3 + slabs.sum(0), formed by `dec_attn_bwd` --,
+    [dW1, db1, dW2, db2, dg2, db2n, dgP | None, dbP | None])."""
+    lib = _lib.load()
+    M, E = t2.shape
+    Fd = W1.shape[0]
+    NS = Fd // 64
+    dev = t2.device
+    post = d_hs is not None
+    names = ("d_r3", "gx3", "dy3", "dr3m", "slabs", "dW1", "db1", "dW2", "db2", "dg2", "db2n") + (("gxP", "dgP", "dbP") if post else ())
+    sizes = dict(d_r3=M * E, gx3=M * E, dy3=M * E, dr3m=M * E, gxP=M * E, slabs=NS * M * E, dW1=Fd * E, db1=Fd, dW2=E * Fd, db2=E, dg2=E,
+                 db2n=E, dgP=E, dbP=E)
+    buf = dict(zip(names, _carve([sizes[n] for n in names], dev)))
+    a = _lib.DecFfnBwdArgs()
+    a.M, a.Fd = M, Fd
+    for n, t in (("d_t3", d_t3), ("d_hs", d_hs)):
+        if t is not None:
+            _chk(t, torch.float32, n)
+            assert t.is_contiguous() and t.numel() == M * E
+            setattr(a, n, t.data_ptr())
+    for n in ("r3", "mean3", "rstd3", "t3", "h1d"):
+        setattr(a, n, saved[n].data_ptr())
+    if post:
+        a.meanP, a.rstdP, a.gP = saved["meanP"].data_ptr(), saved["rstdP"].data_ptr(), gP.data_ptr()
+    a.g2, a.W1, a.W2, a.t2 = g2.data_ptr(), W1.data_ptr(), W2.data_ptr(), t2.data_ptr()
+    a.m1 = m1.data_ptr() if m1 is not None else None
+    a.m2 = m2.data_ptr() if m2 is not None else None
+    for n in names:
+        setattr(a, n, buf[n].data_ptr())
+    t0 = _timer.start("dec_ffn_bwd") if _timer is not None else None
+    rc = lib.simvg_dec_ffn_bwd(C.byref(a), _stream())
+    if t0 is not None:
+        _timer.stop("dec_ffn_bwd", t0, 0.0, 0.0)
+    _lib.check(rc, "simvg_dec_ffn_bwd")
+    grads = [buf["dW1"].view(Fd, E), buf["db1"], buf["dW2"].view(E, Fd), buf["db2"], buf["dg2"], buf["db2n"],
+             buf["dgP"] if post else None, buf["dbP"] if post else None]
+    return buf["d_r3"].view(M, E), buf["slabs"].view(NS, M, E), grads
+
+
 class _PackRing:
     """pinned staging buffers for the one host->device copy of `pack_targets`: a slot is rewritten only after the copy that read it
     has completed (the host may run steps ahead of the device)"""

@@ -145,22 +145,27 @@ def _f32(*shape, device):
 
 
 class LayerCfg:
-    """non-tensor arguments of `DecoderLayerFn` (geometry, cross-attention flavour and its gradient-free operands);
-    mem_grad: the `SharedMemoryGrad` holder of the 16-bit memory rows, or None (the layer returns its own d(mem))"""
+    """non-tensor arguments of `DecoderLayerFn` (geometry, cross-attention flavour and its gradient-free operands).
+    kind "text": the source rows are fp32 [B*Lk, E] (keys = rows + pos, values = rows: the TGQG layers, pos = the 1-D sine table);
+    kind "mem": the image memory [B*Nv, E] (16-bit or fp32), the keys are rows 1 .. Nv-1 of each sample (+ pos, the 2-D sine rows
+    [HW, E] shared by the batch or [B, HW, E]); kpm [B, Lk] uint8 masks keys.
+    mem_grad: the `SharedMemoryGrad` holder of the memory rows, or None (the layer returns its own d(source rows))"""
 
-    def __init__(self, B, H, nq, kind, Lk, kpm=None, pos=None, wb=None, wbT=None, Nv=0, p_attn=0.0, p_ffn=0.0,
-                 training=False, mask_fn=None, mem_grad=None):
+    def __init__(self, B, H, nq, kind, Lk, kpm=None, pos=None, Nv=0, p_attn=0.0, p_ffn=0.0, training=False, mask_fn=None,
+                 mem_grad=None, wb=None, wbT=None):
         self.B, self.H, self.nq, self.kind, self.Lk = B, H, nq, kind, Lk
-        self.kpm, self.pos, self.wb, self.wbT, self.Nv = kpm, pos, wb, wbT, Nv
+        self.kpm, self.pos, self.Nv = kpm, pos, Nv
+        self.wb, self.wbT = wb, wbT          # 16-bit K|V weights of the unfused layer (DecoderLayerUnfusedFn) only
         self.p_attn, self.p_ffn, self.training, self.mask_fn = p_attn, p_ffn, training, mask_fn
         self.mem_grad = mem_grad
 
 
 class SharedMemoryGrad(torch.autograd.Function):
     """The image memory is read by every decoder layer; autograd would add the layers' [B*Nv, E] fp32 gradients pairwise
-    (two 83 MB passes for three layers).  `mem, holder = SharedMemoryGrad.join(mem)`: the layers that get `holder`
-    (LayerCfg.mem_grad) accumulate their d(mem) into ONE buffer through the GEMM epilogue (C = residual + alpha A W^T, in
-    place) and return no gradient for `mem`; this node, which the engine runs once all of them are done, hands the buffer on."""
+    (two 26 MB passes for three layers).  `mem, holder = SharedMemoryGrad.join(mem)`: the layers that get `holder`
+    (LayerCfg.mem_grad) accumulate their d(mem) into ONE buffer (the row-owning backward kernel writes it in the first layer
+    of the backward and adds to it in the others: every sample's rows belong to one workgroup) and return no gradient for
+    `mem`; this node, which the engine runs once all of them are done, hands the buffer on."""
 
     @staticmethod
     def forward(ctx, mem, holder):
@@ -183,6 +188,71 @@ class SharedMemoryGrad(torch.autograd.Function):
 
 class DecoderLayerFn(torch.autograd.Function):
     """One post-norm DETR decoder layer -- self-attention, norm, cross-attention, norm, FFN(ReLU), norm (detrex
+    `BaseTransformerLayer` as configured at heads/tgqs_kd_detr_head/transformer.py:93-131), optionally followed by the
+    decoder's shared post-norm of the layer output (transformer.py:176-183) -- as ONE autograd node over the fused kernels of
+    csrc/decoder.hip (round 5): THREE launches forward (the attention block by a workgroup per sample; the FFN split over its
+    hidden units; the slices' sum + norms) and FOUR backward (FFN slices incl. their weight gradients + the FFN's row sums,
+    the attention block's row-owning backward, its 12 parameter gradients in one launch) instead of ~20 / ~25.
+    The cross-attention contracts the source rows directly (no K / V projection, see decoder.hip); `src` is the source matrix
+    (LayerCfg).  Returns (layer output, post-normed layer output | None)."""
+
+    @staticmethod
+    def forward(ctx, tgt, qpos, src, Ws, bs, Wso, bso, g0, b0, Wc, bc, Wco, bco, g1, b1n, W1, b1, W2, b2, g2, b2n, gP, bP, cfg):
+        dev = tgt.device
+        tgt, qpos = tgt.contiguous(), qpos.contiguous()
+        B, H, nq = cfg.B, cfg.H, cfg.nq
+        train = cfg.training
+        M, Fd = tgt.shape[0], W1.shape[0]
+        mem = cfg.kind == "mem"
+        kv_rows, kv_off = (cfg.Nv, 1) if mem else (cfg.Lk, 0)
+        kpos = cfg.pos.reshape(-1, tgt.shape[1]) if cfg.pos is not None else None
+        dm0 = cfg.mask_fn((B, H, nq, nq), dev) if (train and cfg.p_attn > 0) else None
+        dm1 = cfg.mask_fn((B, H, nq, cfg.Lk), dev) if (train and cfg.p_attn > 0) else None
+        W = [w.contiguous() for w in (Ws, bs, Wso, bso, g0, b0, Wc, bc, Wco, bco, g1, b1n)]
+        sa = ops.dec_attn_fwd(tgt, qpos, W, src, B, nq, cfg.Lk, kv_rows=kv_rows, kv_off=kv_off, kpos=kpos, kpm=cfg.kpm, dm0=dm0, dm1=dm1)
+        m1 = m2 = None
+        if train and cfg.p_ffn > 0:
+            m1, m2 = cfg.mask_fn((M, Fd), dev, cfg.p_ffn), cfg.mask_fn((M, tgt.shape[1]), dev, cfg.p_ffn)
+        sf = ops.dec_ffn_fwd(sa["t2"], W1, b1, W2, b2, g2, b2n, gP=gP, bP=bP, m1=m1, m2=m2)
+        ctx.cfg, ctx.sa, ctx.sf = cfg, sa, sf
+        ctx.geo = (kv_rows, kv_off)
+        ctx.save_for_backward(tgt, qpos, src, kpos, dm0, dm1, m1, m2, *W, W1, W2, g2, gP)
+        ctx.set_materialize_grads(False)
+        return sf["t3"], sf["hs"]
+
+    @staticmethod
+    def backward(ctx, d_t3, d_hs):
+        tgt, qpos, src, kpos, dm0, dm1, m1, m2, *rest = ctx.saved_tensors
+        W, (W1, W2, g2, gP) = rest[:12], rest[12:]
+        cfg, sa, sf = ctx.cfg, ctx.sa, ctx.sf
+        kv_rows, kv_off = ctx.geo
+        B, nq = cfg.B, cfg.nq
+        M, E = tgt.shape
+        if d_t3 is None and d_hs is None:
+            d_t3 = torch.zeros(M, E, device=tgt.device, dtype=torch.float32)
+        d_t3 = None if d_t3 is None else d_t3.contiguous()
+        d_hs = None if (d_hs is None or gP is None) else d_hs.contiguous()
+        d_r3, slabs, gf = ops.dec_ffn_bwd(sf, sa["t2"], W1, W2, g2, gP=gP, d_t3=d_t3, d_hs=d_hs, m1=m1, m2=m2)
+        dsrc, acc, ret_dsrc = None, False, None
+        if ctx.needs_input_grad[2]:
+            holder = cfg.mem_grad
+            if holder is None:
+                dsrc = ret_dsrc = torch.empty(src.shape[0], E, device=tgt.device, dtype=torch.float32)
+            else:
+                dsrc = holder.get("buf")
+                acc = dsrc is not None                      # the first layer of the backward writes the buffer, the others add
+                if dsrc is None:
+                    dsrc = holder["buf"] = torch.empty(src.shape[0], E, device=tgt.device, dtype=torch.float32)
+        d_tgt, d_qpos, ga = ops.dec_attn_bwd(sa, tgt, qpos, W, src, B, nq, cfg.Lk, dt2=d_r3, dt2_slabs=slabs, kv_rows=kv_rows, kv_off=kv_off,
+                                             kpos=kpos, dm0=dm0, dm1=dm1, dsrc=dsrc, dsrc_accumulate=acc)
+        dW1, db1, dW2, db2, dg2, db2n, dgP, dbP = gf
+        return (d_tgt, d_qpos, ret_dsrc, *ga, dW1, db1, dW2, db2, dg2, db2n, dgP, dbP, None)
+
+
+class DecoderLayerUnfusedFn(torch.autograd.Function):
+    """The same layer on the per-stage kernels of rounds 1-4 (csrc/head.hip), kept for cross-attentions with more keys than the
+    fused kernels hold in LDS (`hip_ops.dec_attn_max_keys()`: e.g. patch 16 at 640 px = 1600 keys; no reference config).
+    One post-norm DETR decoder layer -- self-attention, norm, cross-attention, norm, FFN(ReLU), norm (detrex
     `BaseTransformerLayer` as configured at heads/tgqs_kd_detr_head/transformer.py:93-131), optionally followed by the
     decoder's shared post-norm of the layer output (transformer.py:176-183) -- as ONE autograd node with a hand-sequenced
     backward.  The head is a chain of ~5 us launches on [B*nq, 256] rows, so its cost is the NUMBER of launches:

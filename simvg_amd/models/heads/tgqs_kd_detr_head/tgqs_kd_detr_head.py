@@ -11,6 +11,7 @@ Only the branches the reference configs execute are built: `branch_loss_weight` 
 `score_iou_weighted`, TGQG on; SURVEY.md 8(a) "dead branches".  state_dict keys match Appendix B.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -18,7 +19,7 @@ import torch.nn.functional as F
 
 from ... import builder
 from .... import hip_ops as ops
-from ..functions import (Criterion, DecoderLayerFn, LayerCfg, LayerNormF32, LinearLP, LinearF32, SharedMemoryGrad,
+from ..functions import (Criterion, DecoderLayerFn, DecoderLayerUnfusedFn, LayerCfg, LayerNormF32, LinearLP, LinearF32, SharedMemoryGrad,
                          SplitEncoderOutput)
 
 
@@ -199,8 +200,9 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
 
     def _refresh_weights(self, device):
         E, C = self.embed_dim, self.in_channels
-        srcs = [self._P("input_proj.weight")] + [self._P(f"transformer.decoder.layers.{i}.attentions.1.attn.in_proj_weight")
-                                                for i in range(self.num_decoder_layers)]
+        # (round 5: the decoder's cross-attention contracts the memory rows directly -- csrc/decoder.hip --, so input_proj is the
+        # only Linear of the head that runs on the 16-bit MFMA GEMM and needs 16-bit weight copies)
+        srcs = [self._P("input_proj.weight")]
         version = tuple(p._version for p in srcs) + (srcs[0].data_ptr(),)
         if self._prep is not None and version == self._prep_version and not self.training:
             return
@@ -209,9 +211,6 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
                 return torch.empty(*s, device=device, dtype=ops.LP())
             self.wb = {"ip": bf(E, C), "ipT": bf(C, E)}
             entries = [(srcs[0].data.view(E, C), self.wb["ip"], self.wb["ipT"])]
-            for i in range(self.num_decoder_layers):
-                self.wb[f"kv{i}"], self.wb[f"kvT{i}"] = bf(2 * E, E), bf(E, 2 * E)
-                entries.append((srcs[1 + i].data[E:], self.wb[f"kv{i}"], self.wb[f"kvT{i}"]))
             self._prep = ops.WeightPrep(entries, device)
             self._prep_dev, self._prep_ptrs = device, [p.data_ptr() for p in srcs]
         self._prep.run()
@@ -278,13 +277,34 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
                    "ffns.0.layers.0.0.weight", "ffns.0.layers.0.0.bias", "ffns.0.layers.1.weight", "ffns.0.layers.1.bias",
                    "norms.2.weight", "norms.2.bias")
 
-    def _decoder_layer(self, L, tgt, qpos, cfg, xk=None, xv=None, mem=None, post=None):
+    def _decoder_layer(self, L, tgt, qpos, cfg, src, post=None):
         """BaseTransformerLayer, post-norm order (self_attn, norm, cross_attn, norm, ffn, norm) as one autograd node;
-        tgt / qpos [B*nq, E]; `post` = key prefix of a LayerNorm applied to the layer output (the decoder's shared
-        post_norm_layer) -> returns (layer output, post-normed output | None)."""
+        tgt / qpos [B*nq, E]; src: the cross-attention's source rows (LayerCfg); `post` = key prefix of a LayerNorm applied to
+        the layer output (the decoder's shared post_norm_layer) -> returns (layer output, post-normed output | None)."""
         params = [self._P(L + k) for k in self._LAYER_KEYS]
         gP, bP = (self._P(post + ".weight"), self._P(post + ".bias")) if post else (None, None)
-        return DecoderLayerFn.apply(tgt, qpos, xk, xv, mem, *params, gP, bP, cfg)
+        if cfg.Lk > ops.dec_attn_max_keys() or os.environ.get("SIMVG_DEC_UNFUSED") == "1":       # (=1: A/B measurements)
+            # more keys than the fused kernels hold in LDS (patch 16 at 480 / 640 px; no reference config): the per-stage kernels
+            if cfg.kind == "text":
+                xk = (src.view(cfg.B, cfg.Lk, -1) + cfg.pos[None]).reshape(src.shape)
+                return DecoderLayerUnfusedFn.apply(tgt, qpos, xk, src, None, *params, gP, bP, cfg)
+            if src.dtype == ops.LP():
+                cfg.wb, cfg.wbT = self._kv_weights(L, src.device)
+            return DecoderLayerUnfusedFn.apply(tgt, qpos, None, None, src, *params, gP, bP, cfg)
+        return DecoderLayerFn.apply(tgt, qpos, src, *params, gP, bP, cfg)
+
+    def _kv_weights(self, L, device):
+        """16-bit copies (plain, transposed) of a layer's cross-attention K|V in-projection rows, for the unfused layer; refreshed
+        on every call (that path is not a hot one)"""
+        E = self.embed_dim
+        W = self._P(L + "attentions.1.attn.in_proj_weight")
+        key = ("kv", L)
+        ent = self._const.get(key)
+        if ent is None or ent[0].device != device or ent[3] != W.data_ptr():
+            wb, wbT = torch.empty(2 * E, E, device=device, dtype=ops.LP()), torch.empty(E, 2 * E, device=device, dtype=ops.LP())
+            ent = self._const[key] = (wb, wbT, ops.WeightPrep([(W.data[E:], wb, wbT)], device), W.data_ptr())
+        ent[2].run()
+        return ent[0], ent[1]
 
     def _layer_cfg(self, B, kind, Lk, **kw):
         return LayerCfg(B, self.heads, self.num_queries, kind, Lk, p_attn=self.attn_dropout, p_ffn=self.ffn_dropout,
@@ -352,15 +372,15 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
         qe = self._P("query_embed.weight")
         qpos = qe.unsqueeze(0).expand(B, nq, E).reshape(B * nq, E)
         tkpm = (text_mask != 0).to(torch.uint8).contiguous()
-        tk_in = (text3 + c["tpos"][None]).reshape(B * T, E)
 
         tgt = torch.zeros(B * nq, E, device=device)
         pre = "text_guided_query_generation_transformer."
-        cfg_t = self._layer_cfg(B, "text", T, kpm=tkpm)
+        # the TGQG layers attend from the queries to the text rows: keys = text + 1-D sine positions, values = text (:391-399)
+        cfg_t = self._layer_cfg(B, "text", T, kpm=tkpm, pos=c["tpos"])
         g = None
         for i in range(self.num_tgqg_layers):
             last = i == self.num_tgqg_layers - 1
-            tgt, g = self._decoder_layer(f"{pre}layers.{i}.", tgt, qpos, cfg_t, xk=tk_in, xv=text,
+            tgt, g = self._decoder_layer(f"{pre}layers.{i}.", tgt, qpos, cfg_t, text,
                                          post=pre + "post_norm_layer" if last else None)
         query_embed = g.view(B, nq, E) + filt[:, None, :] + qe[None]
         tok = (query_embed + cls[:, None, :]).reshape(B * nq, E)                      # Q5
@@ -381,10 +401,9 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
         if not exact and mem.requires_grad and torch.is_grad_enabled():
             mem, mem_grad = SharedMemoryGrad.join(mem)            # one accumulator for the layers' memory gradients
         for i in range(self.num_decoder_layers):
-            # K = (mem + pos) Wk^T + bk = mem Wk^T + bk + pos Wk^T ; V = mem Wv^T + bv   (key_pos only on K)
-            wb, wbT = (None, None) if exact else (self.wb[f"kv{i}"], self.wb[f"kvT{i}"])
-            cfg_m = self._layer_cfg(B, "mem", HW, kpm=img_kpm, pos=pos2d, wb=wb, wbT=wbT, Nv=Nv, mem_grad=mem_grad)
-            tgt, h = self._decoder_layer(f"transformer.decoder.layers.{i}.", tgt, qpos_d, cfg_m, mem=mem,
+            # keys = mem + pos, values = mem (key_pos on the keys only); the K / V projections are absorbed into the query / output side
+            cfg_m = self._layer_cfg(B, "mem", HW, kpm=img_kpm, pos=pos2d, Nv=Nv, mem_grad=mem_grad)
+            tgt, h = self._decoder_layer(f"transformer.decoder.layers.{i}.", tgt, qpos_d, cfg_m, mem,
                                          post="transformer.decoder.post_norm_layer")
             hs.append(h)
         hs = torch.stack(hs).view(self.num_decoder_layers, B, nq, E)

@@ -149,3 +149,62 @@ def test_attention_block_backward(B, R, Lk, kind, drop, slabs):
         worst = max(worst, e)
         assert e <= 2e-5, (name, e)
     print(f"[attn block bwd B={B} R={R} Lk={Lk} {kind} drop={drop} slabs={slabs}] worst relative error over {len(checks)} gradients {worst:.2e}")
+
+
+@pytest.mark.parametrize("M,Fd,post,drop", [(64, 2048, True, True), (5, 512, False, False), (640, 2048, True, False), (37, 512, True, True)])
+def test_ffn_block_forward_backward(M, Fd, post, drop):
+    """FFN + norm (+ post-norm) of a decoder layer, hidden-split kernels, against autograd in double precision; the gradient of t2
+    is d_r3 + the sum of the slabs (what the attention block's backward forms)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + Fd)
+    W = _layer_params(g, ffn=Fd)
+    gP, bP = 1 + 0.1 * torch.randn(E, generator=g), 0.1 * torch.randn(E, generator=g)
+    t2 = torch.randn(M, E, generator=g)
+    m1 = ((torch.rand(M, Fd, generator=g) > 0.1).float() / 0.9) if drop else None
+    m2 = ((torch.rand(M, E, generator=g) > 0.1).float() / 0.9) if drop else None
+    d_t3 = torch.randn(M, E, generator=g)
+    d_hs = torch.randn(M, E, generator=g) if post else None
+    P = {k: W[k].double().requires_grad_(True) for k in ("W1", "b1f", "W2", "b2f", "g2", "b2")}
+    gPd, bPd = gP.double().requires_grad_(True), bP.double().requires_grad_(True)
+    x = t2.double().requires_grad_(True)
+    h = F.relu(x @ P["W1"].t() + P["b1f"])
+    if drop:
+        h = h * m1.double()
+    y = h @ P["W2"].t() + P["b2f"]
+    if drop:
+        y = y * m2.double()
+    t3 = F.layer_norm(x + y, (E,), P["g2"], P["b2"], 1e-5)
+    loss = (t3 * d_t3.double()).sum()
+    if post:
+        hs = F.layer_norm(t3, (E,), gPd, bPd, 1e-5)
+        loss = loss + (hs * d_hs.double()).sum()
+    loss.backward()
+    d = lambda t: None if t is None else t.to(DEV)
+    Wd = {k: v.to(DEV) for k, v in W.items()}
+    t2d = d(t2)
+    sv = ops.dec_ffn_fwd(t2d, Wd["W1"], Wd["b1f"], Wd["W2"], Wd["b2f"], Wd["g2"], Wd["b2"], gP=d(gP) if post else None,
+                         bP=d(bP) if post else None, m1=d(m1), m2=d(m2))
+    torch.cuda.synchronize()
+    rel = lambda got, ref: float((got.double().cpu() - ref).abs().max() / max(float(ref.abs().max()), 1e-12))
+    assert rel(sv["t3"], t3.detach()) <= 5e-6
+    if post:
+        assert rel(sv["hs"], hs.detach()) <= 5e-6
+    outs = []
+    for _ in range(2):
+        d_r3, slabs, grads = ops.dec_ffn_bwd(sv, t2d, Wd["W1"], Wd["W2"], Wd["g2"], gP=d(gP) if post else None, d_t3=d(d_t3), d_hs=d(d_hs),
+                                             m1=d(m1), m2=d(m2))
+        torch.cuda.synchronize()
+        outs.append([d_r3.clone(), slabs.clone()] + [None if x_ is None else x_.clone() for x_ in grads])
+    for x_, y_ in zip(*outs):
+        assert (x_ is None and y_ is None) or torch.equal(x_, y_)          # bit-reproducible
+    d_r3, slabs, dW1, db1, dW2, db2, dg2, db2n, dgP, dbP = outs[0]
+    checks = [("d_t2", d_r3 + slabs.sum(0), x.grad), ("dW1", dW1, P["W1"].grad), ("db1", db1, P["b1f"].grad), ("dW2", dW2, P["W2"].grad),
+              ("db2", db2, P["b2f"].grad), ("dg2", dg2, P["g2"].grad), ("db2n", db2n, P["b2"].grad)]
+    if post:
+        checks += [("dgP", dgP, gPd.grad), ("dbP", dbP, bPd.grad)]
+    worst = 0.0
+    for name, got, ref in checks:
+        e = rel(got, ref)
+        worst = max(worst, e)
+        assert e <= 2e-5, (name, e)
+    print(f"[ffn block M={M} Fd={Fd} post={post} drop={drop}] forward <= 5e-6, worst relative gradient error {worst:.2e}")

@@ -62,7 +62,7 @@ def _rel(a, b):
     return float((a.float().cpu() - b).abs().max() / max(float(b.abs().max()), 1e-6))
 
 
-def _check_all_grads(fx, params, name, exact):
+def _check_all_grads(fx, params, name, exact, excuse=None):
     """every parameter's gradient against the fixture (tests/gradcheck.py).
     exact=True (precision="fp32"): every sampled entry within 5e-5 of the tensor's largest entry, every norm within 1e-3.
     16-bit engine, fp16 build = measured worst case over all fixtures + margin (round 4: norms 7.9e-3 on the reference-initialised
@@ -78,7 +78,7 @@ def _check_all_grads(fx, params, name, exact):
         # bf16 build (measured, tests/test_bf16_build_gpu.py): reference-initialised fixtures norms <= 4e-2, entries <= 1.3e-1;
         # harsh fixtures norms <= 1.5e-1, entries <= 2.9e-1 on the reference geometries and 8.9e-1 on the 128-wide tiny one
         ntol, stol = (1e-1, 2.5e-1) if strict else (0.3, 1.0 if fx["vit"] == "tiny" else 0.6)
-    return check_all_grads(fx, params, ntol, stol, name)[0]
+    return check_all_grads(fx, params, ntol, stol, name, excuse=excuse)[0]
 
 
 ALL = ["base_nq1_refinit", "base_nq10_grec_refinit", "large_nq10_grec_refinit", "tiny_nq1", "tiny_nq10_grec", "base_nq1",
@@ -180,6 +180,16 @@ def test_forward_train_matches_reference(golden, name):
     # EVERY parameter (fixture `grads_all`: norm + 16 evenly spaced entries of all 612 / 552 gradients) and the two whole-module
     # norms the fixture records
     ga = _check_all_grads(fx, params, name, exact=False)
+    if ga and all("ffns.0.layers" in v[0] for v in ga):
+        # an FFN hidden unit whose pre-activation is below the forward's rounding noise may sit on the other side of its ReLU
+        # than in the reference (seen: large_nq1, decoder layer 0, unit 136 with |pre-activation| 9e-5 -- tools/dev/relu_flip_probe.py):
+        # such entries are excused only where the gate really differs from the exact-fp32 engine's on this input
+        from gradcheck import ffn_unit_excuse, relu_gate_flips
+        grads = {k: p.grad for k, p in params.items()}           # the probe's forwards must not disturb what is being checked
+        flips = relu_gate_flips(model, lambda: model(db["img"], db["ref_expr_inds"], db["img_metas"], return_loss=True,
+                                                     text_attention_mask=db["text_attention_mask"], gt_bbox=batch["gt_bbox"], rescale=False))
+        assert all(p.grad is grads[k] for k, p in params.items())
+        ga = _check_all_grads(fx, params, name, exact=False, excuse=ffn_unit_excuse(model, flips))
     assert not ga, ga[:12]
     if "no_grad_params" in fx:           # parameters the reference's backward leaves without a gradient: the same set here
         mine = sorted(k for k, p in params.items() if p.grad is None)
