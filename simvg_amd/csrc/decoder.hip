@@ -93,7 +93,7 @@ __device__ __forceinline__ void stream_nt_prefetch(int ntiles, BLoad bload, f32x
 }
 template <int KS, int NRT, int U, int RR, class BLoad, class ALoad, class Epi>
 __device__ __forceinline__ void stream_nt(int ntiles, BLoad bload, ALoad aload, Epi epi, f32x4_t (&bq)[U]) {
-  static_assert(KS % U == 0, "a tile's steps are a whole number of prefetch groups");
+  static_assert(KS % U == 0 || U % KS == 0, "prefetch groups and tiles nest");
   static_assert(RR == 0 || NRT == 1, "the small-row form has one row tile");
   const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
   const int total = ntiles * KS;
@@ -105,12 +105,30 @@ __device__ __forceinline__ void stream_nt(int ntiles, BLoad bload, ALoad aload, 
 #pragma unroll
   for (int r = 0; r < (RR > 0 ? RR : 1); ++r) part[r] = 0.f;
   for (int s0 = 0; s0 < total; s0 += U) {
-    const int t = s0 / KS, kb = (s0 % KS) * 16;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int sn = min(s0 + U + u, total - 1);
       bn[u] = bload(sn / KS, (sn % KS) * 16);
     }
+    if constexpr (U > KS) {
+      // a prefetch group spans U / KS whole tiles (short contractions: the FFN's 64-unit slices)
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int su = s0 + u, t = su / KS, k = (su % KS) * 16;
+        if (su < total) {
+#pragma unroll
+          for (int rt = 0; rt < NRT; ++rt) acc[rt] = mfma4(aload(t, k, 16 * rt + j), bq[u], acc[rt]);
+          if ((u + 1) % KS == 0) {
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt) { epi(t, rt, acc[rt]); acc[rt] = f4zero(); }
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) bq[u] = bn[u];
+      continue;
+    }
+    const int t = s0 / KS, kb = (s0 % KS) * 16;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if constexpr (RR == 0) {
@@ -1001,6 +1019,65 @@ __global__ __launch_bounds__(DNT) void dec_attn_bwd_kernel(DecAttnBwdArgs a) {
       *(f32x4_t*)(a.dsrc + ((long)b * a.kv_rows + r) * a.lddsrc + c) = f4zero();
     }
   }
+  if constexpr (RR == 1) {
+    // one query: the 8 (query, head) rows are the heads; every pass over the source rows on the VALU with whole-row loads
+    float* DC8 = BIG;                              // [8][DLD]  d(ctx)   (written by B3)
+    float* QK8 = BIG + 8 * DLD;                    // [8][DLD]  qk
+    float* DST = BIG + 16 * DLD;                   // [Lk][8]   dS transposed
+    float* PPT = DST + 8 * LKP;                    // [Lk][8]   P' transposed
+    float* DS8 = PPT + 8 * LKP;                    // [8][LKP]  d(P'), dead once transposed: the waves' partial sums take its place
+    float* PARTS = DS8;                            // [4][8][256]
+    for (int e = tid; e < 8 * (DE / 4); e += DNT) {
+      const int h = e / (DE / 4), c = 4 * (e % (DE / 4));
+      *(f32x4_t*)(QK8 + h * DLD + c) = ld4(a.qk + (row0 * DH + h) * DE + c);
+    }
+    __syncthreads();
+    rowdot8<S16, false, 8>(src, DC8, Lk, [&](int h, int kk, float v) { DS8[h * LKP + kk] = v + DSP[h]; });
+    __syncthreads();
+    {
+      const int h = wave;
+      const float* dsr = DS8 + h * LKP;
+      const long pg = ((long)b * DH + h) * Lk;
+      float rs = 0.f;
+      for (int kk = lane; kk < Lk; kk += 64) {
+        const float p = a.P1[pg + kk];
+        const float dm = a.dm1 ? a.dm1[pg + kk] : 1.f;
+        rs = fmaf(p, dsr[kk] * dm, rs);
+      }
+      rs = wave_sum(rs);
+      for (int kk = lane; kk < Lk; kk += 64) {
+        const float p = a.P1[pg + kk];
+        const float dm = a.dm1 ? a.dm1[pg + kk] : 1.f;
+        PPT[kk * 8 + h] = p * dm;
+        DST[kk * 8 + h] = p * (dsr[kk] * dm - rs);
+      }
+    }
+    __syncthreads();
+    f32x4_t qacc[8];
+#pragma unroll
+    for (int h = 0; h < 8; ++h) qacc[h] = f4zero();
+    rowacc8<S16, true, 8>(src, DST, Lk, qacc);
+    // d(src)[kk] = sum_h P'[h][kk] d(ctx)[h] + dS[h][kk] qk[h]: a wave per row, 4 columns per lane (its 16 fragment registers stay)
+    if (dsrc_b) {
+      f32x4_t fd[8], fq[8];
+#pragma unroll
+      for (int h = 0; h < 8; ++h) { fd[h] = ld4(DC8 + h * DLD + 4 * lane); fq[h] = ld4(QK8 + h * DLD + 4 * lane); }
+      for (int kk = wave; kk < Lk; kk += DNW) {
+        float* p = dsrc_b + (long)kk * a.lddsrc + 4 * lane;
+        f32x4_t o = a.dsrc_accumulate ? ld4(p) : f4zero();
+        const f32x4_t p0 = ld4(PPT + kk * 8), p1 = ld4(PPT + kk * 8 + 4), s0 = ld4(DST + kk * 8), s1 = ld4(DST + kk * 8 + 4);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          o += p0[h] * fd[h] + s0[h] * fq[h];
+          o += p1[h] * fd[4 + h] + s1[h] * fq[4 + h];
+        }
+        *(f32x4_t*)p = o;
+      }
+    }
+    __syncthreads();                               // (DS8 is dead: PARTS may take its place)
+    rowacc8_combine(qacc, PARTS, A0, a.dqk + row0 * DH * DE);           // d(qk) rows: LDS (A0 rows 0 .. 7) + global
+    __syncthreads();
+  } else {
   for (int q0 = 0; q0 < R; q0 += 2) {
     const int nrho = min(2, R - q0) * DH;
     for (int e = tid; e < CRB * (DE / 4); e += DNT) {
@@ -1111,6 +1188,7 @@ __global__ __launch_bounds__(DNT) void dec_attn_bwd_kernel(DecAttnBwdArgs a) {
       }
     }
     __syncthreads();
+  }
   }
   // ---- B5: d(qc)[r][h*32+d] = Wk_h d(qk)[r][h] ; d(q pre-scale) = d(qc) * 32^-1/2
   {
@@ -1363,13 +1441,18 @@ __global__ __launch_bounds__(256) void dec_ffn_fwd_kernel(DecFfnArgs a) {
   const int s = blockIdx.x, f0 = s * FS, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
   for (int m0 = 0; m0 < a.M; m0 += 64) {
     const int rows = min(64, a.M - m0);
+    auto bload1 = [&](int, int k) { return ld4(a.W1 + (long)(f0 + 16 * wave + j) * DE + k + 4 * g); };
+    auto bload2 = [&](int t, int k) { return ld4(a.W2 + (long)(16 * (wave + 4 * t) + j) * a.Fd + f0 + k + 4 * g); };
+    f32x4_t pf1[16], pf2[16];
+    stream_nt_prefetch<16, 16>(1, bload1, pf1);      // the wave's whole W1 tile and its four W2 tiles, requested before the rows arrive
+    stream_nt_prefetch<4, 16>(4, bload2, pf2);
     for (int e = tid; e < 64 * (DE / 4); e += 256) {
       const int r = e / (DE / 4), c = 4 * (e % (DE / 4));
       *(f32x4_t*)(X + r * DLD + c) = r < rows ? ld4(a.t2 + (long)(m0 + r) * DE + c) : f4zero();
     }
     __syncthreads();
     {   // h_s: one 16-column tile per wave, 4 row tiles
-      auto bload = [&](int, int k) { return ld4(a.W1 + (long)(f0 + 16 * wave + j) * DE + k + 4 * g); };
+      auto& bload = bload1;
       auto aload = [&](int, int k, int row) { return ld4(X + row * DLD + k + 4 * g); };
       auto epi = [&](int, int rt, f32x4_t acc) {
         const int f = 16 * wave + j;
@@ -1386,11 +1469,11 @@ __global__ __launch_bounds__(256) void dec_ffn_fwd_kernel(DecFfnArgs a) {
           HS[r * FLD + f] = y;
         }
       };
-      stream_nt<16, 4, 8, 0>(1, bload, aload, epi);
+      stream_nt<16, 4, 16, 0>(1, bload, aload, epi, pf1);
     }
     __syncthreads();
     {   // slab[s][r][n] = sum_f h_s[r][f] W2[n][f0 + f]: 16 column tiles, 4 per wave
-      auto bload = [&](int t, int k) { return ld4(a.W2 + (long)(16 * (wave + 4 * t) + j) * a.Fd + f0 + k + 4 * g); };
+      auto& bload = bload2;
       auto aload = [&](int, int k, int row) { return ld4(HS + row * FLD + k + 4 * g); };
       auto epi = [&](int t, int rt, f32x4_t acc) {
         const int n = 16 * (wave + 4 * t) + j;
@@ -1400,7 +1483,7 @@ __global__ __launch_bounds__(256) void dec_ffn_fwd_kernel(DecFfnArgs a) {
           if (r < rows) a.slabs[((long)s * a.M + m0 + r) * DE + n] = acc[v];
         }
       };
-      stream_nt<4, 4, 4, 0>(4, bload, aload, epi);
+      stream_nt<4, 4, 16, 0>(4, bload, aload, epi, pf2);
     }
     __syncthreads();
   }
@@ -1462,7 +1545,9 @@ __global__ __launch_bounds__(256) void dec_ffn_bwd_kernel(DecFfnBwdArgs a) {
   for (int m0 = 0; m0 < a.M; m0 += FBR) {
     const int rows = min(FBR, a.M - m0);
     // ---- row-local: dy3 = d(t3) + LN_post backward(d(hs)); d(r3) = LN3 backward(dy3); DRM = d(r3) * m2
-    for (int rr = wave; rr < FBR; rr += 4) {
+#pragma unroll
+    for (int ri = 0; ri < FBR / 4; ++ri) {          // (compile-time trip count: the 8 rows' loads are issued together)
+      const int rr = wave + 4 * ri;
       const long r = m0 + rr;
       f32x4_t drm = f4zero(), t2v = f4zero();
       if (rr < rows) {

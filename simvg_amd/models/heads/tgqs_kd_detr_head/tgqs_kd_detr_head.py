@@ -283,7 +283,12 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
         the layer output (the decoder's shared post_norm_layer) -> returns (layer output, post-normed output | None)."""
         params = [self._P(L + k) for k in self._LAYER_KEYS]
         gP, bP = (self._P(post + ".weight"), self._P(post + ".bias")) if post else (None, None)
-        if cfg.Lk > ops.dec_attn_max_keys() or os.environ.get("SIMVG_DEC_UNFUSED") == "1":       # (=1: A/B measurements)
+        # the fused layer (csrc/decoder.hip: a workgroup owns a sample's query rows) is the faster one for ONE query per sample (the
+        # RefCOCO configs, the benchmark): measured at 64 samples x 10 queries it loses to the per-stage kernels (37.6 vs 32.2 ms per
+        # step: 640 rows on 64 workgroups, the FFN's hidden slices walk them serially) -- profiles/r05_sweeps.md.
+        # SIMVG_DEC_UNFUSED=1 / SIMVG_DEC_FUSED=1 force one form (A/B measurements, tests of the multi-query kernels)
+        env_unfused, env_fused = os.environ.get("SIMVG_DEC_UNFUSED") == "1", os.environ.get("SIMVG_DEC_FUSED") == "1"
+        if cfg.Lk > ops.dec_attn_max_keys() or env_unfused or (cfg.nq > 1 and not env_fused):
             # more keys than the fused kernels hold in LDS (patch 16 at 480 / 640 px; no reference config): the per-stage kernels
             if cfg.kind == "text":
                 xk = (src.view(cfg.B, cfg.Lk, -1) + cfg.pos[None]).reshape(src.shape)
