@@ -522,7 +522,7 @@ __global__ __launch_bounds__(DNT) void dec_attn_fwd_kernel(DecAttnArgs a) {
   for (int e = tid; e < 16 * (DE / 4); e += DNT) {
     const int r = e / (DE / 4), c = 4 * (e % (DE / 4));
     f32x4_t t = f4zero(), q = f4zero();
-    if (r < R) { t = ld4(a.tgt + (row0 + r) * DE + c); q = ld4(a.qpos + (row0 + r) * DE + c); }
+    if (r < R) { if (a.tgt) t = ld4(a.tgt + (row0 + r) * DE + c); q = ld4(a.qpos + (row0 + r) * DE + c); }      // tgt == NULL: zeros (a decoder's first layer)
     *(f32x4_t*)(T + r * DLD + c) = t;
     *(f32x4_t*)(QP + r * DLD + c) = q;
     *(f32x4_t*)(X1 + r * DLD + c) = t + q;
@@ -1341,8 +1341,8 @@ __host__ __device__ inline WP dec_wgrad_problem(const DecWgradArgs& a, int pid) 
     p.A = A; p.lda = lda; p.Bm = Bm; p.B2 = B2; p.ldb = ldb; p.C = C; p.Nn = Nn;
   };
   auto vec = [&](const float* Bm, long ldb, float* C, int Kc) { p.Bm = Bm; p.ldb = ldb; p.C = C; p.Kc = Kc; p.Nn = 1; };
-  if (pid == 0) mat(a.dqkv, 3 * DE, a.tgt, a.qpos, DE, a.dWs, 2 * DE);
-  else if (pid == 1) mat(a.dqkv + 2 * DE, 3 * DE, a.tgt, nullptr, DE, a.dWs + 2 * DE * DE, DE);
+  if (pid == 0) mat(a.dqkv, 3 * DE, a.tgt ? a.tgt : a.qpos, a.tgt ? a.qpos : nullptr, DE, a.dWs, 2 * DE);      // (tgt == NULL: zeros)
+  else if (pid == 1) { mat(a.dqkv + 2 * DE, 3 * DE, a.tgt, nullptr, DE, a.dWs + 2 * DE * DE, DE); p.zero = a.tgt == nullptr; }
   else if (pid == 2) vec(a.dqkv, 3 * DE, a.dbs, 3 * DE);
   else if (pid == 3) mat(a.d_r1, DE, a.o, nullptr, DE, a.dWso, DE);
   else if (pid == 4) vec(a.d_r1, DE, a.dbso, DE);

@@ -50,6 +50,7 @@ __device__ __forceinline__ void sg_store(const SGArgs& a, float v, int m, int n)
   if (!post) v += add;
   if (a.act == 2) v = fmaxf(v, 0.f);
   else if (a.act == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));   // exact mode: libm erf
+  else if (a.act == 3) v = 1.0f / (1.0f + expf(-v));                                 // sigmoid (the box heads' last Linear)
   if (a.mult) v *= a.mult[(long)m * a.ldm + n];
   if (a.gate) v = a.gate[(long)m * a.ldg + n] > 0.f ? v : 0.f;
   if (post) v += add;
@@ -482,7 +483,7 @@ extern "C" int simvg_gemm_f32(const float* A, long sam, long sak, const float* B
                               long ldc, const float* bias, const float* addend, long ld_addend, int addend_rows,
                               int M, int N, int K, int accumulate, int act, hipStream_t stream) {
   SIMVG_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm_f32: empty problem");
-  SIMVG_CHECK_ARG(act >= 0 && act <= 2, "gemm_f32: act must be 0 (none), 1 (gelu) or 2 (relu)");
+  SIMVG_CHECK_ARG(act >= 0 && act <= 3, "gemm_f32: act must be 0 (none), 1 (gelu), 2 (relu) or 3 (sigmoid)");
   SGArgs a{A, sam, sak, B, sbk, sbn, C, ldc, bias, addend, ld_addend, addend_rows > 0 ? addend_rows : 1, M, N, K,
            accumulate, act, nullptr, nullptr, nullptr, 0, nullptr, 0};
   // <= 128 tiles of 64x64: the small-M kernel (one workgroup per 16x16 tile, K split over its waves).  32 in round 1 (tuned at
@@ -509,7 +510,7 @@ extern "C" int simvg_gemm_f32_grouped(const simvg_gemm_f32_problem* problems, in
   for (int i = 0; i < count; ++i) {
     const simvg_gemm_f32_problem& q = problems[i];
     SIMVG_CHECK_ARG(q.M > 0 && q.N > 0 && q.K > 0, "gemm_f32_grouped: empty problem");
-    SIMVG_CHECK_ARG(q.act >= 0 && q.act <= 2, "gemm_f32_grouped: act must be 0 (none), 1 (gelu) or 2 (relu)");
+    SIMVG_CHECK_ARG(q.act >= 0 && q.act <= 3, "gemm_f32_grouped: act must be 0 (none), 1 (gelu), 2 (relu) or 3 (sigmoid)");
     g.p[i] = SGArgs{q.A, q.sam, q.sak, q.B, q.sbk, q.sbn, q.C, q.ldc, q.bias, q.addend, q.ld_addend,
                     q.addend_rows > 0 ? q.addend_rows : 1, q.M, q.N, q.K, q.accumulate, q.act,
                     q.A2, q.B2, q.mult, q.ld_mult, q.gate, q.ld_gate};

@@ -732,8 +732,10 @@ def dec_attn_fwd(tgt, qpos, W, src, B, R, Lk, kv_rows=0, kv_off=0, kpos=None, kp
     multipliers [B,H,R,R] / [B,H,R,Lk].  Returns the dict of saved tensors; ["t2"] is the block's output [B*R, E]."""
     lib = _lib.load()
     E, H, M = DEC_E, DEC_H, B * R
-    dev = tgt.device
+    dev = qpos.device
     for t, n in ((tgt, "tgt"), (qpos, "qpos")):
+        if t is None and n == "tgt":          # None: zeros (the first layer of a decoder) -- no buffer is filled or read
+            continue
         _chk(t, torch.float32, n)
         assert tuple(t.shape) == (M, E) and t.is_contiguous(), n
     for w in W:
@@ -746,7 +748,7 @@ def dec_attn_fwd(tgt, qpos, W, src, B, R, Lk, kv_rows=0, kv_off=0, kpos=None, kp
     bufs = dict(zip(_DEC_SAVED, _carve([sizes[k] for k in _DEC_SAVED], dev)))
     a = _lib.DecAttnArgs()
     a.B, a.R, a.Lk, a.kv_rows, a.kv_off = B, R, Lk, kv_rows, kv_off
-    a.tgt, a.qpos = tgt.data_ptr(), qpos.data_ptr()
+    a.tgt, a.qpos = (tgt.data_ptr() if tgt is not None else None), qpos.data_ptr()
     for name, w in zip(("Ws", "bs", "Wso", "bso", "g0", "b0", "Wc", "bc", "Wco", "bco", "g1", "b1"), W):
         setattr(a, name, w.data_ptr())
     if src.dtype == LP():
@@ -786,7 +788,7 @@ def dec_attn_bwd(saved, tgt, qpos, W, src, B, R, Lk, dt2=None, dt2_slabs=None, k
     computed); written, or added to with dsrc_accumulate.  Returns (d_tgt, d_qpos, {parameter gradients in W's order})."""
     lib = _lib.load()
     E, H, M = DEC_E, DEC_H, B * R
-    dev = tgt.device
+    dev = qpos.device
     kv_rows = kv_rows or Lk
     Ws, bs, Wso, bso, g0, b0, Wc, bc, Wco, bco, g1, b1 = W
     names = ("d_tgt", "d_qpos") + _DEC_BWD_ROWS + ("dctx", "dqk", "dqkv") + _DEC_PARAM_GRADS
@@ -829,7 +831,7 @@ def dec_attn_bwd(saved, tgt, qpos, W, src, B, R, Lk, dt2=None, dt2_slabs=None, k
     _lib.check(rc, "simvg_dec_attn_bwd")
     w = _lib.DecAttnWgradArgs()
     w.MR = M
-    w.tgt, w.qpos = tgt.data_ptr(), qpos.data_ptr()
+    w.tgt, w.qpos = (tgt.data_ptr() if tgt is not None else None), qpos.data_ptr()
     for n in ("t1", "o", "o2", "ctx", "sp", "qc"):
         setattr(w, n, saved[n].data_ptr())
     for n in ("dqkv", "d_r1", "gx1", "d_t1", "dqpre", "dqk", "d_o2", "d_r2", "gx2", "dt2sum") + _DEC_PARAM_GRADS:

@@ -41,19 +41,84 @@ class LinearF32(torch.autograd.Function):
         M, K = x.shape
         N = W.shape[0]
         dx = dW = db = None
+        probs = []                        # weight, bias and input gradient: independent contractions of dy, ONE launch
         if ctx.needs_input_grad[1]:
             dW = torch.empty(N, K, device=dy.device, dtype=torch.float32)
+            probs.append(ops.gp(dy, 1, N, x, x.stride(0), x.stride(1), dW, N, K, M))                     # dW = dy^T x
         if ctx.has_b and ctx.needs_input_grad[2]:
             db = torch.empty(1, N, device=dy.device, dtype=torch.float32)
-        if dW is not None:
-            ops.gemm_f32(dy, 1, N, x, x.stride(0), x.stride(1), dW, N, K, M)        # dW = dy^T x
-        if db is not None:
-            ops.gemm_f32(_ones(M, dy.device), 0, 1, dy, N, 1, db, 1, N, M)          # db = 1^T dy
-            db = db.view(N)
+            probs.append(ops.gp(_ones(M, dy.device), 0, 1, dy, N, 1, db, 1, N, M))                       # db = 1^T dy
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)
-            ops.gemm_f32(dy, N, 1, W, W.stride(0), 1, dx, M, K, N)                      # dx = dy W
-        return dx, dW, db, None
+            probs.append(ops.gp(dy, N, 1, W, W.stride(0), 1, dx, M, K, N))                               # dx = dy W
+        if probs:
+            ops.gemm_f32_group(probs)
+        return dx, dW, None if db is None else db.view(N), None
+
+
+class PredHeadFn(torch.autograd.Function):
+    """The prediction heads on [M, E] query rows as one autograd node: optional leading Linear (the token branch's `mlp.layers.0`,
+    tgqs_kd_detr_head.py:411-413), class Linear, and the 3-layer box MLP (Linear, ReLU, Linear, ReLU, Linear; heads/utils.py:39-46)
+    + sigmoid (:415-420, :427-428).  Forward: 3 (4) launches -- {class logits, first box Linear + ReLU} share one, the sigmoid is the
+    last GEMM's epilogue --; backward: 3 (4) grouped launches + the sigmoid's derivative -- each stage's weight, bias and input
+    gradient are one launch, the ReLU gates ride on the input gradient's epilogue (gate = the saved activation), the class branch's
+    input gradient joins the box branch's as the epilogue's addend -- instead of 5 (6) / 16 (19).
+    Returns (logits [M, C], boxes [M, 4], the leading Linear's output [M, E] | None)."""
+
+    @staticmethod
+    def forward(ctx, x, Wm, bm, Wc, bc, W0, b0, W1, b1, W2, b2):
+        x = x.contiguous()
+        M, E = x.shape
+        dev = x.device
+        xm = x
+        if Wm is not None:
+            xm = _f32(M, Wm.shape[0], device=dev)
+            ops.gemm_f32(x, E, 1, Wm, 1, Wm.stride(0), xm, M, Wm.shape[0], E, bias=bm)
+        C, F0, F1 = Wc.shape[0], W0.shape[0], W1.shape[0]
+        logits, h0, h1, boxes = _f32(M, C, device=dev), _f32(M, F0, device=dev), _f32(M, F1, device=dev), _f32(M, W2.shape[0], device=dev)
+        Em = xm.shape[1]
+        ops.gemm_f32_group([ops.gp(xm, Em, 1, Wc, 1, Wc.stride(0), logits, M, C, Em, bias=bc),
+                            ops.gp(xm, Em, 1, W0, 1, W0.stride(0), h0, M, F0, Em, bias=b0, act=2)])
+        ops.gemm_f32(h0, F0, 1, W1, 1, W1.stride(0), h1, M, F1, F0, bias=b1, act=2)
+        ops.gemm_f32(h1, F1, 1, W2, 1, W2.stride(0), boxes, M, W2.shape[0], F1, bias=b2, act=3)
+        ctx.save_for_backward(x, xm, h0, h1, boxes, Wm, Wc, W0, W1, W2)
+        ctx.set_materialize_grads(False)
+        return logits, boxes, (xm if Wm is not None else None)
+
+    @staticmethod
+    def backward(ctx, dlogits, dboxes, dxm):
+        x, xm, h0, h1, boxes, Wm, Wc, W0, W1, W2 = ctx.saved_tensors
+        M, E = x.shape
+        dev = x.device
+        Em, C, F0, F1, NB = xm.shape[1], Wc.shape[0], W0.shape[0], W1.shape[0], W2.shape[0]
+        ones = _ones(M, dev)
+        z = lambda t, shape: torch.zeros(shape, device=dev, dtype=torch.float32) if t is None else t.contiguous()
+        dlogits, dboxes = z(dlogits, (M, C)), z(dboxes, (M, NB))
+        dpre2 = torch.ops.aten.sigmoid_backward(dboxes, boxes)
+        dWc, dbc, dW0, db0 = _f32(C, Em, device=dev), _f32(1, C, device=dev), _f32(F0, Em, device=dev), _f32(1, F0, device=dev)
+        dW1, db1, dW2, db2 = _f32(F1, F0, device=dev), _f32(1, F1, device=dev), _f32(NB, F1, device=dev), _f32(1, NB, device=dev)
+        dh1, dh0, dxc, dxm_ = _f32(M, F1, device=dev), _f32(M, F0, device=dev), _f32(M, Em, device=dev), _f32(M, Em, device=dev)
+        ops.gemm_f32_group([ops.gp(dpre2, 1, NB, h1, F1, 1, dW2, NB, F1, M),
+                            ops.gp(ones, 0, 1, dpre2, NB, 1, db2, 1, NB, M),
+                            ops.gp(dpre2, NB, 1, W2, W2.stride(0), 1, dh1, M, F1, NB, gate=h1),         # (dpre2 W2) where the ReLU was open
+                            ops.gp(dlogits, C, 1, Wc, Wc.stride(0), 1, dxc, M, Em, C),                  # the class branch's share of d(xm)
+                            ops.gp(dlogits, 1, C, xm, Em, 1, dWc, C, Em, M),
+                            ops.gp(ones, 0, 1, dlogits, C, 1, dbc, 1, C, M)])
+        ops.gemm_f32_group([ops.gp(dh1, 1, F1, h0, F0, 1, dW1, F1, F0, M),
+                            ops.gp(ones, 0, 1, dh1, F1, 1, db1, 1, F1, M),
+                            ops.gp(dh1, F1, 1, W1, W1.stride(0), 1, dh0, M, F0, F1, gate=h0)])
+        addend = dxc if dxm is None else dxc + dxm.contiguous()
+        ops.gemm_f32_group([ops.gp(dh0, 1, F0, xm, Em, 1, dW0, F0, Em, M),
+                            ops.gp(ones, 0, 1, dh0, F0, 1, db0, 1, F0, M),
+                            ops.gp(dh0, F0, 1, W0, W0.stride(0), 1, dxm_, M, Em, F0, addend=addend, addend_rows=M)])
+        dx, dWm, dbm = dxm_, None, None
+        if Wm is not None:
+            dWm, dbm, dx = _f32(Wm.shape[0], E, device=dev), _f32(1, Wm.shape[0], device=dev), _f32(M, E, device=dev)
+            ops.gemm_f32_group([ops.gp(dxm_, 1, Em, x, E, 1, dWm, Em, E, M),
+                                ops.gp(ones, 0, 1, dxm_, Em, 1, dbm, 1, Em, M),
+                                ops.gp(dxm_, Em, 1, Wm, Wm.stride(0), 1, dx, M, E, Em)])
+            dbm = dbm.view(-1)
+        return (dx if ctx.needs_input_grad[0] else None, dWm, dbm, dWc, dbc.view(C), dW0, db0.view(F0), dW1, db1.view(F1), dW2, db2.view(NB))
 
 
 class LinearLP(torch.autograd.Function):
@@ -198,25 +263,25 @@ class DecoderLayerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, tgt, qpos, src, Ws, bs, Wso, bso, g0, b0, Wc, bc, Wco, bco, g1, b1n, W1, b1, W2, b2, g2, b2n, gP, bP, cfg):
-        dev = tgt.device
-        tgt, qpos = tgt.contiguous(), qpos.contiguous()
+        dev = qpos.device
+        tgt, qpos = (None if tgt is None else tgt.contiguous()), qpos.contiguous()       # tgt None: zeros (a decoder's first layer)
         B, H, nq = cfg.B, cfg.H, cfg.nq
         train = cfg.training
-        M, Fd = tgt.shape[0], W1.shape[0]
+        M, Fd = qpos.shape[0], W1.shape[0]
         mem = cfg.kind == "mem"
         kv_rows, kv_off = (cfg.Nv, 1) if mem else (cfg.Lk, 0)
-        kpos = cfg.pos.reshape(-1, tgt.shape[1]) if cfg.pos is not None else None
+        kpos = cfg.pos.reshape(-1, qpos.shape[1]) if cfg.pos is not None else None
         dm0 = cfg.mask_fn((B, H, nq, nq), dev) if (train and cfg.p_attn > 0) else None
         dm1 = cfg.mask_fn((B, H, nq, cfg.Lk), dev) if (train and cfg.p_attn > 0) else None
         W = [w.contiguous() for w in (Ws, bs, Wso, bso, g0, b0, Wc, bc, Wco, bco, g1, b1n)]
         sa = ops.dec_attn_fwd(tgt, qpos, W, src, B, nq, cfg.Lk, kv_rows=kv_rows, kv_off=kv_off, kpos=kpos, kpm=cfg.kpm, dm0=dm0, dm1=dm1)
         m1 = m2 = None
         if train and cfg.p_ffn > 0:
-            m1, m2 = cfg.mask_fn((M, Fd), dev, cfg.p_ffn), cfg.mask_fn((M, tgt.shape[1]), dev, cfg.p_ffn)
+            m1, m2 = cfg.mask_fn((M, Fd), dev, cfg.p_ffn), cfg.mask_fn((M, qpos.shape[1]), dev, cfg.p_ffn)
         sf = ops.dec_ffn_fwd(sa["t2"], W1, b1, W2, b2, g2, b2n, gP=gP, bP=bP, m1=m1, m2=m2)
         ctx.cfg, ctx.sa, ctx.sf = cfg, sa, sf
         ctx.geo = (kv_rows, kv_off)
-        ctx.save_for_backward(tgt, qpos, src, kpos, dm0, dm1, m1, m2, *W, W1, W2, g2, gP)
+        ctx.save_for_backward(tgt, qpos, src, kpos, dm0, dm1, m1, m2, *W, W1, W2, g2, gP)     # (None entries are allowed)
         ctx.set_materialize_grads(False)
         return sf["t3"], sf["hs"]
 
@@ -227,9 +292,9 @@ class DecoderLayerFn(torch.autograd.Function):
         cfg, sa, sf = ctx.cfg, ctx.sa, ctx.sf
         kv_rows, kv_off = ctx.geo
         B, nq = cfg.B, cfg.nq
-        M, E = tgt.shape
+        M, E = qpos.shape
         if d_t3 is None and d_hs is None:
-            d_t3 = torch.zeros(M, E, device=tgt.device, dtype=torch.float32)
+            d_t3 = torch.zeros(M, E, device=qpos.device, dtype=torch.float32)
         d_t3 = None if d_t3 is None else d_t3.contiguous()
         d_hs = None if (d_hs is None or gP is None) else d_hs.contiguous()
         d_r3, slabs, gf = ops.dec_ffn_bwd(sf, sa["t2"], W1, W2, g2, gP=gP, d_t3=d_t3, d_hs=d_hs, m1=m1, m2=m2)
@@ -237,16 +302,16 @@ class DecoderLayerFn(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             holder = cfg.mem_grad
             if holder is None:
-                dsrc = ret_dsrc = torch.empty(src.shape[0], E, device=tgt.device, dtype=torch.float32)
+                dsrc = ret_dsrc = torch.empty(src.shape[0], E, device=qpos.device, dtype=torch.float32)
             else:
                 dsrc = holder.get("buf")
                 acc = dsrc is not None                      # the first layer of the backward writes the buffer, the others add
                 if dsrc is None:
-                    dsrc = holder["buf"] = torch.empty(src.shape[0], E, device=tgt.device, dtype=torch.float32)
+                    dsrc = holder["buf"] = torch.empty(src.shape[0], E, device=qpos.device, dtype=torch.float32)
         d_tgt, d_qpos, ga = ops.dec_attn_bwd(sa, tgt, qpos, W, src, B, nq, cfg.Lk, dt2=d_r3, dt2_slabs=slabs, kv_rows=kv_rows, kv_off=kv_off,
                                              kpos=kpos, dm0=dm0, dm1=dm1, dsrc=dsrc, dsrc_accumulate=acc)
         dW1, db1, dW2, db2, dg2, db2n, dgP, dbP = gf
-        return (d_tgt, d_qpos, ret_dsrc, *ga, dW1, db1, dW2, db2, dg2, db2n, dgP, dbP, None)
+        return (d_tgt if tgt is not None else None, d_qpos, ret_dsrc, *ga, dW1, db1, dW2, db2, dg2, db2n, dgP, dbP, None)
 
 
 class DecoderLayerUnfusedFn(torch.autograd.Function):

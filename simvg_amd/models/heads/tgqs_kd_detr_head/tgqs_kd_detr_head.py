@@ -19,7 +19,7 @@ import torch.nn.functional as F
 
 from ... import builder
 from .... import hip_ops as ops
-from ..functions import (Criterion, DecoderLayerFn, DecoderLayerUnfusedFn, LayerCfg, LayerNormF32, LinearLP, LinearF32, SharedMemoryGrad,
+from ..functions import (Criterion, DecoderLayerFn, DecoderLayerUnfusedFn, LayerCfg, PredHeadFn, LayerNormF32, LinearLP, LinearF32, SharedMemoryGrad,
                          SplitEncoderOutput)
 
 
@@ -230,6 +230,14 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
         y = LinearF32.apply(x.reshape(-1, shp[-1]), W.view(W.shape[0], -1), b, relu)
         return y.view(*shp[:-1], -1)
 
+    def _pred_head(self, x, branch, lead=None):
+        """class_embed_<branch> and bbox_embed_<branch> (+ sigmoid) on the rows x [M, E] as one autograd node (PredHeadFn); lead: key
+        of a Linear applied first (the token branch's mlp)"""
+        P = self._P
+        Wm, bm = (P(lead + ".weight"), P(lead + ".bias")) if lead else (None, None)
+        w = [P(f"bbox_embed_{branch}.layers.{k}.{n}") for k in range(3) for n in ("weight", "bias")]
+        return PredHeadFn.apply(x, Wm, bm, P(f"class_embed_{branch}.weight"), P(f"class_embed_{branch}.bias"), *w)
+
     def _ln(self, x, key):
         shp = x.shape
         return LayerNormF32.apply(x.reshape(-1, shp[-1]), self._P(key + ".weight"), self._P(key + ".bias"), 1e-5).view(shp)
@@ -289,6 +297,8 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
         # SIMVG_DEC_UNFUSED=1 / SIMVG_DEC_FUSED=1 force one form (A/B measurements, tests of the multi-query kernels)
         env_unfused, env_fused = os.environ.get("SIMVG_DEC_UNFUSED") == "1", os.environ.get("SIMVG_DEC_FUSED") == "1"
         if cfg.Lk > ops.dec_attn_max_keys() or env_unfused or (cfg.nq > 1 and not env_fused):
+            if tgt is None:
+                tgt = torch.zeros_like(qpos)
             # more keys than the fused kernels hold in LDS (patch 16 at 480 / 640 px; no reference config): the per-stage kernels
             if cfg.kind == "text":
                 xk = (src.view(cfg.B, cfg.Lk, -1) + cfg.pos[None]).reshape(src.shape)
@@ -378,7 +388,7 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
         qpos = qe.unsqueeze(0).expand(B, nq, E).reshape(B * nq, E)
         tkpm = (text_mask != 0).to(torch.uint8).contiguous()
 
-        tgt = torch.zeros(B * nq, E, device=device)
+        tgt = None                                      # zeros (transformer.py:220: `target = torch.zeros_like(query_embed)`)
         pre = "text_guided_query_generation_transformer."
         # the TGQG layers attend from the queries to the text rows: keys = text + 1-D sine positions, values = text (:391-399)
         cfg_t = self._layer_cfg(B, "text", T, kpm=tkpm, pos=c["tpos"])
@@ -394,13 +404,11 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
         if set(self.branch_loss_weight) == {"decoder"}:
             tok_logits = tok_boxes = None
         else:
-            tok = self._lin(tok, "mlp.layers.0")
-            tok_logits = self._lin(tok, "class_embed_token").view(1, B, nq, -1)
-            tb = self._lin(self._lin(tok, "bbox_embed_token.layers.0", relu=True), "bbox_embed_token.layers.1", relu=True)
-            tok_boxes = self._lin(tb, "bbox_embed_token.layers.2").sigmoid().view(1, B, nq, 4)
+            tl, tbx, tok = self._pred_head(tok, "token", lead="mlp.layers.0")
+            tok_logits, tok_boxes = tl.view(1, B, nq, -1), tbx.view(1, B, nq, 4)
         # ---- decoder branch (:425-428)
         qpos_d = query_embed.reshape(B * nq, E)
-        tgt = torch.zeros(B * nq, E, device=device)
+        tgt = None                                      # zeros (transformer.py:220: `target = torch.zeros_like(query_embed)`)
         hs = []
         mem_grad = None
         if not exact and mem.requires_grad and torch.is_grad_enabled():
@@ -412,9 +420,8 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
                                          post="transformer.decoder.post_norm_layer")
             hs.append(h)
         hs = torch.stack(hs).view(self.num_decoder_layers, B, nq, E)
-        dec_logits = self._lin(hs, "class_embed_decoder")
-        db = self._lin(self._lin(hs, "bbox_embed_decoder.layers.0", relu=True), "bbox_embed_decoder.layers.1", relu=True)
-        dec_boxes = self._lin(db, "bbox_embed_decoder.layers.2").sigmoid()
+        dl, dbx, _ = self._pred_head(hs.reshape(-1, E), "decoder")
+        dec_logits, dec_boxes = dl.view(self.num_decoder_layers, B, nq, -1), dbx.view(self.num_decoder_layers, B, nq, 4)
         self._end_masks()
         return dict(
             token_branch_output={"pred_logits": None if tok_logits is None else tok_logits[-1],

@@ -208,3 +208,33 @@ def test_ffn_block_forward_backward(M, Fd, post, drop):
         worst = max(worst, e)
         assert e <= 2e-5, (name, e)
     print(f"[ffn block M={M} Fd={Fd} post={post} drop={drop}] forward <= 5e-6, worst relative gradient error {worst:.2e}")
+
+
+@pytest.mark.parametrize("M,lead", [(64, True), (192, False), (7, True)])
+def test_prediction_heads_node(M, lead):
+    """class Linear + 3-layer box MLP + sigmoid (+ the token branch's leading Linear) as one autograd node (PredHeadFn) against
+    plain PyTorch: outputs and every gradient, with gradients arriving for the logits, the boxes and (lead) the leading output."""
+    from simvg_amd.models.heads.functions import PredHeadFn
+    g = torch.Generator().manual_seed(M)
+    r = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
+    x = r(M, E)
+    P = [r(E, E, sc=E ** -0.5), r(E, sc=0.1)] if lead else [None, None]
+    P += [r(2, E, sc=E ** -0.5), r(2, sc=0.1), r(E, E, sc=E ** -0.5), r(E, sc=0.1), r(E, E, sc=E ** -0.5), r(E, sc=0.1), r(4, E, sc=E ** -0.5), r(4, sc=0.1)]
+    dl, db_, dxm = r(M, 2), r(M, 4), r(M, E)
+    leaves = lambda dev, dt: [None if t is None else t.clone().to(dev).to(dt).requires_grad_(True) for t in [x] + P]
+    c = leaves("cpu", torch.float64)
+    xm = c[0] @ c[1].t() + c[2] if lead else c[0]
+    lg = xm @ c[3].t() + c[4]
+    bx = torch.sigmoid(F.relu(F.relu(xm @ c[5].t() + c[6]) @ c[7].t() + c[8]) @ c[9].t() + c[10])
+    loss = (lg * dl.double()).sum() + (bx * db_.double()).sum() + ((xm * dxm.double()).sum() if lead else 0)
+    loss.backward()
+    d = leaves(DEV, torch.float32)
+    lgd, bxd, xmd = PredHeadFn.apply(*d)
+    outs, grads = [lgd, bxd] + ([xmd] if lead else []), [dl.to(DEV), db_.to(DEV)] + ([dxm.to(DEV)] if lead else [])
+    torch.autograd.backward(outs, grads)
+    rel = lambda got, ref: float((got.double().cpu() - ref).abs().max() / max(float(ref.abs().max()), 1e-12))
+    assert rel(lgd, lg.detach()) <= 5e-6 and rel(bxd, bx.detach()) <= 5e-6
+    assert (xmd is None) == (not lead)
+    for i, (a, b) in enumerate(zip(d, c)):
+        if b is not None:
+            assert rel(a.grad, b.grad) <= 2e-5, (i, rel(a.grad, b.grad))
