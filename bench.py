@@ -161,12 +161,15 @@ def attention_roofline(B, H, Nv, T, hd, device, reps=50):
         e1.synchronize()
         return e0.elapsed_time(e1) * 1e-3 / reps
 
+    tq = timed(lambda: ops.attn_qk_probe(qkv, B, H, Nv, T, pad=pad)) if (N + 15) // 16 == 27 else None
     tf = timed(lambda: ops.attn_fwd(qkv, B, H, Nv, T, pad=pad, out=out))
     tb = timed(lambda: ops.attn_bwd(qkv, out, dout, lse, B, H, Nv, T, pad=pad, dqkv=dqkv))
     Np = (N + 63) // 64 * 64
     fl = lambda n, gemms: 2.0 * gemms * B * H * n * n * hd       # fwd: QK^T, PV; bwd: S, dP, dV, dQ, dK
     return dict(fwd_us=tf * 1e6, bwd_us=tb * 1e6, fwd_tf=fl(N, 2) / tf / 1e12, bwd_tf=fl(N, 5) / tb / 1e12,
-                fwd_tf_padded=fl(Np, 2) / tf / 1e12, bwd_tf_padded=fl(Np, 5) / tb / 1e12, N=N, Np=Np)
+                fwd_tf_padded=fl(Np, 2) / tf / 1e12, bwd_tf_padded=fl(Np, 5) / tb / 1e12, N=N, Np=Np,
+                qk_us=None if tq is None else tq * 1e6, qk_tf=None if tq is None else fl(N, 1) / tq / 1e12,
+                qk_tf_padded=None if tq is None else 2.0 * B * H * (27 * 16) * (27 * 16) * hd / tq / 1e12)
 
 
 def traffic_stamp(kernel="gemm_nt", source="gemm.hip"):
@@ -217,6 +220,43 @@ def bf16_line(a):
                 "tests/test_model_gpu.py::_box_tol; the fp16 line above is the one that meets 1e-3",
                 "how": "sub-run of this script with SIMVG_HIP_LIB=simvg_amd/lib/libsimvg_hip_bf16.so, 16 timed steps"}
     except Exception as e:     # never let the side measurement take the headline down
+        return {"error": repr(e)}
+
+
+def reducer_overhead(a, ms_plain):
+    """What the gradient exchange costs a step apart from the bytes on the links, measured on ONE GPU: a sub-run of this script under
+    torch.distributed.run with one RCCL rank and SIMVG_FORCE_REDUCE=1 (every message of the N-rank schedule is issued -- 16 collectives
+    over one rank, the token-id gather, the packed head message, the sparse text rows, the per-layer LayerNorm parameter reductions
+    instead of the single batched one) against the plain run's step time."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port",
+           str(port), os.path.abspath(__file__), "--gpus", "1", "--steps", "24", "--warmup", "6", "--batch", str(a.batch), "--vit", a.vit,
+           "--queries", str(a.queries), "--no-cpu-baseline", "--no-forward-test", "--no-extras"]
+    env = dict(os.environ, SIMVG_FORCE_REDUCE="1", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if not lines:
+            return {"error": "reduced sub-run printed no line: " + (r.stderr.strip().splitlines() or ["no stderr"])[-1][:300]}
+        j = json.loads(lines[-1])
+        # a plain sub-run of the same length beside it (same process start-up state, same box, minutes apart from the headline)
+        cmd2 = [sys.executable, os.path.abspath(__file__)] + cmd[cmd.index("--gpus"):]
+        env2 = {k: v for k, v in env.items() if k != "SIMVG_FORCE_REDUCE"}
+        r2 = subprocess.run(cmd2, capture_output=True, text=True, env=env2, timeout=600)
+        l2 = [l for l in r2.stdout.splitlines() if l.startswith("{")]
+        plain = json.loads(l2[-1])["ms_per_step_p50"] if l2 else ms_plain
+        red = j["reducer"]
+        return {"overhead_ms": round(j["ms_per_step_p50"] - plain, 3), "ms_per_step_p50_reduced": j["ms_per_step_p50"], "ms_per_step_p50_plain": plain,
+                "messages": red.get("messages"), "exposed_ms": (red.get("exposed") or {}).get("mean_ms"),
+                "how": "two 24-step sub-runs of this script: torch.distributed.run, 1 RCCL rank, SIMVG_FORCE_REDUCE=1 vs plain; medians of the "
+                       "per-step times"}
+    except Exception as e:
         return {"error": repr(e)}
 
 
@@ -531,6 +571,17 @@ def main():
           "in_situ": {k: {"avg_launch_us": round(d["ms"] / d["calls"] * 1e3, 2), "launches": d["calls"],
                           "tflops": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 2)} for k, d in situ.items()},
       }
+      if iso.get("qk_us") is not None:
+          out["roofline_attn"]["qk_only"] = {
+              "what": "the QK^T contraction of the forward kernel alone (simvg_attn_qk_probe: same K staging in LDS, same 16x16x32 MFMAs, "
+                      "row maxima stored; no exponentials, no row sums, no PV): what north_star's '>= 60 % of MFMA peak on the encoder QK^T "
+                      "GEMM' prices, beside the fused kernel it is part of",
+              "us": round(iso["qk_us"], 2), "tflops": round(iso["qk_tf"], 2), "frac": round(iso["qk_tf"] / MFMA_BF16_PEAK_TFLOPS, 4),
+              "tflops_tile_padded": round(iso["qk_tf_padded"], 2),
+              "bytes_bound": "it reads q and k of every head once: 2 x B x N x D x 2 B = %.1f MB -> %.1f us at 6.3 TB/s: an isolated "
+                             "d = 64 contraction is HBM-bound at %.2f of MFMA peak however it is written (arithmetic intensity N / 2 FLOP per byte)"
+                             % (4.0 * B * iso["N"] * H * hd / 1e6, 4.0 * B * iso["N"] * H * hd / 6.3e12 * 1e6,
+                                2.0 * B * H * iso["N"] * iso["N"] * hd / (4.0 * B * iso["N"] * H * hd / 6.3e12) / 1e12 / MFMA_BF16_PEAK_TFLOPS)}
       # HBM bytes per launch by PMC beside the algorithmic bytes of a call: forward reads qkv and writes o (+ lse), backward reads
       # qkv, o, dO and writes dqkv.  The backward is ONE kernel per call for the path's geometry (csrc/attention_bwd1.hip) unless
       # SIMVG_ATTN_BWD1=0 selects the dq + dkv pair (two launches per call)
@@ -581,8 +632,9 @@ def main():
     if infer:
         out["forward_test"] = dict(infer, note="MIXDETRMB.forward_test incl. post-processing, one synchronisation per call; batches <= 16 replay "
                                    "encoder + head as one hipGraph per input signature (simvg_amd/graphs.py::InferenceGraphs); the encoder's "
-                                   "Linears carry hi + lo 16-bit weights in this forward (precise_inference, simvg_gemm_nt_split: every box of a "
-                                   "full batch within 1e-3 of the reference); `*_single_16bit_weights` = the same call without it")
+                                   "attention projections (qkv, out-proj) carry hi + lo 16-bit weights in this forward (precise_inference, "
+                                   "simvg_gemm_nt_split: every box of a full batch within 1e-3 of the reference, tests/test_fullsize_gpu.py); "
+                                   "`*_single_16bit_weights` = the same call without it")
     if a.breakdown:
         tot = dt * 1e3
         for k, d in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
@@ -592,6 +644,8 @@ def main():
                   f"({100 * d['ms'] / tot:5.1f} %)  {tf:8.1f} TFLOP/s  {gb:8.1f} GB/s(algorithmic)", file=sys.stderr)
     if extras and _lowp == "fp16" and not os.environ.get("SIMVG_HIP_LIB"):
         out["bf16_line"] = bf16_line(a)
+    if extras and not os.environ.get("SIMVG_HIP_LIB"):
+        out["reducer"]["overhead_one_gpu"] = reducer_overhead(a, p50)
     if extras and not a.no_cpu_baseline and a.vit == "base" and a.queries == 1:
         try:
             out["cpu_baseline"] = cpu_baseline()

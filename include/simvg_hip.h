@@ -142,6 +142,11 @@ int simvg_ln_param_reduce_batched(const simvg_ln_reduce_desc* descs, int n, simv
  * csrc/attention_bwd1.hip, default; SIMVG_ATTN_BWD1=0 selects the two kernels) only parks the stores of rows beyond N in it. */
 int simvg_attn_fwd(const void* qkv_lp, int ldqkv, void* out_lp, int ldo, float* lse, const unsigned char* pad,
                    int B, int H, int Nv, int Nt, int D, float scale, simvg_stream_t stream);
+/* Measurement entry point: the QK^T contraction of simvg_attn_fwd alone (same K staging in LDS, same MFMAs; no softmax, no PV) for
+ * the path's geometry; rowmax [B*H, N] = max over the keys of the scaled scores.  BASELINE.json's north_star quotes its target on
+ * "the encoder QK^T GEMM" (torchscale MultiheadAttention's `torch.bmm(q, k.transpose(1, 2))`, called from beit3_base.py:137-145). */
+int simvg_attn_qk_probe(const void* qkv_lp, int ldqkv, float* rowmax, const unsigned char* key_padding_mask, int B, int H, int Nv,
+                        int Nt, int D, float scale, simvg_stream_t stream);
 int simvg_attn_bwd(const void* qkv_lp, int ldqkv, const void* out_lp, int ldo, const void* dout_lp, int lddo,
                    void* dqkv_lp, int lddqkv, const float* lse, float* delta_ws, const unsigned char* pad,
                    int B, int H, int Nv, int Nt, int D, float scale, simvg_stream_t stream);
@@ -277,6 +282,19 @@ typedef struct simvg_dec_ffn_bwd_args {
   float *db2, *dg2, *db2n, *dgP, *dbP;
 } simvg_dec_ffn_bwd_args;
 int simvg_dec_ffn_bwd(const simvg_dec_ffn_bwd_args* args, simvg_stream_t stream);
+
+/* ---- query assembly around the TGQG layers (tgqs_kd_detr_head.py:385-411), E = 256 ------------------------------------------
+ * text_filt: has_pad[b] = any(mask[b] == 1); filt[b] = has_pad ? max(text[b, T-1], text[b, T-2]) : text[b, T-1] -- what the
+ *   reference's `text_feat.masked_fill(~mask, -inf).max(1)` selects when `mask` is int64 (quirk Q1) --; kpm[b][t] = mask[b][t] != 0.
+ *   The backward writes the whole d(text) [B*T, E] (zeros except the two rows; a tie splits the gradient, as torch.maximum does).
+ * query_mix: query_embed[b, q] = g[b, q] + filt[b] + qe[q]; tok[b, q] = query_embed[b, q] + cls[b] (Q5); the backward takes the
+ *   gradients of both outputs (either may be NULL) and writes d(g) [B*R, E], d(filt) [B, E], d(cls) [B, E], d(qe) [R, E]. */
+int simvg_text_filt_fwd(const float* text, const long long* mask, float* filt, unsigned char* kpm, int B, int T, simvg_stream_t stream);
+int simvg_text_filt_bwd(const float* text, const long long* mask, const float* dfilt, float* dtext, int B, int T, simvg_stream_t stream);
+int simvg_query_mix_fwd(const float* g, const float* filt, const float* qe, const float* cls, float* query_embed, float* tok, int B, int R,
+                        simvg_stream_t stream);
+int simvg_query_mix_bwd(const float* d_query_embed, const float* d_tok, float* dg, float* dfilt, float* dcls, float* dqe, int B, int R,
+                        simvg_stream_t stream);
 
 /* exact-fp32 forward pieces (precision="fp32" inference mode: the reference computes in fp32, use_fp16=False in all
  * 53 configs): fp32 im2col and an fp32 encoder attention with the same modality-major row layout as simvg_attn_fwd. */

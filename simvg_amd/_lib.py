@@ -80,6 +80,10 @@ class DecFfnBwdArgs(C.Structure):       # simvg_dec_ffn_bwd_args
 
 
 _SIGS = {
+    "simvg_text_filt_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "simvg_text_filt_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "simvg_query_mix_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "simvg_query_mix_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "simvg_dec_ffn_fwd": [c_void_p, c_void_p],
     "simvg_dec_ffn_finish": [c_void_p, c_void_p],
     "simvg_dec_ffn_bwd": [c_void_p, c_void_p],
@@ -111,6 +115,7 @@ _SIGS = {
     "simvg_ln_param_reduce_batched": [c_void_p, c_int, c_void_p],
     "simvg_attn_fwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                        c_float, c_void_p],
+    "simvg_attn_qk_probe": [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
     "simvg_attn_bwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
                        c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
     "simvg_im2col": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],

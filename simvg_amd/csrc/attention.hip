@@ -133,7 +133,9 @@ __global__ __launch_bounds__(768) void attn_fwd_kernel(AttnArgs a) {
 //   * PV MFMAs of key pair s2 are issued right after its 8 exponentials, so the matrix pipe works under the next pair's
 //     transcendental VALU instead of after all of it.
 // ------------------------------------------------------------------------------------------
-template <int NKT, int KFULL, int NTHREADS, int G = 2>
+// QK_ONLY (measurement: simvg_attn_qk_probe): the same K staging and QK^T contraction, then only the row maximum of the raw scores
+// is stored -- no exponentials, no row sums, no PV -- so that the contraction north_star prices can be timed by itself.
+template <int NKT, int KFULL, int NTHREADS, int G = 2, bool QK_ONLY = false>
 __global__ __launch_bounds__(NTHREADS) void attn_fwd_t_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NS2 = (NKT + 1) / 2, NPAD = NS2 * 32;
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_t_kernel(AttnArgs a) {
   const int j = lane & 15, g = lane >> 4;
 
   load_head_to_lds(a, a.qkv, a.ld, a.D + h * HD, b, N, NPAD, ldsK);
-  load_head_to_lds(a, a.qkv, a.ld, 2 * a.D + h * HD, b, N, NPAD, ldsV);
+  if constexpr (!QK_ONLY) load_head_to_lds(a, a.qkv, a.ld, 2 * a.D + h * HD, b, N, NPAD, ldsV);
   fill_key_bias(a, b, N, NPAD, bias);
   __syncthreads();
 
@@ -202,6 +204,10 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_t_kernel(AttnArgs a) {
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if constexpr (QK_ONLY) {
+      if (tq < N && g == 0 && a.lse) a.lse[(long)blockIdx.x * N + tq] = mx * a.scale;
+      continue;
+    }
     const float mxs = mx * sc2;          // sc2 > 0: max(s) * c == max(s * c)
     f32x4_t o[4], rs = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -936,6 +942,23 @@ extern "C" int simvg_attn_fwd(const void* qkv, int ldqkv, void* out, int ldo, fl
   // 12 waves per workgroup (3 per SIMD): the 27 query strips of a 421-token head take 3 rounds instead of 4 and the
   // MFMA / softmax-VALU / LDS phases of three waves overlap on every SIMD (512 threads: 112 us, 768: 95 us)
   hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H, qsplit), dim3(768), shm, stream, a);
+  SIMVG_LAUNCH_CHECK();
+  return SIMVG_OK;
+}
+
+// The encoder attention's QK^T contraction alone (K of a head staged in LDS, Q fragments from global, 16x16x32 MFMAs), for the
+// path's geometry (27 key tiles): rowmax[b*H + h][t] = max_k scale * q_t . k_k (key padding -> -inf).  A measurement entry point:
+// north_star quotes a target for "the encoder QK^T GEMM", SURVEY 8(d) asks for it beside the fused kernel's figure.
+extern "C" int simvg_attn_qk_probe(const void* qkv, int ldqkv, float* rowmax, const unsigned char* pad, int B, int H, int Nv, int Nt, int D,
+                                   float scale, hipStream_t stream) {
+  SIMVG_CHECK_ARG(attn_check(B, H, Nv, Nt, D, ldqkv) && rowmax, "attn_qk_probe: need head_dim 64, 16-B aligned rows");
+  const int N = Nv + Nt, npad = ((cdiv(N, 16) + 1) / 2) * 32;
+  SIMVG_CHECK_ARG(cdiv(N, 16) == 27 && Nv / 16 >= 25, "attn_qk_probe: built for the path's geometry (417 .. 432 tokens, >= 400 of them vision)");
+  AttnArgs a{(const lp_t*)qkv, ldqkv, nullptr, 0, nullptr, 0, nullptr, 0, rowmax, nullptr, pad, B, H, Nv, Nt, D, scale};
+  const size_t shm = (size_t)2 * npad * ROWB + npad * sizeof(float);
+  static bool once = set_lds_limit(attn_fwd_t_kernel<27, 25, 768, 2, true>, 160 * 1024);
+  (void)once;
+  hipLaunchKernelGGL((attn_fwd_t_kernel<27, 25, 768, 2, true>), dim3(B * H, 1), dim3(768), shm, stream, a);
   SIMVG_LAUNCH_CHECK();
   return SIMVG_OK;
 }

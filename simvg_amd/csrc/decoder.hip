@@ -1692,6 +1692,81 @@ __global__ __launch_bounds__(256) void dec_colsum_kernel(DecColsumArgs a) {
   a.out[i][c] = (s0 + s1) + (s2 + s3);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Query assembly around the TGQG layers (tgqs_kd_detr_head.py:385-411), the element-wise pieces between the fused layers as four
+// small launches instead of ~25 framework ones (comparisons, where / maximum and their backward, broadcast adds, reductions):
+//   text_filt : has_pad[b] = any(mask[b] == 1); filt[b] = has_pad ? max(text[b, T-1], text[b, T-2]) : text[b, T-1]   (quirk Q1: `~mask`
+//               on an int64 mask is a bitwise NOT, which selects exactly these rows); kpm[b][t] = mask[b][t] != 0
+//   query_mix : query_embed[b, q] = g[b, q] + filt[b] + qe[q];  tok[b, q] = query_embed[b, q] + cls[b]                 (Q5)
+// and their gradients (torch.maximum's convention: a tie splits the gradient in halves).
+struct TextFiltArgs { const float* text; const long long* mask; float* filt; unsigned char* kpm; int B, T; };
+__global__ __launch_bounds__(256) void text_filt_fwd_kernel(TextFiltArgs a) {
+  const int b = blockIdx.x, c = threadIdx.x;
+  __shared__ int pad;
+  if (c == 0) pad = 0;
+  __syncthreads();
+  for (int t = c; t < a.T; t += 256) {
+    const long long m = a.mask[(long)b * a.T + t];
+    a.kpm[(long)b * a.T + t] = m != 0;
+    if (m == 1) pad = 1;                      // (benign race: every writer stores 1)
+  }
+  __syncthreads();
+  const float x1 = a.text[((long)b * a.T + a.T - 1) * DE + c], x2 = a.text[((long)b * a.T + a.T - 2) * DE + c];
+  a.filt[(long)b * DE + c] = pad ? fmaxf(x1, x2) : x1;
+}
+struct TextFiltBwdArgs { const float* text; const long long* mask; const float* dfilt; float* dtext; int B, T; };
+__global__ __launch_bounds__(256) void text_filt_bwd_kernel(TextFiltBwdArgs a) {
+  const int b = blockIdx.x, c = threadIdx.x;
+  __shared__ int pad;
+  if (c == 0) pad = 0;
+  __syncthreads();
+  for (int t = c; t < a.T; t += 256)
+    if (a.mask[(long)b * a.T + t] == 1) pad = 1;
+  __syncthreads();
+  const long r1 = ((long)b * a.T + a.T - 1) * DE + c, r2 = ((long)b * a.T + a.T - 2) * DE + c;
+  const float x1 = a.text[r1], x2 = a.text[r2], g = a.dfilt[(long)b * DE + c];
+  for (int t = 0; t < a.T - 2; ++t) a.dtext[((long)b * a.T + t) * DE + c] = 0.f;
+  float g1 = g, g2 = 0.f;
+  if (pad) {
+    if (x1 == x2) { g1 = 0.5f * g; g2 = 0.5f * g; }
+    else if (x1 < x2) { g1 = 0.f; g2 = g; }
+  }
+  a.dtext[r1] = g1;
+  a.dtext[r2] = g2;
+}
+struct QueryMixArgs { const float *g, *filt, *qe, *cls; float *qeo, *tok; int B, R; };
+__global__ __launch_bounds__(256) void query_mix_fwd_kernel(QueryMixArgs a) {
+  const int row = blockIdx.x, c = threadIdx.x, b = row / a.R, q = row % a.R;
+  const float v = a.g[(long)row * DE + c] + a.filt[(long)b * DE + c] + a.qe[(long)q * DE + c];
+  a.qeo[(long)row * DE + c] = v;
+  a.tok[(long)row * DE + c] = v + a.cls[(long)b * DE + c];
+}
+// d(g)[row] = d(qeo)[row] + d(tok)[row]; d(filt)[b] = sum_q that; d(cls)[b] = sum_q d(tok)[b, q]: workgroup per sample;
+// d(qe)[q] = sum_b d(g)[b, q]: workgroups B .. B + R - 1, after ... no: a second launch (it reads what the first wrote)
+struct QueryMixBwdArgs { const float *dqeo, *dtok; float *dg, *dfilt, *dcls, *dqe; int B, R; };
+__global__ __launch_bounds__(256) void query_mix_bwd_kernel(QueryMixBwdArgs a) {
+  const int b = blockIdx.x, c = threadIdx.x;
+  float sf = 0.f, sc = 0.f;
+  for (int q = 0; q < a.R; ++q) {
+    const long i = ((long)b * a.R + q) * DE + c;
+    const float dt = a.dtok ? a.dtok[i] : 0.f, d = (a.dqeo ? a.dqeo[i] : 0.f) + dt;
+    a.dg[i] = d;
+    sf += d;
+    sc += dt;
+  }
+  a.dfilt[(long)b * DE + c] = sf;
+  a.dcls[(long)b * DE + c] = sc;
+}
+__global__ __launch_bounds__(256) void query_mix_bwd_qe_kernel(QueryMixBwdArgs a) {
+  const int q = blockIdx.x, c = threadIdx.x;
+  float s0 = 0.f, s1 = 0.f;
+  int b = 0;
+  for (; b + 2 <= a.B; b += 2) { s0 += a.dg[((long)b * a.R + q) * DE + c]; s1 += a.dg[((long)(b + 1) * a.R + q) * DE + c]; }
+  if (b < a.B) s0 += a.dg[((long)b * a.R + q) * DE + c];
+  a.dqe[(long)q * DE + c] = s0 + s1;
+}
+
 }  // namespace
 
 // mirror of include/simvg_hip.h
@@ -1864,6 +1939,35 @@ extern "C" int simvg_dec_ffn_bwd(const simvg_dec_ffn_bwd_args* p, hipStream_t st
   if (p->d_hs) { add(p->gxP, p->dgP); add(p->d_hs, p->dbP); }
   for (int i = c.n; i < 8; ++i) { c.x[i] = nullptr; c.out[i] = nullptr; }
   hipLaunchKernelGGL(dec_colsum_kernel, dim3(c.n), dim3(256), 0, stream, c);
+  SIMVG_LAUNCH_CHECK();
+  return SIMVG_OK;
+}
+
+extern "C" int simvg_text_filt_fwd(const float* text, const long long* mask, float* filt, unsigned char* kpm, int B, int T, hipStream_t stream) {
+  SIMVG_CHECK_ARG(text && mask && filt && kpm && B > 0 && T >= 2, "text_filt_fwd: need at least two text rows per sample");
+  hipLaunchKernelGGL(text_filt_fwd_kernel, dim3(B), dim3(256), 0, stream, TextFiltArgs{text, mask, filt, kpm, B, T});
+  SIMVG_LAUNCH_CHECK();
+  return SIMVG_OK;
+}
+extern "C" int simvg_text_filt_bwd(const float* text, const long long* mask, const float* dfilt, float* dtext, int B, int T, hipStream_t stream) {
+  SIMVG_CHECK_ARG(text && mask && dfilt && dtext && B > 0 && T >= 2, "text_filt_bwd: need at least two text rows per sample");
+  hipLaunchKernelGGL(text_filt_bwd_kernel, dim3(B), dim3(256), 0, stream, TextFiltBwdArgs{text, mask, dfilt, dtext, B, T});
+  SIMVG_LAUNCH_CHECK();
+  return SIMVG_OK;
+}
+extern "C" int simvg_query_mix_fwd(const float* g, const float* filt, const float* qe, const float* cls, float* qeo, float* tok, int B, int R,
+                                   hipStream_t stream) {
+  SIMVG_CHECK_ARG(g && filt && qe && cls && qeo && tok && B > 0 && R > 0, "query_mix_fwd: null operand");
+  hipLaunchKernelGGL(query_mix_fwd_kernel, dim3(B * R), dim3(256), 0, stream, QueryMixArgs{g, filt, qe, cls, qeo, tok, B, R});
+  SIMVG_LAUNCH_CHECK();
+  return SIMVG_OK;
+}
+extern "C" int simvg_query_mix_bwd(const float* dqeo, const float* dtok, float* dg, float* dfilt, float* dcls, float* dqe, int B, int R,
+                                   hipStream_t stream) {
+  SIMVG_CHECK_ARG((dqeo || dtok) && dg && dfilt && dcls && dqe && B > 0 && R > 0, "query_mix_bwd: null operand");
+  const QueryMixBwdArgs a{dqeo, dtok, dg, dfilt, dcls, dqe, B, R};
+  hipLaunchKernelGGL(query_mix_bwd_kernel, dim3(B), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(query_mix_bwd_qe_kernel, dim3(R), dim3(256), 0, stream, a);
   SIMVG_LAUNCH_CHECK();
   return SIMVG_OK;
 }

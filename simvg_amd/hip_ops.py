@@ -538,6 +538,17 @@ def attn_fwd(qkv, B, H, Nv, Nt, pad=None, out=None, scale=None):
     return out, lse
 
 
+def attn_qk_probe(qkv, B, H, Nv, Nt, pad=None, scale=None):
+    """the QK^T contraction of `attn_fwd` alone (measurement): row maxima of the scaled scores [B*H, N]"""
+    lib = _lib.load()
+    _chk(qkv, LP(), "qkv")
+    D = qkv.shape[1] // 3
+    rowmax = torch.empty(B * H, Nv + Nt, device=qkv.device, dtype=torch.float32)
+    rc = lib.simvg_attn_qk_probe(_p(qkv), qkv.stride(0), _p(rowmax), _p(pad), B, H, Nv, Nt, D, (D // H) ** -0.5 if scale is None else scale, _stream())
+    _lib.check(rc, "simvg_attn_qk_probe")
+    return rowmax
+
+
 def attn_bwd(qkv, out, dout, lse, B, H, Nv, Nt, pad=None, dqkv=None, scale=None):
     lib = _lib.load()
     M, D3 = qkv.shape

@@ -30,10 +30,13 @@ class LinearF32(torch.autograd.Function):
         ops.gemm_f32(x, x.stride(0), x.stride(1), W, 1, W.stride(0), y, M, N, K, bias=b, act=2 if relu else 0)
         ctx.save_for_backward(x, W, y if relu else None)
         ctx.relu, ctx.has_b = relu, b is not None
+        ctx.set_materialize_grads(False)
         return y
 
     @staticmethod
     def backward(ctx, dy):
+        if dy is None:          # reachable in the graph but without a gradient (input_cls_proj under a decoder-only head): no
+            return None, None, None, None        # gradient for the parameters either, as in the reference -- not zeros
         x, W, y = ctx.saved_tensors
         dy = dy.contiguous()
         if ctx.relu:
@@ -54,6 +57,65 @@ class LinearF32(torch.autograd.Function):
         if probs:
             ops.gemm_f32_group(probs)
         return dx, dW, None if db is None else db.view(N), None
+
+
+class TextFilt(torch.autograd.Function):
+    """filt [B, E] (the "filtered" text feature the TGQG adds to the query embedding, tgqs_kd_detr_head.py:385-388, with an int64
+    mask: quirk Q1) and the uint8 key-padding mask of the text rows, one launch; backward one launch."""
+
+    @staticmethod
+    def forward(ctx, text, mask, B, T):
+        text = text.contiguous()
+        lib = ops._lib.load()
+        filt = torch.empty(B, text.shape[1], device=text.device, dtype=torch.float32)
+        kpm = torch.empty(B, T, device=text.device, dtype=torch.uint8)
+        ops._lib.check(lib.simvg_text_filt_fwd(text.data_ptr(), mask.data_ptr(), filt.data_ptr(), kpm.data_ptr(), B, T, ops._stream()),
+                       "simvg_text_filt_fwd")
+        ctx.save_for_backward(text, mask)
+        ctx.geo = (B, T)
+        ctx.mark_non_differentiable(kpm)
+        return filt, kpm
+
+    @staticmethod
+    def backward(ctx, dfilt, _):
+        text, mask = ctx.saved_tensors
+        B, T = ctx.geo
+        dtext = torch.empty_like(text)
+        lib = ops._lib.load()
+        ops._lib.check(lib.simvg_text_filt_bwd(text.data_ptr(), mask.data_ptr(), dfilt.contiguous().data_ptr(), dtext.data_ptr(), B, T,
+                                               ops._stream()), "simvg_text_filt_bwd")
+        return dtext, None, None, None
+
+
+class QueryMix(torch.autograd.Function):
+    """query_embed = g + filt + qe, tok = query_embed + cls (tgqs_kd_detr_head.py:399-411, Q5): one launch; the backward (two small
+    launches) takes the gradients of both outputs and returns those of g, filt, qe, cls."""
+
+    @staticmethod
+    def forward(ctx, g, filt, qe, cls, B, R):
+        g, filt, qe, cls = g.contiguous(), filt.contiguous(), qe.contiguous(), cls.contiguous()
+        qeo, tok = torch.empty_like(g), torch.empty_like(g)
+        lib = ops._lib.load()
+        ops._lib.check(lib.simvg_query_mix_fwd(g.data_ptr(), filt.data_ptr(), qe.data_ptr(), cls.data_ptr(), qeo.data_ptr(), tok.data_ptr(),
+                                               B, R, ops._stream()), "simvg_query_mix_fwd")
+        ctx.geo = (B, R, g.shape[1])
+        ctx.set_materialize_grads(False)
+        return qeo, tok
+
+    @staticmethod
+    def backward(ctx, dqeo, dtok):
+        B, R, E = ctx.geo
+        ref = dqeo if dqeo is not None else dtok
+        dqeo = None if dqeo is None else dqeo.contiguous()
+        dtok = None if dtok is None else dtok.contiguous()
+        buf = torch.empty((B * R + 2 * B + R) * E, device=ref.device, dtype=torch.float32)
+        dg, dfilt, dcls, dqe = buf[:B * R * E], buf[B * R * E:(B * R + B) * E], buf[(B * R + B) * E:(B * R + 2 * B) * E], buf[(B * R + 2 * B) * E:]
+        lib = ops._lib.load()
+        ops._lib.check(lib.simvg_query_mix_bwd(None if dqeo is None else dqeo.data_ptr(), None if dtok is None else dtok.data_ptr(),
+                                               dg.data_ptr(), dfilt.data_ptr(), dcls.data_ptr(), dqe.data_ptr(), B, R, ops._stream()),
+                       "simvg_query_mix_bwd")
+        # (no gradient reaches `tok` when the head has no token branch: `cls` then gets None, as in the reference, not zeros)
+        return dg.view(B * R, E), dfilt.view(B, E), dqe.view(R, E), (dcls.view(B, E) if dtok is not None else None), None, None
 
 
 class PredHeadFn(torch.autograd.Function):

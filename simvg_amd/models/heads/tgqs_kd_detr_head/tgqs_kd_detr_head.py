@@ -19,7 +19,7 @@ import torch.nn.functional as F
 
 from ... import builder
 from .... import hip_ops as ops
-from ..functions import (Criterion, DecoderLayerFn, DecoderLayerUnfusedFn, LayerCfg, PredHeadFn, LayerNormF32, LinearLP, LinearF32, SharedMemoryGrad,
+from ..functions import (Criterion, DecoderLayerFn, DecoderLayerUnfusedFn, LayerCfg, PredHeadFn, QueryMix, TextFilt, LayerNormF32, LinearLP, LinearF32, SharedMemoryGrad,
                          SplitEncoderOutput)
 
 
@@ -381,12 +381,11 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
         text3 = text.view(B, T, E)
         if text_mask.dtype == torch.bool:
             filt = text3.masked_fill(text_mask[:, :, None], float("-inf")).max(1)[0]
+            tkpm = text_mask.to(torch.uint8).contiguous()
         else:   # Q1: `~mask` on an int64 mask is a bitwise NOT -> rows T-1 (mask==0 present) and T-2 (mask==1 present)
-            has_pad = (text_mask == 1).any(1, keepdim=True)
-            filt = torch.where(has_pad, torch.maximum(text3[:, T - 1], text3[:, T - 2]), text3[:, T - 1])
+            filt, tkpm = TextFilt.apply(text, text_mask.to(torch.int64).contiguous(), B, T)
         qe = self._P("query_embed.weight")
         qpos = qe.unsqueeze(0).expand(B, nq, E).reshape(B * nq, E)
-        tkpm = (text_mask != 0).to(torch.uint8).contiguous()
 
         tgt = None                                      # zeros (transformer.py:220: `target = torch.zeros_like(query_embed)`)
         pre = "text_guided_query_generation_transformer."
@@ -397,8 +396,8 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
             last = i == self.num_tgqg_layers - 1
             tgt, g = self._decoder_layer(f"{pre}layers.{i}.", tgt, qpos, cfg_t, text,
                                          post=pre + "post_norm_layer" if last else None)
-        query_embed = g.view(B, nq, E) + filt[:, None, :] + qe[None]
-        tok = (query_embed + cls[:, None, :]).reshape(B * nq, E)                      # Q5
+        query_embed, tok = QueryMix.apply(g, filt, qe, cls, B, nq)                    # g + filt + qe ; + cls (Q5)
+        query_embed = query_embed.view(B, nq, E)
         # ---- token branch (:411-420); with branch_loss_weight == {"decoder": w} the reference skips it, in forward_test
         # as well: the token prediction is {"pred_logits": None, "pred_boxes": None} and `token_features` the pre-MLP sum (:403-409)
         if set(self.branch_loss_weight) == {"decoder"}:
