@@ -1525,11 +1525,10 @@ struct DecFfnBwdArgs {
   float* slabs;                                               // [Fd / 64][M][E]  d(t2) partial sums
   float *dW1, *db1, *dW2;
 };
-constexpr int FBR = 32;            // rows per pass of the backward
+constexpr int FBR = 64;            // rows per pass of the backward (the benchmark's 64 query rows are ONE pass)
 
 __global__ __launch_bounds__(256) void dec_ffn_bwd_kernel(DecFfnBwdArgs a) {
   __shared__ float DRM[FBR * DLD];      // d(r3) * m2
-  __shared__ float T2[FBR * DLD];
   __shared__ float HS[FBR * FLD];       // h1d slice
   __shared__ float DH[FBR * FLD];       // d(pre-activation) slice
   const int s = blockIdx.x, f0 = s * FS, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
@@ -1542,14 +1541,18 @@ __global__ __launch_bounds__(256) void dec_ffn_bwd_kernel(DecFfnBwdArgs a) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) { aw1[i][c] = f4zero(); aw2[i][c] = f4zero(); }
   float ab1 = 0.f;                      // threads 0 .. 63: db1 of hidden unit f0 + tid
+  auto bl_w2 = [&](int n, int) { return ld4(a.W2 + (long)n * a.Fd + f0 + 4 * j); };
+  auto bl_w1 = [&](int f, int) { return ld4(a.W1 + (long)(f0 + f) * DE + 64 * wave + 4 * j); };
   for (int m0 = 0; m0 < a.M; m0 += FBR) {
     const int rows = min(FBR, a.M - m0);
+    f32x4_t pf_w2[16][1];
+    stream_nn_prefetch<1, 16>(0, DE, bl_w2, pf_w2);            // the first W2 rows, requested before the rows' LayerNorm backward
     // ---- row-local: dy3 = d(t3) + LN_post backward(d(hs)); d(r3) = LN3 backward(dy3); DRM = d(r3) * m2
-#pragma unroll
-    for (int ri = 0; ri < FBR / 4; ++ri) {          // (compile-time trip count: the 8 rows' loads are issued together)
+#pragma unroll 8
+    for (int ri = 0; ri < FBR / 4; ++ri) {          // (compile-time trip count: the loads of 8 rows are issued together)
       const int rr = wave + 4 * ri;
       const long r = m0 + rr;
-      f32x4_t drm = f4zero(), t2v = f4zero();
+      f32x4_t drm = f4zero();
       if (rr < rows) {
         f32x4_t dy = a.d_t3 ? ld4(a.d_t3 + r * DE + 4 * lane) : f4zero();
         if (a.d_hs) {
@@ -1571,7 +1574,6 @@ __global__ __launch_bounds__(256) void dec_ffn_bwd_kernel(DecFfnBwdArgs a) {
         const float c2 = wave_sum((t[0] + t[1]) + (t[2] + t[3])) * (1.f / DE);
         const f32x4_t dr = (dyg - c1 - xh * c2) * rstd;
         drm = a.m2 ? dr * ld4(a.m2 + r * DE + 4 * lane) : dr;
-        t2v = ld4(a.t2 + r * DE + 4 * lane);
         if (lead) {
           *(f32x4_t*)(a.d_r3 + r * DE + 4 * lane) = dr;
           *(f32x4_t*)(a.gx3 + r * DE + 4 * lane) = dy * xh;
@@ -1580,55 +1582,44 @@ __global__ __launch_bounds__(256) void dec_ffn_bwd_kernel(DecFfnBwdArgs a) {
         }
       }
       *(f32x4_t*)(DRM + rr * DLD + 4 * lane) = drm;
-      *(f32x4_t*)(T2 + rr * DLD + 4 * lane) = t2v;
     }
     for (int e = tid; e < FBR * (FS / 4); e += 256) {
       const int r = e / (FS / 4), c = 4 * (e % (FS / 4));
       *(f32x4_t*)(HS + r * FLD + c) = r < rows ? ld4(a.h1d + (long)(m0 + r) * a.Fd + f0 + c) : f4zero();
     }
     __syncthreads();
-    // ---- d(h_s)[r][f] = sum_n DRM[r][n] W2[n][f0 + f], gated: waves 0, 1 own a 16-row tile each over half of n ... simpler:
-    // wave w: row tile (w & 1), n half (w >> 1); the halves meet in LDS
+    // ---- d(h_s)[r][f] = sum_n DRM[r][n] W2[n][f0 + f], gated by the ReLU: wave w owns row tile w (16 rows) over all n
     {
-      const int rt = wave & 1, half = wave >> 1;
       f32x4_t acc[1][1][4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc[0][0][c] = f4zero();
-      auto bload = [&](int n, int) { return ld4(a.W2 + (long)n * a.Fd + f0 + 4 * j); };
-      auto aload = [&](int n, int row) { return DRM[(16 * rt + row) * DLD + n]; };
-      stream_nn<1, 1, 8, 0>(half ? DE / 2 : 0, half ? DE : DE / 2, bload, aload, acc);
-      if (half) {
+      auto aload = [&](int n, int row) { return DRM[(16 * wave + row) * DLD + n]; };
+      stream_nn<1, 1, 16, 0>(0, DE, bl_w2, aload, acc, pf_w2);
 #pragma unroll
-        for (int v = 0; v < 4; ++v)
-          *(f32x4_t*)(DH + (16 * rt + 4 * g + v) * FLD + 4 * j) = (f32x4_t){acc[0][0][0][v], acc[0][0][1][v], acc[0][0][2][v], acc[0][0][3][v]};
-      }
-      __syncthreads();
-      if (!half) {
+      for (int v = 0; v < 4; ++v) {
+        const int rr = 16 * wave + 4 * g + v;
+        f32x4_t d = (f32x4_t){acc[0][0][0][v], acc[0][0][1][v], acc[0][0][2][v], acc[0][0][3][v]};
+        const f32x4_t h = ld4(HS + rr * FLD + 4 * j);
+        if (a.m1 && rr < rows) d *= ld4(a.m1 + (long)(m0 + rr) * a.Fd + f0 + 4 * j);
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const int rr = 16 * rt + 4 * g + v;
-          f32x4_t d = (f32x4_t){acc[0][0][0][v], acc[0][0][1][v], acc[0][0][2][v], acc[0][0][3][v]} + ld4(DH + rr * FLD + 4 * j);
-          const f32x4_t h = ld4(HS + rr * FLD + 4 * j);
-          if (a.m1 && rr < rows) d *= ld4(a.m1 + (long)(m0 + rr) * a.Fd + f0 + 4 * j);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) d[c] = h[c] > 0.f ? d[c] : 0.f;
-          *(f32x4_t*)(DH + rr * FLD + 4 * j) = d;      // (the same lanes wrote / read these addresses: no other wave touches them)
-        }
+        for (int c = 0; c < 4; ++c) d[c] = h[c] > 0.f ? d[c] : 0.f;
+        *(f32x4_t*)(DH + rr * FLD + 4 * j) = d;
       }
     }
+    f32x4_t pf_w1[16][1];
+    stream_nn_prefetch<1, 16>(0, FS, bl_w1, pf_w1);
     __syncthreads();
-    // ---- slab[s][r][k] = sum_f d(pre)[r][f] W1[f0 + f][k]: wave = 64-column group, both row tiles
+    // ---- slab[s][r][k] = sum_f d(pre)[r][f] W1[f0 + f][k]: wave = 64-column group, the four row tiles
     {
-      f32x4_t acc[2][1][4];
+      f32x4_t acc[4][1][4];
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
+      for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[rt][0][c] = f4zero();
-      auto bload = [&](int f, int) { return ld4(a.W1 + (long)(f0 + f) * DE + 64 * wave + 4 * j); };
       auto aload = [&](int f, int row) { return DH[row * FLD + f]; };
-      stream_nn<2, 1, 8, 0>(0, FS, bload, aload, acc);
+      stream_nn<4, 1, 16, 0>(0, FS, bl_w1, aload, acc, pf_w1);
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
+      for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const int rr = 16 * rt + 4 * g + v;
@@ -1637,14 +1628,16 @@ __global__ __launch_bounds__(256) void dec_ffn_bwd_kernel(DecFfnBwdArgs a) {
                 (f32x4_t){acc[rt][0][0][v], acc[rt][0][1][v], acc[rt][0][2][v], acc[rt][0][3][v]};
         }
     }
-    // ---- parameter gradients of this pass's rows (rows >= `rows` are zero in every tile)
-#pragma unroll
+    // ---- parameter gradients of this pass's rows (rows >= `rows` are zero in every tile); the t2 fragments come straight from
+    // global memory (64 rows x 1 KB, hot in L2): a fourth [64][256] LDS tile would not fit beside the other three
+#pragma unroll 4
     for (int st = 0; st < FBR / 4; ++st) {
       const int rr = 4 * st + g;
       const float a1 = DH[rr * FLD + 16 * wave + j];             // dW1 rows f = 16 wave + j
+      const float* t2r = a.t2 + (long)(m0 + min(rr, rows - 1)) * DE + 4 * j;
 #pragma unroll
       for (int cg = 0; cg < 4; ++cg) {
-        const f32x4_t bt = ld4(T2 + rr * DLD + 64 * cg + 4 * j);
+        const f32x4_t bt = ld4(t2r + 64 * cg);
 #pragma unroll
         for (int c = 0; c < 4; ++c) aw1[cg][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bt[c], aw1[cg][c], 0, 0, 0);
       }

@@ -535,6 +535,11 @@ class BEIT3(nn.Module):
             wred = self._wg_batch = ops.WgradReduceBatch()
         red.reset()         # a backward that raised half-way must not leave its descriptors to this one's flush
         wred.reset()
+        # the second stage of a weight gradient (sum of the row partitions' slabs -> dW) right behind its kernel: the slabs (75 - 150 MB
+        # per weight) are then still in the 256 MB Infinity Cache; batched per LAYER (round 4: one launch for 309 MB of slabs) they
+        # came from HBM.  Alternating runs on one box: 28.68 / 28.77 ms per step against 28.96 / 28.90 (profiles/r05_sweeps.md);
+        # SIMVG_WG_REDUCE_NOW=0 restores the per-layer launch
+        wg_now = os.environ.get("SIMVG_WG_REDUCE_NOW", "1") != "0"
         ops.ln_bwd(dout, xs[2 * L], mF, rF, V["lnog"], G["lnog"], G["lnob"], split=Mv, dx_f32=dx, dx_scaled=dyb,
                    row_scale=None if dp is None else dp[L - 1][1], rows_per_sample=rps, dy_scale=S, param_scale=inv)
         for i in reversed(range(L)):
@@ -543,21 +548,25 @@ class BEIT3(nn.Module):
             # ---- FFN branch: x_out = x_mid + dp1 * fc2(LN(gelu(fc1(LN(x_mid)))))
             ops.gemm_nt(dyb, self.wb[f"w2T{i}"], out=dF, split=Mv)
             ops.gemm_tn(dyb, st["g2"], G[f"w2{i}"], split=Mv, db=G[f"b2{i}"], out_scale=inv, defer=wred, assign=assign)
+            if wg_now: wred.flush()
             ops.ln_bwd(dF, st["u"], s["m4"], s["r4"], V[f"lnfg{i}"], G[f"lnfg{i}"], G[f"lnfb{i}"], split=Mv,
                        dx_lp=dF2, gelu_u=st["u"], param_scale=inv, defer=red)      # x == gelu_u: LN input gelu(u) and GELU'(u) recomputed from u
             ops.gemm_nt(dF2, self.wb[f"w1T{i}"], out=dD, split=Mv)
             ops.gemm_tn(dF2, st["h2"], G[f"w1{i}"], split=Mv, db=G[f"b1{i}"], out_scale=inv, defer=wred, assign=assign)
+            if wg_now: wred.flush()
             ops.ln_bwd(dD, xs[2 * i + 1], s["m3"], s["r3"], V[f"ln2g{i}"], G[f"ln2g{i}"], G[f"ln2b{i}"], split=Mv,
                        dres=dx, dx_f32=dx, dx_scaled=dyb, row_scale=None if dp is None else dp[i][0], rows_per_sample=rps,
                        param_scale=inv, defer=red)
             # ---- attention branch: x_mid = x_in + dp0 * out_proj(LN(attn(qkv(LN(x_in)))))
             ops.gemm_nt(dyb, self.wb[f"woutT{i}"], out=dD, split=Mv)
             ops.gemm_tn(dyb, st["o2"], G[f"wout{i}"], split=Mv, db=G[f"bout{i}"], out_scale=inv, defer=wred, assign=assign)
+            if wg_now: wred.flush()
             ops.ln_bwd(dD, st["o"], s["m2"], s["r2"], V[f"lnig{i}"], G[f"lnig{i}"], G[f"lnib{i}"], split=Mv, dx_lp=dO,
                        param_scale=inv, defer=red)
             ops.attn_bwd(st["qkv"], st["o"], dO, st["lse"], B, H, Nv, T, pad=pad_u8, dqkv=dQKV)
             ops.gemm_nt(dQKV, self.wb[f"wqkvT{i}"], out=dD, split=Mv)
             ops.gemm_tn(dQKV, st["h"], G[f"wqkv{i}"], split=Mv, db=G[f"bqkv{i}"], out_scale=inv, defer=wred, assign=assign)
+            if wg_now: wred.flush()
             ops.ln_bwd(dD, xs[2 * i], s["m1"], s["r1"], V[f"ln1g{i}"], G[f"ln1g{i}"], G[f"ln1b{i}"], split=Mv,
                        dres=dx, dx_f32=dx, dx_scaled=dyb,
                        row_scale=None if (dp is None or i == 0) else dp[i - 1][1], rows_per_sample=rps, param_scale=inv,

@@ -36,10 +36,13 @@ def main():
     t0 = seg[0][0]
     print(f"step {want}: {len(seg)} launches, {(seg[-1][1] - t0) / 1e6:.3f} ms wall, kernel time {sum(e - s for s, e, _ in seg) / 1e6:.3f} ms")
     names = [short(n) for _, _, n in seg]
-    # the head: after the last encoder-forward LayerNorm (ln_fwd with fp32 + 16-bit outputs is the final norm) up to the first ln_bwd
-    first_bwd = next(i for i, n in enumerate(names) if n.startswith("ln_bwd"))
-    last_fwd = max(i for i, n in enumerate(names[:first_bwd]) if n.startswith(("gemm_nt_kernel_160", "gemm_nt_kernel_256sq", "gemm_nt_kernel_224")))
-    head = range(last_fwd + 2, first_bwd)        # + the final LayerNorm
+    # the head: after the encoder's final LayerNorm (the first `ln_fwd_kernel<float, 3>` of the step: fp32 in, fp32 + 16-bit out) up to
+    # the encoder backward's first LayerNorm backward (the first `ln_bwd*` launch after the last criterion launch)
+    final_ln = next(i for i, n in enumerate(names) if n.startswith("ln_fwd_kernel<float, 3>"))
+    last_crit = max(i for i, n in enumerate(names) if n.startswith("criterion_kernel"))
+    first_bwd = next(i for i, n in enumerate(names) if i > last_crit and n.startswith("ln_bwd") and (seg[i][1] - seg[i][0]) > 20000)
+    head = range(final_ln + 1, first_bwd)
+    last_fwd = final_ln - 1
     ht = sum(seg[i][1] - seg[i][0] for i in head)
     print(f"head region: launches {len(head)}, kernel time {ht / 1e3:.1f} us, wall {(seg[first_bwd][0] - seg[last_fwd + 1][1]) / 1e3:.1f} us, "
           f"at::native launches {sum(names[i].startswith('at::native') or 'rocclr' in names[i] for i in head)}")
