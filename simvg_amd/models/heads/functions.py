@@ -190,16 +190,26 @@ class LinearLP(torch.autograd.Function):
     (S = hip_ops.grad_scale(), fp16's exponent range) and the GEMMs remove the scale again."""
 
     @staticmethod
-    def forward(ctx, x, W, b, w_lp, wT_lp, out_lp):
+    def forward(ctx, x, W, b, w_lp, wT_lp, out_lp, holder=None, xholder=None):
         y = ops.gemm_nt(x, w_lp, bias=b, out_dtype=ops.LP() if out_lp else torch.float32)
         ctx.save_for_backward(x, wT_lp)
         ctx.shapeW = W.shape
+        # holder (the dict of `SharedMemoryGrad.join`): the fp32 gradient of a 16-bit output is handed over on the side -- through the
+        # graph's edge autograd would round it to the output's 16-bit dtype (unscaled!) and this node would widen it again
+        ctx.holder = holder
+        ctx.xholder = xholder        # the same for the 16-bit INPUT: its fp32 gradient is left in xholder["dx32"] for the producer
+        ctx.set_materialize_grads(False)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, wT = ctx.saved_tensors
         S = ops.grad_scale()
+        side = ctx.holder.pop("dy32", None) if ctx.holder is not None else None
+        if side is not None:
+            dy = side if dy is None else side + dy.float()
+        if dy is None:
+            return None, None, None, None, None, None, None, None
         dyb = ops.cast_lp(dy.float().contiguous(), scale=S)
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
@@ -218,7 +228,10 @@ class LinearLP(torch.autograd.Function):
             db = torch.zeros(ctx.shapeW[0], device=dy.device, dtype=torch.float32)
             ops.colsum(dyb, db)
             db.mul_(1.0 / S)
-        return dx, dW, db, None, None, None
+        if dx is not None and ctx.xholder is not None and x.dtype != torch.float32:
+            ctx.xholder["dx32"] = dx         # (through the edge autograd would round these 83 MB to x's 16-bit dtype, unscaled)
+            dx = None
+        return dx, dW, db, None, None, None, None, None
 
 
 class LayerNormF32(torch.autograd.Function):
@@ -297,6 +310,7 @@ class SharedMemoryGrad(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mem, holder):
         ctx.holder = holder
+        ctx.in_dtype = mem.dtype
         ctx.set_materialize_grads(False)
         return mem.view_as(mem)
 
@@ -305,11 +319,21 @@ class SharedMemoryGrad(torch.autograd.Function):
         buf = ctx.holder.pop("buf", None)
         if buf is None:
             return g, None
-        return (buf if g is None else buf + g), None
+        if g is not None:
+            buf = buf + g.float()
+        if ctx.holder.get("side") and buf.dtype != ctx.in_dtype:
+            # the producer (LinearLP) picks the fp32 buffer up itself: returning it here would round it to the memory's 16-bit dtype
+            ctx.holder["dy32"] = buf
+            return None, None
+        return buf, None
 
     @staticmethod
-    def join(mem):
-        holder = {}
+    def join(mem, holder=None):
+        """holder: the dict also given to the producing `LinearLP` (then flagged "side": the gradient bypasses the 16-bit edge)"""
+        if holder is None:
+            holder = {}
+        else:
+            holder["side"] = True
         return SharedMemoryGrad.apply(mem, holder), holder
 
 
@@ -635,9 +659,11 @@ class SplitEncoderOutput(torch.autograd.Function):
     backward assembles the single fp32 gradient the encoder engine expects."""
 
     @staticmethod
-    def forward(ctx, out32, out_lp, B, Nv, T):
+    def forward(ctx, out32, out_lp, B, Nv, T, xholder=None):
         D = out32.shape[1]
         ctx.geo = (B, Nv, T, D)
+        ctx.xholder = xholder            # where the consumer of `vis` (LinearLP) leaves the fp32 gradient of these 16-bit rows
+        ctx.set_materialize_grads(False)
         vis = out_lp[:B * Nv]
         text = out32[B * Nv:].clone()
         cls = out32[:B * Nv].view(B, Nv, D)[:, 0].clone()
@@ -646,7 +672,12 @@ class SplitEncoderOutput(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dvis, dtext, dcls):
         B, Nv, T, D = ctx.geo
+        side = ctx.xholder.pop("dx32", None) if ctx.xholder is not None else None
+        if side is not None:
+            dvis = side if dvis is None else side + dvis.float()
         ref = dvis if dvis is not None else (dtext if dtext is not None else dcls)
+        if ref is None:
+            return None, None, None, None, None, None
         rows = B * (Nv + T)
         if dvis is not None and dvis.dtype == torch.float32 and dvis.is_contiguous() and dvis.storage_offset() == 0 \
                 and tuple(dvis.shape) == (B * Nv, D) and dvis.untyped_storage().nbytes() >= rows * D * 4:
@@ -663,4 +694,4 @@ class SplitEncoderOutput(torch.autograd.Function):
             d[B * Nv:].zero_()
         if dcls is not None:
             d[:B * Nv].view(B, Nv, D)[:, 0] += dcls
-        return d, None, None, None, None
+        return d, None, None, None, None, None

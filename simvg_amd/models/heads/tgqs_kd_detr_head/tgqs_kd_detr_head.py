@@ -370,9 +370,11 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
             mem = LinearF32.apply(vis, self._P("input_proj.weight").view(E, C), self._P("input_proj.bias"), False)
         else:
             self._refresh_weights(device)
-            vis, text32, cls32 = SplitEncoderOutput.apply(enc_out, enc_lp, B, Nv, T)
+            vis_holder = {}
+            vis, text32, cls32 = SplitEncoderOutput.apply(enc_out, enc_lp, B, Nv, T, vis_holder)
             # H1: input_proj on all vision rows (the CLS row is carried along and never used as a key)
-            mem = LinearLP.apply(vis, self._P("input_proj.weight"), self._P("input_proj.bias"), self.wb["ip"], self.wb["ipT"], True)
+            mem_holder = {}
+            mem = LinearLP.apply(vis, self._P("input_proj.weight"), self._P("input_proj.bias"), self.wb["ip"], self.wb["ipT"], True, mem_holder, vis_holder)
         text = self._lin(text32, "input_text_proj")                       # [B*T, E]
         cls = self._lin(cls32, "input_cls_proj")                          # [B, E]
         pos2d, img_kpm = self._image_pos(B, hw, img_metas, device)
@@ -411,7 +413,7 @@ class TextGuidedQuerySelectKDDETRHead(nn.Module):
         hs = []
         mem_grad = None
         if not exact and mem.requires_grad and torch.is_grad_enabled():
-            mem, mem_grad = SharedMemoryGrad.join(mem)            # one accumulator for the layers' memory gradients
+            mem, mem_grad = SharedMemoryGrad.join(mem, mem_holder)     # one fp32 accumulator for the layers' memory gradients
         for i in range(self.num_decoder_layers):
             # keys = mem + pos, values = mem (key_pos on the keys only); the K / V projections are absorbed into the query / output side
             cfg_m = self._layer_cfg(B, "mem", HW, kpm=img_kpm, pos=pos2d, Nv=Nv, mem_grad=mem_grad)
