@@ -28,6 +28,9 @@ Extra objects in the line:
                   same kernels in situ (HIP-event brackets inside the timed steps).  Algorithmic FLOPs (N = 421) beside the
                   tile-padded FLOPs the MFMA pipe actually executes (N rounded up to the 64-row tile).
   ms_per_step_p50: median of the per-step times (one HIP event per step boundary on the training stream).
+  host_ms_per_step: time the host needs to QUEUE a step (mean of the three fastest of the K steps: it never waits for the GPU inside a
+  step, but runs at the GPU's pace once the runtime's queue is full): below ms_per_step = the GPU is the bound, the launch overhead
+  of the ~460 kernels of a step is hidden behind the queue.
   cpu_baseline  : the CPU oracle (oracle/simvg_cpu.py, a restatement pinned to the reference) timed on the host
                   cores of the same box on a bounded sample (rank 0, N == 1 only): one training step at B = 8 and
                   `forward_test` at B = 1 and B = 8 (the protocol of the reference's tools/misc/inference_time.py:68-75:
@@ -224,38 +227,47 @@ def bf16_line(a):
 
 
 def reducer_overhead(a, ms_plain):
-    """What the gradient exchange costs a step apart from the bytes on the links, measured on ONE GPU: a sub-run of this script under
+    """What the gradient exchange costs a step apart from the bytes on the links, measured on ONE GPU: sub-runs of this script under
     torch.distributed.run with one RCCL rank and SIMVG_FORCE_REDUCE=1 (every message of the N-rank schedule is issued -- 16 collectives
-    over one rank, the token-id gather, the packed head message, the sparse text rows, the per-layer LayerNorm parameter reductions
-    instead of the single batched one) against the plain run's step time."""
+    over one rank, the token-id gather, the head's flat gradient buffer, the sparse text rows) against a plain sub-run of the same
+    length.  Two forms: `overhead_ms` with the production op (ncclAvg: with ONE rank RCCL launches a pre-multiply kernel over every
+    message, `oneRankReduce` -- 640 MB read and written on a second stream beside the backward, which no N-rank run contains), and
+    `issue_only_ms` with SIMVG_REDUCE_OP=sum (a one-rank SUM is a no-op inside RCCL): what issuing the exchange costs -- the
+    collectives' launches, the gather / scatter of the sparse rows, the hook's host time."""
     import socket
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port",
-           str(port), os.path.abspath(__file__), "--gpus", "1", "--steps", "24", "--warmup", "6", "--batch", str(a.batch), "--vit", a.vit,
-           "--queries", str(a.queries), "--no-cpu-baseline", "--no-forward-test", "--no-extras"]
-    env = dict(os.environ, SIMVG_FORCE_REDUCE="1", MASTER_ADDR="127.0.0.1")
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
-        env.pop(k, None)
-    try:
-        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+
+    def sub(extra_env, launcher):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        tail = ["--gpus", "1", "--steps", "24", "--warmup", "6", "--batch", str(a.batch), "--vit", a.vit, "--queries", str(a.queries),
+                "--no-cpu-baseline", "--no-forward-test", "--no-extras"]
+        head = [sys.executable]
+        if launcher:
+            head += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port)]
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", **extra_env)
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SIMVG_FORCE_REDUCE", "SIMVG_REDUCE_OP"):
+            if k not in extra_env:
+                env.pop(k, None)
+        r = subprocess.run(head + [os.path.abspath(__file__)] + tail, capture_output=True, text=True, env=env, timeout=600)
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if not lines:
-            return {"error": "reduced sub-run printed no line: " + (r.stderr.strip().splitlines() or ["no stderr"])[-1][:300]}
-        j = json.loads(lines[-1])
+            raise RuntimeError("sub-run printed no line: " + (r.stderr.strip().splitlines() or ["no stderr"])[-1][:300])
+        return json.loads(lines[-1])
+
+    try:
+        j = sub(dict(SIMVG_FORCE_REDUCE="1"), True)
         # a plain sub-run of the same length beside it (same process start-up state, same box, minutes apart from the headline)
-        cmd2 = [sys.executable, os.path.abspath(__file__)] + cmd[cmd.index("--gpus"):]
-        env2 = {k: v for k, v in env.items() if k != "SIMVG_FORCE_REDUCE"}
-        r2 = subprocess.run(cmd2, capture_output=True, text=True, env=env2, timeout=600)
-        l2 = [l for l in r2.stdout.splitlines() if l.startswith("{")]
-        plain = json.loads(l2[-1])["ms_per_step_p50"] if l2 else ms_plain
+        plain = sub({}, False)["ms_per_step_p50"]
+        k = sub(dict(SIMVG_FORCE_REDUCE="1", SIMVG_REDUCE_OP="sum"), True)
         red = j["reducer"]
-        return {"overhead_ms": round(j["ms_per_step_p50"] - plain, 3), "ms_per_step_p50_reduced": j["ms_per_step_p50"], "ms_per_step_p50_plain": plain,
-                "messages": red.get("messages"), "exposed_ms": (red.get("exposed") or {}).get("mean_ms"),
-                "how": "two 24-step sub-runs of this script: torch.distributed.run, 1 RCCL rank, SIMVG_FORCE_REDUCE=1 vs plain; medians of the "
-                       "per-step times"}
+        return {"overhead_ms": round(j["ms_per_step_p50"] - plain, 3), "issue_only_ms": round(k["ms_per_step_p50"] - plain, 3),
+                "ms_per_step_p50_reduced": j["ms_per_step_p50"], "ms_per_step_p50_issue_only": k["ms_per_step_p50"],
+                "ms_per_step_p50_plain": plain, "messages": red.get("messages"), "exposed_ms": (red.get("exposed") or {}).get("mean_ms"),
+                "how": "three 24-step sub-runs of this script: torch.distributed.run with 1 RCCL rank and SIMVG_FORCE_REDUCE=1 (ncclAvg: "
+                       "RCCL's one-rank pre-multiply kernels run beside the backward), the same with SIMVG_REDUCE_OP=sum (a one-rank SUM "
+                       "is a no-op: the cost of issuing the exchange alone), and plain; medians of the per-step times"}
     except Exception as e:
         return {"error": repr(e)}
 
@@ -418,11 +430,17 @@ def main():
         torch.cuda.synchronize()
         reducer._exposed = []               # set-up / warm-up steps are not part of the exposed-exchange statistic
         t0 = time.perf_counter()
+        host_t = [t0]
         for i in range(a.steps):
             marks[i].record()
             hip_ops.set_timer(timer if i % every == 0 else None)
             losses = step()
+            host_t.append(time.perf_counter())
         marks[a.steps].record()
+        # time the host needs to QUEUE a step: it never waits for the GPU inside one, but once it is ~1000 launches ahead the
+        # runtime's queue is full and it proceeds at the GPU's pace -- the first steps after the synchronisation show its own
+        host_dt = sorted(b - a_ for a_, b in zip(host_t, host_t[1:]))[:3]
+        host_dt = sum(host_dt) / len(host_dt)
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -487,7 +505,7 @@ def main():
     out = {
         "metric": "image-text pairs/sec (whole node), RefCOCO 640x640 bs=64/GPU, 1/2/4/8 MI355X",
         "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(dt / a.steps * 1e3, 3), "ms_per_step_p50": round(p50, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(dt / a.steps * 1e3, 3), "ms_per_step_p50": round(p50, 3), "host_ms_per_step": round(host_dt * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": _lowp, "data": "synthetic",
         "config": {"workload": f"ViT-{'B' if a.vit == 'base' else 'L'}/32 SimVG (MIXDETRMB), synthetic RefCOCO 640x640 + 20-token expr, num_queries={a.queries}, "
                                f"full training step: forward+backward {_lowp} MFMA operands (fp32 accumulate, fp32 residual/master), "
@@ -514,7 +532,7 @@ def main():
     if reducer.active:
         sched = {}
         for k, nbytes in reducer.last_schedule:
-            kk = "layer" if k.startswith("layer:") else k
+            kk = "layer" if k.startswith("layer:") else k          # ("layer:<i>" or, for a group of layers, "layer:<top>-<bottom>")
             sched.setdefault(kk, [0, 0])
             sched[kk][0] += 1
             sched[kk][1] += nbytes

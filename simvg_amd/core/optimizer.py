@@ -74,7 +74,7 @@ class _RestArena:
         ps = (self.params[0], self.params[len(self.params) // 2], self.params[-1])
         return all(p.data.untyped_storage().data_ptr() == base for p in ps)
 
-    def gather_grads(self):
+    def gather_grads(self, rebind=False):
         """autograd's per-tensor gradients -> the flat gradient buffer.  A parameter whose `.grad` is None contributes
         zeros: per-tensor Adam SKIPS such a parameter (no moment decay, no step count, no state), and the fused kernel does
         exactly that for an element whose gradient and moments are all zero (the update is exactly zero and nothing is
@@ -83,7 +83,12 @@ class _RestArena:
         without a gradient (its moments decay with a zero gradient and its bias correction uses the flat tensor's step
         count).  That is not the reference optimizer's arithmetic, so a changed set RAISES (round 5; no reference config
         produces one: every head node is in the graph on every step).  SIMVG_ALLOW_GRADED_SET_CHANGE=1 opts into
-        warn-and-continue (the update stays finite and well defined); `optimizer_config.flat=False` is the exact alternative."""
+        warn-and-continue (the update stays finite and well defined); `optimizer_config.flat=False` is the exact alternative.
+
+        A `.grad` that already IS its slice of the flat buffer is left alone: after the gradient exchange (`dist.GradReducer`
+        gathers early, all-reduces the flat buffer in place and re-points every `.grad` at its slice) the optimizer's own gather
+        copies nothing.  rebind=True re-points the gathered `.grad`s right away; `last_gathered` = [(slice, parameter)] of this call.
+        -> number of parameters with a gradient"""
         mask = tuple(p.grad is not None for p in self.params)
         if getattr(self, "_graded", None) is None:
             self._graded = mask
@@ -97,12 +102,19 @@ class _RestArena:
                                    "SIMVG_ALLOW_GRADED_SET_CHANGE=1 to continue with the flat update")
             warnings.warn(msg, RuntimeWarning, stacklevel=2)
             self._graded = mask
-        have = [(v, p.grad) for v, p in zip(self.grad_views, self.params) if p.grad is not None]
-        if len(have) < len(self.params):
-            self.flat_grad.zero_()
-        if have:
-            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
-        return len(have)
+        graded = sum(mask)
+        have = [(v, p) for v, p in zip(self.grad_views, self.params) if p.grad is not None and p.grad is not v]
+        if not have:
+            self.last_gathered = []
+            return graded              # every gradient already lives in its slice (gathered earlier in this step)
+        if graded < len(self.params):
+            torch._foreach_zero_([v for v, p in zip(self.grad_views, self.params) if p.grad is None])
+        torch._foreach_copy_([v for v, _ in have], [p.grad for _, p in have])
+        self.last_gathered = have
+        if rebind:
+            for v, p in have:
+                p.grad = v
+        return graded
 
 
 @OPTIMIZERS.register_module()
@@ -159,6 +171,32 @@ class FlatAdam(torch.optim.Adam):
                     g["params"] = [ra.param]
             groups.append(g)      # empty groups (lan_enc) stay, so group indices match the reference's
         super().__init__(groups, lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=amsgrad)
+        # the gradient exchange (dist.GradReducer) all-reduces these flat gradient buffers in place
+        object.__setattr__(model, "_simvg_rest_arenas", self._rest_arenas)
+
+    def layout_signature(self):
+        """where every parameter sits inside the flat tensors (names are the model's, offsets the arenas'): the per-element moments
+        of a saved state belong to THIS layout only"""
+        import zlib
+        text = ";".join(f"{n}@{o}:{self.arena.params[n].numel()}" for n, o in self.arena.offsets.items())
+        for ra in self._rest_arenas:
+            text += "|" + ";".join(f"{o}:{p.numel()}" for p, o in zip(ra.params, ra.offsets))
+        return zlib.crc32(text.encode())
+
+    def state_dict(self):
+        sd = super().state_dict()
+        sd["simvg_layout"] = self.layout_signature()
+        return sd
+
+    def load_state_dict(self, state_dict):
+        sd = dict(state_dict)
+        sig = sd.pop("simvg_layout", None)
+        if sig != self.layout_signature():
+            # (round 5 moved the encoder's LayerNorm parameters behind the layers' Linears: a state written before has the same
+            # size and a different order -- loading it would hand every element someone else's moments)
+            raise ValueError("FlatAdam state was written for another arena layout (%r, this build: %r)"
+                             % (sig, self.layout_signature()))
+        super().load_state_dict(sd)
 
     def zero_grad(self, set_to_none=True):
         for p in self._rest:

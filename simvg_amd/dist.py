@@ -49,12 +49,17 @@ class GradReducer:
         self.check_ids = os.environ.get("SIMVG_DIST_CHECK") == "1"
         # RCCL averages inside the collective (ncclAvg): no separate 1/world pass over the 640 MB of gradients; gloo (CPU
         # tests) has no AVG -> SUM, then one division per message
-        self._avg = dist.is_initialized() and dist.get_backend() == "nccl"
+        self._nccl = dist.is_initialized() and dist.get_backend() == "nccl"
+        # SIMVG_REDUCE_OP=sum: SUM in the collective + one division per message (what gloo gets).  With ONE rank RCCL's SUM is a
+        # no-op while its AVG launches a pre-multiply kernel over every message (`oneRankReduce`, 2.3 ms of kernel time per step
+        # beside the backward): bench.py's one-GPU overhead run uses this switch to separate the cost of ISSUING the exchange
+        # (this file's) from that one-rank artefact
+        self._avg = self._nccl and os.environ.get("SIMVG_REDUCE_OP", "avg") != "sum"
+        self._dry = self.world == 1 and os.environ.get("SIMVG_REDUCE_DRY") == "1"
         self.enc = getattr(model, "vis_enc", None)
         self._done_layers = set()
         if self.enc is not None:
-            # (an inactive reducer installs no hook: the encoder's backward then batches the second stages of its LayerNorm
-            # parameter reductions into ONE launch instead of one per layer -- 12 x 15.7 us per step on a single GPU)
+            # (an inactive reducer installs no hook; SIMVG_LAYER_HOOK=1 installs it for A/B runs of its host cost)
             self.enc._grad_ready_hook = self._on_layer_done if (self.active or os.environ.get("SIMVG_LAYER_HOOK") == "1") else None   # (=1: A/B)
 
     TEXT_TABLE = "beit3.text_embed.weight"
@@ -69,14 +74,16 @@ class GradReducer:
         self._gather_ids()
         A = self.enc._arena
         if i >= 0:
-            lo, hi = A.slice_of(self.enc.layer_param_names(i))
-            self._launch(A.flat_grad[lo:hi], f"layer:{i}")
+            first = self._group_of(i)        # None: layer i's gradients wait for the lower layers of their group
+            if first is not None:
+                lo, hi = self._layer_span(i)[0], self._layer_span(first)[1]
+                self._launch(A.flat_grad[lo:hi], f"layer:{i}" if first == i else f"layer:{first}-{i}")
             self._done_layers.add(i)
         else:
             # everything that is not a layer slice: embeddings, position tables, final LayerNorm.  The text table
             # (64 010 x D: 197 MB for ViT-B, a third of all gradients, and the LAST thing the backward produces) is
             # exchanged as the rows this step's tokens touch on ANY rank -- all other rows are zero everywhere.
-            spans = sorted(A.slice_of(self.enc.layer_param_names(l)) for l in range(self.enc.L))
+            spans = sorted(self._layer_span(l) for l in range(self.enc.L))
             sparse = self._all_ids is not None and self.TEXT_TABLE in A.params
             if sparse:
                 t_lo = A.offsets[self.TEXT_TABLE]
@@ -99,6 +106,41 @@ class GradReducer:
                 self._text_rows = (table, ids, rows)
                 self.last_sparse_rows = int(ids.numel())
 
+    def _layer_names(self, i):
+        """parameters whose gradients are final when layer i's backward returns: BEIT3 keeps its LayerNorm parameters (reduced
+        once, after layer 0) outside the layers' spans -- `layer_message_names`; an encoder without that method: the whole layer"""
+        f = getattr(self.enc, "layer_message_names", None)
+        return f(i) if f is not None else self.enc.layer_param_names(i)
+
+    def _group_of(self, i):
+        """Layers are sent in groups of consecutive layers (their Linears are one contiguous span of the arena): the message leaves
+        when the group's LOWEST layer is done.  -> the group's highest layer if layer i closes a group, else None.
+        SIMVG_REDUCE_GROUPS="4,4,2,1,1" (sizes in backward order, top layers first); default: every layer its own message."""
+        cache = self.__dict__.setdefault("_groups_cache", {})
+        key = (self.enc.L, os.environ.get("SIMVG_REDUCE_GROUPS"))
+        if key not in cache:
+            L, spec = key
+            sizes = [int(x) for x in spec.split(",")] if spec else [1] * L
+            if sum(sizes) != L or min(sizes) < 1:
+                raise ValueError(f"SIMVG_REDUCE_GROUPS={spec!r} must list positive group sizes summing to {L} layers")
+            closes, top = {}, L - 1
+            for n in sizes:
+                closes[top - n + 1] = top
+                top -= n
+            cache[key] = closes
+        return cache[key].get(i)
+
+    def _layer_span(self, i):
+        """(lo, hi) of layer i's message inside the flat gradient arena; cached per arena (the name walk costs 0.1 ms of host time)"""
+        A = self.enc._arena
+        cache = self.__dict__.setdefault("_span_cache", {})
+        if cache.get("arena") is not A:
+            cache.clear()
+            cache["arena"] = A
+        if i not in cache:
+            cache[i] = A.slice_of(self._layer_names(i))
+        return cache[i]
+
     def _gather_ids(self):
         """token ids of every rank for this step (a few KB), gathered asynchronously when the backward starts"""
         if self._ids_done or self.enc is None:
@@ -110,7 +152,7 @@ class GradReducer:
         ids = ids.reshape(-1).contiguous()
         out = torch.empty(self.world * ids.numel(), dtype=ids.dtype, device=ids.device)
         self.schedule.append(("ids", out.numel() * out.element_size()))
-        if self._avg:      # RCCL
+        if self._nccl:     # RCCL
             work = dist.all_gather_into_tensor(out, ids, async_op=True)
         else:              # gloo (CPU tests)
             parts = [torch.empty_like(ids) for _ in range(self.world)]
@@ -126,15 +168,43 @@ class GradReducer:
                 msg = t.to(self.message_dtype)
                 self._lowp.append((t, msg))
                 t = msg
-            self.pending.append(dist.all_reduce(t, op=op, async_op=True))
             self._n_msgs += 1
+            if self._dry:                # (measurement only, one rank: everything but the collective call itself)
+                return
+            self.pending.append(dist.all_reduce(t, op=op, async_op=True))
             if not self._avg:
                 self._scale.append(t)
 
+    def _head_params(self):
+        """the parameters outside the encoder arena (walked once: the model's parameter set does not change under a reducer)"""
+        ps = self.__dict__.get("_head_param_list")
+        if ps is None:
+            ps = self._head_param_list = [p for n, p in self.model.named_parameters() if not n.startswith("vis_enc.")]
+        return ps
+
     def _launch_head(self):
+        """The head's gradients as ONE message.  With FlatAdam the head's parameters own a flat gradient buffer
+        (`core.optimizer._RestArena`, registered on the model): the autograd-produced `.grad`s are gathered into it by its one
+        multi-tensor copy (the copy the optimizer would make anyway), the buffer is all-reduced IN PLACE and finish() re-points
+        every `.grad` at its slice of it -- no packing `torch.cat`, no scatter back (round 4: ~110 per-tensor copies per step).
+        Any other optimizer: packed copy, scattered back in finish()."""
         if self._head is not None:
             return
-        grads = [p.grad for n, p in self.model.named_parameters() if not n.startswith("vis_enc.") and p.grad is not None]
+        arenas = getattr(self.model, "_simvg_rest_arenas", None)
+        if arenas and os.environ.get("SIMVG_HEAD_MESSAGE_PACKED") != "1":
+            owned = {id(p) for ra in arenas for p in ra.params}
+            loose = [p for p in self._head_params() if p.grad is not None and id(p) not in owned]
+            if not loose and all(ra.intact() for ra in arenas):
+                sent = []
+                for ra in arenas:
+                    if ra.gather_grads():
+                        self._launch(ra.flat_grad, "head")
+                        # (slice, parameter, the autograd-produced tensor, its version): re-pointed in finish(), where a tensor
+                        # that autograd accumulated into after this copy is recognised by its version counter
+                        sent += [(v, p, p.grad, p.grad._version) for v, p in ra.last_gathered]
+                self._head = ("arena", arenas, sent)
+                return
+        grads = [p.grad for p in self._head_params() if p.grad is not None]
         if not grads:
             self._head = ([], None)
             return
@@ -147,7 +217,7 @@ class GradReducer:
         ids[r] on every rank.  An order-sensitive checksum is gathered from every rank and compared."""
         w = torch.arange(1, ids.numel() + 1, device=ids.device, dtype=ids.dtype)
         c = (ids * w).sum().reshape(1)                     # order-sensitive checksum (int64, wraps consistently)
-        if self._avg:
+        if self._nccl:
             every = torch.empty(self.world, dtype=c.dtype, device=c.device)
             dist.all_gather_into_tensor(every, c)
         else:
@@ -173,22 +243,8 @@ class GradReducer:
         self._exposed = []
         return dict(mean_ms=sum(t) / len(t), max_ms=max(t), steps=len(t))
 
-    def finish(self):
-        """Call after loss.backward(): waits for every message, averages, scatters the head gradients back."""
-        if not self.active:
-            return
-        self._launch_head()              # models without an encoder hook (or a frozen encoder) reduce the head here
-        # safety net: a head gradient that the autograd engine accumulated only AFTER the early head message was packed
-        # (none with the current graph -- every head node is upstream of the encoder's backward node -- but a silent
-        # omission would desynchronise the replicas) goes in a second message
-        packed = {id(g) for g in self._head[0]}
-        late = [p.grad for n, p in self.model.named_parameters()
-                if not n.startswith("vis_enc.") and p.grad is not None and id(p.grad) not in packed]
-        late_flat = None
-        self.last_late = len(late)
-        if late:
-            late_flat = torch.cat([g.reshape(-1) for g in late])
-            self._launch(late_flat, "late")
+    def _drain(self):
+        """wait for every message in flight; gloo: divide by the world size; 16-bit messages: back into the fp32 gradients"""
         ev = None
         if self.timing and torch.cuda.is_available() and self.pending:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -198,12 +254,56 @@ class GradReducer:
         if ev is not None:
             ev[1].record()
             self._exposed.append(ev)
-        for t in self._scale:
-            t.div_(self.world)
+        if self.world > 1:
+            for t in self._scale:
+                t.div_(self.world)
         for dst, msg in self._lowp:          # 16-bit messages: back into the fp32 master gradients
             dst.copy_(msg)
-        grads, flat = self._head
-        if grads:
+        self.pending, self._scale, self._lowp = [], [], []
+
+    def finish(self):
+        """Call after loss.backward(): waits for every message, averages, scatters the head gradients back."""
+        if not self.active:
+            return
+        self._launch_head()              # models without an encoder hook (or a frozen encoder) reduce the head here
+        # safety net: a head gradient that the autograd engine accumulated only AFTER the early head message was packed
+        # (none with the current graph -- every head node is upstream of the encoder's backward node -- but a silent
+        # omission would desynchronise the replicas) goes in a second message
+        late_arenas, late, late_flat = [], [], None
+        if self._head[0] == "arena":
+            # gradients that autograd produced after the gather: a parameter that had none then goes in a second message (below);
+            # one that was accumulated INTO its (already travelling) slice cannot be repaired
+            for v, p, g, ver in self._head[2]:
+                if p.grad is not g or g._version != ver:
+                    raise RuntimeError("GradReducer: a head gradient changed after the head message had left (a head node "
+                                       "downstream of the encoder's backward?); SIMVG_HEAD_MESSAGE_PACKED=1 selects the packed "
+                                       "message with its late-gradient pass")
+                p.grad = v               # from here on the gradient IS its slice of the (all-reduced) flat buffer
+            for ra in self._head[1]:
+                fresh = [(v, p) for v, p in zip(ra.grad_views, ra.params) if p.grad is not None and p.grad is not v]
+                if fresh:
+                    late_arenas.append((ra, fresh))
+            self.last_late = sum(len(f) for _, f in late_arenas)
+        else:
+            packed = {id(g) for g in self._head[0]}
+            late = [p.grad for p in self._head_params() if p.grad is not None and id(p.grad) not in packed]
+            self.last_late = len(late)
+            if late:
+                late_flat = torch.cat([g.reshape(-1) for g in late])
+                self._launch(late_flat, "late")
+        self._drain()
+        if late_arenas:
+            # their slices are part of the buffer that has just come back: written only now, sent as messages of their own
+            for ra, fresh in late_arenas:
+                torch._foreach_copy_([v for v, _ in fresh], [p.grad for _, p in fresh])
+                for v, p in fresh:
+                    p.grad = v
+                    self._launch(v, "late")
+            self._drain()
+        grads, flat = self._head[:2]
+        if grads == "arena":
+            pass                         # reduced in place: nothing to scatter
+        elif grads:
             torch._foreach_copy_(grads, [v.view_as(g) for g, v in zip(grads, flat.split([g.numel() for g in grads]))])
         if late_flat is not None:
             torch._foreach_copy_(late, [v.view_as(g) for g, v in zip(late, late_flat.split([g.numel() for g in late]))])
@@ -213,7 +313,7 @@ class GradReducer:
                 self._assert_same_ids(ids)
             table.index_copy_(0, ids, rows)
         self.last_stats = dict(messages=self._n_msgs, avg_in_collective=bool(self._avg),
-                               ids_gathered=self._all_ids is not None, gather_into_tensor=bool(self._avg and self._all_ids is not None),
+                               ids_gathered=self._all_ids is not None, gather_into_tensor=bool(self._nccl and self._all_ids is not None),
                                sparse_rows=int(self._text_rows[1].numel()) if self._text_rows is not None else 0,
                                message_dtype="bf16" if self.message_dtype is not None else "fp32", world=self.world,
                                bytes=sum(b for _, b in self.schedule))

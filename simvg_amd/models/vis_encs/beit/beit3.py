@@ -178,6 +178,10 @@ class BEIT3(nn.Module):
 
     # ------------------------------------------------------------------ arena + bf16 compute copies
     def _groups(self):
+        """Fused views of the arena, in layout order: per layer the four Linears' weights and biases of both experts (one contiguous
+        span per layer = that layer's gradient message, `layer_message_names`), then the LayerNorm parameters of ALL layers in one
+        block (86 KB per layer: their gradients' second stages are one batched launch at the end of the backward, and they travel
+        in the closing message with the embeddings), then the final LayerNorm."""
         D, F_, L = self.D, self.F, self.L
         g = []
         for i in range(L):
@@ -187,15 +191,18 @@ class BEIT3(nn.Module):
             g.append((f"bqkv{i}", [f"{sa}{p}.{m}.bias" for m in "AB" for p in ("q_proj", "k_proj", "v_proj")], (2, 3 * D)))
             g.append((f"wout{i}", [f"{sa}out_proj.{m}.weight" for m in "AB"], (2, D, D)))
             g.append((f"bout{i}", [f"{sa}out_proj.{m}.bias" for m in "AB"], (2, D)))
+            g.append((f"w1{i}", [f"{l}ffn.{m}.fc1.weight" for m in "AB"], (2, F_, D)))
+            g.append((f"b1{i}", [f"{l}ffn.{m}.fc1.bias" for m in "AB"], (2, F_)))
+            g.append((f"w2{i}", [f"{l}ffn.{m}.fc2.weight" for m in "AB"], (2, D, F_)))
+            g.append((f"b2{i}", [f"{l}ffn.{m}.fc2.bias" for m in "AB"], (2, D)))
+        for i in range(L):
+            l = f"beit3.encoder.layers.{i}."
+            sa = l + "self_attn."
             for tag, ln in [("ln1", l + "self_attn_layer_norm"), ("lni", sa + "inner_attn_ln"), ("ln2", l + "final_layer_norm")]:
                 g.append((f"{tag}g{i}", [f"{ln}.{m}.weight" for m in "AB"], (2, D)))
                 g.append((f"{tag}b{i}", [f"{ln}.{m}.bias" for m in "AB"], (2, D)))
-            g.append((f"w1{i}", [f"{l}ffn.{m}.fc1.weight" for m in "AB"], (2, F_, D)))
-            g.append((f"b1{i}", [f"{l}ffn.{m}.fc1.bias" for m in "AB"], (2, F_)))
             g.append((f"lnfg{i}", [f"{l}ffn.{m}.ffn_layernorm.weight" for m in "AB"], (2, F_)))
             g.append((f"lnfb{i}", [f"{l}ffn.{m}.ffn_layernorm.bias" for m in "AB"], (2, F_)))
-            g.append((f"w2{i}", [f"{l}ffn.{m}.fc2.weight" for m in "AB"], (2, D, F_)))
-            g.append((f"b2{i}", [f"{l}ffn.{m}.fc2.bias" for m in "AB"], (2, D)))
         g.append(("lnog", [f"beit3.encoder.layer_norm.{m}.weight" for m in "AB"], (2, D)))
         g.append(("lnob", [f"beit3.encoder.layer_norm.{m}.bias" for m in "AB"], (2, D)))
         return g
@@ -274,6 +281,11 @@ class BEIT3(nn.Module):
     def layer_param_names(self, i):
         pre = f"beit3.encoder.layers.{i}."
         return [n for n in self._arena.params if n.startswith(pre)]
+
+    def layer_message_names(self, i):
+        """the parameters of layer i whose gradients are final when the layer's backward returns (GradReducer sends their
+        contiguous span then): the Linears.  The LayerNorm parameters' gradients are reduced once, after layer 0."""
+        return [n for n in self.layer_param_names(i) if "layer_norm" not in n and "inner_attn_ln" not in n and "layernorm" not in n]
 
     # ------------------------------------------------------------------ workspaces
     def _workspace(self, B, T, device, save):
@@ -523,8 +535,8 @@ class BEIT3(nn.Module):
         S = ops.grad_scale()
         inv = 1.0 / S
         self._scale_tracker.observe(dout)
-        # the second stages of the LayerNorm parameter-gradient reductions: one launch per LAYER when a gradient exchange reads
-        # the layer's slice right after its backward (`layer_done_cb`), one launch for the whole backward otherwise
+        # the second stages of the LayerNorm parameter-gradient reductions: ONE launch for the whole backward (their parameters sit
+        # behind the layers' Linears in the arena, outside the per-layer gradient messages)
         red = getattr(self, "_ln_batch", None)
         if red is None:
             red = self._ln_batch = ops.LnReduceBatch()
@@ -573,8 +585,7 @@ class BEIT3(nn.Module):
                        defer=red)
             wred.flush()
             if layer_done_cb is not None:
-                red.flush()              # this layer's dgamma / dbeta are complete before its gradient message leaves
-                layer_done_cb(i)
+                layer_done_cb(i)         # the Linears' gradients of this layer are final (`layer_message_names`)
         red.flush()
         ops.embed_bwd(dx, ws["dpatch"], A.grad("beit3.vision_embed.cls_token").view(-1),
                       A.grad("beit3.encoder.embed_positions.A.weight"), A.grad("beit3.encoder.embed_positions.B.weight"),

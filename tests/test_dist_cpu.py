@@ -55,13 +55,19 @@ def _rank_ids(rank, g, uneven):
             torch.arange(20, 28).reshape(2, 4)][rank % 4]
 
 
-def _worker(rank, world, port, out, uneven=False, message=None):
+def _worker(rank, world, port, out, uneven=False, message=None, head_arena=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SIMVG_DIST_CHECK="1")   # + the same-id-list assertion
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from simvg_amd.dist import GradReducer
     torch.manual_seed(0)
     model = _FakeModel()
     red = GradReducer(model, message_dtype=message)
+    ra = None
+    if head_arena:      # what FlatAdam registers: the head's parameters own a flat gradient buffer, all-reduced in place
+        from simvg_amd.core.optimizer import _RestArena
+        ra = _RestArena(list(model.head.parameters()))
+        model._simvg_rest_arenas = [ra]
+    early_bias = head_arena == "early"       # "early": every head gradient exists when the head message leaves
     A = model.vis_enc._arena
     g = torch.Generator().manual_seed(100 + rank)
     red.begin()
@@ -76,10 +82,12 @@ def _worker(rank, world, port, out, uneven=False, message=None):
     tg[~keep] = 0.0
     model.head.weight.grad = torch.randn(2, 8, generator=g)
     late_bias = torch.randn(2, generator=g)
+    if early_bias:
+        model.head.bias.grad = late_bias
     local = (A.flat_grad.clone(), model.head.weight.grad.clone(), late_bias.clone())
     for i in reversed(range(model.vis_enc.L)):                     # what BEIT3._engine_backward does
         model.vis_enc._grad_ready_hook(i)
-        if i == model.vis_enc.L - 1:
+        if i == model.vis_enc.L - 1 and not early_bias:
             model.head.bias.grad = late_bias      # a head gradient that lands AFTER the early head message was packed
     model.vis_enc._grad_ready_hook(-1)
     red.finish()
@@ -110,18 +118,29 @@ def _worker(rank, world, port, out, uneven=False, message=None):
     esz = 4 if message is None else 2
     kinds = [k for k, _ in red.last_schedule]
     L = model.vis_enc.L
+    tail = ["text_rows"] if early_bias else ["text_rows", "late"]
     sched_ok = (kinds[:2] in (["head", "ids"], ["ids", "head"]) and kinds[2:2 + L] == [f"layer:{i}" for i in reversed(range(L))]
-                and kinds[-2:] == ["text_rows", "late"] and set(kinds[2 + L:-2]) == {"rest"})
+                and kinds[-len(tail):] == tail and set(kinds[2 + L:-len(tail)]) == {"rest"})
     by = dict()
     for k, b in red.last_schedule:
         by[k] = by.get(k, 0) + b
     layer_bytes = [esz * (A_.slice_of(model.vis_enc.layer_param_names(i))[1] - A_.slice_of(model.vis_enc.layer_param_names(i))[0]) for i in range(L)]
     sched_ok = sched_ok and all(by[f"layer:{i}"] == layer_bytes[i] for i in range(L))
-    sched_ok = sched_ok and by["head"] == esz * model.head.weight.numel() and by["late"] == esz * model.head.bias.numel()
+    if ra is None:
+        sched_ok = sched_ok and by["head"] == esz * model.head.weight.numel() and by["late"] == esz * model.head.bias.numel()
+    else:
+        # the flat buffer travels whole (alignment gaps included); every gradient IS its slice of it afterwards, and the
+        # optimizer's own gather later in the step has nothing left to copy
+        sched_ok = sched_ok and by["head"] == esz * ra.total and (early_bias or by["late"] == esz * model.head.bias.numel())
+        sched_ok = sched_ok and all(p.grad is v for p, v in zip(ra.params, ra.grad_views))
+        if early_bias:
+            before, ver = ra.flat_grad.clone(), ra.flat_grad._version
+            sched_ok = sched_ok and ra.gather_grads() == 2 and ra.flat_grad._version == ver and torch.equal(before, ra.flat_grad)
     sched_ok = sched_ok and by["text_rows"] == esz * world * 8 * 8 and by["ids"] == 8 * world * 8       # int64 ids, D = 8
     # dense remainder = the arena minus the layer slices minus the (sparsely exchanged) text table
     sched_ok = sched_ok and by["rest"] == esz * (A_.total - sum(layer_bytes) // esz - A_.params["beit3.text_embed.weight"].numel())
     sched_ok = sched_ok and red.last_stats["bytes"] == sum(b for _, b in red.last_schedule)
+
     out[rank] = bool(ok) and red.last_sparse_rows == world * 8 and bool(sched_ok)     # the text table went as `world` x 8 token rows
     dist.destroy_process_group()
 
@@ -139,6 +158,43 @@ def test_grad_reducer_world4_uneven_token_sets():
     out = mp.Manager().dict()
     mp.spawn(_worker, args=(world, _free_port(), out, True), nprocs=world, join=True)
     assert dict(out) == {r: True for r in range(world)}
+
+
+def test_grad_reducer_head_message_is_the_optimizers_flat_gradient_buffer():
+    world = 2
+    for mode, message in (("early", None), ("late", None), ("early", "bf16")):
+        out = mp.Manager().dict()
+        mp.spawn(_worker, args=(world, _free_port(), out, False, message, mode), nprocs=world, join=True)
+        assert dict(out) == {0: True, 1: True}, (mode, message)
+
+
+def _accumulate_after_send_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from simvg_amd.dist import GradReducer
+    from simvg_amd.core.optimizer import _RestArena
+    model = _FakeModel()
+    model.vis_enc = None
+    ra = _RestArena(list(model.head.parameters()))
+    model._simvg_rest_arenas = [ra]
+    red = GradReducer(model)
+    red.begin()
+    for p in model.head.parameters():
+        p.grad = torch.ones_like(p)
+    red._launch_head()
+    model.head.weight.grad.add_(1.0)          # autograd accumulating into a slice that is already travelling
+    try:
+        red.finish()
+        out[rank] = "no error"
+    except RuntimeError as e:
+        out[rank] = "changed after the head message had left" in str(e)
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_refuses_a_gradient_accumulated_into_a_message_in_flight():
+    out = mp.Manager().dict()
+    mp.spawn(_accumulate_after_send_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert dict(out) == {0: True, 1: True}
 
 
 def test_grad_reducer_bf16_message_keeps_fp32_master():

@@ -171,13 +171,16 @@ def test_bench_with_two_ranks_finishes_and_reports_the_whole_job(tmp_path):
     assert order[2:14] == [f"layer:{i}" for i in reversed(range(12))], order
     assert order[-1] == "text_rows" and set(order[14:-1]) == {"rest"}, order[14:]
     D, F_ = 768, 3072
-    per_expert = (3 * D * D + 3 * D) + (D * D + D) + 3 * 2 * D + (F_ * D + F_) + 2 * F_ + (D * F_ + D)
+    # a layer's message = the four Linears of both experts (56.7 MB); its LayerNorm parameters (three of width D, one of width F,
+    # weight + bias, both experts) sit behind the layers in the arena and travel in the closing message
+    per_expert = (3 * D * D + 3 * D) + (D * D + D) + (F_ * D + F_) + (D * F_ + D)
+    ln_per_layer = 2 * (3 * 2 * D + 2 * F_)
     mb = sched["messages_bytes"]
-    assert mb["layer"] == {"messages": 12, "bytes": 12 * 2 * per_expert * 4}, mb["layer"]          # 56.8 MB per layer message
+    assert mb["layer"] == {"messages": 12, "bytes": 12 * 2 * per_expert * 4}, mb["layer"]
     assert mb["text_rows"]["bytes"] == 2 * 4 * 20 * D * 4 and mb["ids"]["bytes"] == 2 * 4 * 20 * 8   # world x B x T rows / ids
     # patch embedding (D x 3 x 32 x 32 + D), cls token, both position tables (401 + 2 and 1024 rows), final LayerNorm (2 x 2 D);
     # the 64 010-row text table travels as the rows above, the mask token has no gradient
-    rest = (D * 3 * 32 * 32 + D) + D + (403 + 1024) * D + 4 * D
+    rest = (D * 3 * 32 * 32 + D) + D + (403 + 1024) * D + 4 * D + 12 * ln_per_layer
     assert rest * 4 <= mb["rest"]["bytes"] <= rest * 4 + 65536, (mb["rest"], rest * 4)      # + the mask token's slot and 256-B alignment gaps
     assert line["reducer"]["bytes"] == sum(v["bytes"] for v in mb.values())
     assert line["reducer"]["exposed"]["steps"] == 3 and line["reducer"]["exposed"]["mean_ms"] >= 0.0

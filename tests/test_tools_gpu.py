@@ -177,7 +177,13 @@ def test_flat_adam_views_eval_refresh_and_state_round_trip():
     cfg2, twin, opt2 = make(seed=11)
     twin.load_state_dict(weights)
     opt2.load_state_dict(state)
+    # a state without (or with another) layout signature -- same sizes, parameters in another order inside the flat tensors --
+    # is refused instead of handing every element someone else's moments
+    stale = {k: v for k, v in state.items() if k != "simvg_layout"}
+    with pytest.raises(ValueError, match="another arena layout"):
+        opt2.load_state_dict(stale)
     back = opt2.state_dict()
+    assert back["simvg_layout"] == state["simvg_layout"] == opt.layout_signature()
     assert back["param_groups"] == state["param_groups"] and set(back["state"]) == set(state["state"])
     for idx, st in state["state"].items():
         for k, v in st.items():
