@@ -178,6 +178,13 @@ typedef struct simvg_gemm_f32_problem {
                                          * heads/tgqs_kd_detr_head/transformer.py:106-125) */
 } simvg_gemm_f32_problem;
 int simvg_gemm_f32_grouped(const simvg_gemm_f32_problem* problems, int count, simvg_stream_t stream);
+/* The same launch with a workspace (16-byte aligned device memory, `workspace_floats` floats, owned by the caller and not used by
+ * anything else queued on other streams): problems of the num_queries = 10 size (>= 40 M multiply-adds, few 64 x 64 tiles, long K --
+ * the FFN / projection Linears over B * num_queries rows and their weight gradients, transformer.py:106-125,167-186) split K over
+ * several workgroups per tile; their partial tiles meet in a second launch that adds them in a fixed order and applies the
+ * epilogue (deterministic).  Without a workspace (or a too small one) nothing is split. */
+int simvg_gemm_f32_grouped_ws(const simvg_gemm_f32_problem* problems, int count, float* workspace, long workspace_floats,
+                              simvg_stream_t stream);
 /* torch.nn.MultiheadAttention core (heads of 32) for <= 16 queries: softmax(scale q k^T + key_padding) [* dropout] v
  * (detrex MultiheadAttention wrapper; decoder layers transformer.py:167-186).
  * key_pos (optional): rows [Lk, E] (key_pos_rows_per_batch = 0: shared by the batch) or [B * Lk, E] (= Lk) of the PROJECTED

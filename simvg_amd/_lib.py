@@ -91,6 +91,7 @@ _SIGS = {
     "simvg_dec_attn_bwd": [c_void_p, c_void_p],
     "simvg_dec_attn_wgrad": [c_void_p, c_void_p],
     "simvg_gemm_f32_grouped": [c_void_p, c_int, c_void_p],
+    "simvg_gemm_f32_grouped_ws": [c_void_p, c_int, c_void_p, c_long, c_void_p],
     "simvg_postprocess": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                           c_int, c_int, c_int, c_void_p],
     "simvg_gemm_nt": [c_void_p, c_int, c_void_p, c_long, c_int, c_void_p, c_int, c_void_p, c_int, c_int,

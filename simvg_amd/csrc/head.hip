@@ -58,7 +58,7 @@ __device__ __forceinline__ void sg_store(const SGArgs& a, float v, int m, int n)
   *p = a.accumulate ? *p + v : v;
 }
 
-constexpr int SG_LDS_FLOATS = 2 * 32 * 68;
+constexpr int SG_LDS_FLOATS = 2 * 32 * 80;      // two operand images of a 32-deep chunk ([k][68] / [k][80] / [row][36] floats)
 
 __device__ __forceinline__ void gemm_f32_tile64(const SGArgs& a, int bx, int by, float* smem) {
   // 64x64 tile, K-chunks of 32 staged through LDS, next chunk prefetched into registers while the current one
@@ -120,6 +120,111 @@ __device__ __forceinline__ void gemm_f32_tile64(const SGArgs& a, int bx, int by,
       if (m < a.M) sg_store(a, acc[j][r], m, n);
     }
   }
+}
+
+// Mid-size problems (num_queries = 10: M = B * 10 = 640 query rows; weight gradients over those rows): the 64 x 64 tile again, with
+//   * 16-byte global loads in either orientation -- an operand is K-contiguous (its 64 x 32 part of a chunk = 8 float4 per row,
+//     LDS image [row][36]) or row-contiguous (32 k-lines of 16 float4, LDS image [k][80]); both images take ds_write_b128 and give
+//     conflict-free ds_read_b32 MFMA operands (36 m and 16 k are distinct bank offsets over the 2 x 32 lane groups);
+//   * split-K: one CU streams operands at ~50 GB/s whatever it does (profiles/r05_sweeps.md section 2), so a workgroup that walks
+//     K = 2048 for one tile needs >= 20 us however few tiles there are; `S` workgroups per tile each take K / S and leave their
+//     partial tile in a workspace slab [s][M][N]; `gemm_f32_fixup_kernel` adds the slabs in a fixed order and applies the
+//     epilogue (deterministic: no atomics, no cross-workgroup handshake).  S = 1: epilogue in place, no second launch.
+// Eligible: K % 32 == 0, 16-byte aligned operands and leading strides, row-contiguous operands with M (N) % 4 == 0
+// (`sg_v64_ok`); everything else stays on the kernels above.  (num_queries = 10, 81 launches of a training step: 2.31 ms -> see
+// profiles/r05_sweeps.md section 6.)
+constexpr int SGV_KROW = 36, SGV_NROW = 80, SGV_OP_FLOATS = 32 * SGV_NROW;      // 2560 floats >= 64 * 36
+template <bool AK, bool BK>
+__device__ __forceinline__ void gemm_f32_tile64v_t(const SGArgs& a, int bx, int by, int k_lo, int k_hi, float* partial, float* smem) {
+  float* As = smem;
+  float* Bs = smem + SGV_OP_FLOATS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = by * 64, n0 = bx * 64;
+  f32x4_t acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  f32x4_t ra[2], rb[2];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + 256 * i;
+      const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
+      if (AK) {
+        const int m = e >> 3, kq = e & 7;
+        const long ia = (long)(m0 + m) * a.sam + k0 + 4 * kq;
+        ra[i] = m0 + m < a.M ? (a.A2 ? *(const f32x4_t*)(a.A + ia) + *(const f32x4_t*)(a.A2 + ia) : *(const f32x4_t*)(a.A + ia)) : z;
+      } else {
+        const int k = e >> 4, mq = e & 15;
+        const long ia = (long)(k0 + k) * a.sak + m0 + 4 * mq;
+        ra[i] = m0 + 4 * mq < a.M ? (a.A2 ? *(const f32x4_t*)(a.A + ia) + *(const f32x4_t*)(a.A2 + ia) : *(const f32x4_t*)(a.A + ia)) : z;
+      }
+      if (BK) {
+        const int n = e >> 3, kq = e & 7;
+        const long ib = (long)(n0 + n) * a.sbn + k0 + 4 * kq;
+        rb[i] = n0 + n < a.N ? (a.B2 ? *(const f32x4_t*)(a.B + ib) + *(const f32x4_t*)(a.B2 + ib) : *(const f32x4_t*)(a.B + ib)) : z;
+      } else {
+        const int k = e >> 4, nq = e & 15;
+        const long ib = (long)(k0 + k) * a.sbk + n0 + 4 * nq;
+        rb[i] = n0 + 4 * nq < a.N ? (a.B2 ? *(const f32x4_t*)(a.B + ib) + *(const f32x4_t*)(a.B2 + ib) : *(const f32x4_t*)(a.B + ib)) : z;
+      }
+    }
+  };
+  fetch(k_lo);
+  const int l15 = lane & 15, g = lane >> 4;
+  for (int k0 = k_lo; k0 < k_hi; k0 += 32) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + 256 * i;
+      if (AK) *(f32x4_t*)(As + (e >> 3) * SGV_KROW + 4 * (e & 7)) = ra[i];
+      else *(f32x4_t*)(As + (e >> 4) * SGV_NROW + 4 * (e & 15)) = ra[i];
+      if (BK) *(f32x4_t*)(Bs + (e >> 3) * SGV_KROW + 4 * (e & 7)) = rb[i];
+      else *(f32x4_t*)(Bs + (e >> 4) * SGV_NROW + 4 * (e & 15)) = rb[i];
+    }
+    __syncthreads();
+    if (k0 + 32 < k_hi) fetch(k0 + 32);
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const float av = AK ? As[(wave * 16 + l15) * SGV_KROW + kk * 4 + g] : As[(kk * 4 + g) * SGV_NROW + wave * 16 + l15];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float bv = BK ? Bs[(j * 16 + l15) * SGV_KROW + kk * 4 + g] : Bs[(kk * 4 + g) * SGV_NROW + j * 16 + l15];
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + j * 16 + l15;
+    if (n >= a.N) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + wave * 16 + 4 * g + r;
+      if (m >= a.M) continue;
+      if (partial) partial[(long)m * a.N + n] = acc[j][r];
+      else sg_store(a, acc[j][r], m, n);
+    }
+  }
+}
+__device__ __forceinline__ void gemm_f32_tile64v(const SGArgs& a, int bx, int by, int k_lo, int k_hi, float* partial, float* smem) {
+  if (a.sak == 1) {
+    if (a.sbk == 1) gemm_f32_tile64v_t<true, true>(a, bx, by, k_lo, k_hi, partial, smem);
+    else gemm_f32_tile64v_t<true, false>(a, bx, by, k_lo, k_hi, partial, smem);
+  } else {
+    if (a.sbk == 1) gemm_f32_tile64v_t<false, true>(a, bx, by, k_lo, k_hi, partial, smem);
+    else gemm_f32_tile64v_t<false, false>(a, bx, by, k_lo, k_hi, partial, smem);
+  }
+}
+// host side: may this problem run on the tile above?  (a K-contiguous operand: element stride 1 along k; otherwise it must be
+// contiguous along its rows / columns)
+inline bool sg_v64_ok(const SGArgs& a) {
+  auto al = [](const void* p) { return (((unsigned long)p) & 15) == 0; };
+  if (a.K % 32 != 0 || !al(a.A) || !al(a.B) || (a.A2 && !al(a.A2)) || (a.B2 && !al(a.B2))) return false;
+  if (a.sak == 1) { if (a.sam % 4 != 0) return false; }
+  else if (a.sam != 1 || a.sak % 4 != 0 || a.M % 4 != 0) return false;
+  if (a.sbk == 1) { if (a.sbn % 4 != 0) return false; }
+  else if (a.sbn != 1 || a.sbk % 4 != 0 || a.N % 4 != 0) return false;
+  return (double)a.M * a.N * a.K >= 40e6;        // below: the small-problem kernel (every shape of num_queries = 1 stays where it was)
 }
 
 // Small-problem variant (the head's M = B*num_queries GEMMs: 64x256x256 and friends).  The 64x64 LDS kernel above puts
@@ -206,6 +311,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(SGArgs a) {
   __shared__ float smem[SG_LDS_FLOATS];
   gemm_f32_tile64(a, blockIdx.x, blockIdx.y, smem);
 }
+__global__ __launch_bounds__(256) void gemm_f32_v64_kernel(SGArgs a) {
+  __shared__ float smem[SG_LDS_FLOATS];
+  gemm_f32_tile64v(a, blockIdx.x, blockIdx.y, 0, a.K, nullptr, smem);
+}
 __global__ __launch_bounds__(256) void gemm_f32_small_kernel(SGArgs a) {
   __shared__ float smem[4 * 256];
   gemm_f32_tile16(a, blockIdx.x, blockIdx.y, smem);
@@ -220,18 +329,42 @@ struct SGGroup {
   SGArgs p[SG_MAX];
   int start[SG_MAX + 1];      // first linear block of problem i
   int nx[SG_MAX];             // tiles along N of problem i
-  int small[SG_MAX];
+  int small[SG_MAX];          // 1: one workgroup per 16 x 16 tile; 0: 64 x 64 tiles; 2: 64 x 64 tiles, 16-byte loads, K split S ways
+  int S[SG_MAX];              // kind 2: workgroups per tile (consecutive blocks), each K / S; > 1: partial tiles to `part`
+  int kchunks[SG_MAX];        // kind 2: 32-deep chunks per split
+  float* part[SG_MAX];        // kind 2, S > 1: [S][M][N] partial sums (gemm_f32_fixup_kernel adds them and applies the epilogue)
+  int fix_start[SG_MAX + 1];  // fix-up launch: first block of problem i (256 outputs per block; problems with S == 1 have none)
   int count;
 };
 __global__ __launch_bounds__(256) void gemm_f32_group_kernel(SGGroup g) {
   __shared__ float smem[SG_LDS_FLOATS];
   int i = 0;
   while (i + 1 < g.count && (int)blockIdx.x >= g.start[i + 1]) ++i;
-  const int t = blockIdx.x - g.start[i];
-  const int by = t / g.nx[i], bx = t - by * g.nx[i];
+  int t = blockIdx.x - g.start[i];
   const SGArgs a = g.p[i];
+  if (g.small[i] == 2) {
+    const int S = g.S[i], s = t % S;
+    t /= S;
+    const int by = t / g.nx[i], bx = t - by * g.nx[i];
+    const int k_lo = s * g.kchunks[i] * 32, k_hi = min(a.K, k_lo + g.kchunks[i] * 32);
+    gemm_f32_tile64v(a, bx, by, k_lo, k_hi, S > 1 ? g.part[i] + (long)s * a.M * a.N : nullptr, smem);
+    return;
+  }
+  const int by = t / g.nx[i], bx = t - by * g.nx[i];
   if (g.small[i]) gemm_f32_tile16(a, bx, by, smem);
   else gemm_f32_tile64(a, bx, by, smem);
+}
+// second stage of the split-K problems of a group: output element e of problem i = sum over its S slabs (in slab order), then the
+// problem's epilogue (bias / addend / activation / mult / gate / accumulate)
+__global__ __launch_bounds__(256) void gemm_f32_fixup_kernel(SGGroup g) {
+  int i = 0;
+  while (i + 1 < g.count && (int)blockIdx.x >= g.fix_start[i + 1]) ++i;
+  const SGArgs a = g.p[i];
+  const long e = (long)(blockIdx.x - g.fix_start[i]) * 256 + threadIdx.x, MN = (long)a.M * a.N;
+  if (e >= MN) return;
+  float v = 0.f;
+  for (int s = 0; s < g.S[i]; ++s) v += g.part[i][s * MN + e];
+  sg_store(a, v, (int)(e / a.N), (int)(e % a.N));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -490,7 +623,9 @@ extern "C" int simvg_gemm_f32(const float* A, long sam, long sak, const float* B
   // num_queries = 1); at num_queries = 10 (M = 640 rows) the K = 2048 FFN problems have 40 - 320 such tiles and ran 27+ us each on
   // the 64x64 kernel: 32 -> 128 is 34.2 -> 32.7 ms per step there, no change at num_queries = 1 (profiles/r02_sweeps.md)
   constexpr int small_env = 128;
-  if (cdiv(N, 64) * cdiv(M, 64) <= small_env)   // too few 64x64 tiles to fill the chip: one workgroup per 16x16 tile
+  if (sg_v64_ok(a) && cdiv(N, 64) * cdiv(M, 64) > small_env)     // mid-size, enough tiles without a K split: 16-byte loads
+    hipLaunchKernelGGL(gemm_f32_v64_kernel, dim3(cdiv(N, 64), cdiv(M, 64)), dim3(256), 0, stream, a);
+  else if (cdiv(N, 64) * cdiv(M, 64) <= small_env)   // too few 64x64 tiles to fill the chip: one workgroup per 16x16 tile
     hipLaunchKernelGGL(gemm_f32_small_kernel, dim3(cdiv(N, 16), cdiv(M, 16)), dim3(256), 0, stream, a);
   else
     hipLaunchKernelGGL(gemm_f32_kernel, dim3(cdiv(N, 64), cdiv(M, 64)), dim3(256), 0, stream, a);
@@ -498,15 +633,19 @@ extern "C" int simvg_gemm_f32(const float* A, long sam, long sak, const float* B
   return SIMVG_OK;
 }
 
-extern "C" int simvg_gemm_f32_grouped(const simvg_gemm_f32_problem* problems, int count, hipStream_t stream) {
+static int gemm_f32_grouped_impl(const simvg_gemm_f32_problem* problems, int count, float* ws, long ws_floats, hipStream_t stream) {
   SIMVG_CHECK_ARG(problems != nullptr && count > 0 && count <= SG_MAX, "gemm_f32_grouped: 1..12 problems");
+  SIMVG_CHECK_ARG(ws_floats >= 0 && (ws != nullptr || ws_floats == 0) && ((((unsigned long)ws) & 15) == 0), "gemm_f32_grouped: workspace must be 16-byte aligned");
   // <= 128 tiles of 64x64: the small-M kernel (one workgroup per 16x16 tile, K split over its waves).  32 in round 1 (tuned at
   // num_queries = 1); at num_queries = 10 (M = 640 rows) the K = 2048 FFN problems have 40 - 320 such tiles and ran 27+ us each on
-  // the 64x64 kernel: 32 -> 128 is 34.2 -> 32.7 ms per step there, no change at num_queries = 1 (profiles/r02_sweeps.md)
+  // the 64x64 kernel: 32 -> 128 is 34.2 -> 32.7 ms per step there, no change at num_queries = 1 (profiles/r02_sweeps.md).
+  // Round 5: problems of >= 40 M multiply-adds with aligned operands take the 16-byte-load tile, K split over `S` workgroups
+  // per tile when a workspace is given (target ~320 workgroups, >= 128 k each)
   constexpr int small_env = 128;
   SGGroup g;
   g.count = count;
-  int total = 0;
+  int total = 0, fix_total = 0;
+  long ws_used = 0;
   for (int i = 0; i < count; ++i) {
     const simvg_gemm_f32_problem& q = problems[i];
     SIMVG_CHECK_ARG(q.M > 0 && q.N > 0 && q.K > 0, "gemm_f32_grouped: empty problem");
@@ -514,18 +653,59 @@ extern "C" int simvg_gemm_f32_grouped(const simvg_gemm_f32_problem* problems, in
     g.p[i] = SGArgs{q.A, q.sam, q.sak, q.B, q.sbk, q.sbn, q.C, q.ldc, q.bias, q.addend, q.ld_addend,
                     q.addend_rows > 0 ? q.addend_rows : 1, q.M, q.N, q.K, q.accumulate, q.act,
                     q.A2, q.B2, q.mult, q.ld_mult, q.gate, q.ld_gate};
-    const int sm = cdiv(q.N, 64) * cdiv(q.M, 64) <= small_env;
+    g.S[i] = 1; g.kchunks[i] = 0; g.part[i] = nullptr;
+    g.fix_start[i] = fix_total;
+    g.start[i] = total;
+    const int tiles = cdiv(q.N, 64) * cdiv(q.M, 64);
+    if (sg_v64_ok(g.p[i])) {
+      const int chunks = q.K / 32;
+      static const int target = getenv("SIMVG_SGV_TARGET") ? atoi(getenv("SIMVG_SGV_TARGET")) : 320;     // (sweep knobs)
+      static const int minch = getenv("SIMVG_SGV_MINCH") ? atoi(getenv("SIMVG_SGV_MINCH")) : 4;
+      int S = cdiv(target, tiles);
+      if (S > chunks / minch) S = chunks / minch;
+      const long MN = (long)q.M * q.N;
+      while (S > 1 && ws_used + (long)S * MN > ws_floats) --S;       // (no / a small workspace: fewer splits)
+      if (S < 1) S = 1;
+      int per = cdiv(chunks, S);
+      S = cdiv(chunks, per);
+      if (S == 1 && tiles < 40 && tiles <= small_env) {               // few tiles, no split possible: the small-problem kernel
+        g.small[i] = 1; g.nx[i] = cdiv(q.N, 16);
+        total += cdiv(q.N, 16) * cdiv(q.M, 16);
+        continue;
+      }
+      g.small[i] = 2; g.nx[i] = cdiv(q.N, 64); g.S[i] = S; g.kchunks[i] = per;
+      if (S > 1) {
+        g.part[i] = ws + ws_used;
+        ws_used += (S * MN + 3) / 4 * 4;
+        fix_total += (int)((MN + 255) / 256);
+      }
+      total += tiles * S;
+      continue;
+    }
+    const int sm = tiles <= small_env;
     const int t = sm ? 16 : 64;
     g.small[i] = sm;
     g.nx[i] = cdiv(q.N, t);
-    g.start[i] = total;
     total += cdiv(q.N, t) * cdiv(q.M, t);
   }
-  for (int i = count; i <= SG_MAX; ++i) g.start[i] = total;
-  for (int i = count; i < SG_MAX; ++i) { g.p[i] = g.p[0]; g.nx[i] = 1; g.small[i] = 1; }
+  for (int i = count; i <= SG_MAX; ++i) { g.start[i] = total; g.fix_start[i] = fix_total; }
+  for (int i = count; i < SG_MAX; ++i) { g.p[i] = g.p[0]; g.nx[i] = 1; g.small[i] = 1; g.S[i] = 1; g.kchunks[i] = 0; g.part[i] = nullptr; }
   hipLaunchKernelGGL(gemm_f32_group_kernel, dim3(total), dim3(256), 0, stream, g);
   SIMVG_LAUNCH_CHECK();
+  if (fix_total > 0) {
+    hipLaunchKernelGGL(gemm_f32_fixup_kernel, dim3(fix_total), dim3(256), 0, stream, g);
+    SIMVG_LAUNCH_CHECK();
+  }
   return SIMVG_OK;
+}
+
+extern "C" int simvg_gemm_f32_grouped(const simvg_gemm_f32_problem* problems, int count, hipStream_t stream) {
+  return gemm_f32_grouped_impl(problems, count, nullptr, 0, stream);
+}
+
+extern "C" int simvg_gemm_f32_grouped_ws(const simvg_gemm_f32_problem* problems, int count, float* workspace, long workspace_floats,
+                                         hipStream_t stream) {
+  return gemm_f32_grouped_impl(problems, count, workspace, workspace_floats, stream);
 }
 
 extern "C" int simvg_attn_small_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,

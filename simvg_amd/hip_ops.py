@@ -681,10 +681,26 @@ def gemm_f32_group(problems):
             d.mult, d.ld_mult = (mu.data_ptr(), mu.stride(0)) if mu is not None else (None, 0)
             d.gate, d.ld_gate = (ga.data_ptr(), ga.stride(0)) if ga is not None else (None, 0)
         t0 = _timer.start("gemm_f32_group") if _timer is not None else None
-        rc = lib.simvg_gemm_f32_grouped(C.byref(arr), len(chunk), _stream())
+        stream = _stream()
+        ws = _group_workspace(chunk[0]["C"].device, stream) if any(q["M"] * q["N"] * q["K"] >= 40e6 for q in chunk) else None
+        rc = lib.simvg_gemm_f32_grouped_ws(C.byref(arr), len(chunk), _p(ws), 0 if ws is None else ws.numel(), stream)
         if t0 is not None:
             _timer.stop("gemm_f32_group", t0, sum(2.0 * q["M"] * q["N"] * q["K"] for q in chunk), 0.0)
         _lib.check(rc, "simvg_gemm_f32_grouped")
+
+
+_GROUP_WS = {}
+_GROUP_WS_FLOATS = 16 << 20        # 64 MB: twelve problems' split-K slabs at num_queries = 10 (the largest: 13 MB)
+
+
+def _group_workspace(device, stream):
+    """split-K slabs of `gemm_f32_group` (one buffer per device and stream: launches of one stream are ordered, two streams
+    must not share it)"""
+    key = (device.index, stream.value)
+    ws = _GROUP_WS.get(key)
+    if ws is None:
+        ws = _GROUP_WS[key] = torch.empty(_GROUP_WS_FLOATS, device=device, dtype=torch.float32)
+    return ws
 
 
 def gp(A, sam, sak, Bm, sbk, sbn, Cm, M, N, K, **kw):
