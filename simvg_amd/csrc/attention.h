@@ -32,15 +32,58 @@ __device__ __forceinline__ long tok_row(const AttnArgs& a, int b, int t) {
   return t < a.Nv ? (long)b * a.Nv + t : (long)a.B * a.Nv + (long)b * a.Nt + (t - a.Nv);
 }
 
-// copy rows [0,nrows_pad) x 64 bf16 of one head into LDS (zero beyond N)
+// copy rows [0,nrows_pad) x 64 bf16 of NSRC column blocks (K and V, Q and dO ...) of one head into LDS (zero beyond N).
+// All UNR x NSRC 16-byte loads of a pass are issued before the first LDS write: the former one-load loop
+// (global_load -> s_waitcnt vmcnt(0) -> ds_write per iteration, hipcc does not unroll a run-time trip count) paid one full
+// memory round trip per 16 bytes and thread -- 10 in a row in the forward's prologue, 14 in the one-pass backward's, with one
+// workgroup per CU and nothing else to run (round 5: the QK^T-only probe spent 3/4 of its time there).  Loads are unconditional
+// on clamped indices (a load under a divergent branch is waited for at the branch's end); UNR is chosen per call site so that
+// UNR x blockDim covers nrows_pad x 8 chunks in one pass.
+struct HeadSrc { const lp_t* base; int ld; int col0; char* lds; };
+template <int UNR, int NSRC> struct HeadChunks { u32x4_t v[NSRC][UNR]; };
+// the two halves of a pass (chunks c0 + tid + i * blockDim, i < UNR): callers with more loads to put in flight issue, request their
+// own, and commit afterwards
+template <int UNR, int NSRC>
+__device__ __forceinline__ void heads_issue(const AttnArgs& a, const HeadSrc (&src)[NSRC], int b, int N, int total, int c0,
+                                            HeadChunks<UNR, NSRC>& ch) {
+  const int nt = blockDim.x;
+#pragma unroll
+  for (int i = 0; i < UNR; ++i) {
+    const int c = min(c0 + (int)threadIdx.x + i * nt, total - 1);
+    const int row = min(c >> 3, N - 1), slot = c & 7;
+    const long r = tok_row(a, b, row);
+#pragma unroll
+    for (int k = 0; k < NSRC; ++k) ch.v[k][i] = *(const u32x4_t*)(src[k].base + r * src[k].ld + src[k].col0 + slot * 8);
+  }
+}
+template <int UNR, int NSRC>
+__device__ __forceinline__ void heads_commit(const HeadSrc (&src)[NSRC], int N, int total, int c0, const HeadChunks<UNR, NSRC>& ch) {
+  const int nt = blockDim.x;
+#pragma unroll
+  for (int i = 0; i < UNR; ++i) {
+    const int c = c0 + (int)threadIdx.x + i * nt;
+    const int row = c >> 3, slot = c & 7;
+    if (c < total) {
+#pragma unroll
+      for (int k = 0; k < NSRC; ++k)
+        *(u32x4_t*)(src[k].lds + row * ROWB + lds_slot(row, slot) * 16) = row < N ? ch.v[k][i] : (u32x4_t){0u, 0u, 0u, 0u};
+    }
+  }
+}
+template <int UNR, int NSRC>
+__device__ __forceinline__ void load_heads_to_lds(const AttnArgs& a, const HeadSrc (&src)[NSRC], int b, int N, int nrows_pad) {
+  const int total = nrows_pad * 8;
+  for (int c0 = 0; c0 < total; c0 += UNR * blockDim.x) {
+    HeadChunks<UNR, NSRC> ch;
+    heads_issue<UNR, NSRC>(a, src, b, N, total, c0, ch);
+    heads_commit<UNR, NSRC>(src, N, total, c0, ch);
+  }
+}
+template <int UNR>
 __device__ __forceinline__ void load_head_to_lds(const AttnArgs& a, const lp_t* base, int ld, int col0, int b, int N,
                                                  int nrows_pad, char* lds) {
-  for (int c = threadIdx.x; c < nrows_pad * 8; c += blockDim.x) {
-    const int row = c >> 3, slot = c & 7;
-    u32x4_t v = (u32x4_t){0u, 0u, 0u, 0u};
-    if (row < N) v = *(const u32x4_t*)(base + tok_row(a, b, row) * ld + col0 + slot * 8);
-    *(u32x4_t*)(lds + row * ROWB + lds_slot(row, slot) * 16) = v;
-  }
+  const HeadSrc src[1] = {{base, ld, col0, lds}};
+  load_heads_to_lds<UNR, 1>(a, src, b, N, nrows_pad);
 }
 
 __device__ __forceinline__ lpx8_t lds_frag(const char* lds, int row, int slot) {

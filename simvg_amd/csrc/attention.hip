@@ -42,8 +42,10 @@ __global__ __launch_bounds__(768) void attn_fwd_kernel(AttnArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int j = lane & 15, g = lane >> 4;
 
-  load_head_to_lds(a, a.qkv, a.ld, a.D + h * HD, b, N, npad, ldsK);
-  load_head_to_lds(a, a.qkv, a.ld, 2 * a.D + h * HD, b, N, npad, ldsV);
+  {
+    const HeadSrc hs[2] = {{a.qkv, a.ld, a.D + h * HD, ldsK}, {a.qkv, a.ld, 2 * a.D + h * HD, ldsV}};
+    load_heads_to_lds<5, 2>(a, hs, b, N, npad);
+  }
   fill_key_bias(a, b, N, npad, bias);
   __syncthreads();
 
@@ -144,12 +146,35 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_t_kernel(AttnArgs a) {
   char* ldsV = smem + NPAD * ROWB;
   float* bias = (float*)(smem + 2 * NPAD * ROWB);
   const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = NTHREADS / 64;
   const int j = lane & 15, g = lane >> 4;
 
-  load_head_to_lds(a, a.qkv, a.ld, a.D + h * HD, b, N, NPAD, ldsK);
-  if constexpr (!QK_ONLY) load_head_to_lds(a, a.qkv, a.ld, 2 * a.D + h * HD, b, N, NPAD, ldsV);
-  fill_key_bias(a, b, N, NPAD, bias);
+  // One round trip for the whole prologue (round 5): the key-padding byte, the first strip's Q fragments and all K / V chunks are
+  // requested before anything is waited for; later strips' Q fragments are requested when the previous strip's contraction has
+  // consumed the old ones, i.e. under its softmax / PV phase.
+  static_assert(NPAD <= NTHREADS, "one key-bias entry per thread");
+  const int qstep = nwaves * gridDim.y;
+  int qb = wave + nwaves * blockIdx.y;
+  // 32-bit element offsets from the kernel arguments' (scalar) bases: one VGPR per address instead of two held across the strip
+  // loop (the launcher sends problems whose offsets do not fit to the generic kernel)
+  auto row32 = [&](int t) { return t < a.Nv ? b * a.Nv + t : a.B * a.Nv + b * a.Nt + (t - a.Nv); };
+  auto q_ptr = [&](int qb_) {
+    const int tq_ = qb_ * 16 + j;
+    return a.qkv + (unsigned)(row32(tq_ < N ? tq_ : N - 1) * a.ld + h * HD + 8 * g);   // beyond N: a valid row, never stored
+  };
+  lpx8_t q0 = *(const lpx8_t*)q_ptr(qb), q1 = *(const lpx8_t*)(q_ptr(qb) + 32);
+  constexpr int UNR = (NPAD * 8 + NTHREADS - 1) / NTHREADS, NSRC = QK_ONLY ? 1 : 2;
+  HeadSrc kvs[NSRC];
+  kvs[0] = HeadSrc{a.qkv, a.ld, a.D + h * HD, ldsK};
+  if constexpr (!QK_ONLY) kvs[1] = HeadSrc{a.qkv, a.ld, 2 * a.D + h * HD, ldsV};
+  HeadChunks<UNR, NSRC> kvch;
+  heads_issue<UNR, NSRC>(a, kvs, b, N, NPAD * 8, 0, kvch);
+  const int kbk = threadIdx.x < NPAD ? (int)threadIdx.x : NPAD - 1;
+  const int kbt = min(max(kbk - a.Nv, 0), max(a.Nt - 1, 0));
+  const unsigned char padb = *(a.pad ? a.pad + b * a.Nt + kbt : (const unsigned char*)a.qkv);
+  heads_commit<UNR, NSRC>(kvs, N, NPAD * 8, 0, kvch);
+  if (threadIdx.x < NPAD)
+    bias[threadIdx.x] = (kbk >= N || (a.pad && kbk >= a.Nv && padb != 0)) ? -INFINITY : 0.f;
   __syncthreads();
 
   const float sc2 = a.scale * 1.44269504088896340736f;
@@ -157,10 +182,8 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_t_kernel(AttnArgs a) {
   union { lpx8_t v; unsigned int u[4]; } ones;
   ones.u[0] = ones.u[1] = ones.u[2] = ones.u[3] = one2;
 
-  for (int qb = wave + nwaves * blockIdx.y; qb < NKT; qb += nwaves * gridDim.y) {
+  for (; qb < NKT; qb += qstep) {
     const int tq = qb * 16 + j;
-    const lp_t* qp = a.qkv + tok_row(a, b, tq < N ? tq : N - 1) * a.ld + h * HD + 8 * g;
-    const lpx8_t q0 = *(const lpx8_t*)qp, q1 = *(const lpx8_t*)(qp + 32);
     f32x4_t s[2 * NS2];
     float mx = -INFINITY;
     // K fragments one GROUP of G tiles ahead of their MFMAs (an LDS read takes ~100+ cycles to land, two MFMAs only ~35:
@@ -202,12 +225,23 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_t_kernel(AttnArgs a) {
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    {   // maximum over the four 16-lane rows on the VALU (v_permlane16_swap / v_permlane32_swap: no ds_bpermute round trips, no
+        // index registers held across the strip loop).  Inline asm: hipcc folds fmaxf over the two results of the builtin forms
+        // to the first one (round 5: the QK^T probe's row maxima came out per 16-lane row).  s_nop 1: the wait states hipcc puts
+        // between a VALU write and a permlane swap of the same register.
+      float ma = mx, mb = mx;
+      asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(ma), "+v"(mb));   // {r0 r0 r2 r2}, {r1 r1 r3 r3}
+      ma = fmaxf(ma, mb); mb = ma;
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(ma), "+v"(mb));   // {lo lo}, {hi hi}
+      mx = fmaxf(ma, mb);
+    }
     if constexpr (QK_ONLY) {
       if (tq < N && g == 0 && a.lse) a.lse[(long)blockIdx.x * N + tq] = mx * a.scale;
+      const lp_t* qn = q_ptr(qb + qstep);
+      q0 = *(const lpx8_t*)qn; q1 = *(const lpx8_t*)(qn + 32);
       continue;
     }
+    constexpr int QPF = NS2 / 2;
     const float mxs = mx * sc2;          // sc2 > 0: max(s) * c == max(s * c)
     f32x4_t o[4], rs = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -239,17 +273,21 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_t_kernel(AttnArgs a) {
       rs = mfma_lp(ones.v, pf.v, rs);            // every row of the result = sum over these 32 keys, per query column
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) o[dt] = mfma_lp(vc[dt], pf.v, o[dt]);
+      if (s2 == QPF) {                           // the next strip's Q rows, into registers the consumed score tiles have freed
+        const lp_t* qn = q_ptr(qb + qstep);      // (past the last strip: a valid row, not used)
+        q0 = *(const lpx8_t*)qn; q1 = *(const lpx8_t*)(qn + 32);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     if (tq < N) {
       const float sum = rs[0];
       const float inv = 1.f / sum;
-      lp_t* op = a.out + tok_row(a, b, tq) * a.ldo + h * HD + 4 * g;
+      lp_t* op = a.out + (unsigned)(row32(tq) * a.ldo + h * HD + 4 * g);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
         *(u32x2_t*)(op + dt * 16) = (u32x2_t){pack_lp2(o[dt][0] * inv, o[dt][1] * inv),
                                              pack_lp2(o[dt][2] * inv, o[dt][3] * inv)};
-      if (g == 0 && a.lse) a.lse[(long)blockIdx.x * N + tq] = (mxs + __log2f(sum)) * 0.69314718055994530942f;   // natural log
+      if (g == 0 && a.lse) a.lse[(unsigned)(blockIdx.x * N + tq)] = (mxs + __log2f(sum)) * 0.69314718055994530942f;   // natural log
     }
   }
 }
@@ -268,8 +306,10 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int j = lane & 15, g = lane >> 4;
 
-  load_head_to_lds(a, a.qkv, a.ld, a.D + h * HD, b, N, npad, ldsK);
-  load_head_to_lds(a, a.qkv, a.ld, 2 * a.D + h * HD, b, N, npad, ldsV);
+  {
+    const HeadSrc hs[2] = {{a.qkv, a.ld, a.D + h * HD, ldsK}, {a.qkv, a.ld, 2 * a.D + h * HD, ldsV}};
+    load_heads_to_lds<5, 2>(a, hs, b, N, npad);
+  }
   fill_key_bias(a, b, N, npad, bias);
   __syncthreads();
 
@@ -355,8 +395,10 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_dq_t_kernel(AttnArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int j = lane & 15, g = lane >> 4;
 
-  load_head_to_lds(a, a.qkv, a.ld, a.D + h * HD, b, N, NPAD, ldsK);
-  load_head_to_lds(a, a.qkv, a.ld, 2 * a.D + h * HD, b, N, NPAD, ldsV);
+  {
+    const HeadSrc hs[2] = {{a.qkv, a.ld, a.D + h * HD, ldsK}, {a.qkv, a.ld, 2 * a.D + h * HD, ldsV}};
+    load_heads_to_lds<(NPAD * 8 + NTHREADS - 1) / NTHREADS, 2>(a, hs, b, N, NPAD);
+  }
   fill_key_bias(a, b, N, NPAD, bias);
   __syncthreads();
 
@@ -458,8 +500,10 @@ __global__ __launch_bounds__(768) void attn_bwd_dkv_kernel(AttnArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int j = lane & 15, g = lane >> 4;
 
-  load_head_to_lds(a, a.qkv, a.ld, h * HD, b, N, npad, ldsQ);
-  load_head_to_lds(a, a.dout, a.lddo, h * HD, b, N, npad, ldsDO);
+  {
+    const HeadSrc hs[2] = {{a.qkv, a.ld, h * HD, ldsQ}, {a.dout, a.lddo, h * HD, ldsDO}};
+    load_heads_to_lds<5, 2>(a, hs, b, N, npad);
+  }
   for (int q = threadIdx.x; q < npad; q += blockDim.x) {
     lse_s[q] = q < N ? a.lse[(long)blockIdx.x * N + q] * 1.44269504088896340736f : INFINITY;   // log2 domain; exp2(.. - inf) = 0 for pad rows
     dl_s[q] = q < N ? a.delta[(long)blockIdx.x * N + q] : 0.f;
@@ -611,8 +655,10 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_dkv_t_kernel(AttnArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int j = lane & 15, g = lane >> 4;
 
-  load_head_to_lds(a, a.qkv, a.ld, h * HD, b, N, NPAD, ldsQ);
-  load_head_to_lds(a, a.dout, a.lddo, h * HD, b, N, NPAD, ldsDO);
+  {
+    const HeadSrc hs[2] = {{a.qkv, a.ld, h * HD, ldsQ}, {a.dout, a.lddo, h * HD, ldsDO}};
+    load_heads_to_lds<(NPAD * 8 + NTHREADS - 1) / NTHREADS, 2>(a, hs, b, N, NPAD);
+  }
   for (int q = threadIdx.x; q < NPAD; q += blockDim.x) {
     nlse_s[q] = q < N ? -a.lse[(long)blockIdx.x * N + q] * 1.44269504088896340736f : -INFINITY;   // log2 domain, negated; exp2(.. - inf) = 0 for pad rows
     dl_s[q] = q < N ? a.delta[(long)blockIdx.x * N + q] : 0.f;
@@ -934,7 +980,8 @@ extern "C" int simvg_attn_fwd(const void* qkv, int ldqkv, void* out, int ldo, fl
   // few heads in flight (forward_test at B = 1 ... 4: B * H = 12 ... 48 workgroups on 256 CUs): the query strips of a head
   // are dealt over up to 3 workgroups (each loads the head's K / V; one strip per wave instead of three in a row)
   const int qsplit = B * H * 3 <= 256 ? std::min(3, cdiv(cdiv(N, 16), 12)) : 1;
-  if (cdiv(N, 16) == 27 && Nv / 16 >= 25) {        // the path's geometry: 1 + (640/32)^2 vision + 20 text tokens
+  const bool off32 = (long)B * N * ldqkv < (1L << 31) && (long)B * N * ldo < (1L << 31) && (long)B * H * N < (1L << 31);   // the kernel's 32-bit element offsets
+  if (cdiv(N, 16) == 27 && Nv / 16 >= 25 && off32) {   // the path's geometry: 1 + (640/32)^2 vision + 20 text tokens
     hipLaunchKernelGGL((attn_fwd_t_kernel<27, 25, 768>), dim3(B * H, qsplit), dim3(768), shm, stream, a);
     SIMVG_LAUNCH_CHECK();
     return SIMVG_OK;
@@ -954,6 +1001,7 @@ extern "C" int simvg_attn_qk_probe(const void* qkv, int ldqkv, float* rowmax, co
   SIMVG_CHECK_ARG(attn_check(B, H, Nv, Nt, D, ldqkv) && rowmax, "attn_qk_probe: need head_dim 64, 16-B aligned rows");
   const int N = Nv + Nt, npad = ((cdiv(N, 16) + 1) / 2) * 32;
   SIMVG_CHECK_ARG(cdiv(N, 16) == 27 && Nv / 16 >= 25, "attn_qk_probe: built for the path's geometry (417 .. 432 tokens, >= 400 of them vision)");
+  SIMVG_CHECK_ARG((long)B * N * ldqkv < (1L << 31), "attn_qk_probe: 32-bit element offsets");
   AttnArgs a{(const lp_t*)qkv, ldqkv, nullptr, 0, nullptr, 0, nullptr, 0, rowmax, nullptr, pad, B, H, Nv, Nt, D, scale};
   const size_t shm = (size_t)2 * npad * ROWB + npad * sizeof(float);
   static bool once = set_lds_limit(attn_fwd_t_kernel<27, 25, 768, 2, true>, 160 * 1024);

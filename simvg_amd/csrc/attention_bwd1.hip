@@ -98,34 +98,33 @@ __global__ __launch_bounds__(256) void attn_bwd_one_kernel(AttnArgs a) {
     if (tid < 32) nlse_r[slot * 32 + tid] = pair * 32 + tid < N ? -vl * 1.44269504088896340736f : -INFINITY;   // log2 domain, negated
   };
 
-  // ---- prologue
-  load_head_to_lds(a, a.qkv, a.ld, a.D + h * HD, b, N, NPAD, ldsK);
+  // ---- prologue: every global load of it (V fragments, the padding byte, the first two pairs' rows, the 14 K chunks per thread)
+  // is requested before the first wait -- one memory round trip; the former order (K chunk by chunk, then V, then the pairs) paid 17
   lpx8_t v0[SPW], v1[SPW];
 #pragma unroll
   for (int s = 0; s < SPW; ++s) {
     const int tk = (4 * s + wave) * 16 + j;
-    const lp_t* vp = a.qkv + tok_row(a, b, tk < N ? tk : N - 1) * a.ld + 2 * a.D + h * HD + 8 * g;
+    const lp_t* vp = a.qkv + (unsigned)(row32(tk < N ? tk : N - 1) * a.ld + 2 * a.D + h * HD + 8 * g);
     v0[s] = *(const lpx8_t*)vp;
     v1[s] = *(const lpx8_t*)(vp + 32);
   }
+  u32x4_t pq0, pd0, po0, pq1, pd1, po1;
+  float pl0, pl1;
+  fetch(0, pq0, pd0, po0, pl0);
+  fetch(1, pq1, pd1, po1, pl1);
+  static_assert(NPAD * 8 % 256 == 0, "K chunks per thread");
+  const HeadSrc ksrc[1] = {{a.qkv, a.ld, a.D + h * HD, ldsK}};
+  HeadChunks<NPAD * 8 / 256, 1> kch;
+  heads_issue<NPAD * 8 / 256, 1>(a, ksrc, b, N, NPAD * 8, 0, kch);
+  const int kb_tk = (4 * (SPW - 1) + wave) * 16 + j;          // the last strip of every wave: text / padding keys
+  const unsigned char kb_pad = *(a.pad ? a.pad + b * a.Nt + min(max(kb_tk - a.Nv, 0), max(a.Nt - 1, 0)) : (const unsigned char*)a.qkv);
+  heads_commit<NPAD * 8 / 256, 1>(ksrc, N, NPAD * 8, 0, kch);
 #pragma unroll
   for (int s = 0; s < SPW; ++s) asm volatile("" : "+v"(v0[s]), "+v"(v1[s]));   // waited for HERE, not by a vmcnt(0) at the loop's head
-  float kbias;                                                // the last strip of every wave: text / padding keys
-  {
-    const int tk = (4 * (SPW - 1) + wave) * 16 + j;
-    bool masked = tk >= N;
-    if (!masked && a.pad && tk >= a.Nv) masked = a.pad[b * a.Nt + (tk - a.Nv)] != 0;
-    kbias = masked ? -INFINITY : 0.f;
-  }
+  const float kbias = (kb_tk >= N || (a.pad && kb_tk >= a.Nv && kb_pad != 0)) ? -INFINITY : 0.f;
   for (int i = lane; i < 16 * B1_SROW / 4; i += 64) ((unsigned int*)(st + SPW * 16 * B1_SROW))[i] = 0u;
-  {
-    u32x4_t q0, d0, o0, q1, d1, o1;
-    float l0, l1;
-    fetch(0, q0, d0, o0, l0);
-    fetch(1, q1, d1, o1, l1);
-    commit(0, q0, d0, o0, l0);
-    commit(1, q1, d1, o1, l1);
-  }
+  commit(0, pq0, pd0, po0, pl0);
+  commit(1, pq1, pd1, po1, pl1);
   // the accumulators are born in the first pair's MFMAs (C = 0 literal): 224 zero-initialised values would sit in VGPRs before
   // hipcc moves them to the AccVGPR file, and push the V fragments out to scratch for the whole launch
   f32x4_t dk[SPW][4], dv[SPW][4];
