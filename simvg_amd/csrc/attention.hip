@@ -137,6 +137,13 @@ __global__ __launch_bounds__(768) void attn_fwd_kernel(AttnArgs a) {
 // ------------------------------------------------------------------------------------------
 // QK_ONLY (measurement: simvg_attn_qk_probe): the same K staging and QK^T contraction, then only the row maximum of the raw scores
 // is stored -- no exponentials, no row sums, no PV -- so that the contraction north_star prices can be timed by itself.
+// FWD_PROFILE (development build, tools/dev/attn_fwd_profile.py): workgroups 0 and 600 stamp s_memtime per wave into a.delta
+#ifdef FWD_PROFILE
+#define FWD_T(k_) do { if ((blockIdx.x == 0 || blockIdx.x == 600) && lane == 0 && a.delta) \
+    ((unsigned*)a.delta)[((blockIdx.x ? 1 : 0) * 12 + wave) * 16 + (k_)] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FWD_T(k_) do { } while (0)
+#endif
 template <int NKT, int KFULL, int NTHREADS, int G = 2, bool QK_ONLY = false>
 __global__ __launch_bounds__(NTHREADS) void attn_fwd_t_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -153,6 +160,7 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_t_kernel(AttnArgs a) {
   // requested before anything is waited for; later strips' Q fragments are requested when the previous strip's contraction has
   // consumed the old ones, i.e. under its softmax / PV phase.
   static_assert(NPAD <= NTHREADS, "one key-bias entry per thread");
+  FWD_T(0);
   const int qstep = nwaves * gridDim.y;
   int qb = wave + nwaves * blockIdx.y;
   // 32-bit element offsets from the kernel arguments' (scalar) bases: one VGPR per address instead of two held across the strip
@@ -172,10 +180,14 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_t_kernel(AttnArgs a) {
   const int kbk = threadIdx.x < NPAD ? (int)threadIdx.x : NPAD - 1;
   const int kbt = min(max(kbk - a.Nv, 0), max(a.Nt - 1, 0));
   const unsigned char padb = *(a.pad ? a.pad + b * a.Nt + kbt : (const unsigned char*)a.qkv);
+  FWD_T(1);
   heads_commit<UNR, NSRC>(kvs, N, NPAD * 8, 0, kvch);
   if (threadIdx.x < NPAD)
     bias[threadIdx.x] = (kbk >= N || (a.pad && kbk >= a.Nv && padb != 0)) ? -INFINITY : 0.f;
+  FWD_T(2);
   __syncthreads();
+  FWD_T(3);
+  int fwd_strip = 0;
 
   const float sc2 = a.scale * 1.44269504088896340736f;
   const unsigned int one2 = pack_lp2_raw(1.f, 1.f);
@@ -242,6 +254,7 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_t_kernel(AttnArgs a) {
       continue;
     }
     constexpr int QPF = NS2 / 2;
+    FWD_T(4 + 2 * fwd_strip);
     const float mxs = mx * sc2;          // sc2 > 0: max(s) * c == max(s * c)
     f32x4_t o[4], rs = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -279,16 +292,34 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_t_kernel(AttnArgs a) {
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (tq < N) {
+    {
+      // a lane holds 4 consecutive hd values of query row j per 16-column tile; one v_permlane16_swap per dword between tiles dt and
+      // dt + 1 leaves even-g lanes with 8 consecutive values of tile dt, odd-g lanes with 8 of tile dt + 1: two 16-byte stores
+      // instead of four 8-byte ones (MI355X guide T21; the swaps run on every lane, the stores on valid rows)
       const float sum = rs[0];
       const float inv = 1.f / sum;
-      lp_t* op = a.out + (unsigned)(row32(tq) * a.ldo + h * HD + 4 * g);
+      unsigned ox[4][2];
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-        *(u32x2_t*)(op + dt * 16) = (u32x2_t){pack_lp2(o[dt][0] * inv, o[dt][1] * inv),
-                                             pack_lp2(o[dt][2] * inv, o[dt][3] * inv)};
-      if (g == 0 && a.lse) a.lse[(unsigned)(blockIdx.x * N + tq)] = (mxs + __log2f(sum)) * 0.69314718055994530942f;   // natural log
+      for (int dt = 0; dt < 4; ++dt) {
+        ox[dt][0] = pack_lp2(o[dt][0] * inv, o[dt][1] * inv);
+        ox[dt][1] = pack_lp2(o[dt][2] * inv, o[dt][3] * inv);
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; dt += 2)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const auto r = __builtin_amdgcn_permlane16_swap(ox[dt][hf], ox[dt + 1][hf], false, false);
+          ox[dt][hf] = r[0]; ox[dt + 1][hf] = r[1];
+        }
+      if (tq < N) {
+        lp_t* op = a.out + (unsigned)(row32(tq) * a.ldo + h * HD + (g >> 1) * 8 + (g & 1) * 16);
+        *(u32x4_t*)op = (u32x4_t){ox[0][0], ox[0][1], ox[1][0], ox[1][1]};
+        *(u32x4_t*)(op + 32) = (u32x4_t){ox[2][0], ox[2][1], ox[3][0], ox[3][1]};
+        if (g == 0 && a.lse) a.lse[(unsigned)(blockIdx.x * N + tq)] = (mxs + __log2f(sum)) * 0.69314718055994530942f;   // natural log
+      }
     }
+    FWD_T(5 + 2 * fwd_strip);
+    ++fwd_strip;
   }
 }
 
@@ -961,11 +992,18 @@ static int attn_check(int B, int H, int Nv, int Nt, int D, int ld) {
   return 1;
 }
 
+#ifdef FWD_PROFILE
+static float* g_fwd_profile = nullptr;
+extern "C" void simvg_attn_fwd_profile_buf(float* p) { g_fwd_profile = p; }
+#endif
 extern "C" int simvg_attn_fwd(const void* qkv, int ldqkv, void* out, int ldo, float* lse, const unsigned char* pad,
                               int B, int H, int Nv, int Nt, int D, float scale, hipStream_t stream) {
   SIMVG_CHECK_ARG(attn_check(B, H, Nv, Nt, D, ldqkv) && ldo % 8 == 0,
                   "attn_fwd: need head_dim 64, 16-B aligned rows");
   AttnArgs a{(const lp_t*)qkv, ldqkv, (lp_t*)out, ldo, nullptr, 0, nullptr, 0, lse, nullptr, pad, B, H, Nv, Nt, D, scale};
+#ifdef FWD_PROFILE
+  a.delta = g_fwd_profile;
+#endif
   const int N = Nv + Nt, npad = ((cdiv(N, 16) + 1) / 2) * 32;
   if (N > MAX_KT * 16) {      // K / V do not fit the LDS: stream them in blocks (online softmax)
     static bool oncet = set_lds_limit(attn_fwd_tiled_kernel, TILED_LDS);

@@ -98,6 +98,14 @@ __global__ __launch_bounds__(256) void attn_bwd_one_kernel(AttnArgs a) {
     if (tid < 32) nlse_r[slot * 32 + tid] = pair * 32 + tid < N ? -vl * 1.44269504088896340736f : -INFINITY;   // log2 domain, negated
   };
 
+#ifdef B1_PROFILE
+#define B1_T(k_) do { if (blockIdx.x == 0 && lane == 0) ((unsigned*)a.delta)[(wave * 16 + p) * 8 + (k_)] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
+#define B1_X(k_) do { if (blockIdx.x == 0 && lane == 0) ((unsigned*)a.delta)[(wave * 16 + 14) * 8 + (k_)] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define B1_T(k_) do { } while (0)
+#define B1_X(k_) do { } while (0)
+#endif
+  B1_X(0);
   // ---- prologue: every global load of it (V fragments, the padding byte, the first two pairs' rows, the 14 K chunks per thread)
   // is requested before the first wait -- one memory round trip; the former order (K chunk by chunk, then V, then the pairs) paid 17
   lpx8_t v0[SPW], v1[SPW];
@@ -128,13 +136,10 @@ __global__ __launch_bounds__(256) void attn_bwd_one_kernel(AttnArgs a) {
   // the accumulators are born in the first pair's MFMAs (C = 0 literal): 224 zero-initialised values would sit in VGPRs before
   // hipcc moves them to the AccVGPR file, and push the V fragments out to scratch for the whole launch
   f32x4_t dk[SPW][4], dv[SPW][4];
+  B1_X(1);
   __syncthreads();
+  B1_X(2);
 
-#ifdef B1_PROFILE
-#define B1_T(k_) do { if (blockIdx.x == 0 && lane == 0) ((unsigned*)a.delta)[(wave * 16 + p) * 8 + (k_)] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define B1_T(k_) do { } while (0)
-#endif
   // the pair's Q / dO fragments (row form for S / dP, transposed for dV / dK) and the first K fragments: requested right after the
   // barrier that publishes the pair, i.e. under the previous pair's write-out
   lpx8_t qc[2][2], dc[2][2], qf[4], dof[4], kc0, kc1, kn0, kn1;
@@ -311,23 +316,47 @@ __global__ __launch_bounds__(256) void attn_bwd_one_kernel(AttnArgs a) {
   };
   pair_body(std::true_type{}, 0);
   for (int p = 1; p < NS2; ++p) pair_body(std::false_type{}, p);
+  B1_X(3);
   write_out(NS2 - 1);
-  // ---- dK^T, dV^T of this wave's strips
+  B1_X(4);
+  // ---- dK^T, dV^T of this wave's strips.  A lane holds 4 consecutive hd values of key row j per 16-column tile (8 bytes); one
+  // v_permlane16_swap per dword between the tiles dt and dt + 1 leaves lanes of even g with 8 consecutive values of tile dt and
+  // lanes of odd g with 8 of tile dt + 1: 16-byte stores, half as many (the tail was store-ISSUE-bound: 15 k of a workgroup's
+  // 126 k cycles for 56 8-byte stores per lane, tools/dev/attn_onepass_profile.py; MI355X guide T21)
+  const int col16 = (g >> 1) * 8, odd = g & 1;
 #pragma unroll
   for (int s = 0; s < SPW; ++s) {
     const int tk = (4 * s + wave) * 16 + j;
-    if (tk < N) {
-      lp_t* gk = a.dqkv + tok_row(a, b, tk) * a.lddq + a.D + h * HD + 4 * g;
-      lp_t* gv = a.dqkv + tok_row(a, b, tk) * a.lddq + 2 * a.D + h * HD + 4 * g;
+    unsigned kx[4][2], vx[4][2];
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        *(u32x2_t*)(gk + dt * 16) = (u32x2_t){pack_lp2(dk[s][dt][0] * a.scale, dk[s][dt][1] * a.scale),
-                                             pack_lp2(dk[s][dt][2] * a.scale, dk[s][dt][3] * a.scale)};
-        *(u32x2_t*)(gv + dt * 16) = (u32x2_t){pack_lp2(dv[s][dt][0], dv[s][dt][1]), pack_lp2(dv[s][dt][2], dv[s][dt][3])};
+    for (int dt = 0; dt < 4; ++dt) {
+      kx[dt][0] = pack_lp2(dk[s][dt][0] * a.scale, dk[s][dt][1] * a.scale);
+      kx[dt][1] = pack_lp2(dk[s][dt][2] * a.scale, dk[s][dt][3] * a.scale);
+      vx[dt][0] = pack_lp2(dv[s][dt][0], dv[s][dt][1]);
+      vx[dt][1] = pack_lp2(dv[s][dt][2], dv[s][dt][3]);
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; dt += 2)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const auto rk = __builtin_amdgcn_permlane16_swap(kx[dt][hf], kx[dt + 1][hf], false, false);
+        kx[dt][hf] = rk[0]; kx[dt + 1][hf] = rk[1];
+        const auto rv = __builtin_amdgcn_permlane16_swap(vx[dt][hf], vx[dt + 1][hf], false, false);
+        vx[dt][hf] = rv[0]; vx[dt + 1][hf] = rv[1];
+      }
+    if (tk < N) {
+      lp_t* gk = a.dqkv + tok_row(a, b, tk) * a.lddq + a.D + h * HD + col16;
+      lp_t* gv = gk + a.D;
+#pragma unroll
+      for (int dt = 0; dt < 4; dt += 2) {
+        const int c = (dt + odd) * 16;
+        *(u32x4_t*)(gk + c) = (u32x4_t){kx[dt][0], kx[dt][1], kx[dt + 1][0], kx[dt + 1][1]};
+        *(u32x4_t*)(gv + c) = (u32x4_t){vx[dt][0], vx[dt][1], vx[dt + 1][0], vx[dt + 1][1]};
       }
     }
     __builtin_amdgcn_sched_barrier(0);       // one strip's 32 accumulator values in VGPRs at a time
   }
+  B1_X(5);
 }
 
 }  // namespace

@@ -20,6 +20,10 @@ for _ in range(3):
                             p(delta), None, B, H, Nv, Nt, D, d ** -0.5, ops._stream())
 torch.cuda.synchronize()
 t = delta.view(torch.int32).cpu().view(-1)[:4 * 16 * 8].view(4, 16, 8).long() & 0xffffffff
+x0 = int(t[:, 14, 0].min())
+for w in range(4):
+    r = [(int(v) - x0) & 0xffffffff for v in t[w, 14, :6]]
+    print(f"wave {w}: entry {r[0]}, prologue done {r[1]}, barrier passed {r[2]}, pair loop done {r[3]}, last write-out {r[4]}, dK / dV stores issued {r[5]}")
 names = ["frag reads + wait", "strip loop", "dQ phase", "wait barrier 1", "partial stores + commit", "wait barrier 2", "write-out"]
 for w in range(4):
     seg = (t[w, 2:12, 1:] - t[w, 2:12, :-1]).float().mean(0)
