@@ -12,6 +12,7 @@ struct AttnArgs {
   const unsigned char* pad;     // [B, Nt] 1 = padded text key, or null
   int B, H, Nv, Nt, D;
   float scale;
+  int pf_stride;                // workgroups per residency round (= CUs) for the next round's L2 prefetch; 0 = off
 };
 
 namespace {
@@ -27,6 +28,26 @@ constexpr int ROWB = 128;       // LDS row stride in bytes: 64 bf16, no padding 
 // (and for the 8-lane groups of the ds_write_b128 fill).
 __device__ __forceinline__ int lds_slot(int row, int slot) { return slot ^ (row & 6); }
 constexpr int MAX_KT = 28;      // 28 * 16 = 448 >= 421 keys
+
+// L2 prefetch for the workgroup that follows this one on the same XCD.  One workgroup per CU and equal work per workgroup: the
+// 256 CUs run their residency rounds in lockstep, and every round opens with each CU pulling its head's K / V (115 KB) through an
+// L1 that tracks a few dozen misses -- bound by latency x misses in flight at ~10 B/clk/CU whatever is issued, 12 k of a forward
+// workgroup's 39 k cycles with the matrix pipes idle (tools/dev/attn_fwd_profile.py; starting the CUs staggered changed nothing:
+// it is not HBM contention).  Workgroup i + pf_stride is dispatched to the same XCD as workgroup i (XCD = id mod 8) one round
+// later, so waves of workgroup i that have finished touch one dword of every 128-byte line of that workgroup's K / V rows: the
+// lines sit in the XCD's L2 when the next prologue asks for them (forward: prologue 12 k -> 6.5 k cycles from the second round on,
+// 71.9 -> 69.1 us isolated).  The one-pass backward does NOT gain: in front of its dK / dV tail the stores' 3.5 MB per XCD push the
+// lines out again (+8 us), behind it the wave has to outlive the touches (+4 us; a wave must not end with loads in flight).
+// `rows` rows of 128 B starting at column col0, dealt over `nlanes` lanes.
+__device__ __forceinline__ void l2_touch_rows(const AttnArgs& a, const lp_t* base, int ld, int col0, int b, int N, int rows,
+                                              int lane_id, int nlanes) {
+  for (int r = lane_id; r < rows; r += nlanes) {
+    const int t = r < N ? r : N - 1;
+    const int row = t < a.Nv ? b * a.Nv + t : a.B * a.Nv + b * a.Nt + (t - a.Nv);
+    const int v = *(const volatile int*)(base + (unsigned)(row * ld + col0));
+    asm volatile("" ::"v"(v));
+  }
+}
 
 __device__ __forceinline__ long tok_row(const AttnArgs& a, int b, int t) {
   return t < a.Nv ? (long)b * a.Nv + t : (long)a.B * a.Nv + (long)b * a.Nt + (t - a.Nv);

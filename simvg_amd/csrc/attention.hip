@@ -321,6 +321,16 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_t_kernel(AttnArgs a) {
     FWD_T(5 + 2 * fwd_strip);
     ++fwd_strip;
   }
+  if constexpr (!QK_ONLY) {
+    // waves 3 .. 7 finish a strip early (they take two, the workgroup's last waves are 6 - 12 k cycles behind them): they fetch the
+    // next round's K / V lines into this XCD's L2 (attention.h: l2_touch_rows)
+    const int nb = blockIdx.x + a.pf_stride;
+    if (a.pf_stride > 0 && gridDim.y == 1 && wave >= 3 && wave < 8 && nb < gridDim.x) {
+      const int b2 = nb / a.H, h2 = nb - b2 * a.H;
+      l2_touch_rows(a, a.qkv, a.ld, a.D + h2 * HD, b2, N, N, (wave - 3) * 64 + lane, 320);
+      l2_touch_rows(a, a.qkv, a.ld, 2 * a.D + h2 * HD, b2, N, N, (wave - 3) * 64 + lane, 320);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -996,6 +1006,18 @@ static int attn_check(int B, int H, int Nv, int Nt, int D, int ld) {
 static float* g_fwd_profile = nullptr;
 extern "C" void simvg_attn_fwd_profile_buf(float* p) { g_fwd_profile = p; }
 #endif
+// workgroups per residency round for the L2 prefetch of the next round (attention.h): the CU count when the launch has more
+// workgroups than CUs (one workgroup per CU: the kernels take > 80 KB of LDS), else 0.  SIMVG_ATTN_L2PF=0 switches it off.
+static int attn_pf_stride(int nwg) {
+  static const int cus = [] {
+    if (const char* e = getenv("SIMVG_ATTN_L2PF")) if (atoi(e) == 0) return 0;
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return n;
+  }();
+  return nwg > cus ? cus : 0;
+}
+
 extern "C" int simvg_attn_fwd(const void* qkv, int ldqkv, void* out, int ldo, float* lse, const unsigned char* pad,
                               int B, int H, int Nv, int Nt, int D, float scale, hipStream_t stream) {
   SIMVG_CHECK_ARG(attn_check(B, H, Nv, Nt, D, ldqkv) && ldo % 8 == 0,
@@ -1020,6 +1042,7 @@ extern "C" int simvg_attn_fwd(const void* qkv, int ldqkv, void* out, int ldo, fl
   const int qsplit = B * H * 3 <= 256 ? std::min(3, cdiv(cdiv(N, 16), 12)) : 1;
   const bool off32 = (long)B * N * ldqkv < (1L << 31) && (long)B * N * ldo < (1L << 31) && (long)B * H * N < (1L << 31);   // the kernel's 32-bit element offsets
   if (cdiv(N, 16) == 27 && Nv / 16 >= 25 && off32) {   // the path's geometry: 1 + (640/32)^2 vision + 20 text tokens
+    a.pf_stride = attn_pf_stride(B * H);
     hipLaunchKernelGGL((attn_fwd_t_kernel<27, 25, 768>), dim3(B * H, qsplit), dim3(768), shm, stream, a);
     SIMVG_LAUNCH_CHECK();
     return SIMVG_OK;
