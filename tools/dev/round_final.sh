@@ -14,4 +14,4 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')
 bash tools/dev/round_profiles.sh $TAG
 python bench.py --queries 10 --steps 20 --warmup 5 --no-cpu-baseline --no-forward-test --no-extras 2>/dev/null | tail -1 > gpurun_out/${TAG}_q10_bench_line.json
 python -c "import json; d=json.load(open('gpurun_out/${TAG}_q10_bench_line.json')); print('q10', d['value'], d['ms_per_step'])"
-bash tools/dev/step_trace.sh $TAG > /dev/null 2>&1; cp gpurun_out/${TAG}_trace.txt gpurun_out/${TAG}_step_trace.txt 2>/dev/null; head -3 gpurun_out/${TAG}_step_trace.txt
+
