@@ -144,7 +144,11 @@ __global__ __launch_bounds__(768) void attn_fwd_kernel(AttnArgs a) {
 #else
 #define FWD_T(k_) do { } while (0)
 #endif
-template <int NKT, int KFULL, int NTHREADS, int G = 2, bool QK_ONLY = false>
+#ifndef ATTN_FWD_G
+#define ATTN_FWD_G 2        // key tiles per group of the QK^T loop (round 5 sweep, -DATTN_FWD_G=1 .. 4: isolated 65 - 68 / 70 - 73 / 70 - 72 / 71 - 74 us, but
+                            // IN SITU G = 1 loses: 27.75 / 27.77 ms per step against 27.71 / 27.71 with G = 2, alternating runs; profiles/r05_sweeps.md section 12)
+#endif
+template <int NKT, int KFULL, int NTHREADS, int G = ATTN_FWD_G, bool QK_ONLY = false>
 __global__ __launch_bounds__(NTHREADS) void attn_fwd_t_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NS2 = (NKT + 1) / 2, NPAD = NS2 * 32;
@@ -1065,9 +1069,9 @@ extern "C" int simvg_attn_qk_probe(const void* qkv, int ldqkv, float* rowmax, co
   SIMVG_CHECK_ARG((long)B * N * ldqkv < (1L << 31), "attn_qk_probe: 32-bit element offsets");
   AttnArgs a{(const lp_t*)qkv, ldqkv, nullptr, 0, nullptr, 0, nullptr, 0, rowmax, nullptr, pad, B, H, Nv, Nt, D, scale};
   const size_t shm = (size_t)2 * npad * ROWB + npad * sizeof(float);
-  static bool once = set_lds_limit(attn_fwd_t_kernel<27, 25, 768, 2, true>, 160 * 1024);
+  static bool once = set_lds_limit(attn_fwd_t_kernel<27, 25, 768, ATTN_FWD_G, true>, 160 * 1024);
   (void)once;
-  hipLaunchKernelGGL((attn_fwd_t_kernel<27, 25, 768, 2, true>), dim3(B * H, 1), dim3(768), shm, stream, a);
+  hipLaunchKernelGGL((attn_fwd_t_kernel<27, 25, 768, ATTN_FWD_G, true>), dim3(B * H, 1), dim3(768), shm, stream, a);
   SIMVG_LAUNCH_CHECK();
   return SIMVG_OK;
 }
