@@ -587,7 +587,8 @@ def _mm_rows(B, Nv, Nt):
 # 27 key tiles with >= 24 of them vision keys (the path's geometry, 421 tokens; 424 / 430 as well): the backward runs in one pass
 # (csrc/attention_bwd1.hip) unless SIMVG_ATTN_BWD1=0 selects the dq + dkv kernels
 @pytest.mark.parametrize("B,H,Nv,Nt", [(2, 2, 17, 20), (2, 12, 401, 20), (1, 3, 50, 0), (3, 2, 100, 7), (2, 2, 500, 13),
-                                       (1, 2, 1601, 20), (2, 1, 512, 0), (3, 16, 401, 20), (1, 4, 412, 12), (2, 3, 410, 20)])
+                                       (1, 2, 1601, 20), (2, 1, 512, 0), (3, 16, 401, 20), (1, 4, 412, 12), (2, 3, 410, 20),
+                                       (24, 12, 401, 20)])       # 288 workgroups: more than one residency round (the forward's L2 touches run)
 @pytest.mark.parametrize("one_pass", [True, False])
 def test_attention_fwd_bwd(B, H, Nv, Nt, one_pass, monkeypatch):
     if not one_pass:
