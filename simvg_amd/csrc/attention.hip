@@ -191,7 +191,7 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_t_kernel(AttnArgs a) {
   FWD_T(2);
   __syncthreads();
   FWD_T(3);
-  int fwd_strip = 0;
+  [[maybe_unused]] int fwd_strip = 0;            // FWD_PROFILE: stamp index
 
   const float sc2 = a.scale * 1.44269504088896340736f;
   const unsigned int one2 = pack_lp2_raw(1.f, 1.f);
