@@ -1548,40 +1548,67 @@ __global__ __launch_bounds__(256) void dec_ffn_bwd_kernel(DecFfnBwdArgs a) {
     f32x4_t pf_w2[16][1];
     stream_nn_prefetch<1, 16>(0, DE, bl_w2, pf_w2);            // the first W2 rows, requested before the rows' LayerNorm backward
     // ---- row-local: dy3 = d(t3) + LN_post backward(d(hs)); d(r3) = LN3 backward(dy3); DRM = d(r3) * m2
-#pragma unroll 8
-    for (int ri = 0; ri < FBR / 4; ++ri) {          // (compile-time trip count: the loads of 8 rows are issued together)
-      const int rr = wave + 4 * ri;
-      const long r = m0 + rr;
-      f32x4_t drm = f4zero();
-      if (rr < rows) {
-        f32x4_t dy = a.d_t3 ? ld4(a.d_t3 + r * DE + 4 * lane) : f4zero();
+    // Rows in batches of RB: ALL global loads of a batch first (unconditional, on clamped row indices), then the arithmetic and
+    // the lead slice's stores.  Written row by row, hipcc kept every row's loads behind the previous row's stores (they may alias)
+    // and behind its own branches: sixteen memory round trips in a row per wave (`s_waitcnt vmcnt(0)` five times per row in the
+    // ISA) in front of the first MFMA of a 60 us kernel.
+#ifndef DEC_FFN_RB
+#define DEC_FFN_RB 2       // rows per wave and batch (4: the same 46.8 us against 51.1, with 72 spilled bytes)
+#endif
+    constexpr int RB = DEC_FFN_RB;
+    const f32x4_t gPv = a.d_hs ? ld4(a.gP + 4 * lane) : f4zero(), g2v = ld4(a.g2 + 4 * lane);
+#pragma unroll 1
+    for (int rb = 0; rb < FBR / 4; rb += RB) {
+      f32x4_t Ldy[RB], Ldh[RB], Lt3[RB], Lr3[RB], Lm2[RB];
+      float LmP[RB], LrP[RB], Lm3[RB], Lr3s[RB];
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const long r = m0 + min(wave + 4 * (rb + i), rows - 1);
+        Ldy[i] = a.d_t3 ? ld4(a.d_t3 + r * DE + 4 * lane) : f4zero();
         if (a.d_hs) {
-          const f32x4_t dh = ld4(a.d_hs + r * DE + 4 * lane);
-          const float mean = a.meanP[r], rstd = a.rstdP[r];
-          const f32x4_t xh = (ld4(a.t3 + r * DE + 4 * lane) - mean) * rstd;
-          const f32x4_t dyg = dh * ld4(a.gP + 4 * lane);
+          Ldh[i] = ld4(a.d_hs + r * DE + 4 * lane);
+          Lt3[i] = ld4(a.t3 + r * DE + 4 * lane);
+          LmP[i] = a.meanP[r]; LrP[i] = a.rstdP[r];
+        }
+        Lr3[i] = ld4(a.r3 + r * DE + 4 * lane);
+        Lm3[i] = a.mean3[r]; Lr3s[i] = a.rstd3[r];
+        if (a.m2) Lm2[i] = ld4(a.m2 + r * DE + 4 * lane);
+      }
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const int rr = wave + 4 * (rb + i);
+        const long r = m0 + rr;
+        f32x4_t drm = f4zero();
+        if (rr < rows) {
+          f32x4_t dy = Ldy[i];
+          if (a.d_hs) {
+            const f32x4_t dh = Ldh[i];
+            const float mean = LmP[i], rstd = LrP[i];
+            const f32x4_t xh = (Lt3[i] - mean) * rstd;
+            const f32x4_t dyg = dh * gPv;
+            const float c1 = wave_sum((dyg[0] + dyg[1]) + (dyg[2] + dyg[3])) * (1.f / DE);
+            const f32x4_t t = dyg * xh;
+            const float c2 = wave_sum((t[0] + t[1]) + (t[2] + t[3])) * (1.f / DE);
+            dy += (dyg - c1 - xh * c2) * rstd;
+            if (lead) *(f32x4_t*)(a.gxP + r * DE + 4 * lane) = dh * xh;
+          }
+          const float mean = Lm3[i], rstd = Lr3s[i];
+          const f32x4_t xh = (Lr3[i] - mean) * rstd;
+          const f32x4_t dyg = dy * g2v;
           const float c1 = wave_sum((dyg[0] + dyg[1]) + (dyg[2] + dyg[3])) * (1.f / DE);
           const f32x4_t t = dyg * xh;
           const float c2 = wave_sum((t[0] + t[1]) + (t[2] + t[3])) * (1.f / DE);
-          dy += (dyg - c1 - xh * c2) * rstd;
-          if (lead) *(f32x4_t*)(a.gxP + r * DE + 4 * lane) = dh * xh;
+          const f32x4_t dr = (dyg - c1 - xh * c2) * rstd;
+          drm = a.m2 ? dr * Lm2[i] : dr;
+          if (lead) {
+            *(f32x4_t*)(a.d_r3 + r * DE + 4 * lane) = dr;
+            *(f32x4_t*)(a.gx3 + r * DE + 4 * lane) = dy * xh;
+            *(f32x4_t*)(a.dy3 + r * DE + 4 * lane) = dy;
+            *(f32x4_t*)(a.dr3m + r * DE + 4 * lane) = drm;
+          }
         }
-        const float mean = a.mean3[r], rstd = a.rstd3[r];
-        const f32x4_t xh = (ld4(a.r3 + r * DE + 4 * lane) - mean) * rstd;
-        const f32x4_t dyg = dy * ld4(a.g2 + 4 * lane);
-        const float c1 = wave_sum((dyg[0] + dyg[1]) + (dyg[2] + dyg[3])) * (1.f / DE);
-        const f32x4_t t = dyg * xh;
-        const float c2 = wave_sum((t[0] + t[1]) + (t[2] + t[3])) * (1.f / DE);
-        const f32x4_t dr = (dyg - c1 - xh * c2) * rstd;
-        drm = a.m2 ? dr * ld4(a.m2 + r * DE + 4 * lane) : dr;
-        if (lead) {
-          *(f32x4_t*)(a.d_r3 + r * DE + 4 * lane) = dr;
-          *(f32x4_t*)(a.gx3 + r * DE + 4 * lane) = dy * xh;
-          *(f32x4_t*)(a.dy3 + r * DE + 4 * lane) = dy;
-          *(f32x4_t*)(a.dr3m + r * DE + 4 * lane) = drm;
-        }
+        *(f32x4_t*)(DRM + rr * DLD + 4 * lane) = drm;
       }
-      *(f32x4_t*)(DRM + rr * DLD + 4 * lane) = drm;
     }
     for (int e = tid; e < FBR * (FS / 4); e += 256) {
       const int r = e / (FS / 4), c = 4 * (e % (FS / 4));
