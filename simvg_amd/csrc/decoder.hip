@@ -1446,24 +1446,43 @@ __global__ __launch_bounds__(256) void dec_ffn_fwd_kernel(DecFfnArgs a) {
     f32x4_t pf1[16], pf2[16];
     stream_nt_prefetch<16, 16>(1, bload1, pf1);      // the wave's whole W1 tile and its four W2 tiles, requested before the rows arrive
     stream_nt_prefetch<4, 16>(4, bload2, pf2);
-    for (int e = tid; e < 64 * (DE / 4); e += 256) {
-      const int r = e / (DE / 4), c = 4 * (e % (DE / 4));
-      *(f32x4_t*)(X + r * DLD + c) = r < rows ? ld4(a.t2 + (long)(m0 + r) * DE + c) : f4zero();
+    // the 64 rows, the bias and the dropout multipliers: every load issued before the first wait (written as one-load loops /
+    // inside the tile epilogue they were 16 + 20 memory round trips in a row per wave -- `global_load` / `s_waitcnt vmcnt(0)` /
+    // `ds_write` per trip in the ISA -- in a 26 us kernel)
+    {
+      constexpr int NX = 64 * (DE / 4) / 256;
+      f32x4_t xv[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        const int e = tid + 256 * i, r = e / (DE / 4), c = 4 * (e % (DE / 4));
+        xv[i] = ld4(a.t2 + (long)(m0 + min(r, rows - 1)) * DE + c);
+      }
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        const int e = tid + 256 * i, r = e / (DE / 4), c = 4 * (e % (DE / 4));
+        *(f32x4_t*)(X + r * DLD + c) = r < rows ? xv[i] : f4zero();
+      }
     }
+    const float bias1 = a.b1[f0 + 16 * wave + j];
+    float mk[4][4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        mk[rt][v] = a.m1 ? a.m1[(long)(m0 + min(16 * rt + 4 * g + v, rows - 1)) * a.Fd + f0 + 16 * wave + j] : 1.f;
     __syncthreads();
     {   // h_s: one 16-column tile per wave, 4 row tiles
       auto& bload = bload1;
       auto aload = [&](int, int k, int row) { return ld4(X + row * DLD + k + 4 * g); };
       auto epi = [&](int, int rt, f32x4_t acc) {
         const int f = 16 * wave + j;
-        const float bias = a.b1[f0 + f];
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const int r = 16 * rt + 4 * g + v;
           float y = 0.f;
           if (r < rows) {
-            y = fmaxf(acc[v] + bias, 0.f);
-            if (a.m1) y *= a.m1[(long)(m0 + r) * a.Fd + f0 + f];
+            y = fmaxf(acc[v] + bias1, 0.f);
+            if (a.m1) y *= mk[rt][v];
             a.h1d[(long)(m0 + r) * a.Fd + f0 + f] = y;
           }
           HS[r * FLD + f] = y;
@@ -1499,7 +1518,16 @@ __global__ __launch_bounds__(256) void dec_ffn_finish_kernel(DecFfnFinishArgs a)
   const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= a.M) return;
   f32x4_t y = ld4(a.b2 + 4 * lane);
-  for (int s = 0; s < a.NS; ++s) y += ld4(a.slabs + ((long)s * a.M + r) * DE + 4 * lane);
+  // (eight slices' loads in flight at a time; the sum keeps the slice order: one load per trip was NS round trips in a row)
+  int s = 0;
+  for (; s + 8 <= a.NS; s += 8) {
+    f32x4_t t[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = ld4(a.slabs + ((long)(s + i) * a.M + r) * DE + 4 * lane);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) y += t[i];
+  }
+  for (; s < a.NS; ++s) y += ld4(a.slabs + ((long)s * a.M + r) * DE + 4 * lane);
   if (a.m2) y *= ld4(a.m2 + (long)r * DE + 4 * lane);
   y += ld4(a.t2 + (long)r * DE + 4 * lane);
   *(f32x4_t*)(a.r3 + (long)r * DE + 4 * lane) = y;
@@ -1610,9 +1638,23 @@ __global__ __launch_bounds__(256) void dec_ffn_bwd_kernel(DecFfnBwdArgs a) {
         *(f32x4_t*)(DRM + rr * DLD + 4 * lane) = drm;
       }
     }
-    for (int e = tid; e < FBR * (FS / 4); e += 256) {
-      const int r = e / (FS / 4), c = 4 * (e % (FS / 4));
-      *(f32x4_t*)(HS + r * FLD + c) = r < rows ? ld4(a.h1d + (long)(m0 + r) * a.Fd + f0 + c) : f4zero();
+    f32x4_t m1v[4];                                  // the dropout multipliers of this lane's four rows, requested with the h1d rows
+    {
+      constexpr int NH = FBR * (FS / 4) / 256;
+      f32x4_t hv[NH];
+#pragma unroll
+      for (int i = 0; i < NH; ++i) {
+        const int e = tid + 256 * i, r = e / (FS / 4), c = 4 * (e % (FS / 4));
+        hv[i] = ld4(a.h1d + (long)(m0 + min(r, rows - 1)) * a.Fd + f0 + c);
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        m1v[v] = a.m1 ? ld4(a.m1 + (long)(m0 + min(16 * wave + 4 * g + v, rows - 1)) * a.Fd + f0 + 4 * j) : (f32x4_t){1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+      for (int i = 0; i < NH; ++i) {
+        const int e = tid + 256 * i, r = e / (FS / 4), c = 4 * (e % (FS / 4));
+        *(f32x4_t*)(HS + r * FLD + c) = r < rows ? hv[i] : f4zero();
+      }
     }
     __syncthreads();
     // ---- d(h_s)[r][f] = sum_n DRM[r][n] W2[n][f0 + f], gated by the ReLU: wave w owns row tile w (16 rows) over all n
@@ -1627,7 +1669,7 @@ __global__ __launch_bounds__(256) void dec_ffn_bwd_kernel(DecFfnBwdArgs a) {
         const int rr = 16 * wave + 4 * g + v;
         f32x4_t d = (f32x4_t){acc[0][0][0][v], acc[0][0][1][v], acc[0][0][2][v], acc[0][0][3][v]};
         const f32x4_t h = ld4(HS + rr * FLD + 4 * j);
-        if (a.m1 && rr < rows) d *= ld4(a.m1 + (long)(m0 + rr) * a.Fd + f0 + 4 * j);
+        if (a.m1 && rr < rows) d *= m1v[v];
 #pragma unroll
         for (int c = 0; c < 4; ++c) d[c] = h[c] > 0.f ? d[c] : 0.f;
         *(f32x4_t*)(DH + rr * FLD + 4 * j) = d;
