@@ -950,7 +950,18 @@ __global__ __launch_bounds__(DNT) void dec_attn_bwd_kernel(DecAttnBwdArgs a) {
     f32x4_t v = f4zero();
     if (r < R) {
       if (a.dt2) v = ld4(a.dt2 + (row0 + r) * DE + c);
-      for (int s = 0; s < a.nslab; ++s) v += ld4(a.dt2_slabs + s * a.slab_stride + (row0 + r) * DE + c);
+      // (eight slices' loads in flight, added in slice order: one load per trip was 32 round trips in a row at the head of the
+      // kernel -- with one query per sample a single wave does all of them)
+      const float* sl = a.dt2_slabs + (row0 + r) * DE + c;
+      int s = 0;
+      for (; s + 8 <= a.nslab; s += 8) {
+        f32x4_t t[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = ld4(sl + (long)(s + i) * a.slab_stride);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v += t[i];
+      }
+      for (; s < a.nslab; ++s) v += ld4(sl + (long)s * a.slab_stride);
     }
     *(f32x4_t*)(A0 + r * DLD + c) = v;
     *(f32x4_t*)(A1 + r * DLD + c) = v;
