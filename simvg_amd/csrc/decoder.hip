@@ -698,12 +698,23 @@ __global__ __launch_bounds__(DNT) void dec_attn_fwd_kernel(DecAttnArgs a) {
       const float inv = 1.f / sum;
       const long pg = ((long)b * DH + h) * Lk;
       float sp = 0.f;
-      for (int kk = lane; kk < Lk; kk += 64) {
-        const float p = sr[kk] * inv;
-        a.P1[pg + kk] = p;
-        const float pd = a.dm1 ? p * a.dm1[pg + kk] : p;
-        PT[kk * 8 + h] = pd;
-        sp += pd;
+      // keys in chunks of 448 (seven per lane): the chunk's dropout multipliers are requested before its loop -- inside it each
+      // load waited behind the previous key's store of P1
+      for (int k0 = 0; k0 < Lk; k0 += 448) {
+        float dmv[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) dmv[i] = a.dm1 ? a.dm1[pg + min(k0 + lane + 64 * i, Lk - 1)] : 1.f;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+          const int kk = k0 + lane + 64 * i;
+          if (kk < Lk) {
+            const float p = sr[kk] * inv;
+            a.P1[pg + kk] = p;
+            const float pd = a.dm1 ? p * dmv[i] : p;
+            PT[kk * 8 + h] = pd;
+            sp += pd;
+          }
+        }
       }
       sp = wave_sum(sp);
       if (lane == 0) { a.sp[row0 * DH + h] = sp; SPL[h] = sp; }
@@ -1050,17 +1061,28 @@ __global__ __launch_bounds__(DNT) void dec_attn_bwd_kernel(DecAttnBwdArgs a) {
       const float* dsr = DS8 + h * LKP;
       const long pg = ((long)b * DH + h) * Lk;
       float rs = 0.f;
-      for (int kk = lane; kk < Lk; kk += 64) {
-        const float p = a.P1[pg + kk];
-        const float dm = a.dm1 ? a.dm1[pg + kk] : 1.f;
-        rs = fmaf(p, dsr[kk] * dm, rs);
+      // this lane's probabilities and dropout multipliers (the launcher admits Lk <= 448: seven keys per lane): fourteen loads in
+      // flight once, instead of two per trip of both loops
+      float pv[7], dmv[7];
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        const long o = pg + min(lane + 64 * i, Lk - 1);
+        pv[i] = a.P1[o];
+        dmv[i] = a.dm1 ? a.dm1[o] : 1.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        const int kk = lane + 64 * i;
+        if (kk < Lk) rs = fmaf(pv[i], dsr[kk] * dmv[i], rs);
       }
       rs = wave_sum(rs);
-      for (int kk = lane; kk < Lk; kk += 64) {
-        const float p = a.P1[pg + kk];
-        const float dm = a.dm1 ? a.dm1[pg + kk] : 1.f;
-        PPT[kk * 8 + h] = p * dm;
-        DST[kk * 8 + h] = p * (dsr[kk] * dm - rs);
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        const int kk = lane + 64 * i;
+        if (kk < Lk) {
+          PPT[kk * 8 + h] = pv[i] * dmv[i];
+          DST[kk * 8 + h] = pv[i] * (dsr[kk] * dmv[i] - rs);
+        }
       }
     }
     __syncthreads();
@@ -1908,7 +1930,7 @@ extern "C" int simvg_dec_attn_bwd(const simvg_dec_attn_bwd_args* p, hipStream_t 
   DecAttnBwdArgs a;
   memcpy(&a, p, sizeof(a));
   const size_t shm = (size_t)dec_attn_bwd_lds_floats(p->Lk) * sizeof(float);
-  SIMVG_CHECK_ARG(shm <= 160 * 1024, "dec_attn_bwd: the score strips do not fit the 160 KiB LDS (Lk <= 448)");
+  SIMVG_CHECK_ARG(shm <= 160 * 1024 && p->Lk <= 448, "dec_attn_bwd: the score strips do not fit the 160 KiB LDS (Lk <= 448)");
   // instantiations: one query per sample (num_queries = 1, the RefCOCO configs: the weight phases on the VALU -- a 16-row MFMA tile
   // would be 15/16 padding) or MFMA (GRefCOCO: 10 queries) x 16-bit or fp32 source rows
   typedef void (*kern_t)(DecAttnBwdArgs);
