@@ -74,7 +74,7 @@ class _RestArena:
         ps = (self.params[0], self.params[len(self.params) // 2], self.params[-1])
         return all(p.data.untyped_storage().data_ptr() == base for p in ps)
 
-    def gather_grads(self, rebind=False):
+    def gather_grads(self, rebind=False, check=True):
         """autograd's per-tensor gradients -> the flat gradient buffer.  A parameter whose `.grad` is None contributes
         zeros: per-tensor Adam SKIPS such a parameter (no moment decay, no step count, no state), and the fused kernel does
         exactly that for an element whose gradient and moments are all zero (the update is exactly zero and nothing is
@@ -88,9 +88,14 @@ class _RestArena:
         A `.grad` that already IS its slice of the flat buffer is left alone: after the gradient exchange (`dist.GradReducer`
         gathers early, all-reduces the flat buffer in place and re-points every `.grad` at its slice) the optimizer's own gather
         copies nothing.  rebind=True re-points the gathered `.grad`s right away; `last_gathered` = [(slice, parameter)] of this call.
+        check=False (the reducer's EARLY gather, from inside the backward): the has-a-gradient set is neither recorded nor
+        compared -- a head gradient may still arrive after it (the reducer's late pass copies it into its slice); only the
+        optimizer's own gather, which sees the step's final set, does the bookkeeping.
         -> number of parameters with a gradient"""
         mask = tuple(p.grad is not None for p in self.params)
-        if getattr(self, "_graded", None) is None:
+        if not check:
+            pass
+        elif getattr(self, "_graded", None) is None:
             self._graded = mask
         elif mask != self._graded:
             changed = [i for i, (a, b) in enumerate(zip(mask, self._graded)) if a != b]
@@ -104,11 +109,12 @@ class _RestArena:
             self._graded = mask
         graded = sum(mask)
         have = [(v, p) for v, p in zip(self.grad_views, self.params) if p.grad is not None and p.grad is not v]
+        if graded < len(self.params):
+            # (before the early return below: with NO gradient at all the buffer must not keep the previous step's values)
+            torch._foreach_zero_([v for v, p in zip(self.grad_views, self.params) if p.grad is None])
         if not have:
             self.last_gathered = []
             return graded              # every gradient already lives in its slice (gathered earlier in this step)
-        if graded < len(self.params):
-            torch._foreach_zero_([v for v, p in zip(self.grad_views, self.params) if p.grad is None])
         torch._foreach_copy_([v for v, _ in have], [p.grad for _, p in have])
         self.last_gathered = have
         if rebind:

@@ -197,7 +197,7 @@ class GradReducer:
             if not loose and all(ra.intact() for ra in arenas):
                 sent = []
                 for ra in arenas:
-                    if ra.gather_grads():
+                    if ra.gather_grads(check=False):     # (the graded-set bookkeeping is the optimizer's: a late gradient may follow)
                         self._launch(ra.flat_grad, "head")
                         # (slice, parameter, the autograd-produced tensor, its version): re-pointed in finish(), where a tensor
                         # that autograd accumulated into after this copy is recognised by its version counter

@@ -133,9 +133,11 @@ def _worker(rank, world, port, out, uneven=False, message=None, head_arena=None)
         # optimizer's own gather later in the step has nothing left to copy
         sched_ok = sched_ok and by["head"] == esz * ra.total and (early_bias or by["late"] == esz * model.head.bias.numel())
         sched_ok = sched_ok and all(p.grad is v for p, v in zip(ra.params, ra.grad_views))
-        if early_bias:
-            before, ver = ra.flat_grad.clone(), ra.flat_grad._version
-            sched_ok = sched_ok and ra.gather_grads() == 2 and ra.flat_grad._version == ver and torch.equal(before, ra.flat_grad)
+        # FlatAdam's own gather (the one that keeps the has-a-gradient bookkeeping) comes after finish(): it sees the step's
+        # FINAL set -- also when a gradient arrived after the reducer's early gather ("late") -- and has nothing to copy
+        before, ver = ra.flat_grad.clone(), ra.flat_grad._version
+        sched_ok = sched_ok and ra.gather_grads() == 2 and ra.flat_grad._version == ver and torch.equal(before, ra.flat_grad)
+        sched_ok = sched_ok and ra._graded == (True, True)
     sched_ok = sched_ok and by["text_rows"] == esz * world * 8 * 8 and by["ids"] == 8 * world * 8       # int64 ids, D = 8
     # dense remainder = the arena minus the layer slices minus the (sparsely exchanged) text table
     sched_ok = sched_ok and by["rest"] == esz * (A_.total - sum(layer_bytes) // esz - A_.params["beit3.text_embed.weight"].numel())
@@ -312,3 +314,22 @@ def test_bench_gpus_n_refuses_a_node_with_fewer_gpus_and_a_mismatched_world():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), cwd=root, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and not r.stdout.strip(), (r.returncode, r.stderr[-500:])
+
+
+def test_rest_arena_without_any_gradient_zeroes_its_buffer():
+    """a step on which NO parameter of a rest arena has a gradient must not re-apply the previous step's values"""
+    from simvg_amd.core.optimizer import _RestArena
+    lin = torch.nn.Linear(4, 3)
+    ra = _RestArena(list(lin.parameters()))
+    lin.weight.grad, lin.bias.grad = torch.ones(3, 4), torch.ones(3)
+    assert ra.gather_grads() == 2 and float(ra.flat_grad.abs().sum()) == 15.0
+    lin.weight.grad = lin.bias.grad = None
+    os.environ["SIMVG_ALLOW_GRADED_SET_CHANGE"] = "1"
+    try:
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            assert ra.gather_grads() == 0
+    finally:
+        del os.environ["SIMVG_ALLOW_GRADED_SET_CHANGE"]
+    assert float(ra.flat_grad.abs().sum()) == 0.0
