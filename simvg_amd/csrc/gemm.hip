@@ -595,6 +595,10 @@ __device__ __forceinline__ void lds_write_b64_asm(unsigned addr, u32x2_t v) {
   asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
 __device__ __forceinline__ lpx8_t as_frag(u32x4_t v) { return __builtin_bit_cast(lpx8_t, v); }
+// makes v opaque at this point (no consumer of v is scheduled above it, no copy of it is folded across).  As a device FUNCTION: a
+// kernel TEMPLATE's body is instantiated by the host pass as well, where a bare asm statement with an AMDGPU register constraint is a
+// substitution failure (the specialisation silently loses its host stub); calls into device-only functions are not checked there
+__device__ __forceinline__ void reg_pin(f32x4_t& v) { asm volatile("" : "+v"(v)); }
 
 // All LDS traffic of this kernel is inline asm (common.h: hipcc drains vmcnt in front of compiler-visible LDS accesses that
 // follow a buffer-form LDS-DMA), all DMA addressing is (SGPR descriptor of the tile) + (4 loop-invariant lane offsets).
@@ -832,6 +836,203 @@ __global__ __launch_bounds__(1024) void gemm_nt_kernel_160x256_r3(GemmNTArgs a) 
 #undef STB
 #undef ISSUE
   gemm_nt_epilogue_lds<5, 2>(a, acc, group, row0, row_end, n0, wm, wn, wave, lane, smem);
+}
+
+// ------------------------------------------------------------------------------------------
+// TALL tile (round 6): 64 MI rows x 256 columns per workgroup, sixteen waves as 4 (M) x 4 (N), each 16 MI x 64 = acc[MI][4], in the
+// hand-managed form of the persistent kernel above (SGPR buffer descriptors + loop-invariant lane offsets for the LDS-DMA, inline-asm
+// fragment reads with counted lgkmcnt, a two-entry A-fragment ring, the bias as the accumulators' start value).  MI = 5: ViT-B's
+// N = 768 launches at 64 pairs per step (M = 26 944 = 25 664 | 1 280) are 85 x 3 = 255 tiles of 320 rows -- ONE round on 256 CUs
+// with one prologue / epilogue per CU and 9 fragment reads per 20 MFMAs, instead of two rounds of 160-row tiles (7 per 10).  Round 4's
+// 320-row attempt (tools/dev/gemm_320x256_r04.hip.txt) left reads, waits and the LDS-staged epilogue to the compiler and spilled at
+// the 128-register budget of sixteen waves; here the main loop holds 80 accumulators + 4 B fragments + 2 A fragments, and the
+// epilogues are written for the registers that are left:
+//   EPI 0  16-bit output (+bias): 2 KiB of wave-private staging in the (finished) ring, row-wise 16-B stores;
+//   EPI 1  fp32 output (+bias) (+ residual * row_scale): straight from the accumulator layout, 16 B per lane (a store covers
+//          16 rows x 64 B), the residual rows of block i + 1 requested before block i is finished.
+// Split weights (hi + lo, `ka` < K): the bias starts as bias / lo_scale and the accumulators are rescaled after the lo half.
+// ------------------------------------------------------------------------------------------
+template <int MI> struct TallGeo {
+  static constexpr int ROWS = 64 * MI, WROWS = 16 * MI;
+  static constexpr int A_BYTES = ROWS * BK * 2, STAGE = (ROWS + BNQ) * BK * 2;
+  static constexpr int NPA = ROWS / 8;                 // 1 KiB pieces of an A k-tile (8 rows each)
+  static constexpr int NAI = (NPA + 15) / 16;          // per wave: piece wave + 16 i while < NPA
+  static constexpr int SMEM = 2 * STAGE;
+};
+
+// (a device function template behind plain kernels: the host pass instantiates a KERNEL template's body too, and target builtins /
+// register constraints in it are a substitution failure there that silently drops the specialisation's host stub)
+template <int MI, int EPI>
+__device__ __forceinline__ void gemm_nt_tall_body(const GemmNTArgs& a, char* smem) {
+  using G = TallGeo<MI>;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;   // 4 x 4 waves
+  const int tiles_n = a.N / BNQ;
+  const int tm0 = (a.split + G::ROWS - 1) / G::ROWS;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+  const int group = tile_m >= tm0;
+  const int row0 = group ? a.split + (tile_m - tm0) * G::ROWS : tile_m * G::ROWS;
+  const int row_end = group ? a.M : a.split;
+  const int n0 = tile_n * BNQ;
+  const int nk = a.K / BK;
+  const bool two = a.ka < a.K;               // hi + lo weights
+
+  // LDS-DMA: piece q holds rows 8 q .. 8 q + 7 of an operand's k-tile, lane -> row 8 q + (lane >> 3), 16-B slot (lane & 7) ^ (row & 7)
+  // of the row (the XOR is on the SOURCE address: the LDS image is lane-linear); rows past the row group read as zeros (descriptor)
+  const int din = lane >> 3, dslot = (lane & 7) ^ din;
+  int voffA[G::NAI], voffW[2];
+#pragma unroll
+  for (int i = 0; i < G::NAI; ++i) voffA[i] = ((wave + 16 * i) * 8 + din) * a.lda * 2 + dslot * 16;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) voffW[i] = ((wave * 2 + i) * 8 + din) * a.ldw * 2 + dslot * 16;
+  const __amdgpu_buffer_rsrc_t dA =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(a.A + (long)row0 * a.lda), 0, (int)((long)(row_end - row0) * a.lda * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t dW =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(a.W + (long)group * a.w_gstride + (long)n0 * a.ldw), 0, BNQ * a.ldw * 2, 0x00020000);
+  auto issue = [&](int kt, int st) {
+    char* sA = smem + st * G::STAGE;
+    const int ko = a_koff(a, kt * BK) * 2;
+#pragma unroll
+    for (int i = 0; i < G::NAI; ++i)
+      if (wave + 16 * i < G::NPA)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(dA, LDS_PTR(sA + (wave + 16 * i) * 1024), 16, voffA[i], ko, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(dW, LDS_PTR(sA + G::A_BYTES + (wave * 2 + i) * 1024), 16, voffW[i], kt * (BK * 2), 0, 0);
+  };
+  // fragment reads: row (lane & 15) of a 16-row block, slot (4 s + (lane >> 4)) ^ (row & 7); 16 MI is a multiple of 8 for every MI
+  // that is built (4, 5: 64, 80), so row & 7 == lane & 7
+  static_assert(G::WROWS % 8 == 0, "wave row offset must keep the swizzle phase");
+  const int c0 = (lane >> 4) ^ (lane & 7);
+  const unsigned fA0 = lds_addr(smem) + (wm * G::WROWS + (lane & 15)) * 128 + c0 * 16, fA1 = fA0 ^ 64;
+  const unsigned fB0 = lds_addr(smem) + G::A_BYTES + (wn * 64 + (lane & 15)) * 128 + c0 * 16, fB1 = fB0 ^ 64;
+
+  issue(0, 0);
+  if (nk > 1) issue(1, 1);
+  f32x4_t bn[4];
+  if (a.bias) {
+    const float* bp = a.bias + (long)group * a.bias_gstride + n0 + wn * 64 + 4 * (lane >> 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bn[j] = gload_x4_untracked(bp + j * 16);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bn[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
+  vm_wait<0>();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) reg_pin(bn[j]);
+  if (two) {
+    const float inv = 1.f / a.lo_scale;      // a power of two: exact
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bn[j] *= inv;
+  }
+  f32x4_t acc[MI][4];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[i][j] = bn[j];
+      reg_pin(acc[i][j]);                    // copies now: bn's registers are free during the main loop
+    }
+
+#define TALL_STEP(I_)                                                                                        \
+  if constexpr (MI > (I_)) {                                                                                 \
+    if constexpr ((I_) + 1 < MI) lgkm_wait<1>(); else lgkm_wait<0>();                                        \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                            \
+      acc[(I_)][j] = mfma_lp(as_frag(fb[j]), as_frag(fa[(I_) & 1]), acc[(I_)][j]);                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    if constexpr ((I_) + 2 < MI) fa[(I_) & 1] = lds_b128_asm<((I_) + 2) * 2048>(pa);                          \
+  }
+  const int k_lo = a.ka / BK;                // k-tiles of the lo half (== nk: single weights)
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt >= 1) vm_wait<0>();               // this wave's pieces of k-tile kt have landed (k-tile 0: waited for above)
+    __builtin_amdgcn_s_barrier();            // everyone's have, and everyone is past the MFMAs of kt - 1: its stage is free
+    if (kt >= 1 && kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+    const unsigned so = (kt & 1) * G::STAGE;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const unsigned pa = (s ? fA1 : fA0) + so, pb = (s ? fB1 : fB0) + so;
+      u32x4_t fb[4], fa[2];
+      fb[0] = lds_b128_asm<0>(pb); fb[1] = lds_b128_asm<2048>(pb); fb[2] = lds_b128_asm<4096>(pb); fb[3] = lds_b128_asm<6144>(pb);
+      fa[0] = lds_b128_asm<0>(pa);
+      if constexpr (MI > 1) fa[1] = lds_b128_asm<2048>(pa);
+      TALL_STEP(0) TALL_STEP(1) TALL_STEP(2) TALL_STEP(3) TALL_STEP(4) TALL_STEP(5)
+    }
+    if (two && kt + 1 == k_lo) {             // wave-uniform, once per tile
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] *= a.lo_scale;
+    }
+  }
+#undef TALL_STEP
+
+  if constexpr (EPI == 0) {
+    // 16 bit -> wave-private 2 KiB of the finished ring -> row-wise 16-B stores (the persistent kernel's epilogue)
+    __builtin_amdgcn_s_barrier();            // every wave is done reading the ring
+    const unsigned stg = lds_addr(smem) + wave * 2048;
+    const int er = lane & 15, ecg = lane >> 4;
+    const int rr = lane >> 3, rq = lane & 7;
+    lp_t* cp = (lp_t*)a.C + (long)(row0 + wm * G::WROWS + rr) * a.ldc + n0 + wn * 64 + rq * 8;
+    const int mleft = row_end - (row0 + wm * G::WROWS + rr);
+    const unsigned wa = stg + er * 128, ra = stg + rr * 128 + ((rq ^ (rr >> 1)) << 4);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4_t x = acc[i][j];
+        lds_write_b64_asm(wa + (((j * 4 + ecg) ^ er) << 3), (u32x2_t){pack_lp2(x[0], x[1]), pack_lp2(x[2], x[3])});
+      }
+      lgkm_wait<0>();
+      u32x4_t d0 = lds_b128_asm<0>(ra);
+      u32x4_t d1 = lds_b128_asm<0>(ra ^ 1088);
+      lgkm_wait<0>();
+      if (rr & 1) { d0 = (u32x4_t){d0[2], d0[3], d0[0], d0[1]}; d1 = (u32x4_t){d1[2], d1[3], d1[0], d1[1]}; }
+      if (i * 16 < mleft) *(u32x4_t*)(cp + (long)(i * 16) * a.ldc) = d0;
+      if (i * 16 + 8 < mleft) *(u32x4_t*)(cp + (long)(i * 16 + 8) * a.ldc) = d1;
+    }
+  } else {
+    // fp32 (+ residual * row_scale) straight from the accumulator layout: lane -> row (lane & 15) of block i, columns
+    // j * 16 + 4 (lane >> 4) .. + 3 of the wave's 64; the residual rows of block i + 1 are requested before block i is finished
+    const int mb = row0 + wm * G::WROWS + (lane & 15);
+    const int nb = n0 + wn * 64 + 4 * (lane >> 4);
+    float* cp = (float*)a.C + (long)mb * a.ldc + nb;
+    const float* rp = a.res ? a.res + (long)mb * a.ldres + nb : nullptr;
+    f32x4_t rv[2][4];
+    auto load_res = [&](int i, f32x4_t (&r)[4]) {
+      const bool ok = mb + i * 16 < row_end;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) r[j] = ok ? *(const f32x4_t*)(rp + (long)(i * 16) * a.ldres + j * 16) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    };
+    if (rp) load_res(0, rv[0]);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      if (rp && i + 1 < MI) load_res(i + 1, rv[(i + 1) & 1]);
+      const int m = mb + i * 16;
+      float rs = 1.f;
+      if (a.row_scale && m < row_end) rs = a.row_scale[group ? (m - a.split) / a.rps1 : m / a.rps0];
+      if (m < row_end) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f32x4_t v = acc[i][j];
+          if (rp) v = rv[i & 1][j] + rs * v;
+          else if (a.row_scale) v *= rs;
+          *(f32x4_t*)(cp + (long)(i * 16) * a.ldc + j * 16) = v;
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void gemm_nt_kernel_tall5_lp(GemmNTArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemm_nt_tall_body<5, 0>(a, smem);
+}
+__global__ __launch_bounds__(1024) void gemm_nt_kernel_tall5_f32(GemmNTArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemm_nt_tall_body<5, 1>(a, smem);
 }
 
 // 224x256x64 tile with sixteen waves: 2 (M) x 8 (N), each 112x32 = acc[7][2] (round 4).  For row counts where 256-row tiles
@@ -1410,7 +1611,34 @@ static int gemm_nt_launch(const void* A, int lda, const void* W, long w_gstride,
   // B = 1: 21.7 19.6 20.6 45.5 -> 10.1 8.6 10.5 19.4;  B = 2: 18.8 17.1 19.1 53.1 -> 11.1 9.6 13.2 20.2;
   // B = 4 out, fc2: 17.5 54.0 -> 10.5 25.6;  B = 8 out, fc2: 18.3 55.5 -> 14.7 38.5; above ~800 tiles the big-tile kernels win)
   const long tiles64 = (long)(cdiv(split, 64) + cdiv(M - split, 64)) * cdiv(N, 64);
-  if (tiles64 <= 800) {
+  // ONE round of 320-row tiles (round 6, gemm_nt_kernel_tall5_*): where the 320-row tiles of the problem fit the CUs and cost fewer
+  // rows x rounds than the other extents (ViT-B's N = 768 launches at 64 pairs per step: 255 tiles against two rounds of 160-row
+  // tiles); epilogues: 16-bit (+bias) or fp32 (+bias, + residual * row_scale).  SIMVG_GEMM_TALL = 0 / 1: never / wherever it fits (A/B)
+  auto use_tall = [&]() {
+    const char* e = getenv("SIMVG_GEMM_TALL");
+    if (e && atoi(e) == 0) return false;
+    if (!wide_ok || a.aux || a.act != 0 || a.alpha != 1.f) return false;
+    if (a.c_f32 ? (a.ldc % 4 != 0 || (a.res && a.ldres % 4 != 0)) : (a.res || a.row_scale || a.ldc % 8 != 0)) return false;
+    static const int cus = [] { int dev = 0, n = 256; hipGetDevice(&dev); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+    const long t320 = (long)(cdiv(split, 320) + cdiv(M - split, 320)) * cdiv(N, BNQ);
+    if (t320 > cus) return false;
+    if (e && atoi(e) == 1) return true;
+    const double best = tile_cost(256) < tile_cost(160) ? tile_cost(256) : tile_cost(160);
+    return 320.0 < best;
+  };
+  if (tiles64 > 800 && use_tall()) {
+    using G5 = TallGeo<5>;
+    const int tiles = (cdiv(split, G5::ROWS) + cdiv(M - split, G5::ROWS)) * cdiv(N, BNQ);
+    if (a.c_f32) {
+      static bool once1 = hipFuncSetAttribute((const void*)gemm_nt_kernel_tall5_f32, hipFuncAttributeMaxDynamicSharedMemorySize, G5::SMEM) == hipSuccess;
+      (void)once1;
+      hipLaunchKernelGGL(gemm_nt_kernel_tall5_f32, dim3(tiles), dim3(1024), G5::SMEM, stream, a);
+    } else {
+      static bool once0 = hipFuncSetAttribute((const void*)gemm_nt_kernel_tall5_lp, hipFuncAttributeMaxDynamicSharedMemorySize, G5::SMEM) == hipSuccess;
+      (void)once0;
+      hipLaunchKernelGGL(gemm_nt_kernel_tall5_lp, dim3(tiles), dim3(1024), G5::SMEM, stream, a);
+    }
+  } else if (tiles64 <= 800) {
     static bool oncel = hipFuncSetAttribute((const void*)gemm_nt_kernel_lat<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * LAT_STAGE) == hipSuccess;
     (void)oncel;
     hipLaunchKernelGGL(gemm_nt_kernel_lat<3>, dim3((int)tiles64), dim3(256), 3 * LAT_STAGE, stream, a);

@@ -365,7 +365,11 @@ class DecoderLayerFn(torch.autograd.Function):
         if train and cfg.p_ffn > 0:
             m1, m2 = cfg.mask_fn((M, Fd), dev, cfg.p_ffn), cfg.mask_fn((M, qpos.shape[1]), dev, cfg.p_ffn)
         sf = ops.dec_ffn_fwd(sa["t2"], W1, b1, W2, b2, g2, b2n, gP=gP, bP=bP, m1=m1, m2=m2)
-        ctx.cfg, ctx.sa, ctx.sf = cfg, sa, sf
+        # the node keeps ALIASES of its two outputs (same storage, other tensor objects): the returned tensors carry this node as
+        # their grad_fn, and a node that holds them would be a reference cycle -- the carved activation buffers would live until
+        # Python's cyclic collector runs instead of until the backward has used them
+        ctx.cfg, ctx.sa = cfg, sa
+        ctx.sf = {k: (v.detach() if (k in ("t3", "hs") and v is not None) else v) for k, v in sf.items()}
         ctx.geo = (kv_rows, kv_off)
         ctx.save_for_backward(tgt, qpos, src, kpos, dm0, dm1, m1, m2, *W, W1, W2, g2, gP)     # (None entries are allowed)
         ctx.set_materialize_grads(False)

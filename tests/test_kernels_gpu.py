@@ -123,7 +123,10 @@ def test_probe_glds_lane_linear():
                                          (7000, 3072, 128, 6500),     # 336 tiles: persistent workgroups take two tiles, ragged row groups
                                          (300, 7040, 64, 200),        # few rows, many columns: the 128x128 kernel
                                          (2230, 768, 256, 2000), (2048, 768, 3072, 0),        # 160x256 tile path
-                                         (10300, 1024, 256, 9800), (9900, 1024, 128, 0)])     # 224x256 tile path (one round of 224-row tiles)
+                                         (10300, 1024, 256, 9800), (9900, 1024, 128, 0),      # 224x256 tile path (one round of 224-row tiles)
+                                         # one round of 320-row tiles (round 6, gemm_nt_kernel_tall5_*: the plain / bias / residual modes):
+                                         # BASELINE's N = 768 launch geometry (85 x 3 tiles), ragged row groups, one group
+                                         (26944, 768, 128, 25664), (20011, 768, 192, 18003), (16000, 768, 64, 0)])
 @pytest.mark.parametrize("mode", ["plain", "bias", "bias_gelu_aux", "residual_scale_f32", "relu_f32"])
 def test_gemm_nt(M, N, K, split, mode):
     ops = _ops()
@@ -172,7 +175,8 @@ def test_gemm_nt(M, N, K, split, mode):
                                          (640, 768, 3072, 512),       # 256x128 / k 32 kernel
                                          (300, 7040, 64, 200),        # 128x128 kernel
                                          (2370, 2304, 768, 2100),     # 256x256 kernel (the persistent form is refused)
-                                         (2230, 768, 256, 2000), (2048, 768, 3072, 0)])       # 160x256 kernel
+                                         (2230, 768, 256, 2000), (2048, 768, 3072, 0),        # 160x256 kernel
+                                         (20011, 768, 128, 18003)])                            # one round of 320-row tiles
 @pytest.mark.parametrize("mode", ["bias_lp", "bias_residual_f32"])
 def test_gemm_nt_split_carries_fp32_weights(M, N, K, split, mode):
     """simvg_gemm_nt_split: the weight as a hi + lo pair of 16-bit numbers (rows [lo * 2^11 | hi], A walked twice, accumulators
