@@ -359,7 +359,8 @@ int simvg_embed_bwd(const float* dx, int lddx, void* dpatch_lp, int lddp, float*
 
 /* ---- weight preparation (fp32 master -> 16-bit compute copies, plain + transposed) ---------------- */
 typedef struct {
-  const float* src; void* dst_lp; void* dst_t_lp; int rows, cols; int tile_start; int pad_;
+  const float* src; void* dst_lp; void* dst_t_lp; int rows, cols; int tile_start;
+  int split_shift;   /* > 0: dst_lp rows are 2 * cols long, [lo * 2^shift | hi] (the operand of simvg_gemm_nt_split); 0: plain */
 } simvg_weight_desc;
 int simvg_weight_prep(const void* descs_dev, int n_desc, int total_tiles, simvg_stream_t stream);
 int simvg_cast_f32_to_lp(const float* src, void* dst_lp, long n, float scale, simvg_stream_t stream);

@@ -13,7 +13,7 @@ c_void_p, c_int, c_long, c_float = C.c_void_p, C.c_int, C.c_long, C.c_float
 
 class WeightDesc(C.Structure):
     _fields_ = [("src", c_void_p), ("dst", c_void_p), ("dst_t", c_void_p), ("rows", c_int), ("cols", c_int),
-                ("tile_start", c_int), ("pad_", c_int)]
+                ("tile_start", c_int), ("split_shift", c_int)]
 
 
 class LnReduceDesc(C.Structure):        # simvg_ln_reduce_desc

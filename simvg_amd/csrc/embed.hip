@@ -166,7 +166,8 @@ struct WeightDesc {      // mirrored by simvg_amd/_lib.py (ctypes)
   lp_t* dst_t;         // [cols, rows] bf16 or null
   int rows, cols;
   int tile_start;        // first 64x64 tile index of this matrix in the launch
-  int pad_;
+  int split_shift;       // > 0: dst rows are 2 * cols long, [lo * 2^shift | hi] (operand of simvg_gemm_nt_split; hi = the plain copy,
+                         // lo = the 16-bit rounding of (w - hi) * 2^shift); 0: dst rows are cols long
 };
 
 // 64 x 64 tiles, 16-B loads, 8-B stores in both orientations (the 32 x 32 / 2-B-store version ran at 1.3 TB/s: 0.53 ms per
@@ -185,6 +186,10 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const WeightDesc* __re
   const int r0 = (tl / tiles_c) * 64, c0 = (tl % tiles_c) * 64;
   const int tq = threadIdx.x & 15, ty = threadIdx.x >> 4;      // 16 x 4-element groups across, 16 rows down
   const bool vec = (d.cols & 3) == 0 && (d.rows & 3) == 0;
+  const bool two = d.split_shift > 0;
+  const long ldd = two ? 2L * d.cols : d.cols;           // row length of dst
+  const int hi_off = two ? d.cols : 0;                    // where the plain copy sits inside a dst row
+  const float lo_mul = two ? (float)(1 << d.split_shift) : 0.f;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int r = r0 + ty + 16 * k, c = c0 + 4 * tq;
@@ -193,12 +198,26 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const WeightDesc* __re
       if (vec && c + 3 < d.cols) {
         const f32x4_t t = *(const f32x4_t*)(d.src + (long)r * d.cols + c);
         v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
-        if (d.dst) *(u32x2_t*)(d.dst + (long)r * d.cols + c) = (u32x2_t){pack_lp2(v[0], v[1]), pack_lp2(v[2], v[3])};
+        if (d.dst) {
+          const u32x2_t h = (u32x2_t){pack_lp2(v[0], v[1]), pack_lp2(v[2], v[3])};
+          *(u32x2_t*)(d.dst + (long)r * ldd + hi_off + c) = h;
+          if (two) {
+            float h0, h1, h2, h3;
+            unpack_lp2(h[0], h0, h1);
+            unpack_lp2(h[1], h2, h3);
+            *(u32x2_t*)(d.dst + (long)r * ldd + c) =
+                (u32x2_t){pack_lp2((v[0] - h0) * lo_mul, (v[1] - h1) * lo_mul), pack_lp2((v[2] - h2) * lo_mul, (v[3] - h3) * lo_mul)};
+          }
+        }
       } else {
         for (int e = 0; e < 4; ++e)
           if (c + e < d.cols) {
             v[e] = d.src[(long)r * d.cols + c + e];
-            if (d.dst) d.dst[(long)r * d.cols + c + e] = f32_to_lp(v[e]);
+            if (d.dst) {
+              const lp_t h = f32_to_lp(v[e]);
+              d.dst[(long)r * ldd + hi_off + c + e] = h;
+              if (two) d.dst[(long)r * ldd + c + e] = f32_to_lp((v[e] - lp_to_f32(h)) * lo_mul);
+            }
           }
       }
     }

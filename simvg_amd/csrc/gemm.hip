@@ -137,9 +137,9 @@ __device__ __forceinline__ void gemm_nt_epilogue(const GemmNTArgs& a, f32x4_t (&
         if (full) {
           const f32x4_t rv = *(const f32x4_t*)rp;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = rv[r] + rs * v[r];
+          for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(rs, v[r], rv[r]);
         } else {
-          for (int r = 0; r < 4 && n + r < a.N; ++r) v[r] = rp[r] + rs * v[r];
+          for (int r = 0; r < 4 && n + r < a.N; ++r) v[r] = __builtin_fmaf(rs, v[r], rp[r]);
         }
       } else if (a.row_scale) {
 #pragma unroll
@@ -283,7 +283,7 @@ __device__ __forceinline__ void gemm_nt_epilogue_lds(const GemmNTArgs& a, f32x4_
         if (a.res) {
           const f32x4_t rv = pre_res ? rcur[it] : *(const f32x4_t*)(a.res + (long)m * a.ldres + n);
 #pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = rv[k] + rs * v[k];
+          for (int k = 0; k < 4; ++k) v[k] = __builtin_fmaf(rs, v[k], rv[k]);     // (explicit: every kernel's fp32 epilogue is this fma)
         } else if (a.row_scale) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) v[k] *= rs;
@@ -841,7 +841,7 @@ __global__ __launch_bounds__(1024) void gemm_nt_kernel_160x256_r3(GemmNTArgs a) 
 // ------------------------------------------------------------------------------------------
 // TALL tile (round 6): 64 MI rows x 256 columns per workgroup, sixteen waves as 4 (M) x 4 (N), each 16 MI x 64 = acc[MI][4], in the
 // hand-managed form of the persistent kernel above (SGPR buffer descriptors + loop-invariant lane offsets for the LDS-DMA, inline-asm
-// fragment reads with counted lgkmcnt, a two-entry A-fragment ring, the bias as the accumulators' start value).  MI = 5: ViT-B's
+// fragment reads with counted lgkmcnt, a two-entry A-fragment ring).  MI = 5: ViT-B's
 // N = 768 launches at 64 pairs per step (M = 26 944 = 25 664 | 1 280) are 85 x 3 = 255 tiles of 320 rows -- ONE round on 256 CUs
 // with one prologue / epilogue per CU and 9 fragment reads per 20 MFMAs, instead of two rounds of 160-row tiles (7 per 10).  Round 4's
 // 320-row attempt (tools/dev/gemm_320x256_r04.hip.txt) left reads, waits and the LDS-staged epilogue to the compiler and spilled at
@@ -850,14 +850,16 @@ __global__ __launch_bounds__(1024) void gemm_nt_kernel_160x256_r3(GemmNTArgs a) 
 //   EPI 0  16-bit output (+bias): 2 KiB of wave-private staging in the (finished) ring, row-wise 16-B stores;
 //   EPI 1  fp32 output (+bias) (+ residual * row_scale): straight from the accumulator layout, 16 B per lane (a store covers
 //          16 rows x 64 B), the residual rows of block i + 1 requested before block i is finished.
-// Split weights (hi + lo, `ka` < K): the bias starts as bias / lo_scale and the accumulators are rescaled after the lo half.
+// The accumulators start at zero and the bias is added in the epilogue (as in the other one-tile kernels: bit-identical rows
+// whichever kernel a batch size selects).  Split weights (hi + lo, `ka` < K): the accumulators are rescaled after the lo half.
 // ------------------------------------------------------------------------------------------
 template <int MI> struct TallGeo {
   static constexpr int ROWS = 64 * MI, WROWS = 16 * MI;
   static constexpr int A_BYTES = ROWS * BK * 2, STAGE = (ROWS + BNQ) * BK * 2;
   static constexpr int NPA = ROWS / 8;                 // 1 KiB pieces of an A k-tile (8 rows each)
   static constexpr int NAI = (NPA + 15) / 16;          // per wave: piece wave + 16 i while < NPA
-  static constexpr int SMEM = 2 * STAGE;
+  static constexpr int BIAS_OFF = 2 * STAGE;            // 16 waves x 64 floats of bias behind the ring
+  static constexpr int SMEM = 2 * STAGE + 16 * 256;
 };
 
 // (a device function template behind plain kernels: the host pass instantiates a KERNEL template's body too, and target builtins /
@@ -911,30 +913,23 @@ __device__ __forceinline__ void gemm_nt_tall_body(const GemmNTArgs& a, char* sme
 
   issue(0, 0);
   if (nk > 1) issue(1, 1);
-  f32x4_t bn[4];
-  if (a.bias) {
-    const float* bp = a.bias + (long)group * a.bias_gstride + n0 + wn * 64 + 4 * (lane >> 4);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) bn[j] = gload_x4_untracked(bp + j * 16);
-  } else {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) bn[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  // this wave's 64 bias values -> 256 B of LDS behind the ring: the epilogues read them 16 B at a time when they need them (held in
+  // registers across the epilogue they cost 16 VGPRs next to the 80 accumulators)
+  float* lbias = (float*)(smem + G::BIAS_OFF + wave * 256);
+  if (lane < 16) {
+    const float* bp = a.bias ? a.bias + (long)group * a.bias_gstride + n0 + wn * 64 + 4 * lane : nullptr;
+    *(f32x4_t*)(lbias + 4 * lane) = bp ? *(const f32x4_t*)bp : (f32x4_t){0.f, 0.f, 0.f, 0.f};
   }
-  vm_wait<0>();
-#pragma unroll
-  for (int j = 0; j < 4; ++j) reg_pin(bn[j]);
-  if (two) {
-    const float inv = 1.f / a.lo_scale;      // a power of two: exact
-#pragma unroll
-    for (int j = 0; j < 4; ++j) bn[j] *= inv;
-  }
+  // the accumulators start at zero and the bias is added in the epilogue, exactly as the other non-persistent kernels do it
+  // (fmaf(acc, 1, bias), then residual + row_scale * that): a row's result is bit-identical whichever kernel its batch size selects
+  // (tests/test_properties_gpu.py: batch independence of forward_test)
   f32x4_t acc[MI][4];
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      acc[i][j] = bn[j];
-      reg_pin(acc[i][j]);                    // copies now: bn's registers are free during the main loop
+      acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      reg_pin(acc[i][j]);                    // opaque zeros: no peeled first k-tile (a second copy of the loop body, spills)
     }
 
 #define TALL_STEP(I_)                                                                                        \
@@ -947,7 +942,7 @@ __device__ __forceinline__ void gemm_nt_tall_body(const GemmNTArgs& a, char* sme
   }
   const int k_lo = a.ka / BK;                // k-tiles of the lo half (== nk: single weights)
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt >= 1) vm_wait<0>();               // this wave's pieces of k-tile kt have landed (k-tile 0: waited for above)
+    vm_wait<0>();                            // this wave's pieces of k-tile kt have landed
     __builtin_amdgcn_s_barrier();            // everyone's have, and everyone is past the MFMAs of kt - 1: its stage is free
     if (kt >= 1 && kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
     const unsigned so = (kt & 1) * G::STAGE;
@@ -969,6 +964,7 @@ __device__ __forceinline__ void gemm_nt_tall_body(const GemmNTArgs& a, char* sme
   }
 #undef TALL_STEP
 
+  const float* bias = lbias + 4 * (lane >> 4);      // (wave-private LDS: written by this wave before its main loop)
   if constexpr (EPI == 0) {
     // 16 bit -> wave-private 2 KiB of the finished ring -> row-wise 16-B stores (the persistent kernel's epilogue)
     __builtin_amdgcn_s_barrier();            // every wave is done reading the ring
@@ -982,7 +978,7 @@ __device__ __forceinline__ void gemm_nt_tall_body(const GemmNTArgs& a, char* sme
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const f32x4_t x = acc[i][j];
+        const f32x4_t x = acc[i][j] + *(const f32x4_t*)(bias + j * 16);
         lds_write_b64_asm(wa + (((j * 4 + ecg) ^ er) << 3), (u32x2_t){pack_lp2(x[0], x[1]), pack_lp2(x[2], x[3])});
       }
       lgkm_wait<0>();
@@ -995,31 +991,48 @@ __device__ __forceinline__ void gemm_nt_tall_body(const GemmNTArgs& a, char* sme
     }
   } else {
     // fp32 (+ residual * row_scale) straight from the accumulator layout: lane -> row (lane & 15) of block i, columns
-    // j * 16 + 4 (lane >> 4) .. + 3 of the wave's 64; the residual rows of block i + 1 are requested before block i is finished
+    // j * 16 + 4 (lane >> 4) .. + 3 of the wave's 64 (a load / store covers 16 rows x 64 B).  Two passes over column halves (j = 0, 1 |
+    // 2, 3) keep the live set at 80 accumulators + 2 bias + 2 x 2 residual vectors; the residual rows of block i + 1 are requested
+    // before block i is finished.
     const int mb = row0 + wm * G::WROWS + (lane & 15);
     const int nb = n0 + wn * 64 + 4 * (lane >> 4);
     float* cp = (float*)a.C + (long)mb * a.ldc + nb;
     const float* rp = a.res ? a.res + (long)mb * a.ldres + nb : nullptr;
-    f32x4_t rv[2][4];
-    auto load_res = [&](int i, f32x4_t (&r)[4]) {
-      const bool ok = mb + i * 16 < row_end;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) r[j] = ok ? *(const f32x4_t*)(rp + (long)(i * 16) * a.ldres + j * 16) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    };
-    if (rp) load_res(0, rv[0]);
+    float rsv[MI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-      if (rp && i + 1 < MI) load_res(i + 1, rv[(i + 1) & 1]);
       const int m = mb + i * 16;
-      float rs = 1.f;
-      if (a.row_scale && m < row_end) rs = a.row_scale[group ? (m - a.split) / a.rps1 : m / a.rps0];
-      if (m < row_end) {
+      rsv[i] = (a.row_scale && m < row_end) ? a.row_scale[group ? (m - a.split) / a.rps1 : m / a.rps0] : 1.f;
+    }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          f32x4_t v = acc[i][j];
-          if (rp) v = rv[i & 1][j] + rs * v;
-          else if (a.row_scale) v *= rs;
-          *(f32x4_t*)(cp + (long)(i * 16) * a.ldc + j * 16) = v;
+    for (int h = 0; h < 2; ++h) {
+      f32x4_t bh[2];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) bh[jj] = *(const f32x4_t*)(bias + (2 * h + jj) * 16);
+      f32x4_t rv[2][2];
+      auto load_res = [&](int i, f32x4_t (&r)[2]) {
+        const bool ok = mb + i * 16 < row_end;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+          r[jj] = ok ? *(const f32x4_t*)(rp + (long)(i * 16) * a.ldres + (2 * h + jj) * 16) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      };
+      if (rp) load_res(0, rv[0]);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        if (rp && i + 1 < MI) load_res(i + 1, rv[(i + 1) & 1]);
+        if (mb + i * 16 < row_end) {
+          const float rs = rsv[i];
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            f32x4_t v = acc[i][2 * h + jj] + bh[jj];
+            if (rp) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) v[k] = __builtin_fmaf(rs, v[k], rv[i & 1][jj][k]);
+            } else if (a.row_scale) {
+              v *= rs;
+            }
+            *(f32x4_t*)(cp + (long)(i * 16) * a.ldc + (2 * h + jj) * 16) = v;
+          }
         }
       }
     }

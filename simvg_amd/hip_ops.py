@@ -230,7 +230,11 @@ def gemm_nt_split(a, w2, bias=None, out=None, out_dtype=None, split=0, residual=
         out = torch.empty(M, N, device=a.device, dtype=out_dtype or LP())
     if bias is not None:
         _chk(bias, torch.float32, "bias")
-    tname = "gemm_nt_split"
+    # the roofline family "gemm_nt" counts this launch with the ALGORITHMIC work of the Linear it computes (2 M N K; the kernel executes
+    # twice that on the MFMA pipe): the price of the hi + lo weights shows in the family's fraction instead of hiding beside it
+    tname = "gemm_nt"
+    if _timer is not None and _timer.only is None:      # --breakdown: one line per shape
+        tname = f"gemm_nt_split[{M}x{N}x{K}{'+res' if residual is not None else ''}{'+f32' if out.dtype == torch.float32 else ''}]"
     t0 = _timer.start(tname) if _timer is not None else None
     rc = lib.simvg_gemm_nt_split(_p(a), a.stride(0), _p(w2), w2.stride(0) if w2.dim() == 3 else 0, w2.stride(-2), _p(bias),
                                  (bias.stride(0) if bias.dim() == 2 else 0) if bias is not None else 0,
@@ -238,7 +242,7 @@ def gemm_nt_split(a, w2, bias=None, out=None, out_dtype=None, split=0, residual=
                                  _p(residual), residual.stride(0) if residual is not None else 0,
                                  M, N, K, split, float(2.0 ** -SPLIT_SHIFT), _stream())
     if t0 is not None:
-        _timer.stop(tname, t0, 4.0 * M * N * K, 2.0 * (M * K + 2 * N * K) + out.element_size() * M * N)
+        _timer.stop(tname, t0, 2.0 * M * N * K, 2.0 * (M * K + 2 * N * K) + out.element_size() * M * N)
     _lib.check(rc, "simvg_gemm_nt_split")
     return out
 
@@ -613,7 +617,8 @@ class WeightPrep:
     _generations = 0
 
     def __init__(self, entries, device):
-        # entries: list of (src fp32 2-D tensor, dst lp | None, dst_t lp | None)
+        # entries: list of (src fp32 2-D tensor, dst lp | None, dst_t lp | None[, split_shift]); split_shift > 0: dst is [rows, 2 cols] =
+        # [lo * 2^shift | hi] (the operand of `gemm_nt_split`; its right half is the plain 16-bit copy)
         # generation: a process-wide serial number -- what captured graphs key on to know which set of 16-bit buffers their
         # launches point into (an id() can be handed to a later object)
         WeightPrep._generations += 1
@@ -622,11 +627,14 @@ class WeightPrep:
         arr = (_lib.WeightDesc * n)()
         tiles = 0
         self._keep = entries
-        for i, (src, dst, dst_t) in enumerate(entries):
+        for i, ent in enumerate(entries):
+            src, dst, dst_t = ent[:3]
+            shift = ent[3] if len(ent) > 3 else 0
             rows, cols = src.shape
             assert src.is_contiguous() and (dst is None or dst.is_contiguous()) and (dst_t is None or dst_t.is_contiguous())
+            assert shift == 0 or (dst is not None and tuple(dst.shape) == (rows, 2 * cols))
             arr[i] = _lib.WeightDesc(src.data_ptr(), dst.data_ptr() if dst is not None else None,
-                                     dst_t.data_ptr() if dst_t is not None else None, rows, cols, tiles, 0)
+                                     dst_t.data_ptr() if dst_t is not None else None, rows, cols, tiles, shift)
             tiles += ((rows + 63) // 64) * ((cols + 63) // 64)
         raw = bytes(arr)
         self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
