@@ -607,11 +607,15 @@ __device__ __forceinline__ void reg_pin(f32x4_t& v) { asm volatile("" : "+v"(v))
 #else
 #define PQ_T(k_) do { } while (0)
 #endif
-__global__ __launch_bounds__(1024) void gemm_nt_kernel_256sq_p(GemmNTArgs a, int ntot, unsigned long long* prof) {
+// TWO: hi + lo weights (round 6: the training forward's qkv, `BEIT3.precise_training`): W rows are [lo * 2^s | hi] (ka = K / 2), A is
+// walked twice, the accumulators are multiplied by lo_scale = 2^-s after the lo half -- the bias, which is their start value here,
+// enters as bias * 2^s (a power of two: exact).  A kernel of its own (the plain kernel's registers are untouched), its k loop in two
+// halves with the rescale between them (a branch inside the loop body cost the registers that made the build spill).
+template <bool TWO>
+__device__ __forceinline__ void gemm_nt_pq_body(const GemmNTArgs& a, int ntot, unsigned long long* prof, char* smem) {
   constexpr int MI = 4;
   int tix = 0;
   (void)tix; (void)prof;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;   // 4 x 4 waves
@@ -642,10 +646,21 @@ __global__ __launch_bounds__(1024) void gemm_nt_kernel_256sq_p(GemmNTArgs a, int
   };
   auto issue = [&](const Desc& d, int kt, int st) {
     char* sA = smem + st * PQ_STAGE + wave * 2048;
+    if constexpr (TWO) {
+      // the second piece's row offset rides in the scalar offset (two VGPRs less: this variant's spilled SGPRs need them)
+      const int ka = (kt >= (nk >> 1) ? kt - (nk >> 1) : kt) * (BK * 2);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(d.A, LDS_PTR(sA + i * 1024), 16, voffA[i], kt * (BK * 2), 0, 0);
+      for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(d.A, LDS_PTR(sA + i * 1024), 16, voffA[0], ka + i * 8 * a.lda * 2, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(d.W, LDS_PTR(sA + 256 * BK * 2 + i * 1024), 16, voffW[i], kt * (BK * 2), 0, 0);
+      for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(d.W, LDS_PTR(sA + 256 * BK * 2 + i * 1024), 16, voffW[0], kt * (BK * 2) + i * 8 * a.ldw * 2, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(d.A, LDS_PTR(sA + i * 1024), 16, voffA[i], kt * (BK * 2), 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(d.W, LDS_PTR(sA + 256 * BK * 2 + i * 1024), 16, voffW[i], kt * (BK * 2), 0, 0);
+    }
   };
   // the bias enters as the accumulators' initial value: bn[j] = bias of columns n0 + wn * 64 + j * 16 + 4 (lane >> 4) .. + 3
   f32x4_t bn[4];
@@ -679,6 +694,11 @@ __global__ __launch_bounds__(1024) void gemm_nt_kernel_256sq_p(GemmNTArgs a, int
     if (pend) vm_wait<PQ_NS>(); else vm_wait<0>();
     PQ_T(1);
     asm volatile("" : "+v"(bn[0]), "+v"(bn[1]), "+v"(bn[2]), "+v"(bn[3]));
+    if constexpr (TWO) {
+      const float inv = 1.f / a.lo_scale;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bn[j] *= inv;
+    }
     f32x4_t acc[MI][4];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -687,7 +707,7 @@ __global__ __launch_bounds__(1024) void gemm_nt_kernel_256sq_p(GemmNTArgs a, int
         acc[i][j] = bn[j];
         asm volatile("" : "+v"(acc[i][j]));   // copies now: bn's registers are free during the main loop
       }
-    for (int kt = 0; kt < nk; ++kt) {
+    auto ktile = [&](int kt) {
       if (kt == 1) PQ_T(2);
       if (kt >= 1) vm_wait<0>();             // k-tile 0: waited for above;  k-tile 1: FIFO = [S] L1, the stores have to be through
       if (kt == 1) PQ_T(3);
@@ -722,6 +742,16 @@ __global__ __launch_bounds__(1024) void gemm_nt_kernel_256sq_p(GemmNTArgs a, int
         for (int j = 0; j < 4; ++j) acc[3][j] = mfma_lp(as_frag(fb[j]), as_frag(fa[1]), acc[3][j]);
         __builtin_amdgcn_sched_barrier(0);
       }
+    };
+    if constexpr (TWO) {
+      for (int kt = 0; kt < (nk >> 1); ++kt) ktile(kt);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] *= a.lo_scale;      // the lo half is complete
+      for (int kt = nk >> 1; kt < nk; ++kt) ktile(kt);
+    } else {
+      for (int kt = 0; kt < nk; ++kt) ktile(kt);
     }
     PQ_T(4);
     if (has_next) load_bias(dnxt);
@@ -762,6 +792,14 @@ __global__ __launch_bounds__(1024) void gemm_nt_kernel_256sq_p(GemmNTArgs a, int
     v = vn;
     first = false;
   }
+}
+__global__ __launch_bounds__(1024) void gemm_nt_kernel_256sq_p(GemmNTArgs a, int ntot, unsigned long long* prof) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemm_nt_pq_body<false>(a, ntot, prof, smem);
+}
+__global__ __launch_bounds__(1024) void gemm_nt_kernel_256sq_p2(GemmNTArgs a, int ntot, unsigned long long* prof) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemm_nt_pq_body<true>(a, ntot, prof, smem);
 }
 
 // 160x256x64 tile with sixteen waves: 2 (M) x 8 (N), each 80x32 = acc[5][2] -- the 16-wave layout for the N = 768 problems
@@ -1543,8 +1581,12 @@ static bool persist_ok(const GemmNTArgs& a) {
     hipFuncAttributes fa{};
     return hipFuncGetAttributes(&fa, (const void*)gemm_nt_kernel_256sq_p) == hipSuccess && fa.localSizeBytes == 0;
   }();
-  return !off && no_scratch && !a.c_f32 && !a.aux && !a.res && !a.row_scale && a.act == 0 && a.alpha == 1.f && (a.K / BK) % 2 == 0 && a.ldc % 8 == 0 &&
-         a.ka == a.K;      // split weights: the bias is this kernel's accumulator start value, which the lo-half rescale would hit
+  static const bool no_scratch2 = [] {
+    hipFuncAttributes fa{};
+    return hipFuncGetAttributes(&fa, (const void*)gemm_nt_kernel_256sq_p2) == hipSuccess && fa.localSizeBytes == 0;
+  }();
+  if (a.ka < a.K && (2 * a.ka != a.K || (a.K / BK) % 4 != 0)) return false;     // split weights: two halves of an even number of k-tiles
+  return !off && (a.ka < a.K ? no_scratch2 : no_scratch) && !a.c_f32 && !a.aux && !a.res && !a.row_scale && a.act == 0 && a.alpha == 1.f && (a.K / BK) % 2 == 0 && a.ldc % 8 == 0;
 }
 
 static int gemm_nt_launch(const void* A, int lda, const void* W, long w_gstride, int ldw,
@@ -1662,12 +1704,14 @@ static int gemm_nt_launch(const void* A, int lda, const void* W, long w_gstride,
     const int tiles = (cdiv(split, 224) + cdiv(M - split, 224)) * cdiv(N, BNQ);
     hipLaunchKernelGGL(gemm_nt_kernel_224x256_w16, dim3(tiles), dim3(1024), SM224, stream, a);
   } else if (wide_ok && tile_cost(256) <= tile_cost(160) && persist_ok(a)) {
-    static bool oncep = hipFuncSetAttribute((const void*)gemm_nt_kernel_256sq_p, hipFuncAttributeMaxDynamicSharedMemorySize, PQ_SMEM) == hipSuccess;
+    static bool oncep = hipFuncSetAttribute((const void*)gemm_nt_kernel_256sq_p, hipFuncAttributeMaxDynamicSharedMemorySize, PQ_SMEM) == hipSuccess &&
+                        hipFuncSetAttribute((const void*)gemm_nt_kernel_256sq_p2, hipFuncAttributeMaxDynamicSharedMemorySize, PQ_SMEM) == hipSuccess;
     (void)oncep;
     const int tiles = (cdiv(split, 256) + cdiv(M - split, 256)) * cdiv(N, BNQ);
     static const int cus = [] { int dev = 0, n = 256; hipGetDevice(&dev); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n & ~7; }();
     static unsigned long long* prof = getenv("SIMVG_PQ_PROF_PTR") ? (unsigned long long*)strtoull(getenv("SIMVG_PQ_PROF_PTR"), nullptr, 0) : nullptr;
-    hipLaunchKernelGGL(gemm_nt_kernel_256sq_p, dim3(tiles < cus ? tiles : cus), dim3(1024), PQ_SMEM, stream, a, tiles, prof);
+    if (a.ka < a.K) hipLaunchKernelGGL(gemm_nt_kernel_256sq_p2, dim3(tiles < cus ? tiles : cus), dim3(1024), PQ_SMEM, stream, a, tiles, prof);
+    else hipLaunchKernelGGL(gemm_nt_kernel_256sq_p, dim3(tiles < cus ? tiles : cus), dim3(1024), PQ_SMEM, stream, a, tiles, prof);
   } else if (wide_ok && tile_cost(256) <= tile_cost(160)) {
     constexpr int SMW = 160 * 1024;      // ring 128 KiB; the 16-wave epilogue staging needs 136 KiB
     static bool oncew = hipFuncSetAttribute((const void*)gemm_nt_kernel_256sq_w16, hipFuncAttributeMaxDynamicSharedMemorySize, SMW) == hipSuccess;
