@@ -226,6 +226,30 @@ def bf16_line(a):
         return {"error": repr(e)}
 
 
+def single_weights_line(a):
+    """What `BEIT3.precise_training` (hi + lo weights in the training forward: the boxes that feed the matcher and the losses within
+    1e-3 of the reference at the full batch) costs a step: a short sub-run of this script with SIMVG_PRECISE_TRAIN=0."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "16", "--warmup", "4", "--batch", str(a.batch), "--vit", a.vit,
+           "--queries", str(a.queries), "--no-cpu-baseline", "--no-forward-test", "--no-extras"]
+    env = dict(os.environ, SIMVG_PRECISE_TRAIN="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SIMVG_FORCE_REDUCE"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if not lines:
+            return {"error": "sub-run printed no line: " + (r.stderr.strip().splitlines() or ["no stderr"])[-1][:300]}
+        j = json.loads(lines[-1])
+        return {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "ms_per_step_p50": j["ms_per_step_p50"], "steps": j["steps"],
+                "roofline_frac_gemm_nt": j["roofline"]["frac"],
+                "box_parity": "token-branch boxes of the training forward at the full batch: max 1.11e-3 (ViT-B) / 1.17e-3 (ViT-L) on the harsh "
+                              "fixtures (round 5's state; tools/dev/precise_train_sweep.py)",
+                "how": "sub-run of this script with SIMVG_PRECISE_TRAIN=0, 16 timed steps"}
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 def reducer_overhead(a, ms_plain):
     """What the gradient exchange costs a step apart from the bytes on the links, measured on ONE GPU: sub-runs of this script under
     torch.distributed.run with one RCCL rank and SIMVG_FORCE_REDUCE=1 (every message of the N-rank schedule is issued -- 16 collectives
@@ -514,8 +538,9 @@ def main():
                    "parallelism": f"dp{world}", "loss_total": round(loss_val, 4)},
         "model_tflops_per_gpu": round(value / world * FLOP_PER_PAIR_FWD_BWD[a.vit] / 1e12, 2),
         "model_mfma_frac": round(value / world * FLOP_PER_PAIR_FWD_BWD[a.vit] / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
-        "roofline": {"kernel": f"gemm_nt ({_lowp} MFMA 16x16x32, fp32 accumulate; every launch: 16-wave 256x256x64 tiles for N >= 2304, "
-                               "16-wave 160x256x64 with a 3-stage ring for N = 768, global_load_lds, LDS-staged coalesced epilogue)", "bound": "mfma",
+        "roofline": {"kernel": f"gemm_nt ({_lowp} MFMA 16x16x32, fp32 accumulate; every launch: persistent 16-wave 256x256x64 tiles for N >= 2304, "
+                               "one round of 16-wave 320x256x64 tiles for N = 768 (gemm_nt_kernel_tall5_*), LDS-DMA with the swizzle on the source "
+                               "address, counted waits; the hi + lo launches of precise_training at their ALGORITHMIC FLOPs)", "bound": "mfma",
                      "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "sustained_mfma_ceiling": {"value": 1930.0, "unit": "TFLOP/s", "frac_of_it": round(ach / 1930.0, 4),
@@ -649,8 +674,9 @@ def main():
     model.train()
     if infer:
         out["forward_test"] = dict(infer, note="MIXDETRMB.forward_test incl. post-processing, one synchronisation per call; batches <= 16 replay "
-                                   "encoder + head as one hipGraph per input signature (simvg_amd/graphs.py::InferenceGraphs); the encoder's "
-                                   "attention projections (qkv, out-proj) carry hi + lo 16-bit weights in this forward (precise_inference, "
+                                   "encoder + head as one hipGraph per input signature (simvg_amd/graphs.py::InferenceGraphs); the patch "
+                                   "kernel and the qkv projection of the first half of the layers (ViT-L: qkv + fc2 of every layer) carry hi + lo "
+                                   "16-bit weights in this forward (precise_inference, "
                                    "simvg_gemm_nt_split: every box of a full batch within 1e-3 of the reference, tests/test_fullsize_gpu.py); "
                                    "`*_single_16bit_weights` = the same call without it")
     if a.breakdown:
@@ -662,6 +688,14 @@ def main():
                   f"({100 * d['ms'] / tot:5.1f} %)  {tf:8.1f} TFLOP/s  {gb:8.1f} GB/s(algorithmic)", file=sys.stderr)
     if extras and _lowp == "fp16" and not os.environ.get("SIMVG_HIP_LIB"):
         out["bf16_line"] = bf16_line(a)
+    enc = model.vis_enc
+    out["precise_training"] = {"layers": enc.precise_training_layers, "which": list(enc.precise_training_which),
+                               "split_linears_per_step": len(enc.wbs),
+                               "what": "Linears whose weight the TRAINING forward carries as a hi + lo pair of 16-bit numbers (2 x the MFMA work of "
+                                       "those launches, inside the timed step and inside `roofline` at their algorithmic FLOPs): every box of "
+                                       "the full batch within 1e-3 of the reference (tests/test_fullsize_gpu.py)"}
+    if extras and not os.environ.get("SIMVG_HIP_LIB") and enc.wbs and os.environ.get("SIMVG_PRECISE_TRAIN") is None:
+        out["precise_training"]["single_weights_line"] = single_weights_line(a)
     if extras and not os.environ.get("SIMVG_HIP_LIB"):
         out["reducer"]["overhead_one_gpu"] = reducer_overhead(a, p50)
     if extras and not a.no_cpu_baseline and a.vit == "base" and a.queries == 1:

@@ -86,40 +86,46 @@ class BEIT3(nn.Module):
         # of 16-bit numbers (`simvg_gemm_nt_split`, twice the MFMA work of those GEMMs): rounding the weights to 16 bits is the
         # largest single term of the box error on trained-scale weights and the only one that every row shares
         # (tools/dev/token_tail.py); with it the boxes of a full batch stay within the path's 1e-3 bound (tests/test_fullsize_gpu.py).
-        # The training forward keeps single 16-bit weights (its boxes only feed the loss).  False = the round-3 behaviour.
-        # precise_inference: True (default) = the ATTENTION projections (qkv, out-proj) of every layer; "full" = all four Linears of
-        # every layer (round 4's default); an int k = all four Linears of the first k layers; False = none.  Measured on the
-        # full-size fixtures (tools/dev/precise_sweep.py, profiles/r05_sweeps.md: token-branch max over the batch, ViT-B 64 pairs /
-        # ViT-L 32 x 10): none 1.11e-3 / 1.17e-3; attention projections 7.2e-4 / 9.2e-4 at +12 % / +16 % of the forward's time;
-        # all four 5.8e-4 / 8.0e-4 at +45 % / +53 %; first half of the layers 8.3e-4 / 8.7e-4 at +20 % / +24 %: the q / k weights'
-        # rounding moves every row's attention logits coherently, the FFN weights' rounding is averaged by the LayerNorm behind it.
+        # False = the round-3 behaviour.
+        # precise_inference: True (default, round 6) = the patch kernel + the qkv projection of the first half of the layers (12-layer
+        # encoders) / + qkv and fc2 of every layer (24-layer encoders); "full" = all four Linears of every layer (round 4's default);
+        # an int k = all four Linears of the first k layers; False = none.  Measured on the full-size fixtures
+        # (tools/dev/precise_sweep.py, profiles/r05_sweeps.md / r06_sweeps.md: token-branch max over the batch, ViT-B 64 pairs /
+        # ViT-L 32 x 10 queries): none 1.11e-3 / 1.17e-3; qkv of 6 layers (ViT-B) 7.7e-4; qkv + fc2 of 24 layers (ViT-L) 7.5e-4;
+        # qkv + out-proj of every layer (round 5's default) 7.2e-4 / 9.2e-4; all four 5.8e-4 / 8.0e-4 at +45 % / +53 % of the
+        # forward's time: the q / k weights' rounding moves every row's attention logits coherently and the early layers carry it.
         # SIMVG_PRECISE_LAYERS / SIMVG_PRECISE_WHICH (= wqkv,wout,w1,w2) override it (measurements)
-        which = ("wqkv", "wout") if precise_inference is True else ("wqkv", "wout", "w1", "w2")
+        large = self.L >= 24
+        if precise_inference is True:
+            which, precise_inference = (("wqkv", "w2"), self.L) if large else (("wqkv",), max(1, self.L // 2))
+        else:
+            which = ("wqkv", "wout", "w1", "w2")
         if precise_inference == "full":
-            precise_inference = True
+            precise_inference = self.L
         if os.environ.get("SIMVG_PRECISE_LAYERS"):
             precise_inference = int(os.environ["SIMVG_PRECISE_LAYERS"])
-        self.precise_layers = self.L if precise_inference is True else (0 if precise_inference is False else
-                                                                       max(0, min(int(precise_inference), self.L)))
+        self.precise_layers = 0 if precise_inference is False else max(0, min(int(precise_inference), self.L))
         self.precise_inference = self.precise_layers > 0
         if os.environ.get("SIMVG_PRECISE_WHICH"):
             which = tuple(t for t in os.environ["SIMVG_PRECISE_WHICH"].split(",") if t)
         self.precise_which = which
         assert set(self.precise_which) <= {"wqkv", "wout", "w1", "w2"}, self.precise_which
-        # precise_training (round 6): the TRAINING forward (everything kept for the backward) carries the qkv weight of the first k
-        # layers as a hi + lo pair as well -- its boxes feed the matcher and the losses, and with single 16-bit weights the token
-        # branch of a full batch misses the path's 1e-3 bound on the harsh fixtures (1.11e-3 / 1.17e-3, tests/test_fullsize_gpu.py).
-        # True = every layer, an int k = the first k layers, False = single weights (round 5).  The backward keeps the single
-        # transposed copies (dgrad of a function that differs by 2^-12 relative); the [lo | hi] rows are written by the per-step
-        # weight refresh itself (`simvg_weight_prep`, split_shift), the plain copy IS their right half.
-        # SIMVG_PRECISE_TRAIN (layers) / SIMVG_PRECISE_TRAIN_WHICH (= wqkv,wout,w1,w2; Linears behind DropPath keep single weights
-        # while it is active) override it (measurements: profiles/r06_sweeps.md)
+        # precise_training (round 6): the TRAINING forward (everything kept for the backward) carries hi + lo weights as well -- its
+        # boxes feed the matcher and the losses, and with single 16-bit weights the token branch of a full batch misses the path's
+        # 1e-3 bound on the harsh fixtures (1.11e-3 / 1.17e-3, tests/test_fullsize_gpu.py).  True (default) = the patch kernel + qkv
+        # of the first half of the layers (+ fc2 of those layers in 24-layer encoders, which run without DropPath: a Linear whose
+        # epilogue carries a DropPath row scale keeps its single weight); an int k = the first k layers; False = single weights
+        # (round 5).  Measured (tools/dev/precise_train_sweep.py, profiles/r06_sweeps.md): ViT-B 8.2e-4 at +0.35 ms per step,
+        # ViT-L 9.2e-4 at +1.9 ms.  The backward keeps the single transposed copies (the dgrad of a function that differs by 2^-12
+        # relative); the [lo | hi] rows are written by the per-step weight refresh itself (`simvg_weight_prep`, split_shift), the
+        # plain copy IS their right half.  SIMVG_PRECISE_TRAIN (layers) / SIMVG_PRECISE_TRAIN_WHICH (= patch,wqkv,wout,w1,w2)
+        # override it (measurements)
         pt = precise_training
         if os.environ.get("SIMVG_PRECISE_TRAIN"):
             pt = int(os.environ["SIMVG_PRECISE_TRAIN"])
-        self.precise_training_layers = self.L if pt is True else (0 if not pt else max(0, min(int(pt), self.L)))
-        self.precise_training_which = tuple(t for t in os.environ.get("SIMVG_PRECISE_TRAIN_WHICH", "wqkv").split(",") if t)
-        assert set(self.precise_training_which) <= {"wqkv", "wout", "w1", "w2"}, self.precise_training_which
+        self.precise_training_layers = max(1, self.L // 2) if pt is True else (0 if not pt else max(0, min(int(pt), self.L)))
+        self.precise_training_which = tuple(t for t in os.environ.get("SIMVG_PRECISE_TRAIN_WHICH", "patch,wqkv,w2" if large else "patch,wqkv").split(",") if t)
+        assert set(self.precise_training_which) <= {"patch", "wqkv", "wout", "w1", "w2"}, self.precise_training_which
         self.wbs = {}
         self.wb2 = None
         self._build_parameters()
@@ -236,9 +242,15 @@ class BEIT3(nn.Module):
         def bf(*shape):
             return torch.empty(*shape, device=device, dtype=ops.LP())
 
-        self.wb = {"patch": bf(D, 3 * P * P)}
-        entries = [(A.params["beit3.vision_embed.proj.weight"].data.view(D, 3 * P * P), self.wb["patch"], None)]
         self.wbs = {}
+        kp = 3 * P * P
+        if self.precision == "lowp" and self.precise_training_layers > 0 and "patch" in self.precise_training_which:
+            self.wbs["patch"] = bf(D, 2 * kp)             # the patch kernel, every image token's first Linear, as [lo * 2^11 | hi] rows
+            self.wb = {"patch": self.wbs["patch"][:, kp:]}
+            entries = [(A.params["beit3.vision_embed.proj.weight"].data.view(D, kp), self.wbs["patch"], None, ops.SPLIT_SHIFT)]
+        else:
+            self.wb = {"patch": bf(D, kp)}
+            entries = [(A.params["beit3.vision_embed.proj.weight"].data.view(D, kp), self.wb["patch"], None)]
         for i in range(L):
             for tag, n, k in [("wqkv", 3 * D, D), ("wout", D, D), ("w1", F_, D), ("w2", D, F_)]:
                 self.wb[f"{tag}T{i}"] = bf(2, k, n)

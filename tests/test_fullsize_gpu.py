@@ -73,7 +73,7 @@ def _tol():
     8 significand bits on trained-scale weights -- the bound test_model_gpu.py::_box_tol states for it (1.5e-2), losses 2e-2,
     gradient norms / entries as in test_model_gpu.py::_check_all_grads, direction cosine 0.97."""
     if _fp16():
-        return dict(box=1e-3, train_tok=1.25e-3, alone=1e-3, loss=2e-3, gnorm=6e-2, gent=1.2e-1, cos=0.99, nratio=0.03)
+        return dict(box=1e-3, train_tok=1e-3, alone=1e-3, loss=2e-3, gnorm=6e-2, gent=1.2e-1, cos=0.99, nratio=0.03)
     return dict(box=1.5e-2, train_tok=1.5e-2, alone=1.5e-2, loss=2e-2, gnorm=0.3, gent=0.6, cos=0.97, nratio=0.06)
 
 
@@ -155,10 +155,10 @@ def test_full_size_training_step_properties(golden, vit, B, nq, grec):
         # and 16 sampled entries
         ltol, ntol, stol = (1e-4, 1e-3, 5e-5) if prec == "fp32" else (T["loss"], T["gnorm"], T["gent"])
         assert list(losses) == list(fx["losses"])
-        # round 5: the boxes of the TRAINING forward at the full batch (single 16-bit weights: the hi + lo pairs are forward_test's).
-        # Decoder branch within the north_star's 1e-3; token branch: the stated bound is 1.25e-3 -- measured max 1.11e-3 (ViT-B,
-        # 64 pairs) / 1.17e-3 (ViT-L, 32 x 10) on the harsh weights, mean 4.8e-4 / 5.2e-4 (profiles/r04_sweeps.md section 1): these
-        # boxes feed the losses (asserted right below), the boxes a user receives come from forward_test (<= 1e-3, test above)
+        # the boxes of the TRAINING forward at the full batch: every box of both branches within the north_star's 1e-3 (round 6:
+        # `BEIT3.precise_training` -- hi + lo weights for the patch kernel and the qkv (+ fc2, ViT-L) projections of the first half of
+        # the layers; measured max 8.2e-4 (ViT-B, 64 pairs) / 9.2e-4 (ViT-L, 32 x 10) on the harsh weights; single 16-bit weights:
+        # 1.11e-3 / 1.17e-3, the bound of round 5 was 1.25e-3).  These boxes feed the matcher and the losses (asserted right below)
         out = model._last_output
         for k, rb in ref_boxes.items():
             mx, p99, mean, n = _l1_stats(out[k].detach().float().cpu(), rb)

@@ -22,8 +22,11 @@ def main():
         fx = torch.load(os.path.join(ROOT, "tests", "golden", FULL_FIXTURE[(vit, B, nq)] + ".pt"), weights_only=False)
         ref = {"outputs_coord_decoder_branch": fx["dec_boxes"].float(), "outputs_coord_token_branch": fx["tok_boxes"].float()}
         L = 12 if vit == "base" else 24
-        for which in whichs:
-            for layers in (0, L // 4, L // 2, 3 * L // 4, L):
+        combos = [("wqkv", 0), ("patch", L), ("patch,wqkv", L // 2), ("patch,wqkv", L), ("patch,wqkv,w1", L // 2), ("patch,wqkv,w1", L)]
+        if whichs != ["wqkv"]:
+            combos = [(w, l) for w in whichs for l in (L // 2, L)]
+        for which, layers in combos:
+            if True:
                 os.environ["SIMVG_PRECISE_TRAIN"] = str(layers)
                 os.environ["SIMVG_PRECISE_TRAIN_WHICH"] = which
                 model, cfg = _model(vit, nq)
@@ -46,7 +49,7 @@ def main():
                 ms = (time.perf_counter() - t0) / 5 * 1e3
                 d = _l1_stats(out["outputs_coord_decoder_branch"], ref["outputs_coord_decoder_branch"])
                 t = _l1_stats(out["outputs_coord_token_branch"], ref["outputs_coord_token_branch"])
-                print(f"[{vit}] train fwd: {which:10s} first {layers:2d} layers  fwd+bwd {ms:7.2f} ms  decoder max {d[0]:.2e} mean {d[2]:.2e}  "
+                print(f"[{vit}] train fwd: {which:16s} first {layers:2d} layers  fwd+bwd {ms:7.2f} ms  decoder max {d[0]:.2e} mean {d[2]:.2e}  "
                       f"token max {t[0]:.2e} p99 {t[1]:.2e} mean {t[2]:.2e}", flush=True)
                 del model
                 torch.cuda.empty_cache()
