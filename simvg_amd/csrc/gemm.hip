@@ -1085,6 +1085,12 @@ __global__ __launch_bounds__(1024) void gemm_nt_kernel_tall5_f32(GemmNTArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   gemm_nt_tall_body<5, 1>(a, smem);
 }
+// MI = 4 (256 rows, one round): ViT-L's N = 1024 launches at 32 pairs per step (M = 13 472: 54 x 4 = 216 tiles) whose epilogue the
+// persistent kernel does not take -- the fp32 + residual forwards of out-proj / fc2, which ran on the compiler-scheduled 224-row kernel
+__global__ __launch_bounds__(1024) void gemm_nt_kernel_tall4_f32(GemmNTArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemm_nt_tall_body<4, 1>(a, smem);
+}
 
 // 224x256x64 tile with sixteen waves: 2 (M) x 8 (N), each 112x32 = acc[7][2] (round 4).  For row counts where 256-row tiles
 // leave CUs idle: ViT-L at 32 pairs per step has M = 13 472 = 52.6 x 256 -- 53 x 4 = 212 tiles of 256 x 256 for the N = 1024
@@ -1682,7 +1688,27 @@ static int gemm_nt_launch(const void* A, int lda, const void* W, long w_gstride,
     const double best = tile_cost(256) < tile_cost(160) ? tile_cost(256) : tile_cost(160);
     return 320.0 < best;
   };
-  if (tiles64 > 800 && use_tall()) {
+  // ONE round of 256-row tiles on the same kernel body (gemm_nt_kernel_tall4_f32) for fp32 epilogues, where it needs fewer rows x
+  // rounds than the compiler-scheduled extents (these cost ~1.2 x their rows: 224-row / 160-row kernels).  SIMVG_GEMM_TALL4 = 0: never
+  auto use_tall4 = [&]() {
+    const char* e = getenv("SIMVG_GEMM_TALL4");
+    if (e && atoi(e) == 0) return false;
+    if (!wide_ok || !a.c_f32 || a.aux || a.act != 0 || a.alpha != 1.f || a.ldc % 4 != 0 || (a.res && a.ldres % 4 != 0)) return false;
+    static const int cus = [] { int dev = 0, n = 256; hipGetDevice(&dev); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+    const long t256 = (long)(cdiv(split, 256) + cdiv(M - split, 256)) * cdiv(N, BNQ);
+    if (t256 > cus) return false;
+    const long t224 = (long)(cdiv(split, 224) + cdiv(M - split, 224)) * cdiv(N, BNQ);
+    const double c224 = (double)cdiv((int)t224, 256) * 224 * 1.2;
+    const double c160 = tile_cost(160);
+    return 256.0 <= (c224 < c160 ? c224 : c160);
+  };
+  if (tiles64 > 800 && !use_tall() && use_tall4()) {
+    using G4 = TallGeo<4>;
+    const int tiles = (cdiv(split, G4::ROWS) + cdiv(M - split, G4::ROWS)) * cdiv(N, BNQ);
+    static bool once4 = hipFuncSetAttribute((const void*)gemm_nt_kernel_tall4_f32, hipFuncAttributeMaxDynamicSharedMemorySize, G4::SMEM) == hipSuccess;
+    (void)once4;
+    hipLaunchKernelGGL(gemm_nt_kernel_tall4_f32, dim3(tiles), dim3(1024), G4::SMEM, stream, a);
+  } else if (tiles64 > 800 && use_tall()) {
     using G5 = TallGeo<5>;
     const int tiles = (cdiv(split, G5::ROWS) + cdiv(M - split, G5::ROWS)) * cdiv(N, BNQ);
     if (a.c_f32) {

@@ -26,6 +26,9 @@ for name, N, K, res, per_layer in cases:
     for rnd in range(ROUNDS):
         for v in VARIANTS:
             os.environ.pop("SIMVG_GEMM_224", None)
+            os.environ.pop("SIMVG_GEMM_TALL4", None)
+            if v == "notall4":          # round 6: without the one-round 256-row hand-managed kernel for the fp32 epilogues
+                os.environ["SIMVG_GEMM_TALL4"] = "0"
             if v == "off":
                 os.environ["SIMVG_GEMM_224"] = "0"
             elif v == "on":

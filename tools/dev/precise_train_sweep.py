@@ -23,6 +23,8 @@ def main():
         ref = {"outputs_coord_decoder_branch": fx["dec_boxes"].float(), "outputs_coord_token_branch": fx["tok_boxes"].float()}
         L = 12 if vit == "base" else 24
         combos = [("wqkv", 0), ("patch", L), ("patch,wqkv", L // 2), ("patch,wqkv", L), ("patch,wqkv,w1", L // 2), ("patch,wqkv,w1", L)]
+        if os.environ.get("ZERO_LO"):
+            combos = [("patch,wqkv", L // 4), ("patch,wqkv", L // 2), ("patch,wqkv", L)]
         if whichs != ["wqkv"]:
             combos = [(w, l) for w in whichs for l in (L // 2, L)]
         for which, layers in combos:
@@ -40,6 +42,16 @@ def main():
                     losses["loss_total"].backward()
                     return losses
                 step()
+                zero = os.environ.get("ZERO_LO", "")          # emulate "no lo half" for the q / k / v rows of the qkv weights (eval mode:
+                if zero:                                      # the [lo | hi] rows are rewritten only when the master weights move)
+                    enc = model.vis_enc
+                    D = enc.D
+                    for tag, w in enc.wbs.items():
+                        if tag.startswith("wqkv"):
+                            for part in zero.split(","):
+                                r0 = {"q": 0, "k": D, "v": 2 * D}[part]
+                                w[:, r0:r0 + D, :D] = 0
+                    step()
                 out = {k: model._last_output[k].detach().float().cpu() for k in ref}
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
