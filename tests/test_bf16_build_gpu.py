@@ -64,6 +64,10 @@ def test_bf16_build_whole_model_vs_reference_fixtures():
     # near-tied Hungarian assignment (seen on base_nq10_grec_deconly), after which the loss terms belong to other pairs.
     # Anything else that skipped -- or more than two such cases -- fails HERE, and the count is printed
     print(f"[bf16 build] fixture cases compared: {passed} passed, {skipped} skipped ({len(reasons)} reasons listed)")
+    # (as a warning too: pytest's end-of-run warnings summary is what the driver's tail of the `-m gpu` run shows)
+    import warnings
+    warnings.warn(UserWarning(f"bf16 build: {passed} of {passed + skipped} fixture cases compared with the reference"
+                              + (f" ({skipped} skipped: Hungarian assignment flipped by the bf16 build's box deviations)" if skipped else "")))
     assert passed >= 12, (passed, skipped)
     assert skipped <= 2, (skipped, reasons)
     for r_ in reasons:
@@ -74,6 +78,9 @@ def test_bf16_build_encoder_vs_oracle():
     out = _run(["tests/test_encoder_gpu.py", "tests/test_kernels_gpu.py", "-rs"])
     passed, skipped, reasons = _counts(out)
     print(f"[bf16 build] kernel / encoder cases: {passed} passed, {skipped} skipped")
+    import warnings
+    warnings.warn(UserWarning(f"bf16 build: {passed} of {passed + skipped} kernel / encoder cases compared ({skipped} skipped: "
+                              "geometries the one-pass attention backward does not serve / the gradient-scale test)"))
     # the only skips of these two modules: the one-pass attention backward's switch on geometries it does not serve (a
     # parametrisation artefact: attn_bwd_one_kernel exists for 27 key tiles, on either build) and the gradient-scale test (bf16 has
     # fp32's exponent range: the build carries no gradient scale)

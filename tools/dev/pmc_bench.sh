@@ -4,6 +4,7 @@
 # gpurun_out/pmc/hbm_traffic.json in the schema of profiles/gemm_nt_hbm_traffic.json (copy it there and commit): the dominant
 # kernel (gemm_nt) at the top level, every other family under other_kernels_hbm_bytes_per_launch, and the sha256 of the csrc
 # file each family was measured on -- bench.py reports a `traffic` figure only while that hash matches the built source.
+# Call it with SIMVG_COMMIT=$(git rev-parse --short HEAD) in the environment (the GPU box has no .git): the JSON is stamped with it.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/pmc
 for set in "FETCH_SIZE" "WRITE_SIZE"; do
@@ -50,7 +51,8 @@ out = dict(kernel="gemm_nt (all launches of the gemm_nt_kernel_* family during 3
                       "counters are L2 misses to the fabric (Infinity-Cache hits included): an upper bound of the HBM bytes",
            hbm_bytes_per_launch=g["hbm_bytes_per_launch"], launches=g["launches"],
            algorithmic_bytes_per_launch_avg=old.get("algorithmic_bytes_per_launch_avg"),
-           history=dict(old.get("history", {}), **({f"round 3 final ({old.get('measured')})": old.get("hbm_bytes_per_launch")} if old.get("hbm_bytes_per_launch") else {})),
+           history=dict(old.get("history", {}), **({f"{old.get('round', 'round 5')} ({old.get('measured')}, commit {old.get('commit')})": old.get("hbm_bytes_per_launch")} if old.get("hbm_bytes_per_launch") else {})),
+           round=os.environ.get("SIMVG_ROUND", "round 6"),
            other_kernels_hbm_bytes_per_launch=fam)
 json.dump(out, open("gpurun_out/pmc/hbm_traffic.json", "w"), indent=1)
 print(json.dumps({k: (round(v["hbm_bytes_per_launch"] / 1e6, 1), v["launches"]) for k, v in dict(fam, gemm_nt=g).items()}, indent=1))
