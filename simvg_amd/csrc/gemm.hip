@@ -1092,6 +1092,181 @@ __global__ __launch_bounds__(1024) void gemm_nt_kernel_tall4_f32(GemmNTArgs a) {
   gemm_nt_tall_body<4, 1>(a, smem);
 }
 
+// ------------------------------------------------------------------------------------------
+// The same hand-managed form with the sixteen waves as 2 (M) x 8 (N), each 16 MI x 32 = acc[MI][2] (round 6): MI = 7 -> 224 x 256
+// tiles, the row extent of ViT-L at 32 pairs per step (M = 13 472 = 12 832 | 640: 61 row tiles, 95 % of the CUs per round where
+// 256-row tiles leave 16 % idle) that `gemm_nt_kernel_224x256_w16` serves with compiler-scheduled reads.  All nine fragments of a
+// k-half are requested up front (56 accumulators leave the registers for it) and consumed behind counted lgkmcnt waits.
+// EPI 0: 16-bit output through 1 KiB of wave-private staging per 16-row block (a store covers 16 rows x 64 B); EPI 1: fp32
+// (+ residual * row_scale) straight from the accumulator layout.  Bias in the epilogue, zero start (see gemm_nt_tall_body).
+// ------------------------------------------------------------------------------------------
+template <int MI> struct Tall28Geo {
+  static constexpr int ROWS = 32 * MI, WROWS = 16 * MI;
+  static constexpr int A_BYTES = ROWS * BK * 2, STAGE = (ROWS + BNQ) * BK * 2;
+  static constexpr int NPA = ROWS / 8, NAI = (NPA + 15) / 16;
+  static constexpr int BIAS_OFF = 2 * STAGE;
+  static constexpr int SMEM = 2 * STAGE + 16 * 128;       // + 32 bias floats per wave
+};
+
+template <int MI, int EPI>
+__device__ __forceinline__ void gemm_nt_tall28_body(const GemmNTArgs& a, char* smem) {
+  using G = Tall28Geo<MI>;
+  static_assert(G::WROWS % 8 == 0, "wave row offset must keep the swizzle phase");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 3, wn = wave & 7;   // 2 x 8 waves
+  const int tiles_n = a.N / BNQ;
+  const int tm0 = (a.split + G::ROWS - 1) / G::ROWS;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  int tile_m, tile_n;
+  tile_order(bid, (int)gridDim.x / tiles_n, tiles_n, a.gn, tile_m, tile_n);
+  const int group = tile_m >= tm0;
+  const int row0 = group ? a.split + (tile_m - tm0) * G::ROWS : tile_m * G::ROWS;
+  const int row_end = group ? a.M : a.split;
+  const int n0 = tile_n * BNQ;
+  const int nk = a.K / BK;
+  const bool two = a.ka < a.K;
+  const int din = lane >> 3, dslot = (lane & 7) ^ din;
+  int voffA[G::NAI], voffW[2];
+#pragma unroll
+  for (int i = 0; i < G::NAI; ++i) voffA[i] = ((wave + 16 * i) * 8 + din) * a.lda * 2 + dslot * 16;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) voffW[i] = ((wave * 2 + i) * 8 + din) * a.ldw * 2 + dslot * 16;
+  const __amdgpu_buffer_rsrc_t dA =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(a.A + (long)row0 * a.lda), 0, (int)((long)(row_end - row0) * a.lda * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t dW =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(a.W + (long)group * a.w_gstride + (long)n0 * a.ldw), 0, BNQ * a.ldw * 2, 0x00020000);
+  auto issue = [&](int kt, int st) {
+    char* sA = smem + st * G::STAGE;
+    const int ko = a_koff(a, kt * BK) * 2;
+#pragma unroll
+    for (int i = 0; i < G::NAI; ++i)
+      if (wave + 16 * i < G::NPA)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(dA, LDS_PTR(sA + (wave + 16 * i) * 1024), 16, voffA[i], ko, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(dW, LDS_PTR(sA + G::A_BYTES + (wave * 2 + i) * 1024), 16, voffW[i], kt * (BK * 2), 0, 0);
+  };
+  const int c0 = (lane >> 4) ^ (lane & 7);
+  const unsigned fA0 = lds_addr(smem) + (wm * G::WROWS + (lane & 15)) * 128 + c0 * 16, fA1 = fA0 ^ 64;
+  const unsigned fB0 = lds_addr(smem) + G::A_BYTES + (wn * 32 + (lane & 15)) * 128 + c0 * 16, fB1 = fB0 ^ 64;
+
+  issue(0, 0);
+  if (nk > 1) issue(1, 1);
+  float* lbias = (float*)(smem + G::BIAS_OFF + wave * 128);
+  if (lane < 8) {
+    const float* bp = a.bias ? a.bias + (long)group * a.bias_gstride + n0 + wn * 32 + 4 * lane : nullptr;
+    *(f32x4_t*)(lbias + 4 * lane) = bp ? *(const f32x4_t*)bp : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
+  f32x4_t acc[MI][2];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      reg_pin(acc[i][j]);
+    }
+#define T28_READ(I_) if constexpr (MI > (I_)) fa[(I_)] = lds_b128_asm<(I_) * 2048>(pa);
+#define T28_STEP(I_)                                                                                   \
+  if constexpr (MI > (I_)) {                                                                           \
+    lgkm_wait<MI - 1 - (I_)>();                                                                        \
+    acc[(I_)][0] = mfma_lp(as_frag(fb[0]), as_frag(fa[(I_)]), acc[(I_)][0]);                           \
+    acc[(I_)][1] = mfma_lp(as_frag(fb[1]), as_frag(fa[(I_)]), acc[(I_)][1]);                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+  }
+  const int k_lo = a.ka / BK;
+  for (int kt = 0; kt < nk; ++kt) {
+    vm_wait<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt >= 1 && kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+    const unsigned so = (kt & 1) * G::STAGE;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const unsigned pa = (s ? fA1 : fA0) + so, pb = (s ? fB1 : fB0) + so;
+      u32x4_t fb[2], fa[MI];
+      fb[0] = lds_b128_asm<0>(pb); fb[1] = lds_b128_asm<2048>(pb);
+      T28_READ(0) T28_READ(1) T28_READ(2) T28_READ(3) T28_READ(4) T28_READ(5) T28_READ(6) T28_READ(7)
+      T28_STEP(0) T28_STEP(1) T28_STEP(2) T28_STEP(3) T28_STEP(4) T28_STEP(5) T28_STEP(6) T28_STEP(7)
+    }
+    if (two && kt + 1 == k_lo) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] *= a.lo_scale;
+    }
+  }
+#undef T28_READ
+#undef T28_STEP
+  const float* bias = lbias + 4 * (lane >> 4);
+  if constexpr (EPI == 0) {
+    __builtin_amdgcn_s_barrier();            // every wave is done reading the ring
+    const unsigned stg = lds_addr(smem) + wave * 1024;
+    const int er = lane & 15, ecg = lane >> 4;         // accumulator layout: row er, columns 4 ecg .. + 3 of each 16 x 16 block
+    const int rr = lane >> 2, rq = lane & 3;           // read-out layout: row rr, 16-B chunk rq of the wave's 64 B
+    lp_t* cp = (lp_t*)a.C + (long)(row0 + wm * G::WROWS + rr) * a.ldc + n0 + wn * 32 + rq * 8;
+    const int mleft = row_end - (row0 + wm * G::WROWS + rr);
+    // staged row = 64 B; 8-B chunk c (= 4 j + ecg) of row er at chunk c ^ (er & 7): the 16 rows of a write hit distinct bank pairs;
+    // the 16-B chunk rq of row rr is then chunks 2 rq and 2 rq + 1 XOR (rr & 7), i.e. 16-B chunk rq ^ ((rr & 7) >> 1), halves swapped
+    // for odd rr
+    const unsigned wa = stg + er * 64, ra = stg + rr * 64 + ((rq ^ ((rr & 7) >> 1)) << 4);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const f32x4_t x = acc[i][j] + *(const f32x4_t*)(bias + j * 16);
+        lds_write_b64_asm(wa + (((j * 4 + ecg) ^ (er & 7)) << 3), (u32x2_t){pack_lp2(x[0], x[1]), pack_lp2(x[2], x[3])});
+      }
+      lgkm_wait<0>();
+      u32x4_t d0 = lds_b128_asm<0>(ra);
+      lgkm_wait<0>();
+      if (rr & 1) d0 = (u32x4_t){d0[2], d0[3], d0[0], d0[1]};
+      if (i * 16 < mleft) *(u32x4_t*)(cp + (long)(i * 16) * a.ldc) = d0;
+    }
+  } else {
+    const int mb = row0 + wm * G::WROWS + (lane & 15);
+    const int nb = n0 + wn * 32 + 4 * (lane >> 4);
+    float* cp = (float*)a.C + (long)mb * a.ldc + nb;
+    const float* rp = a.res ? a.res + (long)mb * a.ldres + nb : nullptr;
+    f32x4_t bh[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bh[j] = *(const f32x4_t*)(bias + j * 16);
+    f32x4_t rv[2][2];
+    auto load_res = [&](int i, f32x4_t (&r)[2]) {
+      const bool ok = mb + i * 16 < row_end;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) r[j] = ok ? *(const f32x4_t*)(rp + (long)(i * 16) * a.ldres + j * 16) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    };
+    if (rp) load_res(0, rv[0]);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      if (rp && i + 1 < MI) load_res(i + 1, rv[(i + 1) & 1]);
+      const int m = mb + i * 16;
+      if (m < row_end) {
+        const float rs = a.row_scale ? a.row_scale[group ? (m - a.split) / a.rps1 : m / a.rps0] : 1.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          f32x4_t v = acc[i][j] + bh[j];
+          if (rp) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = __builtin_fmaf(rs, v[k], rv[i & 1][j][k]);
+          } else if (a.row_scale) {
+            v *= rs;
+          }
+          *(f32x4_t*)(cp + (long)(i * 16) * a.ldc + j * 16) = v;
+        }
+      }
+    }
+  }
+}
+__global__ __launch_bounds__(1024) void gemm_nt_kernel_t224_lp(GemmNTArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemm_nt_tall28_body<7, 0>(a, smem);
+}
+__global__ __launch_bounds__(1024) void gemm_nt_kernel_t224_f32(GemmNTArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemm_nt_tall28_body<7, 1>(a, smem);
+}
+
 // 224x256x64 tile with sixteen waves: 2 (M) x 8 (N), each 112x32 = acc[7][2] (round 4).  For row counts where 256-row tiles
 // leave CUs idle: ViT-L at 32 pairs per step has M = 13 472 = 52.6 x 256 -- 53 x 4 = 212 tiles of 256 x 256 for the N = 1024
 // launches (out-proj, fc2, three dgrads per layer) on 256 CUs, 61 x 4 = 244 tiles of 224 rows fill 95 % of them in one round of
@@ -1702,7 +1877,31 @@ static int gemm_nt_launch(const void* A, int lda, const void* W, long w_gstride,
     const double c160 = tile_cost(160);
     return 256.0 <= (c224 < c160 ? c224 : c160);
   };
-  if (tiles64 > 800 && !use_tall() && use_tall4()) {
+  // 224-row tiles on the hand-managed 2 x 8-wave body (gemm_nt_kernel_t224_*): where they need fewer rows x rounds than every other
+  // extent (ViT-L at 32 pairs per step: 61 row tiles).  SIMVG_GEMM_T224 = 0: never; 2: also over several dispatch rounds (measurement)
+  auto use_t224 = [&]() {
+    const char* e = getenv("SIMVG_GEMM_T224");
+    if (e && atoi(e) == 0) return false;
+    if (!wide_ok || a.aux || a.act != 0 || a.alpha != 1.f) return false;
+    if (a.c_f32 ? (a.ldc % 4 != 0 || (a.res && a.ldres % 4 != 0)) : (a.res || a.row_scale || a.ldc % 8 != 0)) return false;
+    static const int cus = [] { int dev = 0, n = 256; hipGetDevice(&dev); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+    const long t224 = (long)(cdiv(split, 224) + cdiv(M - split, 224)) * cdiv(N, BNQ);
+    if (t224 > cus && !(e && atoi(e) == 2)) return false;
+    const double c224 = (double)cdiv((int)t224, cus) * 224;
+    const long t320 = (long)(cdiv(split, 320) + cdiv(M - split, 320)) * cdiv(N, BNQ);
+    double best = tile_cost(256) < tile_cost(160) ? tile_cost(256) : tile_cost(160);
+    if (t320 <= cus && 320.0 < best) best = 320.0;
+    return c224 < 0.97 * best;
+  };
+  if (tiles64 > 800 && !use_tall() && use_t224()) {
+    using G7 = Tall28Geo<7>;
+    const int tiles = (cdiv(split, G7::ROWS) + cdiv(M - split, G7::ROWS)) * cdiv(N, BNQ);
+    static bool once7 = hipFuncSetAttribute((const void*)gemm_nt_kernel_t224_lp, hipFuncAttributeMaxDynamicSharedMemorySize, G7::SMEM) == hipSuccess &&
+                        hipFuncSetAttribute((const void*)gemm_nt_kernel_t224_f32, hipFuncAttributeMaxDynamicSharedMemorySize, G7::SMEM) == hipSuccess;
+    (void)once7;
+    if (a.c_f32) hipLaunchKernelGGL(gemm_nt_kernel_t224_f32, dim3(tiles), dim3(1024), G7::SMEM, stream, a);
+    else hipLaunchKernelGGL(gemm_nt_kernel_t224_lp, dim3(tiles), dim3(1024), G7::SMEM, stream, a);
+  } else if (tiles64 > 800 && !use_tall() && use_tall4()) {
     using G4 = TallGeo<4>;
     const int tiles = (cdiv(split, G4::ROWS) + cdiv(M - split, G4::ROWS)) * cdiv(N, BNQ);
     static bool once4 = hipFuncSetAttribute((const void*)gemm_nt_kernel_tall4_f32, hipFuncAttributeMaxDynamicSharedMemorySize, G4::SMEM) == hipSuccess;

@@ -7,9 +7,15 @@ from simvg_amd import hip_ops as ops
 
 dev = "cuda"
 torch.manual_seed(0)
-os.environ["SIMVG_GEMM_TALL"] = "1"
-for (M, SPLIT, N, K) in [(26944, 25664, 768, 768), (26944, 25664, 768, 128), (20011, 18003, 768, 192), (16000, 0, 768, 64),
-                         (60000, 58000, 256, 128)]:
+CASES = [("1", (26944, 25664, 768, 768)), ("1", (26944, 25664, 768, 128)), ("1", (20011, 18003, 768, 192)), ("1", (16000, 0, 768, 64)),
+         ("1", (60000, 58000, 256, 128)),
+         # the 2 x 8-wave 224-row body (gemm_nt_kernel_t224_*): ViT-L's row count, ragged groups, one group
+         (None, (13472, 12832, 1024, 256)), (None, (10300, 9800, 1024, 128)), (None, (9900, 0, 1024, 64)), (None, (13472, 12832, 1024, 1024))]
+for (TALL, (M, SPLIT, N, K)) in CASES:
+    if TALL is None:
+        os.environ.pop("SIMVG_GEMM_TALL", None)
+    else:
+        os.environ["SIMVG_GEMM_TALL"] = TALL
     a = torch.randn(M, K, device=dev).to(ops.LP())
     w = (torch.randn(2, N, K, device=dev) * K ** -0.5).to(ops.LP())
     bias = torch.randn(2, N, device=dev)
@@ -44,11 +50,17 @@ for (M, SPLIT, N, K) in [(26944, 25664, 768, 768), (26944, 25664, 768, 128), (20
     assert max(e1, e2, e3) <= 2e-4, (e1, e2, e3)
     # bit-identical to the other kernels' results (same MFMA order per accumulator along k)
     os.environ["SIMVG_GEMM_TALL"] = "0"
+    os.environ["SIMVG_GEMM_T224"] = "0"
+    os.environ["SIMVG_GEMM_TALL4"] = "0"
     o2 = torch.empty_like(o32)
     ops.gemm_nt(a, w, bias=bias, out=o2, split=SPLIT)
-    os.environ["SIMVG_GEMM_TALL"] = "1"
+    for kk in ("SIMVG_GEMM_TALL", "SIMVG_GEMM_T224", "SIMVG_GEMM_TALL4"):
+        os.environ.pop(kk, None)
+    if TALL is not None:
+        os.environ["SIMVG_GEMM_TALL"] = TALL
     print("        vs the other kernels: max diff", (o2 - o32).abs().max().item(), flush=True)
 # split weights (hi + lo)
+os.environ["SIMVG_GEMM_TALL"] = "1"
 M, SPLIT, N, K = 26944, 25664, 768, 768
 a = torch.randn(M, K, device=dev).to(ops.LP())
 wf = torch.randn(2, N, K, device=dev) * K ** -0.5

@@ -27,6 +27,11 @@ for name, N, K, res, per_layer in cases:
         for v in VARIANTS:
             os.environ.pop("SIMVG_GEMM_224", None)
             os.environ.pop("SIMVG_GEMM_TALL4", None)
+            os.environ.pop("SIMVG_GEMM_T224", None)
+            if v == "not224":           # round 6: without the hand-managed 224-row kernel (2 x 8 waves)
+                os.environ["SIMVG_GEMM_T224"] = "0"
+            if v == "t224all":          # ... and with it wherever N is a multiple of 256, over several dispatch rounds too
+                os.environ["SIMVG_GEMM_T224"] = "2"
             if v == "notall4":          # round 6: without the one-round 256-row hand-managed kernel for the fp32 epilogues
                 os.environ["SIMVG_GEMM_TALL4"] = "0"
             if v == "off":
