@@ -61,6 +61,22 @@ int simvg_gemm_nt_split(const void* A_lp, int lda, const void* W2_lp, long w_gro
                         const float* bias, int bias_group_stride, void* C, int ldc, int c_is_f32,
                         const float* residual, int ldres, int M, int N, int K, int split, float lo_scale,
                         simvg_stream_t stream);
+/* Which kernel simvg_gemm_nt / simvg_gemm_nt_split would launch for a problem (host logic only, nothing is launched): the
+ * dispatcher's tile-extent cost model -- rounds x rows per tile on the CUs of the device (256 without one) -- as data, so that it
+ * can be tested without a GPU (tests/test_abi.py).  -> SIMVG_GEMM_PLAN_*, or a negative error code. */
+#define SIMVG_GEMM_PLAN_LAT 1            /* 64 x 64 latency kernel (few tiles: forward_test at small batches) */
+#define SIMVG_GEMM_PLAN_TALL5 2          /* one round of 320 x 256 tiles, hand-managed loop (ViT-B's N = 768 launches at 64 pairs) */
+#define SIMVG_GEMM_PLAN_T224 3           /* one round of 224 x 256 tiles, 2 x 8 waves, hand-managed (ViT-L's N = 1024 launches at 32 pairs) */
+#define SIMVG_GEMM_PLAN_TALL4 4          /* one round of 256 x 256 tiles, hand-managed, fp32 epilogues */
+#define SIMVG_GEMM_PLAN_224 5            /* 224 x 256, compiler-scheduled (epilogues with an activation) */
+#define SIMVG_GEMM_PLAN_PERSIST 6        /* persistent 256 x 256 (16-bit output + bias) */
+#define SIMVG_GEMM_PLAN_PERSIST_SPLIT 7  /* ... with hi + lo weights */
+#define SIMVG_GEMM_PLAN_256 8            /* 256 x 256, one tile per workgroup */
+#define SIMVG_GEMM_PLAN_160 9            /* 160 x 256, three-stage ring */
+#define SIMVG_GEMM_PLAN_256K32 10        /* 256 x 128, k-tiles of 32 */
+#define SIMVG_GEMM_PLAN_128 11           /* 128 x 128 */
+int simvg_gemm_nt_plan(int M, int N, int K, int split, int c_is_f32, int has_residual, int has_row_scale, int act, int has_aux,
+                       int split_weights);
 /* dW[g][N,K] += out_scale * dY[M,N]^T . X[M,K]  (weight gradient of the same Linears; fp32 accumulate); optional fused bias
  * gradient db[g][N] += out_scale * column sums of dY over the rows of group g (extra streaming blocks of the same
  * launch).  out_scale = 1 / (gradient scale carried by dY). */

@@ -99,6 +99,7 @@ _SIGS = {
                       c_float, c_void_p],
     "simvg_gemm_nt_split": [c_void_p, c_int, c_void_p, c_long, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
                             c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
+    "simvg_gemm_nt_plan": [c_int] * 10,
     "simvg_gemm_tn": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_long, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                       c_float, c_void_p],
     "simvg_gemm_tn_ws": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_long, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,

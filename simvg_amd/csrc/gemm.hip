@@ -23,6 +23,11 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
 
+// ids of simvg_gemm_nt_plan (mirrored in include/simvg_hip.h)
+enum { SIMVG_GEMM_PLAN_LAT = 1, SIMVG_GEMM_PLAN_TALL5 = 2, SIMVG_GEMM_PLAN_T224 = 3, SIMVG_GEMM_PLAN_TALL4 = 4, SIMVG_GEMM_PLAN_224 = 5,
+       SIMVG_GEMM_PLAN_PERSIST = 6, SIMVG_GEMM_PLAN_PERSIST_SPLIT = 7, SIMVG_GEMM_PLAN_256 = 8, SIMVG_GEMM_PLAN_160 = 9,
+       SIMVG_GEMM_PLAN_256K32 = 10, SIMVG_GEMM_PLAN_128 = 11 };
+
 struct GemmNTArgs {
   const lp_t* A; int lda;
   const lp_t* W; long w_gstride; int ldw;
@@ -1758,11 +1763,13 @@ static bool persist_ok(const GemmNTArgs& a) {
   // the kernel's counted vmcnt waits assume that its ONLY vector-memory operations are the ones written in the source: a build
   // that spills (scratch loads / stores share the FIFO) would consume k-tile 0 or the bias before they land.  Refuse such a build
   // (the non-persistent 256x256 kernel takes over), as the streamed attention launcher does.
-  static const bool no_scratch = [] {
+  // (a host without a device -- simvg_gemm_nt_plan in the CPU tests -- cannot run anything: the build is taken as clean there)
+  static const bool no_device = [] { int n = 0; return hipGetDeviceCount(&n) != hipSuccess || n == 0; }();
+  static const bool no_scratch = no_device || [] {
     hipFuncAttributes fa{};
     return hipFuncGetAttributes(&fa, (const void*)gemm_nt_kernel_256sq_p) == hipSuccess && fa.localSizeBytes == 0;
   }();
-  static const bool no_scratch2 = [] {
+  static const bool no_scratch2 = no_device || [] {
     hipFuncAttributes fa{};
     return hipFuncGetAttributes(&fa, (const void*)gemm_nt_kernel_256sq_p2) == hipSuccess && fa.localSizeBytes == 0;
   }();
@@ -1774,7 +1781,8 @@ static int gemm_nt_launch(const void* A, int lda, const void* W, long w_gstride,
                           const float* bias, int bias_gstride, void* C, int ldc, int c_is_f32,
                           void* aux_preact, int ldaux, const float* residual, int ldres,
                           const float* row_scale, int rows_per_sample0, int rows_per_sample1,
-                          int M, int N, int K, int split, int act, float alpha, int ka, float lo_scale, hipStream_t stream);
+                          int M, int N, int K, int split, int act, float alpha, int ka, float lo_scale, hipStream_t stream,
+                          int* plan = nullptr);
 
 extern "C" int simvg_gemm_nt(const void* A, int lda, const void* W, long w_gstride, int ldw,
                              const float* bias, int bias_gstride, void* C, int ldc, int c_is_f32,
@@ -1806,7 +1814,10 @@ static int gemm_nt_launch(const void* A, int lda, const void* W, long w_gstride,
                           const float* bias, int bias_gstride, void* C, int ldc, int c_is_f32,
                           void* aux_preact, int ldaux, const float* residual, int ldres,
                           const float* row_scale, int rows_per_sample0, int rows_per_sample1,
-                          int M, int N, int K, int split, int act, float alpha, int ka, float lo_scale, hipStream_t stream) {
+                          int M, int N, int K, int split, int act, float alpha, int ka, float lo_scale, hipStream_t stream,
+                          int* plan) {
+  // plan != NULL (simvg_gemm_nt_plan): the dispatcher's choice is written to *plan and nothing is launched
+#define PLAN(ID_) do { if (plan) { *plan = (ID_); return SIMVG_OK; } } while (0)
   SIMVG_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm_nt: empty problem");
   SIMVG_CHECK_ARG(K % BK == 0, "gemm_nt: K must be a multiple of 64");
   SIMVG_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0, "gemm_nt: leading dims must keep 16-B alignment");
@@ -1894,6 +1905,7 @@ static int gemm_nt_launch(const void* A, int lda, const void* W, long w_gstride,
     return c224 < 0.97 * best;
   };
   if (tiles64 > 800 && !use_tall() && use_t224()) {
+    PLAN(SIMVG_GEMM_PLAN_T224);
     using G7 = Tall28Geo<7>;
     const int tiles = (cdiv(split, G7::ROWS) + cdiv(M - split, G7::ROWS)) * cdiv(N, BNQ);
     static bool once7 = hipFuncSetAttribute((const void*)gemm_nt_kernel_t224_lp, hipFuncAttributeMaxDynamicSharedMemorySize, G7::SMEM) == hipSuccess &&
@@ -1902,12 +1914,14 @@ static int gemm_nt_launch(const void* A, int lda, const void* W, long w_gstride,
     if (a.c_f32) hipLaunchKernelGGL(gemm_nt_kernel_t224_f32, dim3(tiles), dim3(1024), G7::SMEM, stream, a);
     else hipLaunchKernelGGL(gemm_nt_kernel_t224_lp, dim3(tiles), dim3(1024), G7::SMEM, stream, a);
   } else if (tiles64 > 800 && !use_tall() && use_tall4()) {
+    PLAN(SIMVG_GEMM_PLAN_TALL4);
     using G4 = TallGeo<4>;
     const int tiles = (cdiv(split, G4::ROWS) + cdiv(M - split, G4::ROWS)) * cdiv(N, BNQ);
     static bool once4 = hipFuncSetAttribute((const void*)gemm_nt_kernel_tall4_f32, hipFuncAttributeMaxDynamicSharedMemorySize, G4::SMEM) == hipSuccess;
     (void)once4;
     hipLaunchKernelGGL(gemm_nt_kernel_tall4_f32, dim3(tiles), dim3(1024), G4::SMEM, stream, a);
   } else if (tiles64 > 800 && use_tall()) {
+    PLAN(SIMVG_GEMM_PLAN_TALL5);
     using G5 = TallGeo<5>;
     const int tiles = (cdiv(split, G5::ROWS) + cdiv(M - split, G5::ROWS)) * cdiv(N, BNQ);
     if (a.c_f32) {
@@ -1920,16 +1934,19 @@ static int gemm_nt_launch(const void* A, int lda, const void* W, long w_gstride,
       hipLaunchKernelGGL(gemm_nt_kernel_tall5_lp, dim3(tiles), dim3(1024), G5::SMEM, stream, a);
     }
   } else if (tiles64 <= 800) {
+    PLAN(SIMVG_GEMM_PLAN_LAT);
     static bool oncel = hipFuncSetAttribute((const void*)gemm_nt_kernel_lat<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * LAT_STAGE) == hipSuccess;
     (void)oncel;
     hipLaunchKernelGGL(gemm_nt_kernel_lat<3>, dim3((int)tiles64), dim3(256), 3 * LAT_STAGE, stream, a);
   } else if (wide_ok && use224()) {
+    PLAN(SIMVG_GEMM_PLAN_224);
     constexpr int SM224 = 2 * (224 + BNQ) * BK * 2;   // 120 KiB ring; the epilogue staging (16 waves x 32 x 36 x 4 B = 72 KiB) fits
     static bool once224 = hipFuncSetAttribute((const void*)gemm_nt_kernel_224x256_w16, hipFuncAttributeMaxDynamicSharedMemorySize, SM224) == hipSuccess;
     (void)once224;
     const int tiles = (cdiv(split, 224) + cdiv(M - split, 224)) * cdiv(N, BNQ);
     hipLaunchKernelGGL(gemm_nt_kernel_224x256_w16, dim3(tiles), dim3(1024), SM224, stream, a);
   } else if (wide_ok && tile_cost(256) <= tile_cost(160) && persist_ok(a)) {
+    PLAN(a.ka < a.K ? SIMVG_GEMM_PLAN_PERSIST_SPLIT : SIMVG_GEMM_PLAN_PERSIST);
     static bool oncep = hipFuncSetAttribute((const void*)gemm_nt_kernel_256sq_p, hipFuncAttributeMaxDynamicSharedMemorySize, PQ_SMEM) == hipSuccess &&
                         hipFuncSetAttribute((const void*)gemm_nt_kernel_256sq_p2, hipFuncAttributeMaxDynamicSharedMemorySize, PQ_SMEM) == hipSuccess;
     (void)oncep;
@@ -1939,31 +1956,50 @@ static int gemm_nt_launch(const void* A, int lda, const void* W, long w_gstride,
     if (a.ka < a.K) hipLaunchKernelGGL(gemm_nt_kernel_256sq_p2, dim3(tiles < cus ? tiles : cus), dim3(1024), PQ_SMEM, stream, a, tiles, prof);
     else hipLaunchKernelGGL(gemm_nt_kernel_256sq_p, dim3(tiles < cus ? tiles : cus), dim3(1024), PQ_SMEM, stream, a, tiles, prof);
   } else if (wide_ok && tile_cost(256) <= tile_cost(160)) {
+    PLAN(SIMVG_GEMM_PLAN_256);
     constexpr int SMW = 160 * 1024;      // ring 128 KiB; the 16-wave epilogue staging needs 136 KiB
     static bool oncew = hipFuncSetAttribute((const void*)gemm_nt_kernel_256sq_w16, hipFuncAttributeMaxDynamicSharedMemorySize, SMW) == hipSuccess;
     (void)oncew;
     const int tiles = (cdiv(split, 256) + cdiv(M - split, 256)) * cdiv(N, BNQ);
     hipLaunchKernelGGL(gemm_nt_kernel_256sq_w16, dim3(tiles), dim3(1024), SMW, stream, a);
   } else if (wide_ok) {
+    PLAN(SIMVG_GEMM_PLAN_160);
     constexpr int SM3 = 3 * (160 + BNQ) * BK * 2;     // 156 KiB ring; 16 waves x 32 x 36 x 4 B = 72 KiB of epilogue staging fit
     static bool once3r = hipFuncSetAttribute((const void*)gemm_nt_kernel_160x256_r3, hipFuncAttributeMaxDynamicSharedMemorySize, SM3) == hipSuccess;
     (void)once3r;
     const int tiles = (cdiv(split, 160) + cdiv(M - split, 160)) * cdiv(N, BNQ);
     hipLaunchKernelGGL(gemm_nt_kernel_160x256_r3, dim3(tiles), dim3(1024), SM3, stream, a);
   } else if (M >= 512) {
+    PLAN(SIMVG_GEMM_PLAN_256K32);
     static bool once3 = hipFuncSetAttribute((const void*)gemm_nt_kernel_256k32, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             3 * STAGE3) == hipSuccess;
     (void)once3;
     const int tiles = (cdiv(split, BM2) + cdiv(M - split, BM2)) * cdiv(N, BN);
     hipLaunchKernelGGL(gemm_nt_kernel_256k32, dim3(tiles), dim3(512), 3 * STAGE3, stream, a);
   } else {
+    PLAN(SIMVG_GEMM_PLAN_128);
     const int tiles = (cdiv(split, BM) + cdiv(M - split, BM)) * cdiv(N, BN);
     static bool oncem = hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MID_NST * 2 * TILE_BYTES) == hipSuccess;
     (void)oncem;
     hipLaunchKernelGGL(gemm_nt_kernel, dim3(tiles), dim3(256), MID_NST * 2 * TILE_BYTES, stream, a);
   }
+#undef PLAN
   SIMVG_LAUNCH_CHECK();
   return SIMVG_OK;
+}
+
+// Which kernel simvg_gemm_nt / simvg_gemm_nt_split would launch for a problem (host logic only: nothing is launched, no device is
+// touched beyond the attribute queries the dispatcher makes): the tile-extent cost model is testable without a GPU.
+// -> one of SIMVG_GEMM_PLAN_* (include/simvg_hip.h), or a negative error code
+extern "C" int simvg_gemm_nt_plan(int M, int N, int K, int split, int c_is_f32, int has_residual, int has_row_scale, int act,
+                                  int has_aux, int split_weights) {
+  int plan = 0;
+  void* p = (void*)(uintptr_t)256;     // (never dereferenced)
+  const int kk = split_weights ? 2 * K : K, ld = (kk + 7) / 8 * 8, ldn = (N + 7) / 8 * 8;
+  const int rc = gemm_nt_launch(p, (K + 7) / 8 * 8, p, 0, ld, nullptr, 0, p, ldn, c_is_f32, has_aux ? p : nullptr, ldn, has_residual ? (const float*)p : nullptr,
+                                ldn, has_row_scale ? (const float*)p : nullptr, 1, 1, M, N, kk, split, act, 1.f, K, split_weights ? 0.5f : 1.f,
+                                nullptr, &plan);
+  return rc == SIMVG_OK ? plan : rc;
 }
 
 static int gemm_tn_impl(const void* dY, int lddy, const void* X, int ldx, float* dW, long dw_gstride,

@@ -37,6 +37,45 @@ def test_argument_errors_are_reported_not_thrown():
     assert b"multiple of 64" in lib.simvg_last_error()
 
 
+def test_gemm_nt_dispatcher_plans_the_baseline_launches_as_documented():
+    """`simvg_gemm_nt_plan`: the dispatcher's choice of kernel / tile extent (rounds x rows per tile on 256 CUs) as data, no launch.
+    Pins the plan of every gemm_nt form of BASELINE's configurations and of the shapes the GPU kernel tests use to
+    reach each kernel (tests/test_kernels_gpu.py::test_gemm_nt)."""
+    import re
+    from simvg_amd import _lib
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "simvg_hip.h")).read()
+    ids = {int(v): k for k, v in re.findall(r"#define SIMVG_GEMM_PLAN_(\w+) (\d+)", hdr)}
+    assert len(ids) == 11
+
+    def plan(M, N, K, split, f32=0, res=0, rs=0, act=0, aux=0, two=0):
+        r = lib.simvg_gemm_nt_plan(M, N, K, split, f32, res, rs, act, aux, two)
+        assert r > 0, (r, lib.simvg_last_error())
+        return ids[r]
+    Mb, Sb = 64 * 421, 64 * 401                   # ViT-B, 64 pairs per step (BASELINE config 2)
+    assert plan(Mb, 2304, 768, Sb) == "PERSIST" and plan(Mb, 3072, 768, Sb) == "PERSIST"            # qkv, fc1 forward / dgrad fc2
+    assert plan(Mb, 2304, 768, Sb, two=1) == "PERSIST_SPLIT"                                          # precise_training's qkv
+    assert plan(Mb, 768, 768, Sb, f32=1, res=1, rs=1) == "TALL5" and plan(Mb, 768, 3072, Sb, f32=1, res=1, rs=1) == "TALL5"
+    assert [plan(Mb, 768, K, Sb) for K in (768, 2304, 3072)] == ["TALL5"] * 3                        # the three N = 768 dgrads
+    assert plan(64 * 400, 768, 3072, 0, two=1) == "TALL5"                                             # the patch kernel with hi + lo weights
+    assert plan(Mb, 3072, 768, Sb, act=1, aux=1) == "256"                                             # an activation epilogue: no hand-managed form
+    Ml, Sl = 32 * 421, 32 * 401                   # ViT-L, 32 pairs per step (configs 4 / 5)
+    assert plan(Ml, 1024, 1024, Sl, f32=1, res=1) == "T224" and plan(Ml, 1024, 4096, Sl, f32=1, res=1) == "T224"
+    assert [plan(Ml, 1024, K, Sl) for K in (1024, 3072, 4096)] == ["T224"] * 3
+    assert plan(Ml, 3072, 1024, Sl) == "PERSIST" and plan(Ml, 4096, 1024, Sl) == "PERSIST"
+    assert plan(Ml, 1024, 4096, Sl, f32=1, res=1, two=1) == "T224"                                    # precise_training's fc2 (ViT-L)
+    # forward_test at small batches: the latency kernel while its 64 x 64 tiles fit about one residency round, then one round of 224-row tiles
+    assert plan(421, 768, 768, 401) == "LAT" and plan(8 * 421, 768, 768, 8 * 401) == "LAT" and plan(8 * 421, 3072, 768, 8 * 401) == "T224"
+    # half the batch (what forward_test's batch-independence property compares with): another kernel, the same bits
+    assert plan(32 * 421, 768, 768, 32 * 401, f32=1, res=1) == "160"
+    # the shapes tests/test_kernels_gpu.py uses to reach the remaining kernels
+    assert plan(300, 12800, 64, 200) == "128" and plan(12000, 320, 64, 11000) == "256K32" and plan(7300, 768, 192, 6000) == "160"
+    assert plan(20011, 768, 192, 18003, f32=1, res=1, rs=1) == "TALL4" and plan(10300, 1024, 256, 9800, act=1, aux=1) == "224"
+    assert plan(7000, 2304, 128, 6500, two=1) == "PERSIST_SPLIT"
+    # argument errors come back as codes
+    assert lib.simvg_gemm_nt_plan(100, 64, 30, 0, 0, 0, 0, 0, 0, 0) < 0 and b"multiple of 64" in lib.simvg_last_error()
+
+
 def test_grouped_gemm_rejects_bad_problem_lists():
     import ctypes as C
     from simvg_amd import _lib

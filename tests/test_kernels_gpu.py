@@ -116,16 +116,21 @@ def test_probe_glds_lane_linear():
 # ------------------------------------------------------------------------------------------
 # GEMMs
 # ------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("M,N,K,split", [(300, 192, 128, 200), (1684, 768, 768, 1604), (257, 64, 64, 0),
-                                         (1684, 3072, 768, 1604), (640, 768, 3072, 512),
-                                         (2370, 2304, 768, 2100), (2112, 3072, 128, 0),     # 256x256 tile path
-                                         (2306, 4096, 64, 2100),      # 16 column tiles walked in groups of 6 / 6 / 4
-                                         (7000, 3072, 128, 6500),     # 336 tiles: persistent workgroups take two tiles, ragged row groups
-                                         (300, 7040, 64, 200),        # few rows, many columns: the 128x128 kernel
-                                         (2230, 768, 256, 2000), (2048, 768, 3072, 0),        # 160x256 tile path
-                                         (10300, 1024, 256, 9800), (9900, 1024, 128, 0),      # 224x256 tile path (one round of 224-row tiles)
+# (which kernel a shape / epilogue selects: `simvg_gemm_nt_plan`, pinned as data in tests/test_abi.py)
+@pytest.mark.parametrize("M,N,K,split", [(300, 192, 128, 200), (1684, 768, 768, 1604), (257, 64, 64, 0),      # 64x64 latency kernel
+                                         (640, 768, 3072, 512), (2230, 768, 256, 2000), (2048, 768, 3072, 0), (300, 7040, 64, 200),
+                                         (1684, 3072, 768, 1604), (12000, 320, 64, 11000),                     # 256x128 / k 32 kernel
+                                         (300, 12800, 64, 200),                                                # 128x128 kernel
+                                         (2370, 2304, 768, 2100), (2112, 3072, 128, 0),                        # 160x256 kernel
+                                         (2306, 4096, 64, 2100),      # ... 16 column tiles
+                                         (7300, 768, 192, 6000), (9900, 1024, 128, 0),
+                                         (7000, 3072, 128, 6500),     # 336 tiles of 256 rows: persistent workgroups take two (plain / bias), the
+                                                                      # one-tile 256x256 kernel (other epilogues); walked in column groups, ragged row groups
+                                         (10300, 1024, 256, 9800),    # one round of 224-row tiles: hand-managed 2 x 8 waves (round 6: plain / bias /
+                                                                      # residual), compiler-scheduled (round 4: activations)
                                          # one round of 320-row tiles (round 6, gemm_nt_kernel_tall5_*: the plain / bias / residual modes):
-                                         # BASELINE's N = 768 launch geometry (85 x 3 tiles), ragged row groups, one group
+                                         # BASELINE's N = 768 launch geometry (85 x 3 tiles); one round of 256-row hand-managed tiles for the
+                                         # fp32 epilogue (tall4) beside the one-tile 256x256 kernel; one row group on 224-row tiles
                                          (26944, 768, 128, 25664), (20011, 768, 192, 18003), (16000, 768, 64, 0)])
 @pytest.mark.parametrize("mode", ["plain", "bias", "bias_gelu_aux", "residual_scale_f32", "relu_f32"])
 def test_gemm_nt(M, N, K, split, mode):
@@ -171,12 +176,42 @@ def test_gemm_nt(M, N, K, split, mode):
         assert_close(out, F.relu(ref_lin(True)), 1e-3, "gemm relu f32")
 
 
+@pytest.mark.parametrize("M,N,K,split,part", [(26944, 768, 256, 25664, 6000),    # one round of 320-row tiles vs the 160-row kernel
+                                              (13472, 1024, 256, 12832, 3000),   # the 2 x 8-wave 224-row kernel vs the 256-row / 160-row ones
+                                              (26944, 2304, 128, 25664, 5000)])  # persistent 256-row kernel at both sizes
+def test_gemm_nt_rows_do_not_depend_on_the_kernel_their_batch_selects(M, N, K, split, part):
+    """A row of a Linear is the same dot products in the same k order whichever tile extent / kernel the problem's row count selects
+    (round 6: the one-round 320-row and 224-row kernels start their accumulators at zero and add the bias in the epilogue like the
+    other one-tile kernels; every fp32 epilogue is fmaf(row_scale, acc + bias, residual)): the first `part` vision rows and all text
+    rows of the big problem == the same rows computed as a small problem, bit for bit.  What forward_test's batch independence
+    (tests/test_properties_gpu.py) rests on."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K + 7)
+    a = bf(rnd_bf16(M, K, gen=g)).to(DEV)
+    w = bf(rnd_bf16(2, N, K, scale=K ** -0.5, gen=g)).to(DEV)
+    bias = torch.randn(2, N, generator=g).to(DEV)
+    res = torch.randn(M, N, generator=g).to(DEV)
+    nt = M - split
+    rows = torch.cat([torch.arange(part), torch.arange(split, M)]).to(DEV)
+    a_s, res_s = a[rows].contiguous(), res[rows].contiguous()
+    for kw, kw_s in ((dict(residual=res, out_dtype=torch.float32), dict(residual=res_s, out_dtype=torch.float32)),
+                     (dict(), dict())):
+        if N > 1024 and kw:
+            continue                      # (the wide launches of the path have 16-bit outputs)
+        big = ops.gemm_nt(a, w, bias=bias, split=split, **kw)
+        small = ops.gemm_nt(a_s, w, bias=bias, split=part, **kw_s)
+        assert small.shape[0] == part + nt
+        assert torch.equal(big[rows], small), (M, N, K, "fp32 + residual" if kw else "16-bit",
+                                               float((big[rows].float() - small.float()).abs().max()))
+
+
 @pytest.mark.parametrize("M,N,K,split", [(300, 192, 128, 200),        # latency kernel (64x64 tiles)
                                          (640, 768, 3072, 512),       # 256x128 / k 32 kernel
                                          (300, 7040, 64, 200),        # 128x128 kernel
                                          (2370, 2304, 768, 2100),     # 256x256 kernel (the persistent form is refused)
-                                         (2230, 768, 256, 2000), (2048, 768, 3072, 0),        # 160x256 kernel
-                                         (20011, 768, 128, 18003)])                            # one round of 320-row tiles
+                                         (7300, 768, 192, 6000),                               # 160x256 kernel
+                                         (7000, 2304, 128, 6500),                              # persistent 256x256 kernel, split variant (round 6)
+                                         (26944, 768, 128, 25664)])                            # one round of 320-row tiles
 @pytest.mark.parametrize("mode", ["bias_lp", "bias_residual_f32"])
 def test_gemm_nt_split_carries_fp32_weights(M, N, K, split, mode):
     """simvg_gemm_nt_split: the weight as a hi + lo pair of 16-bit numbers (rows [lo * 2^11 | hi], A walked twice, accumulators
