@@ -124,7 +124,11 @@ class BEIT3(nn.Module):
         if os.environ.get("SIMVG_PRECISE_TRAIN"):
             pt = int(os.environ["SIMVG_PRECISE_TRAIN"])
         self.precise_training_layers = max(1, self.L // 2) if pt is True else (0 if not pt else max(0, min(int(pt), self.L)))
-        self.precise_training_which = tuple(t for t in os.environ.get("SIMVG_PRECISE_TRAIN_WHICH", "patch,wqkv,w2" if large else "patch,wqkv").split(",") if t)
+        # ("tag:k" = that Linear in the first k layers only, e.g. "patch,wqkv,w2:6")
+        spec = [t for t in os.environ.get("SIMVG_PRECISE_TRAIN_WHICH", "patch,wqkv,w2" if large else "patch,wqkv").split(",") if t]
+        self.precise_training_which = tuple(t.split(":")[0] for t in spec)
+        self._precise_training_depth = {t.split(":")[0]: min(int(t.split(":")[1]), self.precise_training_layers) if ":" in t
+                                        else self.precise_training_layers for t in spec}
         assert set(self.precise_training_which) <= {"patch", "wqkv", "wout", "w1", "w2"}, self.precise_training_which
         self.wbs = {}
         self.wb2 = None
@@ -254,7 +258,7 @@ class BEIT3(nn.Module):
         for i in range(L):
             for tag, n, k in [("wqkv", 3 * D, D), ("wout", D, D), ("w1", F_, D), ("w2", D, F_)]:
                 self.wb[f"{tag}T{i}"] = bf(2, k, n)
-                two = self.precision == "lowp" and i < self.precise_training_layers and tag in self.precise_training_which
+                two = self.precision == "lowp" and tag in self.precise_training_which and i < self._precise_training_depth[tag]
                 if two:          # [lo * 2^11 | hi] rows; the plain copy every other consumer reads is the right half
                     self.wbs[f"{tag}{i}"] = bf(2, n, 2 * k)
                     self.wb[f"{tag}{i}"] = self.wbs[f"{tag}{i}"][..., k:]

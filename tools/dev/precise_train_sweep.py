@@ -26,7 +26,7 @@ def main():
         if os.environ.get("ZERO_LO"):
             combos = [("patch,wqkv", L // 4), ("patch,wqkv", L // 2), ("patch,wqkv", L)]
         if whichs != ["wqkv"]:
-            combos = [(w, l) for w in whichs for l in (L // 2, L)]
+            combos = [(w, l) for w in whichs for l in ((L // 2, L) if ":" not in w else (L,))]
         for which, layers in combos:
             if True:
                 os.environ["SIMVG_PRECISE_TRAIN"] = str(layers)
@@ -61,7 +61,7 @@ def main():
                 ms = (time.perf_counter() - t0) / 5 * 1e3
                 d = _l1_stats(out["outputs_coord_decoder_branch"], ref["outputs_coord_decoder_branch"])
                 t = _l1_stats(out["outputs_coord_token_branch"], ref["outputs_coord_token_branch"])
-                print(f"[{vit}] train fwd: {which:16s} first {layers:2d} layers  fwd+bwd {ms:7.2f} ms  decoder max {d[0]:.2e} mean {d[2]:.2e}  "
+                print(f"[{vit}] train fwd: {which:24s} first {layers:2d} layers  fwd+bwd {ms:7.2f} ms  decoder max {d[0]:.2e} mean {d[2]:.2e}  "
                       f"token max {t[0]:.2e} p99 {t[1]:.2e} mean {t[2]:.2e}", flush=True)
                 del model
                 torch.cuda.empty_cache()
