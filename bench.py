@@ -689,7 +689,7 @@ def main():
     if extras and _lowp == "fp16" and not os.environ.get("SIMVG_HIP_LIB"):
         out["bf16_line"] = bf16_line(a)
     enc = model.vis_enc
-    out["precise_training"] = {"layers": enc.precise_training_layers, "which": list(enc.precise_training_which),
+    out["precise_training"] = {"layers": dict(enc._precise_training_depth) if enc.wbs else 0, "which": list(enc.precise_training_which),
                                "split_linears_per_step": len(enc.wbs),
                                "what": "Linears whose weight the TRAINING forward carries as a hi + lo pair of 16-bit numbers (2 x the MFMA work of "
                                        "those launches, inside the timed step and inside `roofline` at their algorithmic FLOPs): every box of "

@@ -113,10 +113,11 @@ class BEIT3(nn.Module):
         # precise_training (round 6): the TRAINING forward (everything kept for the backward) carries hi + lo weights as well -- its
         # boxes feed the matcher and the losses, and with single 16-bit weights the token branch of a full batch misses the path's
         # 1e-3 bound on the harsh fixtures (1.11e-3 / 1.17e-3, tests/test_fullsize_gpu.py).  True (default) = the patch kernel + qkv
-        # of the first half of the layers (+ fc2 of those layers in 24-layer encoders, which run without DropPath: a Linear whose
-        # epilogue carries a DropPath row scale keeps its single weight); an int k = the first k layers; False = single weights
-        # (round 5).  Measured (tools/dev/precise_train_sweep.py, profiles/r06_sweeps.md): ViT-B 8.2e-4 at +0.35 ms per step,
-        # ViT-L 9.2e-4 at +1.9 ms.  The backward keeps the single transposed copies (the dgrad of a function that differs by 2^-12
+        # of the first third of the layers (12-layer encoders) / + qkv of the first half and fc2 of the first quarter of the layers
+        # (24-layer encoders, which run without DropPath: a Linear whose epilogue carries a DropPath row scale keeps its single
+        # weight); an int k = at most the first k layers; False = single weights (round 5).  Measured
+        # (tools/dev/precise_train_sweep.py, profiles/r06_sweeps.md section 2): ViT-B 8.25e-4 at +0.2 ... +0.4 ms per step, ViT-L
+        # 8.6e-4 at +1.3 ms.  The backward keeps the single transposed copies (the dgrad of a function that differs by 2^-12
         # relative); the [lo | hi] rows are written by the per-step weight refresh itself (`simvg_weight_prep`, split_shift), the
         # plain copy IS their right half.  SIMVG_PRECISE_TRAIN (layers) / SIMVG_PRECISE_TRAIN_WHICH (= patch,wqkv,wout,w1,w2)
         # override it (measurements)
@@ -125,7 +126,8 @@ class BEIT3(nn.Module):
             pt = int(os.environ["SIMVG_PRECISE_TRAIN"])
         self.precise_training_layers = max(1, self.L // 2) if pt is True else (0 if not pt else max(0, min(int(pt), self.L)))
         # ("tag:k" = that Linear in the first k layers only, e.g. "patch,wqkv,w2:6")
-        spec = [t for t in os.environ.get("SIMVG_PRECISE_TRAIN_WHICH", "patch,wqkv,w2" if large else "patch,wqkv").split(",") if t]
+        dflt = f"patch,wqkv:{self.L // 2},w2:{self.L // 4}" if large else f"patch,wqkv:{max(1, self.L // 3)}"
+        spec = [t for t in os.environ.get("SIMVG_PRECISE_TRAIN_WHICH", dflt).split(",") if t]
         self.precise_training_which = tuple(t.split(":")[0] for t in spec)
         self._precise_training_depth = {t.split(":")[0]: min(int(t.split(":")[1]), self.precise_training_layers) if ":" in t
                                         else self.precise_training_layers for t in spec}
