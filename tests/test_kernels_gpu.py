@@ -746,6 +746,36 @@ def test_weight_prep():
             assert torch.equal(dst_t, m.t().contiguous().to(LPD()))
 
 
+def test_weight_prep_writes_hi_lo_rows():
+    """`simvg_weight_prep` with split_shift (round 6, `BEIT3.precise_training`): dst rows are [lo * 2^11 | hi] -- bit for bit what
+    `hip_ops.split_weight` (torch arithmetic: hi = the 16-bit rounding of w, lo = the 16-bit rounding of (w - hi) * 2^11) builds for
+    forward_test; the right half IS the plain 16-bit copy; the transposed copy is untouched by the mode; ragged shapes take the
+    element-wise path."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    mats = [(torch.randn(r, c, generator=g) * sc).to(DEV) for r, c, sc in [(768, 768, 0.03), (132, 200, 1.0), (70, 33, 0.5), (2304, 768, 0.02)]]
+    entries = []
+    for i, m in enumerate(mats):
+        dst = torch.full((m.shape[0], 2 * m.shape[1]), float("nan"), device=DEV, dtype=LPD())
+        dst_t = torch.empty(m.shape[1], m.shape[0], device=DEV, dtype=LPD()) if i != 2 else None
+        entries.append((m, dst, dst_t, ops.SPLIT_SHIFT))
+    plain = torch.empty_like(mats[0], dtype=LPD())
+    entries.append((mats[0], plain, None))                    # a plain entry beside them in the same launch
+    ops.WeightPrep(entries, DEV).run()
+    torch.cuda.synchronize()
+    for m, dst, dst_t, _ in entries[:-1]:
+        K = m.shape[1]
+        assert torch.equal(dst, ops.split_weight(m)), m.shape
+        assert torch.equal(dst[:, K:], m.to(LPD()))
+        if dst_t is not None:
+            assert torch.equal(dst_t, m.t().contiguous().to(LPD()))
+        # hi + lo carries the weight to ~2^-22 relative (fp16 build; bf16: 2^-16)
+        rec = dst[:, K:].double() + dst[:, :K].double() * 2.0 ** -ops.SPLIT_SHIFT
+        rel = float((rec - m.double()).abs().max() / m.double().abs().max())
+        assert rel <= (2e-6 if LPD() == torch.float16 else 1e-4), rel
+    assert torch.equal(plain, mats[0].to(LPD()))
+
+
 def test_dropout_multipliers_philox():
     """csrc/rng.hip: multipliers are 0 or 1 / keep with the right frequency, a pure function of (key, index) -- the key of
     every call is drawn from torch's CPU generator, so `torch.manual_seed` reproduces the sequence of masks -- and the
