@@ -150,6 +150,7 @@ class FlatAdam(torch.optim.Adam):
         # parameters' version counters, which is what those modules watch in eval mode)
         self._weight_watchers = [m.mark_weights_dirty for m in model.modules() if hasattr(m, "mark_weights_dirty")]
         in_arena = {id(p) for p in arena.params.values()}
+        self._names = {id(p): n for n, p in model.named_parameters()}      # (layout signature: which parameter sits where)
         self.flat = torch.nn.Parameter(arena.flat)
         self.flat.grad = arena.flat_grad
         self._clip = None
@@ -186,7 +187,8 @@ class FlatAdam(torch.optim.Adam):
         import zlib
         text = ";".join(f"{n}@{o}:{self.arena.params[n].numel()}" for n, o in self.arena.offsets.items())
         for ra in self._rest_arenas:
-            text += "|" + ";".join(f"{o}:{p.numel()}" for p, o in zip(ra.params, ra.offsets))
+            # (names too since round 6: two same-sized head parameters that swap places change the signature)
+            text += "|" + ";".join(f"{self._names.get(id(p), '?')}@{o}:{p.numel()}" for p, o in zip(ra.params, ra.offsets))
         return zlib.crc32(text.encode())
 
     def state_dict(self):
@@ -200,8 +202,12 @@ class FlatAdam(torch.optim.Adam):
         if sig != self.layout_signature():
             # (round 5 moved the encoder's LayerNorm parameters behind the layers' Linears: a state written before has the same
             # size and a different order -- loading it would hand every element someone else's moments)
-            raise ValueError("FlatAdam state was written for another arena layout (%r, this build: %r)"
-                             % (sig, self.layout_signature()))
+            # No migration path: a state written before the signature existed (or for another layout) carries per-element moments
+            # whose owner cannot be recovered from the flat tensors alone.  Resume such a run with a fresh optimizer state (the
+            # model weights load independently: checkpoint.load_checkpoint(model, path) without `resume`), or train with
+            # optimizer_config.flat=False, whose state is torch.optim.Adam's per-parameter dict.
+            raise ValueError("FlatAdam state was written for another arena layout (%r, this build: %r): resume with a fresh "
+                             "optimizer state, or use optimizer_config.flat=False" % (sig, self.layout_signature()))
         super().load_state_dict(sd)
 
     def zero_grad(self, set_to_none=True):
