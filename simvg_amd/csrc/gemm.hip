@@ -9,10 +9,13 @@
 //  simvg_gemm_tn : dW[g][N,K] += dY[M,N]^T · X[M,K]   (wgrad; the encoder shapes go to wgrad.hip, the rest is split over M
 //                  here and meets through fp32 atomics)
 //
-// Kernels by shape (dispatch in gemm_nt_launch): 16-wave 256x256x64 tiles, persistent with a 2-stage ring (N >= 2304, big M);
-// 16-wave 160x256x64 with a 3-stage ring (N = 768); 128x128x64 / latency variants for the small head shapes.  All of them:
-// v_mfma_f32_16x16x32, HBM->LDS by global_load_lds (16 B/lane, LDS image lane-linear, XOR swizzle applied on the SOURCE
-// address and on the ds_read address), counted vmcnt, LDS-staged coalesced epilogue.
+// Kernels by shape (dispatch in gemm_nt_launch; `simvg_gemm_nt_plan` returns the choice without launching): 16-wave 256x256x64
+// tiles, persistent with a 2-stage ring (N >= 2304, big M; `_p2`: hi + lo weights); ONE round of 320x256x64 tiles on the same
+// hand-managed loop (round 6: N = 768 at M = 26 944 -- `gemm_nt_kernel_tall5_*`; 256 / 224 rows for ViT-L's row count:
+// `_tall4_f32`, `_t224_*`); 16-wave 160x256x64 with a 3-stage ring and 224x256 / 256x256 one-tile kernels with compiler-scheduled
+// reads (other row counts, epilogues with an activation); 128x128x64 / 256x128x32 / latency variants for the small shapes.  All of
+// them: v_mfma_f32_16x16x32, HBM->LDS by LDS-DMA (16 B/lane, LDS image lane-linear, XOR swizzle applied on the SOURCE address and
+// on the ds_read address), counted vmcnt, coalesced epilogues.
 #include <stdlib.h>
 #include <string.h>
 

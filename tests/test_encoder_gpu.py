@@ -167,3 +167,47 @@ def test_gradient_scale_follows_the_incoming_gradient():
         ops.set_grad_scale(None)
     rel = lambda a, b: float((a - b).norm() / b.norm())
     assert rel(g1, g2) <= 1e-6 and rel(g4 * 512.0, g2) <= 2e-3, (rel(g1, g2), rel(g4 * 512.0, g2))
+
+
+def test_precise_training_keeps_hi_lo_rows_in_step_with_the_master_weights():
+    """`BEIT3.precise_training` (round 6): the Linears of its set own `[lo * 2^11 | hi]` rows that the per-step weight refresh rewrites
+    from the fp32 master weights (bit for bit `hip_ops.split_weight`), every other consumer's plain 16-bit copy IS the right half of
+    those rows (no second buffer), Linears outside the set keep plain copies, and `precise_training=False` builds none."""
+    from oracle import simvg_cpu as O, weights as W
+    from simvg_amd import hip_ops as ops
+    from simvg_amd.models import build_vis_enc
+    cfg = O.make_cfg("tiny", 1, 128)
+    sd = _enc_sd(W.golden_state_dict(cfg, 11))
+    kw = dict(type="BEIT3", img_size=cfg.img_size, patch_size=cfg.patch_size, vocab_size=cfg.vocab_size, pretrain=None, drop_path_rate=0.0,
+              encoder_cfg=dict(embed_dim=cfg.embed_dim, heads=cfg.heads, ffn_dim=cfg.ffn_dim, layers=cfg.layers))
+    batch = W.synthetic_batch(cfg, 2, 21)
+    args = (batch["img"].to(DEV), batch["ref_expr_inds"].to(DEV), batch["text_attention_mask"].to(DEV))
+    outs = {}
+    for flag in (True, False):
+        enc = build_vis_enc(dict(kw, precise_training=flag))
+        enc.load_state_dict(sd, strict=True)
+        enc.to(DEV).train()
+        outs[flag] = enc.encode(*args).detach().float().clone()
+        A = enc._arena
+        D, P = enc.D, enc.patch_size
+        if not flag:
+            assert enc.wbs == {}
+            continue
+        depth = max(1, cfg.layers // 3)
+        assert set(enc.wbs) == {"patch"} | {f"wqkv{i}" for i in range(depth)}, sorted(enc.wbs)
+        for round_ in range(2):
+            if round_ == 1:                      # the master weights move (what an optimizer step does): the next forward refreshes the rows
+                with torch.no_grad():
+                    A.flat.mul_(1.0 + 1e-3)
+                enc.encode(*args)
+            torch.cuda.synchronize()
+            want = {"patch": A.params["beit3.vision_embed.proj.weight"].data.view(D, 3 * P * P)}
+            want.update({f"wqkv{i}": A.views[f"wqkv{i}"] for i in range(depth)})
+            for tag, w32 in want.items():
+                assert torch.equal(enc.wbs[tag], ops.split_weight(w32)), (tag, round_)
+                K = w32.shape[-1]
+                assert enc.wb[tag].data_ptr() == enc.wbs[tag][..., K:].data_ptr() and torch.equal(enc.wb[tag], w32.to(ops.LP()))
+            assert torch.equal(enc.wb["wout0"], A.views["wout0"].to(ops.LP())) and enc.wb["wout0"].is_contiguous()
+    # the two forwards compute the same function up to the weights' 16-bit rounding
+    scale = float(outs[False].abs().max())
+    assert float((outs[True] - outs[False]).abs().max()) <= 1e-2 * scale
